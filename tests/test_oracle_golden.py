@@ -1,0 +1,274 @@
+"""Pins the CPU oracle (oracle/anofox_oracle.c) against every golden vector the
+reference holds for this path: the R-generated fixtures under
+test/data/ (copied to tests/golden/), the sqllogictest known answers, the AIC/BIC
+unit-test values and the recorded ridge-raw identity.  CPU only."""
+import numpy as np
+import pytest
+from scipy import stats as sps
+from scipy import special as spsp
+
+import oracle
+from conftest import load_csv, load_json, nan_or, rel_err
+
+# tolerances declared by the reference: test/data/ols_tests/metadata.json ("strict" 1e-10, "relaxed" 1e-8)
+STRICT = 1e-10
+RELAXED = 1e-8
+
+
+def _xcols(d, names):
+    return [d[n] for n in names]
+
+
+@pytest.mark.parametrize("case,xn,icpt", [
+    ("simple_linear", ["x"], True),
+    ("multiple_regression", ["x1", "x2", "x3"], True),
+    ("no_intercept", ["x"], False),
+    ("rank_deficient", ["x1", "x2"], True),
+    ("perfect_collinearity", ["x1", "x2"], True),
+])
+def test_ols_fixtures(case, xn, icpt):
+    d = load_csv(f"ols_tests/input/{case}.csv")
+    e = load_json(f"ols_tests/expected/{case}.json")
+    code, r = oracle.fit(d["y"], _xcols(d, xn), model="ols", fit_intercept=icpt)
+    assert code == 0
+    coefs = e["coefficients"] if isinstance(e["coefficients"], list) else [e["coefficients"]]
+    coefs = [nan_or(c) for c in coefs]
+    if icpt:
+        assert rel_err(r["intercept"], coefs[0]) < STRICT
+        slopes = coefs[1:]
+    else:
+        assert np.isnan(r["intercept"])
+        slopes = coefs
+    for got, want in zip(r["coefficients"], slopes):
+        if np.isnan(want):
+            assert np.isnan(got)  # R reports NA for the dropped / aliased column
+        else:
+            assert rel_err(got, want) < STRICT
+    assert rel_err(r["r_squared"], e["r_squared"]) < STRICT
+    assert rel_err(r["adj_r_squared"], e["adj_r_squared"]) < STRICT
+    assert rel_err(r["residual_std_error"], e["sigma"]) < STRICT
+    assert r["n_observations"] == len(d["y"])
+    assert r["n_features"] == len(xn)
+    if "df_residual" in e:
+        assert r["n_observations"] - r["rank"] == e["df_residual"]
+
+
+@pytest.mark.parametrize("case", ["wls_equal_weights", "wls_inverse_variance"])
+def test_wls_fixtures(case):
+    d = load_csv(f"wls_tests/input/{case}.csv")
+    e = load_json(f"wls_tests/expected/{case}.json")
+    code, r = oracle.fit(d["y"], [d["x"]], w=d["weight"], model="wls")
+    assert code == 0
+    assert rel_err(r["intercept"], e["coefficients"][0]) < STRICT
+    assert rel_err(r["coefficients"][0], e["coefficients"][1]) < STRICT
+    assert rel_err(r["r_squared"], e["r_squared"]) < STRICT
+    assert rel_err(r["adj_r_squared"], e["adj_r_squared"]) < STRICT
+    assert rel_err(r["residual_std_error"], e["sigma"]) < STRICT
+
+
+def test_wls_equal_weights_is_ols():
+    d = load_csv("wls_tests/input/wls_equal_weights.csv")
+    _, a = oracle.fit(d["y"], [d["x"]], w=d["weight"], model="wls")
+    _, b = oracle.fit(d["y"], [d["x"]], model="ols")
+    assert rel_err(a["coefficients"][0], b["coefficients"][0]) < 1e-12
+    assert rel_err(a["r_squared"], b["r_squared"]) < 1e-12
+
+
+@pytest.mark.parametrize("case,xn", [("simple_inference", ["x"]), ("multiple_inference", ["x1", "x2", "x3"])])
+def test_inference_fixtures(case, xn):
+    d = load_csv(f"inference_tests/input/{case}.csv")
+    e = load_json(f"inference_tests/expected/{case}.json")
+    code, r = oracle.fit(d["y"], _xcols(d, xn), model="ols", compute_inference=True, confidence_level=0.95)
+    assert code == 0 and r["has_inference"] == 1
+    c = e["coefficients"]
+    assert rel_err(r["intercept"], c["estimates"][0]) < STRICT
+    assert np.all(rel_err(r["coefficients"], c["estimates"][1:]) < STRICT)
+    # inference arrays are slopes only (ols.rs:189-261) -> compare with R's rows 1..p
+    assert np.all(rel_err(r["std_errors"], c["std_errors"][1:]) < STRICT)
+    assert np.all(rel_err(r["t_values"], c["t_values"][1:]) < STRICT)
+    assert np.all(rel_err(r["p_values"], c["p_values"][1:]) < RELAXED)  # down to 1.28e-85
+    ci = e["confidence_intervals"]
+    assert np.all(rel_err(r["ci_lower"], ci["lower_95"][1:]) < RELAXED)
+    assert np.all(rel_err(r["ci_upper"], ci["upper_95"][1:]) < RELAXED)
+    ms = e["model_stats"]
+    assert rel_err(r["r_squared"], ms["r_squared"]) < STRICT
+    assert rel_err(r["adj_r_squared"], ms["adj_r_squared"]) < STRICT
+    assert rel_err(r["residual_std_error"], ms["sigma"]) < STRICT
+    assert rel_err(r["f_statistic"], ms["fstatistic"][0]) < STRICT
+    assert r["n_observations"] - r["rank"] == ms["df_residual"]
+    assert rel_err(r["f_pvalue"], sps.f.sf(ms["fstatistic"][0], ms["fstatistic"][1], ms["fstatistic"][2])) < RELAXED
+
+
+def test_prediction_fixture_fit_only():
+    # only the fit (coefficients, sigma) matches: the reference's predict_with_interval uses the
+    # simplified sqrt(1+1/n) form (lib.rs:2340-2347), not R's exact interval
+    d = load_csv("inference_tests/input/prediction_train.csv")
+    e = load_json("inference_tests/expected/prediction_intervals.json")
+    xn = [n for n in d if n != "y"]
+    code, r = oracle.fit(d["y"], _xcols(d, xn), model="ols")
+    assert code == 0
+    assert rel_err(r["intercept"], e["model_coefficients"][0]) < STRICT
+    assert rel_err(r["coefficients"][0], e["model_coefficients"][1]) < STRICT
+    assert rel_err(r["residual_std_error"], e["model_sigma"]) < STRICT
+    new = load_csv("inference_tests/input/prediction_new.csv")
+    fit = r["intercept"] + r["coefficients"][0] * new[xn[0]]
+    assert np.all(rel_err(fit, e["predictions"]["fit"]) < STRICT)
+
+
+@pytest.mark.parametrize("case", ["ridge_lambda_0.1", "ridge_lambda_1.0"])
+def test_ridge_glmnet_fixtures(case):
+    # glmnet(alpha=0, standardize=FALSE): reproduced only to glmnet's own convergence (~2e-6), SURVEY.md §8c-(i)
+    d = load_csv(f"ridge_tests/input/{case}.csv")
+    e = load_json(f"ridge_tests/expected/{case}.json")
+    code, r = oracle.fit(d["y"], _xcols(d, ["x1", "x2", "x3"]), model="ridge", alpha=e["lambda"],
+                         lambda_scaling="glmnet")
+    assert code == 0
+    got = np.concatenate([[r["intercept"]], r["coefficients"]])
+    assert np.all(rel_err(got, e["coefficients"]) < 2e-5)
+
+
+def test_ridge_raw_identity(known_answers):
+    k = known_answers["ridge_raw_identity"]
+    # build a centred single predictor with Sxx = 10 and Sxy = slope*Sxx, exactly representable
+    x = np.array([-2.0, -1.0, 0.0, 1.0, 2.0])
+    assert x @ x == k["sxx"]
+    y = k["ols_slope"] * x + np.array([0.3, -0.6, 0.6, -0.6, 0.3])  # noise orthogonal to 1 and x
+    code, r = oracle.fit(y, [x], model="ridge", alpha=k["lambda"], lambda_scaling="raw")
+    assert code == 0
+    assert rel_err(r["coefficients"][0], k["ridge_slope"]) < 1e-13
+    code, r0 = oracle.fit(y, [x], model="ols")
+    assert rel_err(r0["coefficients"][0], k["ols_slope"]) < 1e-13
+
+
+def test_ridge_alpha_zero_is_ols():
+    d = load_csv("ols_tests/input/multiple_regression.csv")
+    xs = _xcols(d, ["x1", "x2", "x3"])
+    _, a = oracle.fit(d["y"], xs, model="ridge", alpha=0.0)
+    _, b = oracle.fit(d["y"], xs, model="ols")
+    assert np.all(rel_err(a["coefficients"], b["coefficients"]) < 1e-11)
+    assert rel_err(a["intercept"], b["intercept"]) < 1e-11
+    assert rel_err(a["r_squared"], b["r_squared"]) < 1e-12
+
+
+def _check_expect(r, exp):
+    for key, val in exp.items():
+        if key == "coefficients":
+            for got, w in zip(r["coefficients"], val):
+                if w is None:
+                    continue
+                assert round(float(got), w[1]) == w[0]
+        elif key == "coefficients_abs":
+            for got, w in zip(r["coefficients"], val):
+                assert abs(got - w[0]) < w[1]
+        elif key == "intercept_abs":
+            assert abs(r["intercept"] - val[0]) < val[1]
+        elif key == "intercept_is_nan":
+            assert np.isnan(r["intercept"])
+        elif key == "residual_std_error_lt":
+            assert r["residual_std_error"] < val
+        elif key == "r_squared_gt":
+            assert r["r_squared"] > val
+        else:
+            assert round(float(r[key]), val[1]) + 0.0 == val[0]
+
+
+def test_sqllogictest_scalar_known_answers(known_answers):
+    for case in known_answers["scalar_fits"]:
+        code, r = oracle.fit(case["y"], case["x"], model=case["model"], fit_intercept=case["fit_intercept"])
+        assert code == 0, case["name"]
+        _check_expect(r, case["expect"])
+
+
+def test_sqllogictest_group_by_known_answers(known_answers):
+    for case in known_answers["group_by"]:
+        rows = case["rows"]
+        groups = sorted({r[0] for r in rows})
+        ncol = len(rows[0]) - 2
+        y, cols, offs = [], [[] for _ in range(ncol)], [0]
+        for g in groups:
+            for r in rows:
+                if r[0] == g:
+                    for j in range(ncol):
+                        cols[j].append(r[1 + j])
+                    y.append(r[-1])
+            offs.append(len(y))
+        core, _ = oracle.fit_groups(y, cols, offs, model=case["model"], fit_intercept=case["fit_intercept"])
+        p = ncol
+        for gi, g in enumerate(groups):
+            exp = case["expect"][g]
+            status = int(core[gi, p + 5])
+            if exp == "NULL":
+                assert status != 0 and np.isnan(core[gi, p + 1])
+            elif exp == "OK":
+                assert status == 0 and not np.isnan(core[gi, p + 1])
+            else:
+                assert status == 0
+                _check_expect({"coefficients": core[gi, :p], "intercept": core[gi, p]}, exp)
+
+
+def test_series_known_answers(known_answers):
+    for case in known_answers["series"]:
+        i = np.arange(1, case["n"] + 1, dtype=np.float64)
+        code, r = oracle.fit(2 * i + 1, [i], model=case["model"], alpha=case.get("alpha", 1.0))
+        assert code == 0
+        _check_expect(r, case["expect"])
+
+
+def test_aic_bic_known_answers(known_answers):
+    for k in known_answers["information_criteria"]:
+        rc, a = oracle.aic(k["rss"], k["n"], k["k"])
+        assert rc == 0 and abs(a - k["aic"]) < k["abs_tol"]
+        rc, b = oracle.bic(k["rss"], k["n"], k["k"])
+        assert rc == 0 and abs(b - k["bic"]) < k["abs_tol"]
+    assert oracle.aic(0.0, 10, 2) == (0, -np.inf)  # information_criteria.rs: rss == 0 -> -inf
+    assert oracle.aic(1.0, 0, 2)[0] != 0
+    assert oracle.bic(-1.0, 10, 2)[0] != 0
+
+
+def test_special_functions_against_scipy():
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        a, b = rng.uniform(0.5, 600, 2)
+        x = rng.uniform(0, 1)
+        assert abs(L.oracle_betainc(a, b, x) - spsp.betainc(a, b, x)) < 1e-12 * max(1.0, 1.0)
+    for df in (1, 2, 5, 30, 146, 991, 3967):
+        for t in (0.0, 0.3, 1.0, 2.5, 8.0, 20.0, 43.6):
+            want = 2 * sps.t.sf(t, df)
+            assert rel_err(L.oracle_t_two_sided_p(t, df), want) < 1e-9
+        for q in (0.9, 0.95, 0.975, 0.995):
+            assert rel_err(L.oracle_t_quantile(q, df), sps.t.ppf(q, df)) < 1e-10
+        for f in (0.1, 1.0, 3.0, 50.0, 1028.9):
+            assert rel_err(L.oracle_f_sf(f, 8, df), sps.f.sf(f, 8, df)) < 1e-9
+
+
+def test_error_codes_and_edge_cases():
+    y = np.arange(6.0)
+    x = [np.array([1.0, 2.0, 4.0, 3.0, 5.0, 9.0])]
+    assert oracle.fit(y, x, model="ridge", alpha=-1.0)[0] == 4            # InvalidAlpha (ridge.rs:38-40)
+    assert oracle.fit(np.full(6, np.nan), x)[0] == 10                      # NoValidData (ols.rs:68-70)
+    assert oracle.fit(y[:1], [x[0][:1], x[0][:1] * 2 + 1])[0] == 0         # one row: both columns constant -> intercept only
+    # two non-constant features + intercept with 2 rows -> InsufficientData (ols.rs:132-139)
+    assert oracle.fit([1.0, 2.0], [[1.0, 2.0], [2.0, 5.0]])[0] == 6
+    # equality is allowed: 2 rows, one feature + intercept
+    code, r = oracle.fit([1.0, 3.0], [[1.0, 2.0]])
+    assert code == 0 and abs(r["coefficients"][0] - 2.0) < 1e-12
+    # all-constant features: intercept-only result (ols.rs:101-130)
+    code, r = oracle.fit([1.0, 2.0, 6.0], [[5.0, 5.0, 5.0]])
+    assert code == 0 and np.isnan(r["coefficients"][0]) and r["intercept"] == 3.0
+    assert r["r_squared"] == 0.0 and r["adj_r_squared"] == 0.0
+    assert abs(r["residual_std_error"] - np.std([1.0, 2.0, 6.0], ddof=1)) < 1e-14
+    assert oracle.fit([1.0, 2.0, 6.0], [[5.0, 5.0, 5.0]], fit_intercept=False)[0] == 6
+    # non-finite rows are dropped; n_observations counts survivors
+    yy = np.array([1.0, 2.0, np.nan, 4.0, 5.0, np.inf, 7.5])
+    xx = np.array([1.0, 2.0, 3.0, np.nan, 5.0, 6.0, 7.0])
+    code, r = oracle.fit(yy, [xx])
+    assert code == 0 and r["n_observations"] == 4
+    # WLS drops non-positive / non-finite weights (wls.rs:76-86)
+    code, r = oracle.fit(y, x, w=[1.0, 0.0, -1.0, np.nan, 2.0, 1.0], model="wls")
+    assert code == 0 and r["n_observations"] == 3
+    # WLS intercept-only: weighted mean, sqrt(sum w d^2 / sum w) (wls.rs:126-135)
+    code, r = oracle.fit([1.0, 2.0, 6.0], [[5.0, 5.0, 5.0]], w=[1.0, 2.0, 1.0], model="wls")
+    m = (1 + 4 + 6) / 4
+    assert code == 0 and abs(r["intercept"] - m) < 1e-15
+    assert abs(r["residual_std_error"] - np.sqrt(((1 - m) ** 2 + 2 * (2 - m) ** 2 + (6 - m) ** 2) / 4)) < 1e-15
