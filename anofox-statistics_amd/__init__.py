@@ -1,0 +1,29 @@
+"""anofox-statistics_amd — MI355X-native grouped least-squares (ols_fit_agg / ridge_fit_agg / wls_fit_agg).
+
+The product is libanofox_stats_hip.so (hand-written HIP for gfx950 behind the C ABI of
+include/anofox_stats_hip.h).  This package is its host-side mirror of the reference's operator
+interface: the aggregates (aggregate.py), the scalar functions (scalar.py), the options parser
+(options.py), plus device-resident and multi-GPU drivers (runtime.py, distributed.py).
+
+Importing the package loads the shared library and fails if it is missing — there is no CPU fallback.
+"""
+from . import _abi
+
+_abi.load()
+
+from ._abi import AnofoxStatsError  # noqa: E402
+from .aggregate import (FitAggResult, OlsFitAgg, RidgeFitAgg, WlsFitAgg, SQL_FUNCTIONS,  # noqa: E402
+                        ols_fit_agg, ridge_fit_agg, wls_fit_agg, result_from_records)
+from .options import InvalidInputException, RegressionOptions, parse_options  # noqa: E402
+from .runtime import Context, fit_batch_host  # noqa: E402
+from .scalar import aic, bic, ols_fit, ridge_fit, wls_fit  # noqa: E402
+
+__all__ = [
+    "AnofoxStatsError", "Context", "FitAggResult", "InvalidInputException", "OlsFitAgg", "RegressionOptions",
+    "RidgeFitAgg", "SQL_FUNCTIONS", "WlsFitAgg", "aic", "bic", "fit_batch_host", "ols_fit", "ols_fit_agg",
+    "parse_options", "result_from_records", "ridge_fit", "ridge_fit_agg", "wls_fit", "wls_fit_agg",
+]
+
+
+def version() -> str:
+    return _abi.load().anofox_hip_version().decode()

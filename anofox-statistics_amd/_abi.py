@@ -1,0 +1,143 @@
+"""ctypes binding of libanofox_stats_hip.so (include/anofox_stats_hip.h).
+
+The library is the product; this module only declares its C ABI.  There is no
+fallback: if the shared object is missing or a symbol is absent, import fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libanofox_stats_hip.so")
+
+# --- enums (anofox_stats_hip.h) ------------------------------------------------
+ERROR_SUCCESS = 0
+ERROR_INVALID_INPUT = 1
+ERROR_SINGULAR_MATRIX = 2
+ERROR_CONVERGENCE_FAILURE = 3
+ERROR_INVALID_ALPHA = 4
+ERROR_INVALID_L1_RATIO = 5
+ERROR_INSUFFICIENT_DATA = 6
+ERROR_ALLOCATION_FAILURE = 7
+ERROR_SERIALIZATION_ERROR = 8
+ERROR_DIMENSION_MISMATCH = 9
+ERROR_NO_VALID_DATA = 10
+ERROR_INTERNAL = 99
+STATUS_NULL_TOO_FEW_ROWS = 100
+
+SOLVER = {"qr": 0, "svd": 1, "cholesky": 2}
+LAMBDA_SCALING = {"raw": 0, "glmnet": 1}
+HC_TYPE = {"none": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}
+MODEL = {"ols": 0, "ridge": 1, "wls": 2}
+
+_DP = C.POINTER(C.c_double)
+
+
+class AnofoxError(C.Structure):
+    _fields_ = [("code", C.c_int), ("message", C.c_char * 256)]
+
+    def text(self) -> str:
+        return self.message.decode("utf-8", "replace")
+
+
+class AnofoxDataArray(C.Structure):
+    _fields_ = [("data", _DP), ("validity", C.POINTER(C.c_uint8)), ("len", C.c_size_t)]
+
+
+class AnofoxFitResultCore(C.Structure):
+    _fields_ = [("coefficients", _DP), ("coefficients_len", C.c_size_t), ("intercept", C.c_double),
+                ("r_squared", C.c_double), ("adj_r_squared", C.c_double), ("residual_std_error", C.c_double),
+                ("n_observations", C.c_size_t), ("n_features", C.c_size_t)]
+
+
+class AnofoxFitResultInference(C.Structure):
+    _fields_ = [("std_errors", _DP), ("t_values", _DP), ("p_values", _DP), ("ci_lower", _DP), ("ci_upper", _DP),
+                ("len", C.c_size_t), ("confidence_level", C.c_double), ("f_statistic", C.c_double),
+                ("f_pvalue", C.c_double)]
+
+
+class AnofoxOlsOptions(C.Structure):
+    _fields_ = [("fit_intercept", C.c_bool), ("compute_inference", C.c_bool), ("confidence_level", C.c_double),
+                ("solver", C.c_int), ("hc_type", C.c_int)]
+
+
+class AnofoxRidgeOptions(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("fit_intercept", C.c_bool), ("compute_inference", C.c_bool),
+                ("confidence_level", C.c_double), ("solver", C.c_int), ("lambda_scaling", C.c_int)]
+
+
+class AnofoxWlsOptions(C.Structure):
+    _fields_ = AnofoxOlsOptions._fields_
+
+
+class AnofoxHipBatchOptions(C.Structure):
+    _fields_ = [("model", C.c_int), ("fit_intercept", C.c_bool), ("compute_inference", C.c_bool),
+                ("confidence_level", C.c_double), ("alpha", C.c_double), ("solver", C.c_int),
+                ("lambda_scaling", C.c_int), ("hc_type", C.c_int)]
+
+
+class AnofoxHipKernelTimes(C.Structure):
+    _fields_ = [("accumulate_ms", C.c_double), ("accumulate_count", C.c_int64), ("solve_ms", C.c_double),
+                ("solve_count", C.c_int64)]
+
+
+# every symbol include/anofox_stats_hip.h declares: name -> (restype, argtypes)
+_ERRP = C.POINTER(AnofoxError)
+_CTX = C.c_void_p
+SYMBOLS = {
+    "anofox_ols_fit": (C.c_bool, [AnofoxDataArray, C.POINTER(AnofoxDataArray), C.c_size_t, AnofoxOlsOptions,
+                                  C.POINTER(AnofoxFitResultCore), C.POINTER(AnofoxFitResultInference), _ERRP]),
+    "anofox_ridge_fit": (C.c_bool, [AnofoxDataArray, C.POINTER(AnofoxDataArray), C.c_size_t, AnofoxRidgeOptions,
+                                    C.POINTER(AnofoxFitResultCore), C.POINTER(AnofoxFitResultInference), _ERRP]),
+    "anofox_wls_fit": (C.c_bool, [AnofoxDataArray, C.POINTER(AnofoxDataArray), C.c_size_t, AnofoxDataArray,
+                                  AnofoxWlsOptions, C.POINTER(AnofoxFitResultCore),
+                                  C.POINTER(AnofoxFitResultInference), _ERRP]),
+    "anofox_free_result_core": (None, [C.POINTER(AnofoxFitResultCore)]),
+    "anofox_free_result_inference": (None, [C.POINTER(AnofoxFitResultInference)]),
+    "anofox_compute_aic": (C.c_bool, [C.c_double, C.c_size_t, C.c_size_t, _DP, _ERRP]),
+    "anofox_compute_bic": (C.c_bool, [C.c_double, C.c_size_t, C.c_size_t, _DP, _ERRP]),
+    "anofox_hip_core_record_len": (C.c_size_t, [C.c_size_t]),
+    "anofox_hip_inference_record_len": (C.c_size_t, [C.c_size_t]),
+    "anofox_hip_max_features": (C.c_size_t, []),
+    "anofox_hip_context_create": (C.c_bool, [C.c_int, C.POINTER(_CTX), _ERRP]),
+    "anofox_hip_context_destroy": (None, [_CTX]),
+    "anofox_hip_context_set_stream": (C.c_bool, [_CTX, C.c_void_p, _ERRP]),
+    "anofox_hip_context_synchronize": (C.c_bool, [_CTX, _ERRP]),
+    "anofox_hip_fit_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_void_p), C.c_void_p, AnofoxHipBatchOptions, C.c_void_p,
+                                               C.c_void_p, _ERRP]),
+    "anofox_hip_fit_batch_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), _DP,
+                                             C.POINTER(_DP), _DP, AnofoxHipBatchOptions, _DP, _DP, _ERRP]),
+    "anofox_hip_context_enable_timing": (C.c_bool, [_CTX, C.c_bool, _ERRP]),
+    "anofox_hip_context_collect_timing": (C.c_bool, [_CTX, C.POINTER(AnofoxHipKernelTimes), _ERRP]),
+    "anofox_hip_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C anofox-statistics_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class AnofoxStatsError(RuntimeError):
+    """A failed library call; carries the AnofoxErrorCode."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code

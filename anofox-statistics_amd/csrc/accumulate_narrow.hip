@@ -1,0 +1,245 @@
+// accumulate_narrow.hip — the HBM-streaming kernel of the grouped least-squares path (p <= 8).
+//
+// Replaces, for a whole batch of groups at once, what the reference does per group on the CPU:
+// buffer every row (src/aggregate_functions/ols_aggregate.cpp:120-186), copy the buffers twice
+// (crates/anofox-stats-ffi/src/lib.rs:128-132, crates/anofox-stats-core/src/models/ols.rs:149-152),
+// filter non-finite rows (ols.rs:59-66, wls.rs:76-86), test columns for constancy (ols.rs:76-87) and
+// hand the dense design to a QR/SVD (ols.rs:155-161).  Here each group's columns are read from HBM
+// exactly once and reduced to the O(p^2) moment record of common.h.
+//
+// Mapping: one 64-lane wavefront per group, four groups per 256-thread workgroup.  A tile is 128
+// consecutive rows; lane l owns rows 2l and 2l+1 of the tile and loads them with one 16-byte access per
+// column (the wave reads 1 KiB contiguous per column per tile).  Every lane keeps the whole moment
+// triangle (s, q, sw: 55 f64 at p = 8) in VGPRs; rows are shifted by the group's first valid row so the
+// one-pass accumulation is as well conditioned as a centred one.  The per-lane partials are summed with a
+// transposing butterfly (v_permlane32_swap / v_permlane16_swap, then 4 shuffle steps) that leaves moment
+// k on lane k, so the record is written with one coalesced store.
+//
+// Roofline: HBM-bound.  Algorithmic bytes per row 8(p+1) (+8 with weights); 63 f64 VALU ops per row at
+// p = 8 (~20 % of the f64 vector rate at the HBM-bound row rate).
+#include "common.h"
+
+namespace anofox {
+
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+	return __hiloint2double(hi, lo);
+}
+
+// After the call: lanes [0,32) hold a[l] + a[l+32] (both halves' partials of `a`), lanes [32,64) hold
+// the same for `b`.
+__device__ __forceinline__ double fold32(double a, double b) {
+	auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+	auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+	return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// Even 16-lane rows end up with a[l] + a[l+16], odd rows with b[l-16] + b[l].
+__device__ __forceinline__ double fold16(double a, double b) {
+	auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+	auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+	return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// Lanes with (lane & M) == 0 end up with a summed over the pair {l, l^M}, the others with b.
+template <int M>
+__device__ __forceinline__ double fold_shfl(double a, double b, int lane) {
+	const bool upper = (lane & M) != 0;
+	const double keep = upper ? b : a;
+	const double send = upper ? a : b;
+	return keep + __shfl_xor(send, M, 64);
+}
+
+template <int P, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) {
+	using L = MomentLayout<P>;
+	constexpr int Z = L::Z;
+	constexpr int ZZ = L::ZZ;
+
+	const int lane = threadIdx.x & 63;
+	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+	if (g >= args.n_groups) return;
+
+	const int64_t lo = args.row_offsets[g];
+	const int64_t hi = args.row_offsets[g + 1];
+
+	double s[Z];
+	double q[ZZ];
+	double sw = 0.0;
+#pragma unroll
+	for (int a = 0; a < Z; ++a) s[a] = 0.0;
+#pragma unroll
+	for (int k = 0; k < ZZ; ++k) q[k] = 0.0;
+
+	double first[Z]; // wave-uniform: z at the first valid row
+#pragma unroll
+	for (int a = 0; a < Z; ++a) first[a] = 0.0;
+	bool have_first = false;
+	int cnt = 0;
+	unsigned mask = 0;
+
+	for (int64_t base = lo; base < hi; base += 128) {
+		const int64_t r0 = base + 2 * lane;
+		double z0[Z], z1[Z];
+		double w0 = 1.0, w1 = 1.0;
+		bool in0, in1;
+		if (base + 128 <= hi) { // full tile (wave-uniform): one 16-byte load per column
+			in0 = in1 = true;
+#pragma unroll
+			for (int j = 0; j < P; ++j) {
+				const dbl2u v = *reinterpret_cast<const dbl2u *>(args.x[j] + r0);
+				z0[j] = v.x;
+				z1[j] = v.y;
+			}
+			{
+				const dbl2u v = *reinterpret_cast<const dbl2u *>(args.y + r0);
+				z0[P] = v.x;
+				z1[P] = v.y;
+			}
+			if (WEIGHTED) {
+				const dbl2u v = *reinterpret_cast<const dbl2u *>(args.w + r0);
+				w0 = v.x;
+				w1 = v.y;
+			}
+		} else { // ragged tail: guarded 8-byte loads
+			in0 = r0 < hi;
+			in1 = r0 + 1 < hi;
+#pragma unroll
+			for (int j = 0; j < P; ++j) {
+				z0[j] = in0 ? args.x[j][r0] : 0.0;
+				z1[j] = in1 ? args.x[j][r0 + 1] : 0.0;
+			}
+			z0[P] = in0 ? args.y[r0] : 0.0;
+			z1[P] = in1 ? args.y[r0 + 1] : 0.0;
+			if (WEIGHTED) {
+				w0 = in0 ? args.w[r0] : 0.0;
+				w1 = in1 ? args.w[r0 + 1] : 0.0;
+			}
+		}
+
+		// row filter: everything finite (and w > 0), ols.rs:59-66 / wls.rs:76-86
+		bool v0 = in0, v1 = in1;
+#pragma unroll
+		for (int a = 0; a < Z; ++a) {
+			v0 = v0 && isfinite(z0[a]);
+			v1 = v1 && isfinite(z1[a]);
+		}
+		if (WEIGHTED) {
+			v0 = v0 && (w0 > 0.0) && isfinite(w0);
+			v1 = v1 && (w1 > 0.0) && isfinite(w1);
+		}
+
+		const unsigned long long b0 = __ballot(v0);
+		const unsigned long long b1 = __ballot(v1);
+		const unsigned long long bany = b0 | b1;
+		if (bany == 0ull) continue; // no valid row in this tile (wave-uniform)
+
+		if (!have_first) {
+			const int fl = __ffsll((long long)bany) - 1; // lowest lane with a valid row = lowest row index
+#pragma unroll
+			for (int a = 0; a < Z; ++a) first[a] = readlane_f64(v0 ? z0[a] : z1[a], fl);
+			have_first = true;
+		}
+		cnt += __popcll(b0) + __popcll(b1);
+
+		// constant-column test against the first valid row: |x - x_first| >= 1e-10 anywhere -> not constant
+#pragma unroll
+		for (int j = 0; j < P; ++j) {
+			const unsigned long long nc = __ballot((v0 && !(fabs(z0[j] - first[j]) < 1e-10)) ||
+			                                       (v1 && !(fabs(z1[j] - first[j]) < 1e-10)));
+			mask |= (nc != 0ull) ? (1u << j) : 0u;
+		}
+
+		double d0[Z], d1[Z];
+#pragma unroll
+		for (int a = 0; a < Z; ++a) {
+			const double sh = CENTER ? first[a] : 0.0;
+			d0[a] = v0 ? z0[a] - sh : 0.0;
+			d1[a] = v1 ? z1[a] - sh : 0.0;
+		}
+		const double ww0 = v0 ? w0 : 0.0;
+		const double ww1 = v1 ? w1 : 0.0;
+		sw += ww0 + ww1;
+#pragma unroll
+		for (int a = 0; a < Z; ++a) {
+			const double wd0 = WEIGHTED ? ww0 * d0[a] : d0[a];
+			const double wd1 = WEIGHTED ? ww1 * d1[a] : d1[a];
+			s[a] += wd0 + wd1;
+#pragma unroll
+			for (int b = a; b < Z; ++b) {
+				const int k = a * Z - a * (a - 1) / 2 + (b - a);
+				q[k] = fma(wd0, d0[b], q[k]);
+				q[k] = fma(wd1, d1[b], q[k]);
+			}
+		}
+	}
+
+	// ---- cross-lane reduction: transposing butterfly, moment k lands on lane k ----
+	double v[64];
+#pragma unroll
+	for (int k = 0; k < 64; ++k) v[k] = 0.0;
+#pragma unroll
+	for (int a = 0; a < Z; ++a) v[L::OFF_S + a] = s[a];
+#pragma unroll
+	for (int k = 0; k < ZZ; ++k) v[L::OFF_Q + k] = q[k];
+	v[L::OFF_SW] = sw;
+
+#pragma unroll
+	for (int i = 0; i < 32; ++i) v[i] = fold32(v[i], v[i + 32]);
+#pragma unroll
+	for (int i = 0; i < 16; ++i) v[i] = fold16(v[i], v[i + 16]);
+#pragma unroll
+	for (int i = 0; i < 8; ++i) v[i] = fold_shfl<8>(v[i], v[i + 8], lane);
+#pragma unroll
+	for (int i = 0; i < 4; ++i) v[i] = fold_shfl<4>(v[i], v[i + 4], lane);
+#pragma unroll
+	for (int i = 0; i < 2; ++i) v[i] = fold_shfl<2>(v[i], v[i + 2], lane);
+	v[0] = fold_shfl<1>(v[0], v[1], lane);
+
+	double *rec = args.moments + g * (int64_t)L::REC;
+	if (lane < L::KRED) rec[lane] = v[0];
+
+	// wave-uniform extras: first[], cnt, mask
+	double e = 0.0;
+#pragma unroll
+	for (int a = 0; a < Z; ++a) e = (lane == a) ? first[a] : e;
+	e = (lane == Z) ? (double)cnt : e;
+	e = (lane == Z + 1) ? (double)mask : e;
+	if (lane < Z + 2) rec[L::KRED + lane] = e;
+}
+
+template <int P>
+static hipError_t launch_p(const BatchArgs &a, hipStream_t stream) {
+	const dim3 block(256);
+	const dim3 grid((unsigned)((a.n_groups + 3) / 4));
+	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
+	const bool center = a.fit_intercept != 0;
+	if (weighted) {
+		if (center) hipLaunchKernelGGL((accumulate_narrow_kernel<P, true, true>), grid, block, 0, stream, a);
+		else hipLaunchKernelGGL((accumulate_narrow_kernel<P, true, false>), grid, block, 0, stream, a);
+	} else {
+		if (center) hipLaunchKernelGGL((accumulate_narrow_kernel<P, false, true>), grid, block, 0, stream, a);
+		else hipLaunchKernelGGL((accumulate_narrow_kernel<P, false, false>), grid, block, 0, stream, a);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	switch (a.p) {
+	case 1: return launch_p<1>(a, stream);
+	case 2: return launch_p<2>(a, stream);
+	case 3: return launch_p<3>(a, stream);
+	case 4: return launch_p<4>(a, stream);
+	case 5: return launch_p<5>(a, stream);
+	case 6: return launch_p<6>(a, stream);
+	case 7: return launch_p<7>(a, stream);
+	case 8: return launch_p<8>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+} // namespace anofox

@@ -1,0 +1,624 @@
+// host_api.hip — host side of libanofox_stats_hip.so: contexts, workspace, the batched entry points and
+// the reference-compatible single-group symbols (include/anofox_stats_hip.h).
+//
+// The single-group symbols keep the conventions of the reference's Rust FFI shims
+// (crates/anofox-stats-ffi/src/lib.rs:98-311, 984-1155, 1384-1555): error struct reset first, NULL
+// out_core / x / x_count == 0 -> InvalidInput, NULL entries replaced by NaN through the validity bitmask
+// (types.rs:66-89), outputs malloc'ed and released only by anofox_free_result_*, nothing handed out on
+// failure.  They run the same GPU kernels as the batch path with a batch of one group.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace anofox;
+
+struct AnofoxHipContext {
+	int device = 0;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	std::mutex mu;
+	// device workspace (moments, refine queue, direct RSS)
+	void *ws = nullptr;
+	size_t ws_bytes = 0;
+	// device staging for the host-pointer entry points
+	void *stage = nullptr;
+	size_t stage_bytes = 0;
+	// timing
+	bool timing = false;
+	std::vector<hipEvent_t> free_events;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_events, solve_events;
+};
+
+namespace {
+
+void set_error(AnofoxError *e, AnofoxErrorCode code, const std::string &msg) {
+	if (!e) return;
+	e->code = code;
+	const size_t n = msg.size() < 255 ? msg.size() : 255;
+	memcpy(e->message, msg.data(), n);
+	e->message[n] = 0;
+}
+
+void reset_error(AnofoxError *e) {
+	if (!e) return;
+	e->code = ANOFOX_ERROR_SUCCESS;
+	memset(e->message, 0, sizeof e->message);
+}
+
+bool hip_fail(hipError_t rc, const char *what, AnofoxError *e) {
+	if (rc == hipSuccess) return false;
+	set_error(e, ANOFOX_ERROR_INTERNAL, std::string("HIP error in ") + what + ": " + hipGetErrorString(rc));
+	return true;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+bool ensure_buffer(void **buf, size_t *cap, size_t need, const char *what, AnofoxError *e) {
+	if (need <= *cap) return true;
+	if (*buf) {
+		if (hip_fail(hipFree(*buf), "hipFree", e)) return false; // hipFree synchronises the device
+		*buf = nullptr;
+		*cap = 0;
+	}
+	const size_t want = align_up(need + need / 8, 1 << 20);
+	if (hipMalloc(buf, want) != hipSuccess) {
+		(void)hipGetLastError();
+		*buf = nullptr;
+		set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE, std::string("hipMalloc failed for ") + what);
+		return false;
+	}
+	*cap = want;
+	return true;
+}
+
+hipEvent_t get_event(AnofoxHipContext *ctx) {
+	if (!ctx->free_events.empty()) {
+		hipEvent_t ev = ctx->free_events.back();
+		ctx->free_events.pop_back();
+		return ev;
+	}
+	hipEvent_t ev = nullptr;
+	(void)hipEventCreate(&ev);
+	return ev;
+}
+
+struct Workspace {
+	double *moments;
+	double *rss_direct;
+	int32_t *refine_list;
+	int32_t *refine_count;
+};
+
+bool carve_workspace(AnofoxHipContext *ctx, int64_t G, int p, Workspace *out, AnofoxError *e) {
+	const size_t rec = (size_t)moment_record_len(p);
+	const size_t b_mom = align_up((size_t)G * rec * sizeof(double), 256);
+	const size_t b_rss = align_up((size_t)G * sizeof(double), 256);
+	const size_t b_lst = align_up((size_t)G * sizeof(int32_t), 256);
+	const size_t total = b_mom + b_rss + b_lst + 256;
+	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, total, "workspace", e)) return false;
+	char *base = (char *)ctx->ws;
+	out->moments = (double *)base;
+	out->rss_direct = (double *)(base + b_mom);
+	out->refine_list = (int32_t *)(base + b_mom + b_rss);
+	out->refine_count = (int32_t *)(base + b_mom + b_rss + b_lst);
+	return true;
+}
+
+// Core of the device path: accumulate -> solve -> (queued groups only) residual RSS -> solve again.
+// Everything is enqueued on the context's stream; no host synchronisation.
+bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const int64_t *d_off,
+                      const double *d_y, const double *const *x_cols, const double *d_w,
+                      const AnofoxHipBatchOptions &opt, double *d_core, double *d_inf, AnofoxError *e) {
+	if (G == 0) return true;
+	Workspace ws;
+	if (!carve_workspace(ctx, G, (int)p, &ws, e)) return false;
+
+	BatchArgs a;
+	memset(&a, 0, sizeof a);
+	a.row_offsets = d_off;
+	a.y = d_y;
+	for (size_t j = 0; j < p; ++j) a.x[j] = x_cols[j];
+	a.w = d_w;
+	a.n_groups = G;
+	a.n_rows = n_rows;
+	a.p = (int)p;
+	a.model = (int)opt.model;
+	a.fit_intercept = opt.fit_intercept ? 1 : 0;
+	a.compute_inference = opt.compute_inference ? 1 : 0;
+	a.lambda_scaling = (int)opt.lambda_scaling;
+	a.confidence_level = opt.confidence_level;
+	a.alpha = opt.alpha;
+	a.moments = ws.moments;
+	a.core = d_core;
+	a.inference = opt.compute_inference ? d_inf : nullptr;
+	a.refine_list = ws.refine_list;
+	a.refine_count = ws.refine_count;
+	a.rss_direct = ws.rss_direct;
+
+	hipStream_t st = ctx->stream;
+	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, sizeof(int32_t), st), "hipMemsetAsync", e)) return false;
+
+	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+	if (ctx->timing) {
+		e0 = get_event(ctx);
+		e1 = get_event(ctx);
+		e2 = get_event(ctx);
+		(void)hipEventRecord(e0, st);
+	}
+	if (hip_fail(launch_accumulate_narrow(a, st), "accumulate kernel launch", e)) return false;
+	if (ctx->timing) (void)hipEventRecord(e1, st);
+	if (hip_fail(launch_solve_narrow(a, false, st), "solve kernel launch", e)) return false;
+	if (hip_fail(launch_residual_rss(a, st), "residual kernel launch", e)) return false;
+	if (hip_fail(launch_solve_narrow(a, true, st), "refine kernel launch", e)) return false;
+	if (ctx->timing) {
+		(void)hipEventRecord(e2, st);
+		ctx->acc_events.emplace_back(e0, e1);   // owns e0 and e1
+		ctx->solve_events.emplace_back(e1, e2); // shares e1, owns e2
+	}
+	return true;
+}
+
+bool validate_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const void *off, const void *y,
+                    const double *const *x_cols, const void *w, const AnofoxHipBatchOptions &opt, const void *core,
+                    const void *inf, AnofoxError *e) {
+	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (G < 0 || n_rows < 0) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "negative n_groups or n_rows"); return false; }
+	if (p == 0 || !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x is NULL or empty"); return false; }
+	if (p > (size_t)kNarrowMaxP) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT,
+		          "n_features = " + std::to_string(p) + " exceeds the supported maximum of " + std::to_string(kNarrowMaxP));
+		return false;
+	}
+	if (G > 0 && (!off || !y || !core)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "row_offsets, y or core is NULL"); return false; }
+	for (size_t j = 0; j < p; ++j)
+		if (G > 0 && !x_cols[j]) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x column pointer is NULL"); return false; }
+	if (opt.model != ANOFOX_HIP_MODEL_OLS && opt.model != ANOFOX_HIP_MODEL_RIDGE && opt.model != ANOFOX_HIP_MODEL_WLS) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "unknown model");
+		return false;
+	}
+	if (opt.model == ANOFOX_HIP_MODEL_WLS && G > 0 && !w) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "weights is NULL"); return false; }
+	if (opt.compute_inference && G > 0 && !inf) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "inference buffer is NULL"); return false; }
+	if (opt.hc_type != ANOFOX_HC_NONE) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "hc_type other than 'none' is not implemented on the GPU path");
+		return false;
+	}
+	return true;
+}
+
+thread_local std::unique_ptr<AnofoxHipContext, void (*)(AnofoxHipContext *)> tls_ctx(nullptr, anofox_hip_context_destroy);
+
+AnofoxHipContext *default_context(AnofoxError *e) {
+	if (!tls_ctx) {
+		AnofoxHipContext *c = nullptr;
+		if (!anofox_hip_context_create(-1, &c, e)) return nullptr;
+		tls_ctx.reset(c);
+	}
+	return tls_ctx.get();
+}
+
+} // namespace
+
+extern "C" {
+
+const char *anofox_hip_version(void) { return "anofox_stats_hip 0.1 gfx950"; }
+
+size_t anofox_hip_core_record_len(size_t p) { return p + 6; }
+size_t anofox_hip_inference_record_len(size_t p) { return 5 * p + 2; }
+size_t anofox_hip_max_features(void) { return (size_t)kNarrowMaxP; }
+
+bool anofox_hip_context_create(int device_id, AnofoxHipContext **out_ctx, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!out_ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "out_ctx is NULL"); return false; }
+	*out_ctx = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+		(void)hipGetLastError();
+		set_error(out_error, ANOFOX_ERROR_INTERNAL, "no HIP device available (this library has no CPU fallback)");
+		return false;
+	}
+	int dev = device_id;
+	if (dev < 0) {
+		if (hip_fail(hipGetDevice(&dev), "hipGetDevice", out_error)) return false;
+	}
+	if (dev >= count) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "device_id out of range"); return false; }
+	if (hip_fail(hipSetDevice(dev), "hipSetDevice", out_error)) return false;
+	auto *ctx = new (std::nothrow) AnofoxHipContext();
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_ALLOCATION_FAILURE, "context allocation failed"); return false; }
+	ctx->device = dev;
+	if (hip_fail(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking), "hipStreamCreate", out_error)) {
+		delete ctx;
+		return false;
+	}
+	ctx->stream = ctx->own_stream;
+	*out_ctx = ctx;
+	return true;
+}
+
+void anofox_hip_context_destroy(AnofoxHipContext *ctx) {
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipStreamSynchronize(ctx->stream);
+	for (auto &pr : ctx->acc_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+	for (auto &pr : ctx->solve_events) { (void)hipEventDestroy(pr.second); }
+	for (auto ev : ctx->free_events) (void)hipEventDestroy(ev);
+	if (ctx->ws) (void)hipFree(ctx->ws);
+	if (ctx->stage) (void)hipFree(ctx->stage);
+	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+	delete ctx;
+}
+
+bool anofox_hip_context_set_stream(AnofoxHipContext *ctx, void *hip_stream, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+	return true;
+}
+
+bool anofox_hip_context_synchronize(AnofoxHipContext *ctx, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	return !hip_fail(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize", out_error);
+}
+
+bool anofox_hip_context_enable_timing(AnofoxHipContext *ctx, bool enable, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	ctx->timing = enable;
+	return true;
+}
+
+bool anofox_hip_context_collect_timing(AnofoxHipContext *ctx, AnofoxHipKernelTimes *out, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx || !out) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context or out is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	if (hip_fail(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize", out_error)) return false;
+	memset(out, 0, sizeof *out);
+	for (auto &pr : ctx->acc_events) {
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { out->accumulate_ms += ms; out->accumulate_count++; }
+	}
+	for (auto &pr : ctx->solve_events) {
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { out->solve_ms += ms; out->solve_count++; }
+	}
+	for (auto &pr : ctx->acc_events) { ctx->free_events.push_back(pr.first); ctx->free_events.push_back(pr.second); }
+	for (auto &pr : ctx->solve_events) { ctx->free_events.push_back(pr.second); }
+	ctx->acc_events.clear();
+	ctx->solve_events.clear();
+	return true;
+}
+
+bool anofox_hip_fit_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                 const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
+                                 const double *d_w, AnofoxHipBatchOptions options, double *d_core, double *d_inference,
+                                 AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!validate_batch(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, options, d_core,
+	                    d_inference, out_error))
+		return false;
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	return run_device_batch(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, options, d_core,
+	                        d_inference, out_error);
+}
+
+bool anofox_hip_fit_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                               const int64_t *row_offsets, const double *y, const double *const *x_cols,
+                               const double *w, AnofoxHipBatchOptions options, double *core, double *inference,
+                               AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) {
+		ctx = default_context(out_error);
+		if (!ctx) return false;
+	}
+	if (!validate_batch(ctx, n_groups, n_features, n_rows, row_offsets, y, x_cols, w, options, core, inference,
+	                    out_error))
+		return false;
+	if (n_groups == 0) return true;
+	for (int64_t g = 0; g < n_groups; ++g) {
+		if (row_offsets[g + 1] < row_offsets[g] || row_offsets[g] < 0 || row_offsets[g + 1] > n_rows) {
+			set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must be non-decreasing and within [0, n_rows]");
+			return false;
+		}
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+
+	const size_t p = n_features;
+	const bool weighted = options.model == ANOFOX_HIP_MODEL_WLS;
+	const size_t ncol = p + 1 + (weighted ? 1 : 0);
+	const size_t core_len = p + 6, inf_len = 5 * p + 2;
+	// stream the groups through the GPU in slabs of at most ~32M rows
+	const int64_t slab_rows = 32ll << 20;
+	std::vector<int64_t> off;
+	int64_t g0 = 0;
+	while (g0 < n_groups) {
+		int64_t g1 = g0 + 1;
+		while (g1 < n_groups && row_offsets[g1 + 1] - row_offsets[g0] <= slab_rows) ++g1;
+		const int64_t G = g1 - g0;
+		const int64_t r0 = row_offsets[g0], r1 = row_offsets[g1];
+		const int64_t R = r1 - r0;
+		off.resize((size_t)G + 1);
+		for (int64_t g = 0; g <= G; ++g) off[(size_t)g] = row_offsets[g0 + g] - r0;
+
+		const size_t b_off = align_up(((size_t)G + 1) * sizeof(int64_t), 256);
+		const size_t b_col = align_up(((size_t)R + 2) * sizeof(double), 256);
+		const size_t b_core = align_up((size_t)G * core_len * sizeof(double), 256);
+		const size_t b_inf = options.compute_inference ? align_up((size_t)G * inf_len * sizeof(double), 256) : 0;
+		const size_t total = b_off + ncol * b_col + b_core + b_inf;
+		if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, total, "staging", out_error)) return false;
+		char *base = (char *)ctx->stage;
+		int64_t *d_off = (int64_t *)base;
+		char *cur = base + b_off;
+		hipStream_t st = ctx->stream;
+		if (hip_fail(hipMemcpyAsync(d_off, off.data(), ((size_t)G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D offsets", out_error)) return false;
+		const double *d_x[kNarrowMaxP];
+		for (size_t j = 0; j < p; ++j) {
+			if (R > 0 && hip_fail(hipMemcpyAsync(cur, x_cols[j] + r0, (size_t)R * sizeof(double), hipMemcpyHostToDevice, st), "H2D x", out_error)) return false;
+			d_x[j] = (const double *)cur;
+			cur += b_col;
+		}
+		if (R > 0 && hip_fail(hipMemcpyAsync(cur, y + r0, (size_t)R * sizeof(double), hipMemcpyHostToDevice, st), "H2D y", out_error)) return false;
+		const double *d_y = (const double *)cur;
+		cur += b_col;
+		const double *d_w = nullptr;
+		if (weighted) {
+			if (R > 0 && hip_fail(hipMemcpyAsync(cur, w + r0, (size_t)R * sizeof(double), hipMemcpyHostToDevice, st), "H2D w", out_error)) return false;
+			d_w = (const double *)cur;
+			cur += b_col;
+		}
+		double *d_core = (double *)cur;
+		cur += b_core;
+		double *d_inf = options.compute_inference ? (double *)cur : nullptr;
+		if (!run_device_batch(ctx, G, p, R, d_off, d_y, d_x, d_w, options, d_core, d_inf, out_error)) return false;
+		if (hip_fail(hipMemcpyAsync(core + (size_t)g0 * core_len, d_core, (size_t)G * core_len * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;
+		if (d_inf && hip_fail(hipMemcpyAsync(inference + (size_t)g0 * inf_len, d_inf, (size_t)G * inf_len * sizeof(double), hipMemcpyDeviceToHost, st), "D2H inference", out_error)) return false;
+		if (hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error)) return false;
+		g0 = g1;
+	}
+	return true;
+}
+
+} // extern "C"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Reference-compatible single-group symbols                                                          */
+/* ------------------------------------------------------------------------------------------------ */
+
+namespace {
+
+// DataArray::to_vec (types.rs:79-89): NULL -> NaN
+void expand(const AnofoxDataArray &a, std::vector<double> &out) {
+	out.resize(a.len);
+	for (size_t i = 0; i < a.len; ++i) {
+		const bool valid = !a.validity || ((a.validity[i / 8] >> (i % 8)) & 1);
+		out[i] = valid ? a.data[i] : NAN;
+	}
+}
+
+std::string fmt_g(double v) {
+	char buf[64];
+	snprintf(buf, sizeof buf, "%g", v);
+	return buf;
+}
+
+void default_inference(AnofoxFitResultInference *inf) { // FitResultInference::default(), types.rs:151-165
+	memset(inf, 0, sizeof *inf);
+	inf->confidence_level = 0.95;
+	inf->f_statistic = NAN;
+	inf->f_pvalue = NAN;
+}
+
+bool fit_single(const char *what, AnofoxDataArray y, const AnofoxDataArray *x, size_t x_count, const AnofoxDataArray *weights,
+                AnofoxHipBatchOptions opt, AnofoxFitResultCore *out_core, AnofoxFitResultInference *out_inference,
+                AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!out_core) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "out_core is NULL"); return false; }          // lib.rs:113-118
+	if (!x || x_count == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "x is NULL or empty"); return false; } // lib.rs:120-125
+	// core-crate validation order: ridge alpha first (ridge.rs:38-40), then emptiness and lengths (ols.rs:38-56, wls.rs:44-73)
+	if (opt.model == ANOFOX_HIP_MODEL_RIDGE && opt.alpha < 0.0) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_ALPHA, "Invalid alpha parameter: " + fmt_g(opt.alpha) + " (must be >= 0)");
+		return false;
+	}
+	if (y.len == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Empty input: y cannot be empty"); return false; }
+	if (weights) {
+		if (weights->len == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Empty input: weights cannot be empty"); return false; }
+		if (weights->len != y.len) {
+			set_error(out_error, ANOFOX_ERROR_DIMENSION_MISMATCH, "Dimension mismatch: y has " + std::to_string(y.len) + " elements, X has " + std::to_string(weights->len) + " rows");
+			return false;
+		}
+	}
+	for (size_t j = 0; j < x_count; ++j) {
+		if (x[j].len != y.len) {
+			set_error(out_error, ANOFOX_ERROR_DIMENSION_MISMATCH, "Dimension mismatch: y has " + std::to_string(y.len) + " elements, X has " + std::to_string(x[j].len) + " rows");
+			return false;
+		}
+	}
+	const size_t p = x_count, n = y.len;
+	if (p > (size_t)kNarrowMaxP) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, std::string(what) + ": more than " + std::to_string(kNarrowMaxP) + " features are not supported by the GPU path yet");
+		return false;
+	}
+	// The kernels apply the aggregate's "< 2 rows -> NULL" rule from row_offsets; a single-group call has no
+	// such rule (ols.rs accepts n == 1), so a one-row input is padded with one all-NaN row, which the row
+	// filter drops again.
+	const size_t n_pad = n < 2 ? 2 : n;
+	std::vector<std::vector<double>> cols(p);
+	std::vector<double> yv, wv;
+	expand(y, yv);
+	yv.resize(n_pad, NAN);
+	for (size_t j = 0; j < p; ++j) { expand(x[j], cols[j]); cols[j].resize(n_pad, NAN); }
+	if (weights) { expand(*weights, wv); wv.resize(n_pad, NAN); }
+
+	std::vector<const double *> xp(p);
+	for (size_t j = 0; j < p; ++j) xp[j] = cols[j].data();
+	const int64_t off[2] = {0, (int64_t)n_pad};
+	std::vector<double> core(p + 6), inf(5 * p + 2);
+	if (!anofox_hip_fit_batch_host(nullptr, 1, p, (int64_t)n_pad, off, yv.data(), xp.data(), weights ? wv.data() : nullptr, opt,
+	                               core.data(), inf.data(), out_error))
+		return false;
+	const int status = (int)core[p + 5];
+	if (status != ANOFOX_ERROR_SUCCESS) {
+		size_t n_valid = 0;
+		for (size_t i = 0; i < n; ++i) {
+			bool ok = isfinite(yv[i]);
+			for (size_t j = 0; ok && j < p; ++j) ok = isfinite(cols[j][i]);
+			if (ok && weights) ok = wv[i] > 0.0 && isfinite(wv[i]);
+			n_valid += ok;
+		}
+		std::string msg;
+		switch (status) { // error strings: crates/anofox-stats-core/src/errors.rs:5-59
+		case ANOFOX_ERROR_NO_VALID_DATA: msg = "All rows filtered due to NULL/NaN values"; break;
+		case ANOFOX_ERROR_INSUFFICIENT_DATA:
+			msg = "Insufficient data: " + std::to_string(n_valid) + " rows, " + std::to_string(p) + " features (need rows > features)";
+			break;
+		case ANOFOX_ERROR_INVALID_ALPHA: msg = "Invalid alpha parameter: " + fmt_g(opt.alpha) + " (must be >= 0)"; break;
+		default: msg = std::string(what) + " failed on the GPU path"; break;
+		}
+		set_error(out_error, (AnofoxErrorCode)status, msg);
+		return false;
+	}
+	double *coef = (double *)malloc(p * sizeof(double));
+	if (!coef) { set_error(out_error, ANOFOX_ERROR_ALLOCATION_FAILURE, "Failed to allocate coefficients"); return false; }
+	memcpy(coef, core.data(), p * sizeof(double));
+	double *arr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+	// the reference returns inference: None for the intercept-only shortcut even when requested (ols.rs:128);
+	// that shortcut is the only successful fit whose coefficients are all NaN
+	bool any_coef = false;
+	for (size_t j = 0; j < p; ++j) any_coef = any_coef || !isnan(core[j]);
+	const bool got_inf = out_inference != nullptr && opt.compute_inference && any_coef;
+	if (got_inf) {
+		for (int k = 0; k < 5; ++k) {
+			arr[k] = (double *)malloc(p * sizeof(double));
+			if (!arr[k]) {
+				for (int m = 0; m < k; ++m) free(arr[m]);
+				free(coef);
+				set_error(out_error, ANOFOX_ERROR_ALLOCATION_FAILURE, "Failed to allocate inference arrays");
+				return false;
+			}
+			memcpy(arr[k], inf.data() + (size_t)k * p, p * sizeof(double));
+		}
+	}
+	out_core->coefficients = coef;
+	out_core->coefficients_len = p;
+	out_core->intercept = core[p];
+	out_core->r_squared = core[p + 1];
+	out_core->adj_r_squared = core[p + 2];
+	out_core->residual_std_error = core[p + 3];
+	out_core->n_observations = (size_t)core[p + 4];
+	out_core->n_features = p;
+	if (out_inference) {
+		if (got_inf) {
+			out_inference->std_errors = arr[0];
+			out_inference->t_values = arr[1];
+			out_inference->p_values = arr[2];
+			out_inference->ci_lower = arr[3];
+			out_inference->ci_upper = arr[4];
+			out_inference->len = p;
+			out_inference->confidence_level = opt.confidence_level;
+			out_inference->f_statistic = inf[5 * p];
+			out_inference->f_pvalue = inf[5 * p + 1];
+		} else {
+			default_inference(out_inference);
+		}
+	}
+	return true;
+}
+
+} // namespace
+
+extern "C" {
+
+bool anofox_ols_fit(AnofoxDataArray y, const AnofoxDataArray *x, size_t x_count, AnofoxOlsOptions options,
+                    AnofoxFitResultCore *out_core, AnofoxFitResultInference *out_inference, AnofoxError *out_error) {
+	AnofoxHipBatchOptions o;
+	memset(&o, 0, sizeof o);
+	o.model = ANOFOX_HIP_MODEL_OLS;
+	o.fit_intercept = options.fit_intercept;
+	o.compute_inference = options.compute_inference;
+	o.confidence_level = options.confidence_level;
+	o.solver = options.solver;
+	o.hc_type = options.hc_type;
+	return fit_single("OLS fit", y, x, x_count, nullptr, o, out_core, out_inference, out_error);
+}
+
+bool anofox_ridge_fit(AnofoxDataArray y, const AnofoxDataArray *x, size_t x_count, AnofoxRidgeOptions options,
+                      AnofoxFitResultCore *out_core, AnofoxFitResultInference *out_inference, AnofoxError *out_error) {
+	AnofoxHipBatchOptions o;
+	memset(&o, 0, sizeof o);
+	o.model = ANOFOX_HIP_MODEL_RIDGE;
+	o.alpha = options.alpha;
+	o.fit_intercept = options.fit_intercept;
+	o.compute_inference = options.compute_inference;
+	o.confidence_level = options.confidence_level;
+	o.solver = options.solver;
+	o.lambda_scaling = options.lambda_scaling;
+	o.hc_type = ANOFOX_HC_NONE;
+	return fit_single("Ridge fit", y, x, x_count, nullptr, o, out_core, out_inference, out_error);
+}
+
+bool anofox_wls_fit(AnofoxDataArray y, const AnofoxDataArray *x, size_t x_count, AnofoxDataArray weights,
+                    AnofoxWlsOptions options, AnofoxFitResultCore *out_core, AnofoxFitResultInference *out_inference,
+                    AnofoxError *out_error) {
+	AnofoxHipBatchOptions o;
+	memset(&o, 0, sizeof o);
+	o.model = ANOFOX_HIP_MODEL_WLS;
+	o.fit_intercept = options.fit_intercept;
+	o.compute_inference = options.compute_inference;
+	o.confidence_level = options.confidence_level;
+	o.solver = options.solver;
+	o.hc_type = options.hc_type;
+	return fit_single("WLS fit", y, x, x_count, &weights, o, out_core, out_inference, out_error);
+}
+
+void anofox_free_result_core(AnofoxFitResultCore *result) {
+	if (!result) return;
+	if (result->coefficients) {
+		free(result->coefficients);
+		result->coefficients = nullptr;
+	}
+}
+
+void anofox_free_result_inference(AnofoxFitResultInference *result) {
+	if (!result) return;
+	double **arr[5] = {&result->std_errors, &result->t_values, &result->p_values, &result->ci_lower, &result->ci_upper};
+	for (auto pp : arr) {
+		if (*pp) {
+			free(*pp);
+			*pp = nullptr;
+		}
+	}
+}
+
+bool anofox_compute_aic(double rss, size_t n, size_t k, double *out_aic, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!out_aic) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "out_aic is NULL"); return false; }
+	if (n == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Invalid input: n must be > 0"); return false; }
+	if (rss < 0.0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Invalid input: RSS must be non-negative"); return false; }
+	*out_aic = rss == 0.0 ? -INFINITY : (double)n * log(rss / (double)n) + 2.0 * (double)k;
+	return true;
+}
+
+bool anofox_compute_bic(double rss, size_t n, size_t k, double *out_bic, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!out_bic) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "out_bic is NULL"); return false; }
+	if (n == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Invalid input: n must be > 0"); return false; }
+	if (rss < 0.0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Invalid input: RSS must be non-negative"); return false; }
+	*out_bic = rss == 0.0 ? -INFINITY : (double)n * log(rss / (double)n) + (double)k * log((double)n);
+	return true;
+}
+
+} // extern "C"

@@ -1,0 +1,344 @@
+// solve_narrow.hip — per-group solve and diagnostics (p <= 8), one lane per group.
+//
+// Consumes the moment records of accumulate_narrow.hip and produces the reference's result STRUCT fields
+// (src/aggregate_functions/ols_aggregate.cpp:74-96) as dense records.  Restates, per group:
+//   - the model's pre-checks and shortcuts: crates/anofox-stats-core/src/models/ols.rs:68-139,
+//     ridge.rs:38-40,104-146, wls.rs:119-157
+//   - the regressor (anofox-regression OlsRegressor / RidgeRegressor / WlsRegressor, call sites
+//     ols.rs:155-161, ridge.rs:156-164, wls.rs:174-182): here a Cholesky factorisation of the centred
+//     (shifted) moment matrix with aliased-pivot detection, two triangular solves, and the closed forms for
+//     R^2, adjusted R^2, sigma, SE, t, p, CI and F
+//   - NaN re-expansion at dropped columns: ols.rs:167-171,191-206
+// Groups whose residual sum of squares is too small relative to the total to be trusted from the moment
+// identity (RSS = Syy - b'Sxy) are queued for residual_rss_kernel, which re-reads the group's rows and sums
+// squared residuals directly; the solve then runs a second time for those groups only.
+#include "common.h"
+#include "device_math.h"
+
+namespace anofox {
+
+namespace {
+
+constexpr double kAliasTol = 1e-11;  // pivot / original diagonal below this => column aliased (collinear)
+constexpr double kRefineTol = 1e-7;  // RSS / TSS below this => recompute RSS from residuals
+
+__device__ __forceinline__ double nan64() { return __builtin_nan(""); }
+
+template <int P>
+__device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, double rss_in) {
+	using L = MomentLayout<P>;
+	constexpr int Z = L::Z;
+	const int p = P;
+	const bool icpt = args.fit_intercept != 0;
+	const int model = args.model;
+
+	double *core = args.core + g * (int64_t)(p + 6);
+	double *inf = (args.inference && args.compute_inference) ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
+
+	// default: NULL record
+	int status = ANOFOX_ERROR_SUCCESS;
+	double coef[P];
+	double se[P], tv[P], pv[P], cl[P], cu[P];
+#pragma unroll
+	for (int j = 0; j < P; ++j) coef[j] = se[j] = tv[j] = pv[j] = cl[j] = cu[j] = nan64();
+	double intercept = nan64(), r2 = nan64(), adj = nan64(), rse = nan64(), fstat = nan64(), fp = nan64();
+	double nobs = nan64();
+	bool has_inf = false;
+	bool refine = false;
+
+	const double *rec = args.moments + g * (int64_t)L::REC;
+	const int64_t nrows = args.row_offsets[g + 1] - args.row_offsets[g];
+
+	do {
+		if (nrows < 2) { status = ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS; break; }           // ols_aggregate.cpp:263-267
+		if (model == ANOFOX_HIP_MODEL_RIDGE && args.alpha < 0.0) { status = ANOFOX_ERROR_INVALID_ALPHA; break; } // ridge.rs:38-40
+		const double cnt = rec[L::OFF_CNT];
+		if (!(cnt > 0.0)) { status = ANOFOX_ERROR_NO_VALID_DATA; break; }                 // ols.rs:68-70
+		const double sw = rec[L::OFF_SW];
+		const unsigned mask = (unsigned)rec[L::OFF_MASK];
+		const int p_eff = __popc(mask);
+
+		double s[Z], first[Z];
+#pragma unroll
+		for (int a = 0; a < Z; ++a) { s[a] = rec[L::OFF_S + a]; first[a] = rec[L::OFF_FIRST + a]; }
+		const double qyy = rec[L::q_index(P, P)];
+		// centred second moment of y about its (weighted) mean; the accumulate kernel shifts only when an
+		// intercept is fitted, the identity holds either way
+		const double cyy_centred = qyy - s[P] * s[P] / sw;
+		const double ymean = (icpt ? first[P] : 0.0) + s[P] / sw;
+
+		if (p_eff == 0) { // ols.rs:101-130, wls.rs:119-150
+			if (!icpt) { status = ANOFOX_ERROR_INSUFFICIENT_DATA; break; }
+			intercept = ymean;
+			r2 = 0.0;
+			adj = 0.0;
+			rse = (model == ANOFOX_HIP_MODEL_WLS) ? sqrt(cyy_centred / sw) : sqrt(cyy_centred / (cnt - 1.0));
+			nobs = cnt;
+			break; // inference: None
+		}
+		if (cnt < (double)(p_eff + (icpt ? 1 : 0))) { status = ANOFOX_ERROR_INSUFFICIENT_DATA; break; } // ols.rs:132-139
+
+		// moment matrix of the kept columns: centred when an intercept is fitted, raw otherwise
+		double A[P][P]; // lower triangle used
+		double c[P];
+		bool active[P];
+#pragma unroll
+		for (int i = 0; i < P; ++i) {
+			active[i] = (mask >> i) & 1u;
+#pragma unroll
+			for (int j = 0; j <= i; ++j) {
+				const double qij = rec[L::q_index(j, i)];
+				A[i][j] = icpt ? qij - s[i] * s[j] / sw : qij;
+			}
+			const double qiy = rec[L::q_index(i, P)];
+			c[i] = icpt ? qiy - s[i] * s[P] / sw : qiy;
+		}
+		const double tss = icpt ? cyy_centred : qyy;
+
+		double lam = 0.0;
+		if (model == ANOFOX_HIP_MODEL_RIDGE) {
+			lam = args.alpha;
+			if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) lam = cnt * args.alpha / sqrt(cyy_centred / cnt);
+#pragma unroll
+			for (int i = 0; i < P; ++i) A[i][i] += lam;
+		}
+
+		// Cholesky (left-looking, in place), deactivating constant and aliased columns
+		double diag0[P];
+#pragma unroll
+		for (int j = 0; j < P; ++j) diag0[j] = A[j][j];
+#pragma unroll
+		for (int j = 0; j < P; ++j) {
+			double d = A[j][j];
+#pragma unroll
+			for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+			const bool ok = active[j] && (d > kAliasTol * diag0[j]) && (d > 0.0);
+			active[j] = ok;
+			const double ljj = ok ? sqrt(d) : 1.0;
+			A[j][j] = ljj;
+			const double inv = 1.0 / ljj;
+#pragma unroll
+			for (int i = j + 1; i < P; ++i) {
+				double t = A[i][j];
+#pragma unroll
+				for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
+				A[i][j] = ok ? t * inv : 0.0;
+			}
+			if (!ok) {
+#pragma unroll
+				for (int k = 0; k < j; ++k) A[j][k] = 0.0;
+			}
+		}
+		int rank = 0;
+#pragma unroll
+		for (int j = 0; j < P; ++j) rank += active[j] ? 1 : 0;
+
+		// forward solve L zf = c, back solve L' beta = zf
+		double zf[P], beta[P];
+		double zz = 0.0;
+#pragma unroll
+		for (int i = 0; i < P; ++i) {
+			double t = c[i];
+#pragma unroll
+			for (int k = 0; k < i; ++k) t -= A[i][k] * zf[k];
+			zf[i] = active[i] ? t / A[i][i] : 0.0;
+			zz += zf[i] * zf[i];
+		}
+#pragma unroll
+		for (int i = P - 1; i >= 0; --i) {
+			double t = zf[i];
+#pragma unroll
+			for (int k = i + 1; k < P; ++k) t -= A[k][i] * beta[k];
+			beta[i] = active[i] ? t / A[i][i] : 0.0;
+		}
+
+		double rss;
+		if (have_rss) {
+			rss = rss_in;
+		} else if (model == ANOFOX_HIP_MODEL_RIDGE) {
+			double bc = 0.0, bb = 0.0;
+#pragma unroll
+			for (int i = 0; i < P; ++i) { bc += beta[i] * c[i]; bb += beta[i] * beta[i]; }
+			rss = tss - bc - lam * bb;
+		} else {
+			rss = tss - zz;
+		}
+		if (!have_rss && !(rss > kRefineTol * tss)) refine = true;
+
+		const int n_par = rank + (icpt ? 1 : 0);
+		const double df = cnt - (double)n_par;
+		const double dfm = (double)rank;
+
+		double b0 = 0.0;
+		if (icpt) {
+			b0 = ymean;
+#pragma unroll
+			for (int i = 0; i < P; ++i) b0 -= beta[i] * (first[i] + s[i] / sw);
+			intercept = b0;
+		}
+#pragma unroll
+		for (int i = 0; i < P; ++i) coef[i] = active[i] ? beta[i] : nan64();
+		r2 = 1.0 - rss / tss;
+		adj = 1.0 - (1.0 - r2) * (cnt - (icpt ? 1.0 : 0.0)) / df;
+		rse = sqrt(rss / df);
+		nobs = cnt;
+		fstat = ((tss - rss) / dfm) / (rss / df);
+
+		if (inf) {
+			has_inf = true;
+			fp = dm_f_sf(fstat, dfm, df);
+			const double sigma2 = rss / df;
+			const double tcrit = dm_t_quantile_upper(0.5 * (1.0 + args.confidence_level), df);
+			// diag of (L L')^-1 through the columns of L^-1
+#pragma unroll
+			for (int j = 0; j < P; ++j) {
+				double wcol[P];
+				double dj = 0.0;
+#pragma unroll
+				for (int i = j; i < P; ++i) {
+					double t = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+					for (int k = j; k < i; ++k) t -= A[i][k] * wcol[k];
+					wcol[i] = active[i] ? t / A[i][i] : 0.0;
+					dj += wcol[i] * wcol[i];
+				}
+				if (active[j]) {
+					se[j] = sqrt(sigma2 * dj);
+					tv[j] = beta[j] / se[j];
+					pv[j] = dm_t_two_sided_p(tv[j], df);
+					cl[j] = beta[j] - tcrit * se[j];
+					cu[j] = beta[j] + tcrit * se[j];
+				}
+			}
+		}
+	} while (false);
+
+	if (status != ANOFOX_ERROR_SUCCESS) {
+#pragma unroll
+		for (int j = 0; j < P; ++j) coef[j] = nan64();
+		intercept = r2 = adj = rse = nobs = nan64();
+	}
+#pragma unroll
+	for (int j = 0; j < P; ++j) core[j] = coef[j];
+	core[p] = intercept;
+	core[p + 1] = r2;
+	core[p + 2] = adj;
+	core[p + 3] = rse;
+	core[p + 4] = nobs;
+	core[p + 5] = (double)status;
+	if (inf) {
+		if (!has_inf) {
+#pragma unroll
+			for (int j = 0; j < P; ++j) se[j] = tv[j] = pv[j] = cl[j] = cu[j] = nan64();
+			fstat = fp = nan64();
+		}
+#pragma unroll
+		for (int j = 0; j < P; ++j) {
+			inf[j] = se[j];
+			inf[p + j] = tv[j];
+			inf[2 * p + j] = pv[j];
+			inf[3 * p + j] = cl[j];
+			inf[4 * p + j] = cu[j];
+		}
+		inf[5 * p] = fstat;
+		inf[5 * p + 1] = fp;
+	}
+	if (refine && status == ANOFOX_ERROR_SUCCESS) {
+		const int slot = atomicAdd(args.refine_count, 1);
+		args.refine_list[slot] = (int32_t)g;
+	}
+}
+
+template <int P>
+__global__ __launch_bounds__(64) void solve_narrow_kernel(BatchArgs args) {
+	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= args.n_groups) return;
+	solve_one<P>(args, g, false, 0.0);
+}
+
+// second pass over the queued groups only, with the directly summed RSS
+template <int P>
+__global__ __launch_bounds__(64) void solve_refine_kernel(BatchArgs args) {
+	const int n = *args.refine_count;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const int64_t g = args.refine_list[i];
+		solve_one<P>(args, g, true, args.rss_direct[g]);
+	}
+}
+
+// One wavefront per queued group: RSS = sum w (y - b0 - x'b)^2 over the valid rows, from the data.
+__global__ __launch_bounds__(256) void residual_rss_kernel(BatchArgs args) {
+	const int lane = threadIdx.x & 63;
+	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int n_waves = (gridDim.x * blockDim.x) >> 6;
+	const int n = *args.refine_count;
+	const int p = args.p;
+	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
+	for (int i = wave; i < n; i += n_waves) {
+		const int64_t g = args.refine_list[i];
+		const double *core = args.core + g * (int64_t)(p + 6);
+		double b[kNarrowMaxP];
+		for (int j = 0; j < p; ++j) {
+			const double bj = core[j];
+			b[j] = isnan(bj) ? 0.0 : bj; // dropped / aliased columns do not enter the fit
+		}
+		const double b0 = args.fit_intercept ? core[p] : 0.0;
+		const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+		double acc = 0.0;
+		for (int64_t r = lo + lane; r < hi; r += 64) {
+			const double yv = args.y[r];
+			bool ok = isfinite(yv);
+			double fit = b0;
+			for (int j = 0; j < p; ++j) {
+				const double xv = args.x[j][r];
+				ok = ok && isfinite(xv);
+				fit = fma(b[j], xv, fit);
+			}
+			double wv = 1.0;
+			if (weighted) {
+				wv = args.w[r];
+				ok = ok && (wv > 0.0) && isfinite(wv);
+			}
+			const double e = yv - fit;
+			if (ok) acc = fma(wv * e, e, acc);
+		}
+		for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+		if (lane == 0) args.rss_direct[g] = acc;
+	}
+}
+
+template <int P>
+hipError_t launch_solve_p(const BatchArgs &a, bool refine_pass, hipStream_t stream) {
+	if (refine_pass) {
+		hipLaunchKernelGGL((solve_refine_kernel<P>), dim3(256), dim3(64), 0, stream, a);
+	} else {
+		const unsigned grid = (unsigned)((a.n_groups + 63) / 64);
+		hipLaunchKernelGGL((solve_narrow_kernel<P>), dim3(grid), dim3(64), 0, stream, a);
+	}
+	return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_solve_narrow(const BatchArgs &a, bool refine_pass, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	switch (a.p) {
+	case 1: return launch_solve_p<1>(a, refine_pass, stream);
+	case 2: return launch_solve_p<2>(a, refine_pass, stream);
+	case 3: return launch_solve_p<3>(a, refine_pass, stream);
+	case 4: return launch_solve_p<4>(a, refine_pass, stream);
+	case 5: return launch_solve_p<5>(a, refine_pass, stream);
+	case 6: return launch_solve_p<6>(a, refine_pass, stream);
+	case 7: return launch_solve_p<7>(a, refine_pass, stream);
+	case 8: return launch_solve_p<8>(a, refine_pass, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+hipError_t launch_residual_rss(const BatchArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	hipLaunchKernelGGL(residual_rss_kernel, dim3(512), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+} // namespace anofox

@@ -1,0 +1,122 @@
+"""Contexts and the two batch entry points (host pointers / device pointers)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from ._abi import AnofoxStatsError
+
+
+class Context:
+    """Owns one AnofoxHipContext (device + stream + reusable workspace)."""
+
+    def __init__(self, device: int = -1):
+        lib = _abi.load()
+        err = _abi.AnofoxError()
+        handle = C.c_void_p()
+        if not lib.anofox_hip_context_create(int(device), C.byref(handle), C.byref(err)):
+            raise AnofoxStatsError(err.code, err.text())
+        self._h = handle
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.anofox_hip_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, ok, err):
+        if not ok:
+            raise AnofoxStatsError(err.code, err.text())
+
+    def set_stream(self, hip_stream: Optional[int]):
+        err = _abi.AnofoxError()
+        self._check(self._lib.anofox_hip_context_set_stream(self._h, C.c_void_p(hip_stream or 0), C.byref(err)), err)
+
+    def synchronize(self):
+        err = _abi.AnofoxError()
+        self._check(self._lib.anofox_hip_context_synchronize(self._h, C.byref(err)), err)
+
+    def enable_timing(self, enable: bool = True):
+        err = _abi.AnofoxError()
+        self._check(self._lib.anofox_hip_context_enable_timing(self._h, bool(enable), C.byref(err)), err)
+
+    def collect_timing(self) -> dict:
+        err = _abi.AnofoxError()
+        t = _abi.AnofoxHipKernelTimes()
+        self._check(self._lib.anofox_hip_context_collect_timing(self._h, C.byref(t), C.byref(err)), err)
+        return {"accumulate_ms": t.accumulate_ms, "accumulate_count": t.accumulate_count,
+                "solve_ms": t.solve_ms, "solve_count": t.solve_count}
+
+    # ---- device-resident batch (torch tensors on this context's GPU) -------------------------
+    def fit_batch_device(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
+                         core=None, inference=None, use_current_torch_stream: bool = True):
+        """row_offsets: int64[G+1]; y, x_cols[j], w: float64[N] CUDA tensors.  Asynchronous.
+        Returns (core[G, p+6], inference[G, 5p+2] or None) CUDA tensors."""
+        import torch
+
+        p = len(x_cols)
+        G = int(row_offsets.numel()) - 1
+        N = int(y.numel())
+        for t in (row_offsets, y, *x_cols) + ((w,) if w is not None else ()):
+            if not t.is_cuda or not t.is_contiguous():
+                raise ValueError("device batch needs contiguous CUDA tensors")
+        if row_offsets.dtype != torch.int64 or y.dtype != torch.float64 or any(c.dtype != torch.float64 for c in x_cols):
+            raise ValueError("row_offsets must be int64 and data float64")
+        if any(int(c.numel()) != N for c in x_cols) or (w is not None and int(w.numel()) != N):
+            raise ValueError("every column must have y's length")
+        if core is None:
+            core = torch.empty((G, p + 6), dtype=torch.float64, device=y.device)
+        if options.compute_inference and inference is None:
+            inference = torch.empty((G, 5 * p + 2), dtype=torch.float64, device=y.device)
+        if use_current_torch_stream:
+            self.set_stream(torch.cuda.current_stream(y.device).cuda_stream)
+        cols = (C.c_void_p * p)(*[c.data_ptr() for c in x_cols])
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_fit_batch_device(
+            self._h, G, p, N, C.c_void_p(row_offsets.data_ptr()), C.c_void_p(y.data_ptr()), cols,
+            C.c_void_p(w.data_ptr() if w is not None else 0), options, C.c_void_p(core.data_ptr()),
+            C.c_void_p(inference.data_ptr() if inference is not None else 0), C.byref(err))
+        self._check(ok, err)
+        return core, (inference if options.compute_inference else None)
+
+    # ---- host-resident batch (numpy) ----------------------------------------------------------
+    def fit_batch_host(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions):
+        return fit_batch_host(row_offsets, y, x_cols, w, options, ctx=self)
+
+
+_DP = C.POINTER(C.c_double)
+
+
+def fit_batch_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
+                   ctx: Optional[Context] = None):
+    """numpy in, numpy out: (core[G, p+6], inference[G, 5p+2] or None)."""
+    lib = _abi.load()
+    off = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    wv = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    p = len(cols)
+    G = len(off) - 1
+    N = len(yv)
+    if any(len(c) != N for c in cols) or (wv is not None and len(wv) != N):
+        raise ValueError("every column must have y's length")
+    core = np.empty((G, p + 6), dtype=np.float64)
+    inf = np.empty((G, 5 * p + 2), dtype=np.float64) if options.compute_inference else None
+    colp = (_DP * max(p, 1))(*[c.ctypes.data_as(_DP) for c in cols])
+    err = _abi.AnofoxError()
+    ok = lib.anofox_hip_fit_batch_host(
+        ctx._h if ctx is not None else None, G, p, N, off.ctypes.data_as(C.POINTER(C.c_int64)),
+        yv.ctypes.data_as(_DP), colp, None if wv is None else wv.ctypes.data_as(_DP), options,
+        core.ctypes.data_as(_DP), None if inf is None else inf.ctypes.data_as(_DP), C.byref(err))
+    if not ok:
+        raise AnofoxStatsError(err.code, err.text())
+    return core, inf

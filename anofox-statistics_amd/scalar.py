@@ -1,0 +1,119 @@
+"""Scalar `anofox_stats_{ols,ridge,wls}_fit(y LIST, x LIST(LIST) [, w] [, options])` — mirror of
+src/table_functions/{ols,ridge,wls}_fit.cpp (one group per call, x column-major, failures THROW,
+ols_fit.cpp:176-178), bound to the reference-compatible C symbols of libanofox_stats_hip.so
+(anofox_ols_fit / anofox_ridge_fit / anofox_wls_fit / anofox_free_result_*)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Mapping, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from .options import InvalidInputException, parse_options
+
+_DP = C.POINTER(C.c_double)
+
+
+def _data_array(v):
+    """(AnofoxDataArray, keepalive): None entries become NULLs through the validity bitmask."""
+    vals = list(v)
+    nulls = [x is None for x in vals]
+    data = np.array([0.0 if x is None else float(x) for x in vals], dtype=np.float64)
+    arr = _abi.AnofoxDataArray()
+    arr.data = data.ctypes.data_as(_DP)
+    arr.len = len(vals)
+    keep = [data]
+    if any(nulls):
+        bits = np.zeros((len(vals) + 7) // 8, dtype=np.uint8)
+        for i, isnull in enumerate(nulls):
+            if not isnull:
+                bits[i // 8] |= 1 << (i % 8)
+        arr.validity = bits.ctypes.data_as(C.POINTER(C.c_uint8))
+        keep.append(bits)
+    else:
+        arr.validity = None
+    return arr, keep
+
+
+def _call(model: str, y, x: Sequence[Sequence[float]], weights, options: Optional[Mapping[str, Any]]) -> dict:
+    lib = _abi.load()
+    o = parse_options(options)
+    ya, k0 = _data_array(y)
+    xs = (_abi.AnofoxDataArray * max(len(x), 1))()
+    keep = [k0]
+    for j, col in enumerate(x):
+        a, k = _data_array(col)
+        xs[j] = a
+        keep.append(k)
+    core = _abi.AnofoxFitResultCore()
+    inf = _abi.AnofoxFitResultInference()
+    err = _abi.AnofoxError()
+    infp = C.byref(inf) if o.compute_inference else None
+    if model == "ols":
+        opt = _abi.AnofoxOlsOptions(o.fit_intercept, o.compute_inference, o.confidence_level, _abi.SOLVER[o.solver],
+                                    _abi.HC_TYPE[o.hc_type])
+        ok = lib.anofox_ols_fit(ya, xs, len(x), opt, C.byref(core), infp, C.byref(err))
+        label = "OLS"
+    elif model == "ridge":
+        opt = _abi.AnofoxRidgeOptions(o.alpha, o.fit_intercept, o.compute_inference, o.confidence_level,
+                                      _abi.SOLVER[o.solver], _abi.LAMBDA_SCALING[o.lambda_scaling])
+        ok = lib.anofox_ridge_fit(ya, xs, len(x), opt, C.byref(core), infp, C.byref(err))
+        label = "Ridge"
+    else:
+        wa, kw = _data_array(weights)
+        keep.append(kw)
+        opt = _abi.AnofoxWlsOptions(o.fit_intercept, o.compute_inference, o.confidence_level, _abi.SOLVER[o.solver],
+                                    _abi.HC_TYPE[o.hc_type])
+        ok = lib.anofox_wls_fit(ya, xs, len(x), wa, opt, C.byref(core), infp, C.byref(err))
+        label = "WLS"
+    if not ok:
+        e = InvalidInputException(f"{label} fit failed: {err.text()}")
+        e.code = err.code
+        raise e
+    try:
+        p = core.coefficients_len
+        out = {"coefficients": [core.coefficients[i] for i in range(p)], "intercept": core.intercept,
+               "r_squared": core.r_squared, "adj_r_squared": core.adj_r_squared,
+               "residual_std_error": core.residual_std_error, "n_observations": core.n_observations,
+               "n_features": core.n_features}
+        if o.compute_inference:
+            n = inf.len
+            for name in ("std_errors", "t_values", "p_values", "ci_lower", "ci_upper"):
+                ptr = getattr(inf, name)
+                out[name] = [ptr[i] for i in range(n)] if n else None
+            out["f_statistic"] = inf.f_statistic
+            out["f_pvalue"] = inf.f_pvalue
+        return out
+    finally:
+        lib.anofox_free_result_core(C.byref(core))
+        if o.compute_inference:
+            lib.anofox_free_result_inference(C.byref(inf))
+
+
+def ols_fit(y, x, options=None) -> dict:
+    """anofox_stats_ols_fit([y...], [[x1...], [x2...]], {...})"""
+    return _call("ols", y, x, None, options)
+
+
+def ridge_fit(y, x, options=None) -> dict:
+    return _call("ridge", y, x, None, options)
+
+
+def wls_fit(y, x, weights, options=None) -> dict:
+    return _call("wls", y, x, weights, options)
+
+
+def aic(rss: float, n: int, k: int) -> Optional[float]:
+    """aic(rss, n, k) scalar function (src/scalar_functions/aic_bic.cpp:12-60): NULL (None) on error."""
+    lib = _abi.load()
+    out = C.c_double()
+    err = _abi.AnofoxError()
+    return out.value if lib.anofox_compute_aic(float(rss), int(n), int(k), C.byref(out), C.byref(err)) else None
+
+
+def bic(rss: float, n: int, k: int) -> Optional[float]:
+    lib = _abi.load()
+    out = C.c_double()
+    err = _abi.AnofoxError()
+    return out.value if lib.anofox_compute_bic(float(rss), int(n), int(k), C.byref(out), C.byref(err)) else None

@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — group fits/s of the grouped least-squares hot path on MI355X.
+
+A "step" is one pass of the hot path over the whole synthetic GROUP BY: accumulate + solve on every
+rank's groups and (N > 1) the all-gather of the per-group records.  Workload = BASELINE.json's metric
+config: OLS, 1M groups x n = 1000 x p = 8, inputs resident in HBM before the timed region; with N ranks
+the same 1M groups are partitioned across the ranks ("strong" scaling, BASELINE config 4).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (metric / roofline / cpu_baseline), see DESIGN.md "Measurement".
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PKG = "anofox-statistics_amd"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def algorithmic_bytes_per_fit(n: int, p: int, weighted: bool, inference: bool) -> int:
+    """8 n (p+1) [+ 8 n weights] input + 8 (p+6) core record [+ 8 (5p+2) inference]."""
+    return 8 * n * (p + 1) + (8 * n if weighted else 0) + 8 * (p + 6) + (8 * (5 * p + 2) if inference else 0)
+
+
+def parity_gate(pkg, core, inf, offs, y, x_cols, w, model, kw, p, sample):
+    """Re-check a sample of groups against the CPU oracle; returns (ok, max coef err, max diag err)."""
+    import oracle  # checker only
+    S = min(sample, core.shape[0])
+    n_rows = int(offs[S].item())
+    ys = y[:n_rows].cpu().numpy()
+    xs = [c[:n_rows].cpu().numpy() for c in x_cols]
+    ws = w[:n_rows].cpu().numpy() if w is not None else None
+    rcore, rinf = oracle.fit_groups(ys, xs, offs[:S + 1].cpu().numpy(), w=ws, model=model,
+                                    n_threads=len(os.sched_getaffinity(0)), **kw)
+    c = core[:S].cpu().numpy()
+    if not np.array_equal(c[:, p + 5], rcore[:, p + 5]):
+        return False, float("inf"), float("inf")
+    scale = np.max(np.abs(rcore[:, :p + 1]), axis=1, keepdims=True)
+    cerr = float(np.max(np.abs(c[:, :p + 1] - rcore[:, :p + 1]) / np.maximum(np.abs(rcore[:, :p + 1]), 1e-3 * scale)))
+    derr = float(np.max(np.abs(c[:, p + 1:p + 4] / rcore[:, p + 1:p + 4] - 1.0)))
+    if rinf is not None:
+        derr = max(derr, float(np.max(np.abs(inf[:S].cpu().numpy() / rinf - 1.0))))
+    return (cerr < 1e-9 and derr < 1e-6), cerr, derr
+
+
+def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=12.0):
+    """Time the oracle (a port of the reference's algorithm class: dense QR per group) on the host cores,
+    on a bounded sample of the same workload."""
+    import oracle
+    cores = len(os.sched_getaffinity(0))
+    G = offs.numel() - 1
+    probe = min(G, 64 * cores)
+
+    def run(S):
+        n_rows = int(offs[S].item())
+        ys = y[:n_rows].cpu().numpy()
+        xs = [c[:n_rows].cpu().numpy() for c in x_cols]
+        ws = w[:n_rows].cpu().numpy() if w is not None else None
+        so = offs[:S + 1].cpu().numpy()
+        t0 = time.perf_counter()
+        oracle.fit_groups(ys, xs, so, w=ws, model=model, n_threads=cores, **kw)
+        return time.perf_counter() - t0
+
+    t_probe = run(probe)
+    S = int(min(G, max(probe, probe * budget_s / max(t_probe, 1e-6)), 65536))
+    t = run(S)
+    return {"value": S / t, "unit": "fits/s", "cores": cores, "kind": "port",
+            "sample": f"{S} groups x {n} rows x p={p} ({model}), one pass of oracle.fit_groups (dense Householder QR "
+                      f"per group, {cores} threads), {t:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--groups", type=int, default=1_000_000, help="total groups over all ranks")
+    ap.add_argument("--rows", type=int, default=1000, help="rows per group")
+    ap.add_argument("--features", type=int, default=8)
+    ap.add_argument("--model", default="ols", choices=["ols", "ridge", "wls"])
+    ap.add_argument("--inference", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-sample", type=int, default=1024)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module(PKG)
+    synth = importlib.import_module(PKG + ".synth")
+    dmod = importlib.import_module(PKG + ".distributed")
+
+    G, n, p = args.groups, args.rows, args.features
+    weighted = args.model == "wls"
+    lo, hi = dmod.shard_range(G, rank, world)
+    G_local = hi - lo
+    # bound the footprint by what the card has free (288 GB nominal): inputs are resident, never re-generated
+    need = G_local * n * (p + 1 + int(weighted)) * 8
+    free, _ = torch.cuda.mem_get_info()
+    if need > 0.9 * free:
+        raise SystemExit(f"rank {rank}: workload needs {need / 1e9:.1f} GB, only {free / 1e9:.1f} GB free")
+    offs, y, x_cols, w = synth.make_grouped(G_local, n, p, group_start=lo, weights=weighted, device=dev,
+                                            chunk_groups=32768)
+    kw = {"compute_inference": args.inference}
+    if args.model == "ridge":
+        kw["alpha"] = 1.0
+    opts = pkg.RegressionOptions(**kw).batch_options(args.model)
+    ctx = pkg.Context(local_rank)
+    sharded = dmod.ShardedBatchFit(ctx, G)
+
+    def step():
+        return sharded.fit(offs, y, x_cols, w, opts)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ctx.enable_timing(True)
+    ctx.collect_timing()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        core_all, inf_all = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kt = ctx.collect_timing()
+    ctx.enable_timing(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ok, cerr, derr = True, 0.0, 0.0
+    if args.parity_sample > 0:
+        # every rank checks the head of its own shard (the gathered block [lo:hi] must be its own records)
+        mine = core_all[lo:hi]
+        mine_inf = inf_all[lo:hi] if inf_all is not None else None
+        ok, cerr, derr = parity_gate(pkg, mine, mine_inf, offs, y, x_cols, w, args.model, kw, p, args.parity_sample)
+        if world > 1:
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item() > 0.5)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        fits_per_s = G * args.steps / elapsed
+        bytes_fit = algorithmic_bytes_per_fit(n, p, weighted, args.inference)
+        acc_ms = kt["accumulate_ms"] / max(kt["accumulate_count"], 1)
+        achieved = (G_local * bytes_fit) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                t = json.load(open(tpath))
+                key = f"{args.model}_G{G_local}_n{n}_p{p}"
+                traffic = t.get(key)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "group_fits_per_sec", "value": fits_per_s if ok else None, "unit": "fits/s",
+            "ns_per_row": (elapsed / args.steps) * 1e9 / (G * n),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.model}_fit_agg: {G} groups x n={n} x p={p}, device-resident grouped columns, "
+                                   f"fit_intercept=true, compute_inference={str(args.inference).lower()}",
+                       "groups_total": G, "groups_per_gpu": G_local, "rows_per_group": n, "features": p,
+                       "partition": f"contiguous key ranges over {world} rank(s); all-gather of {p + 6}-double records"},
+            "parity": {"ok": ok, "sample_groups_per_rank": min(args.parity_sample, G_local),
+                       "max_coef_rel_err": cerr, "max_diag_rel_err": derr},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "accumulate_narrow_kernel", "avg_launch_ms": acc_ms,
+                         "algorithmic_bytes_per_launch": G_local * bytes_fit,
+                         "solve_avg_ms": kt["solve_ms"] / max(kt["solve_count"], 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(offs, y, x_cols, w, args.model, kw, n, p)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("parity gate failed: no throughput reported")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,276 @@
+/*
+ * anofox_stats_hip.h — C ABI of libanofox_stats_hip.so, the MI355X (gfx950)
+ * implementation of anofox-statistics' grouped least-squares path
+ * (ols_fit_agg / ridge_fit_agg / wls_fit_agg).
+ *
+ * Two layers:
+ *
+ *  (1) The reference's own FFI surface for this path, same symbols, same
+ *      struct layouts, same ownership and error conventions, so that the
+ *      DuckDB C++ layer (src/aggregate_functions/{ols,ridge,wls}_aggregate.cpp,
+ *      src/table_functions/{ols,ridge,wls}_fit.cpp, ...) links against this
+ *      library instead of the Rust staticlib without source changes.
+ *      Each declaration cites the reference interface it replaces
+ *      (paths under the reference repository).
+ *
+ *  (2) New batched entry points (no reference counterpart): one call fits
+ *      every group of an aggregate Finalize vector — or a whole GROUP BY —
+ *      on the GPU.  Plain pointers and sizes only; no HIP, torch or C++ types.
+ *
+ * All arithmetic is IEEE-754 binary64.  Every entry point runs on the GPU;
+ * there is no CPU fallback: without a usable HIP device the calls fail with
+ * ANOFOX_ERROR_INTERNAL and a message.
+ */
+#ifndef ANOFOX_STATS_HIP_H
+#define ANOFOX_STATS_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* exported symbols (the library is built with -fvisibility=hidden) */
+#if defined(__GNUC__)
+#define ANOFOX_HIP_API __attribute__((visibility("default")))
+#else
+#define ANOFOX_HIP_API
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* (1) Reference-compatible types.  Skipped when the reference's own header */
+/* (src/include/anofox_stats_ffi.h) was included first.                     */
+/* ------------------------------------------------------------------------ */
+#ifndef ANOFOX_STATS_FFI_H
+
+/* replaces AnofoxErrorCode, src/include/anofox_stats_ffi.h:18-31
+ * (Rust mirror: crates/anofox-stats-ffi/src/types.rs:6-21) */
+typedef enum {
+	ANOFOX_ERROR_SUCCESS = 0,
+	ANOFOX_ERROR_INVALID_INPUT = 1,
+	ANOFOX_ERROR_SINGULAR_MATRIX = 2,
+	ANOFOX_ERROR_CONVERGENCE_FAILURE = 3,
+	ANOFOX_ERROR_INVALID_ALPHA = 4,
+	ANOFOX_ERROR_INVALID_L1_RATIO = 5,
+	ANOFOX_ERROR_INSUFFICIENT_DATA = 6,
+	ANOFOX_ERROR_ALLOCATION_FAILURE = 7,
+	ANOFOX_ERROR_SERIALIZATION_ERROR = 8,
+	ANOFOX_ERROR_DIMENSION_MISMATCH = 9,
+	ANOFOX_ERROR_NO_VALID_DATA = 10,
+	ANOFOX_ERROR_INTERNAL = 99
+} AnofoxErrorCode;
+
+/* replaces AnofoxError, anofox_stats_ffi.h:36-39 — 260 bytes, message NUL-terminated, <= 255 chars */
+typedef struct {
+	AnofoxErrorCode code;
+	char message[256];
+} AnofoxError;
+
+/* replaces AnofoxDataArray, anofox_stats_ffi.h:44-51 — 24 bytes, passed by value.
+ * validity: LSB-first bitmask, bit i == 0 means NULL (treated as NaN, types.rs:66-89); may be NULL. */
+typedef struct {
+	const double *data;
+	const uint8_t *validity;
+	size_t len;
+} AnofoxDataArray;
+
+/* replaces AnofoxFitResultCore, anofox_stats_ffi.h:56-73 — 64 bytes */
+typedef struct {
+	double *coefficients; /* malloc'ed by the callee, released by anofox_free_result_core */
+	size_t coefficients_len;
+	double intercept; /* NaN when fit_intercept == false */
+	double r_squared;
+	double adj_r_squared;
+	double residual_std_error;
+	size_t n_observations;
+	size_t n_features;
+} AnofoxFitResultCore;
+
+/* replaces AnofoxFitResultInference, anofox_stats_ffi.h:78-97 — 72 bytes; arrays are slopes only */
+typedef struct {
+	double *std_errors;
+	double *t_values;
+	double *p_values;
+	double *ci_lower;
+	double *ci_upper;
+	size_t len;
+	double confidence_level;
+	double f_statistic;
+	double f_pvalue;
+} AnofoxFitResultInference;
+
+/* replaces AnofoxSolverType, anofox_stats_ffi.h:102-106.  Accepted for API
+ * compatibility; the GPU path always factors the shifted normal equations by
+ * Cholesky (the reference's solvers agree to 1e-10 on well-conditioned data,
+ * test/sql/regression/test_map_options.test:65-79). */
+typedef enum { ANOFOX_SOLVER_QR = 0, ANOFOX_SOLVER_SVD = 1, ANOFOX_SOLVER_CHOLESKY = 2 } AnofoxSolverType;
+
+/* replaces AnofoxLambdaScaling, anofox_stats_ffi.h:111-114 */
+typedef enum { ANOFOX_LAMBDA_SCALING_RAW = 0, ANOFOX_LAMBDA_SCALING_GLMNET = 1 } AnofoxLambdaScaling;
+
+/* replaces AnofoxHcType, anofox_stats_ffi.h:119-125 */
+typedef enum {
+	ANOFOX_HC_NONE = 0,
+	ANOFOX_HC_HC0 = 1,
+	ANOFOX_HC_HC1 = 2,
+	ANOFOX_HC_HC2 = 3,
+	ANOFOX_HC_HC3 = 4
+} AnofoxHcType;
+
+/* replaces AnofoxOlsOptions, anofox_stats_ffi.h:130-141 — 24 bytes */
+typedef struct {
+	bool fit_intercept;
+	bool compute_inference;
+	double confidence_level;
+	AnofoxSolverType solver;
+	AnofoxHcType hc_type;
+} AnofoxOlsOptions;
+
+/* replaces AnofoxRidgeOptions, anofox_stats_ffi.h:352-364 — 32 bytes */
+typedef struct {
+	double alpha;
+	bool fit_intercept;
+	bool compute_inference;
+	double confidence_level;
+	AnofoxSolverType solver;
+	AnofoxLambdaScaling lambda_scaling;
+} AnofoxRidgeOptions;
+
+/* replaces AnofoxWlsOptions, anofox_stats_ffi.h:446-457 — 24 bytes */
+typedef struct {
+	bool fit_intercept;
+	bool compute_inference;
+	double confidence_level;
+	AnofoxSolverType solver;
+	AnofoxHcType hc_type;
+} AnofoxWlsOptions;
+
+/* replaces anofox_ols_fit, anofox_stats_ffi.h:155-156 (Rust: crates/anofox-stats-ffi/src/lib.rs:98-265).
+ * One group, column-major x (one AnofoxDataArray per feature).  Returns false and fills *out_error on
+ * failure, handing out no allocation.  out_inference may be NULL; when it is not and the fit produced
+ * no inference block it is reset to {NULLs, len 0, NaNs} (types.rs:151-165). */
+ANOFOX_HIP_API bool anofox_ols_fit(AnofoxDataArray y, const AnofoxDataArray *x, size_t x_count, AnofoxOlsOptions options,
+                    AnofoxFitResultCore *out_core, AnofoxFitResultInference *out_inference, AnofoxError *out_error);
+
+/* replaces anofox_ridge_fit, anofox_stats_ffi.h:378-379 (lib.rs:984-1155) */
+ANOFOX_HIP_API bool anofox_ridge_fit(AnofoxDataArray y, const AnofoxDataArray *x, size_t x_count, AnofoxRidgeOptions options,
+                      AnofoxFitResultCore *out_core, AnofoxFitResultInference *out_inference, AnofoxError *out_error);
+
+/* replaces anofox_wls_fit, anofox_stats_ffi.h:472-474 (lib.rs:1384-1555) */
+ANOFOX_HIP_API bool anofox_wls_fit(AnofoxDataArray y, const AnofoxDataArray *x, size_t x_count, AnofoxDataArray weights,
+                    AnofoxWlsOptions options, AnofoxFitResultCore *out_core, AnofoxFitResultInference *out_inference,
+                    AnofoxError *out_error);
+
+/* replaces anofox_free_result_core, anofox_stats_ffi.h:161 (lib.rs:272-280) — NULL-safe, idempotent */
+ANOFOX_HIP_API void anofox_free_result_core(AnofoxFitResultCore *result);
+
+/* replaces anofox_free_result_inference, anofox_stats_ffi.h:166 (lib.rs:287-311) */
+ANOFOX_HIP_API void anofox_free_result_inference(AnofoxFitResultInference *result);
+
+/* replaces anofox_compute_aic / anofox_compute_bic, anofox_stats_ffi.h:570,582 (lib.rs:1932-2011):
+ * n ln(rss/n) + 2k  and  n ln(rss/n) + k ln n;  rss == 0 -> -inf;  n == 0 or rss < 0 -> InvalidInput.
+ * Scalar helpers, evaluated on the host (they touch no data). */
+ANOFOX_HIP_API bool anofox_compute_aic(double rss, size_t n, size_t k, double *out_aic, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_compute_bic(double rss, size_t n, size_t k, double *out_bic, AnofoxError *out_error);
+
+#endif /* ANOFOX_STATS_FFI_H */
+
+/* ------------------------------------------------------------------------ */
+/* (2) Batched GPU entry points (new surface).                               */
+/*                                                                          */
+/* Natural call site in the reference: the per-state loop of                 */
+/* OlsAggFinalize (src/aggregate_functions/ols_aggregate.cpp:249-338, and    */
+/* ridge_aggregate.cpp:255-345, wls_aggregate.cpp:268-362), which today      */
+/* makes one anofox_*_fit call per group.                                    */
+/*                                                                          */
+/* Data layout ("grouped columns"): rows sorted by group; group g owns rows  */
+/* [row_offsets[g], row_offsets[g+1]).  y is one array of n_rows doubles,    */
+/* each feature j is one array x_cols[j] of n_rows doubles (the same         */
+/* one-array-per-feature layout as AnofoxDataArray x[] — just concatenated   */
+/* over groups), w likewise for WLS.  NULL inputs are encoded as NaN.        */
+/* ------------------------------------------------------------------------ */
+
+typedef struct AnofoxHipContext AnofoxHipContext; /* one device + one stream + reusable workspace */
+
+typedef enum { ANOFOX_HIP_MODEL_OLS = 0, ANOFOX_HIP_MODEL_RIDGE = 1, ANOFOX_HIP_MODEL_WLS = 2 } AnofoxHipModel;
+
+/* Union of AnofoxOlsOptions / AnofoxRidgeOptions / AnofoxWlsOptions (same field meaning). */
+typedef struct {
+	AnofoxHipModel model;
+	bool fit_intercept;
+	bool compute_inference;
+	double confidence_level;
+	double alpha; /* ridge only; < 0 -> every group fails with ANOFOX_ERROR_INVALID_ALPHA */
+	AnofoxSolverType solver;
+	AnofoxLambdaScaling lambda_scaling;
+	AnofoxHcType hc_type; /* only ANOFOX_HC_NONE is implemented on the GPU path */
+} AnofoxHipBatchOptions;
+
+/* Per-group status word stored in the core record: an AnofoxErrorCode, or this value for groups the
+ * aggregate maps to SQL NULL before calling the fit (fewer than 2 rows, ols_aggregate.cpp:263-267). */
+#define ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS 100
+
+/* Result records, row-major f64, one per group:
+ *   core[g]      = { coefficients[0..p), intercept, r_squared, adj_r_squared, residual_std_error,
+ *                    n_observations, status }                                   length p + 6
+ *   inference[g] = { std_errors[p], t_values[p], p_values[p], ci_lower[p], ci_upper[p],
+ *                    f_statistic, f_pvalue }                                    length 5p + 2
+ * Fields of the STRUCT the aggregates return (ols_aggregate.cpp:74-96); n_features is the constant p.
+ * status != 0  =>  the group is SQL NULL and every other field is NaN.
+ * Constant columns give NaN coefficients / inference entries (models/ols.rs:167-171,191-206). */
+ANOFOX_HIP_API size_t anofox_hip_core_record_len(size_t n_features);
+ANOFOX_HIP_API size_t anofox_hip_inference_record_len(size_t n_features);
+
+/* Largest n_features the library accepts. */
+ANOFOX_HIP_API size_t anofox_hip_max_features(void);
+
+/* device_id < 0 selects the current HIP device.  The context owns a stream; calls on one context are
+ * serialised, different contexts (e.g. one per DuckDB worker thread) are independent. */
+ANOFOX_HIP_API bool anofox_hip_context_create(int device_id, AnofoxHipContext **out_ctx, AnofoxError *out_error);
+ANOFOX_HIP_API void anofox_hip_context_destroy(AnofoxHipContext *ctx);
+
+/* Launch on a caller-owned hipStream_t (passed as void*) instead of the context's own stream;
+ * NULL restores the context's stream. */
+ANOFOX_HIP_API bool anofox_hip_context_set_stream(AnofoxHipContext *ctx, void *hip_stream, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_context_synchronize(AnofoxHipContext *ctx, AnofoxError *out_error);
+
+/*
+ * Device-resident batch fit.  d_* are device pointers on the context's device; x_cols is a HOST array of
+ * n_features device pointers.  d_w may be NULL unless model == WLS.  d_inference may be NULL unless
+ * options.compute_inference.  Asynchronous on the context's stream; outputs are complete after
+ * anofox_hip_context_synchronize (or a synchronisation of the caller's stream).
+ * Returns false (nothing launched) on invalid arguments; per-group failures are reported in the records.
+ */
+ANOFOX_HIP_API bool anofox_hip_fit_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                 const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
+                                 const double *d_w, AnofoxHipBatchOptions options, double *d_core, double *d_inference,
+                                 AnofoxError *out_error);
+
+/* Same with host pointers: stages inputs to the GPU, runs the device path, copies the records back,
+ * synchronous.  ctx may be NULL (a per-thread default context on the current device is used). */
+ANOFOX_HIP_API bool anofox_hip_fit_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                               const int64_t *row_offsets, const double *y, const double *const *x_cols,
+                               const double *w, AnofoxHipBatchOptions options, double *core, double *inference,
+                               AnofoxError *out_error);
+
+/* Measurement hooks (bench.py): when enabled, every accumulate-kernel launch of this context is
+ * bracketed by HIP events on the launch stream. */
+typedef struct {
+	double accumulate_ms;     /* summed duration of the dominant (HBM-streaming) kernel */
+	int64_t accumulate_count; /* launches summed */
+	double solve_ms;          /* summed duration of the per-group solve/diagnostics kernels */
+	int64_t solve_count;
+} AnofoxHipKernelTimes;
+ANOFOX_HIP_API bool anofox_hip_context_enable_timing(AnofoxHipContext *ctx, bool enable, AnofoxError *out_error);
+/* synchronises, returns the sums since the last call and resets them */
+ANOFOX_HIP_API bool anofox_hip_context_collect_timing(AnofoxHipContext *ctx, AnofoxHipKernelTimes *out, AnofoxError *out_error);
+
+/* Library / build identification, e.g. "anofox_stats_hip 0.1 gfx950". */
+ANOFOX_HIP_API const char *anofox_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANOFOX_STATS_HIP_H */

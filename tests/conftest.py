@@ -44,3 +44,71 @@ def rel_err(a, b):
 @pytest.fixture(scope="session")
 def known_answers():
     return load_json("known_answers.json")
+
+
+def import_pkg(sub: str = ""):
+    """Import the product package (its directory name has a hyphen, so go through importlib)."""
+    import importlib
+    return importlib.import_module("anofox-statistics_amd" + (("." + sub) if sub else ""))
+
+
+COEF_RTOL = 1e-9      # north_star: coefficients within 1e-9 relative
+DIAG_RTOL = 1e-6      # north_star: diagnostic statistics within 1e-6
+
+
+def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=COEF_RTOL, diag_rtol=DIAG_RTOL,
+                         what=""):
+    """Compare (core, inference) records of the HIP path with the oracle's, group by group.
+
+    Coefficients: |got - ref| <= coef_rtol * max(|ref_j|, 1e-3 * max_k |ref_k|)  — strict relative error for
+    every coefficient that is not negligible against the group's largest one, normwise for the rest
+    (the achievable absolute error of any least-squares solver scales with ||beta||, not with |beta_j|).
+    Diagnostics: relative diag_rtol (absolute for values that are exactly 0).
+    NaN patterns and status words must agree exactly.
+    """
+    core = np.asarray(core)
+    ref_core = np.asarray(ref_core)
+    assert core.shape == ref_core.shape, what
+    st, rst = core[:, p + 5], ref_core[:, p + 5]
+    bad = np.nonzero(st != rst)[0]
+    assert bad.size == 0, f"{what}: status differs at groups {bad[:10]}: {st[bad[:10]]} vs {rst[bad[:10]]}"
+    ok = rst == 0
+    c, rc = core[ok, :p], ref_core[ok, :p]
+    assert np.array_equal(np.isnan(c), np.isnan(rc)), f"{what}: NaN pattern of coefficients differs"
+    scale = np.nanmax(np.abs(np.concatenate([rc, ref_core[ok, p:p + 1]], axis=1)), axis=1, keepdims=True)
+    scale = np.where(np.isfinite(scale), scale, 0.0)
+
+    def chk_coef(g, r, name):
+        tol = coef_rtol * np.maximum(np.abs(r), 1e-3 * scale)
+        err = np.abs(g - r)
+        m = ~np.isnan(r)
+        worst = np.max((err[m] / np.maximum(tol[m], 1e-300))) if m.any() else 0.0
+        assert worst <= 1.0, f"{what}: {name} off by {worst:.3g} x tolerance"
+
+    chk_coef(c, rc, "coefficients")
+    gi, ri = core[ok, p:p + 1], ref_core[ok, p:p + 1]
+    assert np.array_equal(np.isnan(gi), np.isnan(ri)), f"{what}: intercept NaN pattern differs"
+    chk_coef(gi, ri, "intercept")
+
+    def chk_diag(g, r, name, rtol=diag_rtol):
+        g = np.asarray(g, dtype=np.float64)
+        r = np.asarray(r, dtype=np.float64)
+        assert np.array_equal(np.isnan(g), np.isnan(r)), f"{what}: NaN pattern of {name} differs"
+        m = ~np.isnan(r)
+        fin = m & np.isfinite(r)
+        assert np.array_equal(g[m & ~fin], r[m & ~fin]), f"{what}: infinities of {name} differ"
+        err = np.abs(g[fin] - r[fin])
+        tol = rtol * np.abs(r[fin]) + 1e-300
+        worst = np.max(err / tol) if err.size else 0.0
+        assert worst <= 1.0, f"{what}: {name} off by {worst:.3g} x tolerance"
+
+    for k, name in ((1, "r_squared"), (2, "adj_r_squared"), (3, "residual_std_error"), (4, "n_observations")):
+        chk_diag(core[ok, p + k], ref_core[ok, p + k], name, rtol=(0.0 if k == 4 else diag_rtol))
+    if ref_inf is not None:
+        inf = np.asarray(inf)
+        ref_inf = np.asarray(ref_inf)
+        names = ["std_errors", "t_values", "p_values", "ci_lower", "ci_upper"]
+        for k, name in enumerate(names):
+            chk_diag(inf[ok, k * p:(k + 1) * p], ref_inf[ok, k * p:(k + 1) * p], name)
+        chk_diag(inf[ok, 5 * p], ref_inf[ok, 5 * p], "f_statistic")
+        chk_diag(inf[ok, 5 * p + 1], ref_inf[ok, 5 * p + 1], "f_pvalue")
