@@ -54,34 +54,34 @@ def parity_gate(pkg, core, inf, offs, y, x_cols, w, model, kw, p, sample):
     cerr = float(np.max(np.abs(c[:, :p + 1] - rcore[:, :p + 1]) / np.maximum(np.abs(rcore[:, :p + 1]), 1e-3 * scale)))
     derr = float(np.max(np.abs(c[:, p + 1:p + 4] / rcore[:, p + 1:p + 4] - 1.0)))
     if rinf is not None:
-        derr = max(derr, float(np.max(np.abs(inf[:S].cpu().numpy() / rinf - 1.0))))
+        gi = inf[:S].cpu().numpy()
+        derr = max(derr, float(np.max(np.abs(gi - rinf) / np.maximum(np.abs(rinf), 1e-300))))
     return (cerr < 1e-9 and derr < 1e-6), cerr, derr
 
 
 def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=12.0):
     """Time the oracle (a port of the reference's algorithm class: dense QR per group) on the host cores,
-    on a bounded sample of the same workload."""
+    on a bounded sample of the same workload: passes over the first S groups until ~budget_s of wall time."""
     import oracle
     cores = len(os.sched_getaffinity(0))
     G = offs.numel() - 1
-    probe = min(G, 64 * cores)
-
-    def run(S):
-        n_rows = int(offs[S].item())
-        ys = y[:n_rows].cpu().numpy()
-        xs = [c[:n_rows].cpu().numpy() for c in x_cols]
-        ws = w[:n_rows].cpu().numpy() if w is not None else None
-        so = offs[:S + 1].cpu().numpy()
-        t0 = time.perf_counter()
+    S = int(min(G, 256 * cores, 65536))
+    n_rows = int(offs[S].item())
+    ys = y[:n_rows].cpu().numpy()
+    xs = [c[:n_rows].cpu().numpy() for c in x_cols]
+    ws = w[:n_rows].cpu().numpy() if w is not None else None
+    so = offs[:S + 1].cpu().numpy()
+    oracle.fit_groups(ys, xs, so, w=ws, model=model, n_threads=cores, **kw)       # warm the pages
+    passes, t0 = 0, time.perf_counter()
+    while True:
         oracle.fit_groups(ys, xs, so, w=ws, model=model, n_threads=cores, **kw)
-        return time.perf_counter() - t0
-
-    t_probe = run(probe)
-    S = int(min(G, max(probe, probe * budget_s / max(t_probe, 1e-6)), 65536))
-    t = run(S)
-    return {"value": S / t, "unit": "fits/s", "cores": cores, "kind": "port",
-            "sample": f"{S} groups x {n} rows x p={p} ({model}), one pass of oracle.fit_groups (dense Householder QR "
-                      f"per group, {cores} threads), {t:.1f} s"}
+        passes += 1
+        t = time.perf_counter() - t0
+        if t >= budget_s or passes >= 200:
+            break
+    return {"value": S * passes / t, "unit": "fits/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} passes over the first {S} groups x {n} rows x p={p} ({model}) with oracle.fit_groups "
+                      f"(dense Householder QR per group, {cores} threads), {t:.1f} s"}
 
 
 def main():
