@@ -1,0 +1,355 @@
+// accumulate_wide.hip — moment accumulation for wide designs (8 < p <= 128) on the FP64 matrix cores.
+//
+// Same role as accumulate_narrow.hip (it replaces the reference's row buffering + dense decomposition,
+// src/aggregate_functions/ols_aggregate.cpp:120-186,249-296 and crates/anofox-stats-core/src/models/ols.rs:59-87,
+// 149-161), for designs whose (p+1)(p+2)/2 moments no longer fit a lane's registers.  The X'WX block is a
+// symmetric rank-n update and goes to v_mfma_f64_16x16x4_f64; X'Wy, the column sums, y'Wy and the
+// constant-column / finite-row predicates stay on the VALU (they are O(p) per row).
+//
+// Mapping: one 256-thread workgroup (4 wavefronts) per group.
+//   * A chunk is 16 consecutive rows of every column (x_1..x_p, y, [w]).  The four waves load it coalesced
+//     (each load instruction: 8 columns x 128 contiguous bytes) one chunk ahead into registers and write it to
+//     a double-buffered LDS image laid out [column][18 doubles] (conflict-free for the fragment reads below).
+//   * A slab is 4 rows.  For the 16-column block I, lane l of a wave reads the fragment element
+//     (row 4t + (l>>4), column 16I + (l&15)) with one ds_read_b64; after shifting by the group's first valid
+//     row (and zeroing invalid rows) the same register is the MFMA's A operand for tile row I and the B
+//     operand for tile column I:  M[16I+i][16J+j] += sum_k w_k d[k][16I+i] d[k][16J+j].
+//   * The T(T+1)/2 upper-triangular 16x16 tiles are dealt round-robin to the four waves (9 tiles = 72
+//     accumulator registers each at p = 128), so every wave issues the same number of MFMAs per slab.
+//   * Column block I is "owned" by wave I % 4, which also accumulates sum w d, sum w d dy and the
+//     constant-column flags for those 16 columns; wave 0 accumulates the y moments.
+//
+// Roofline: FP64 MFMA (matrix-core) bound for p >= ~48: 2*256*4 flop per instruction, T(T+1)/2 instructions
+// per 4 rows; HBM traffic 8(p+1) B per row is read once.
+#include "common.h"
+
+namespace anofox {
+
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kChunkRows = 16;
+constexpr int kLdsStride = 18;   // doubles per column in the LDS image (16 rows + 2 pad: conflict-free b64 reads)
+constexpr int kWaves = 4;
+
+__device__ __forceinline__ double readlane_d(double v, int src) {
+	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+	                        __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+template <int T>
+struct WideCfg {
+	static constexpr int NT = T * (T + 1) / 2;             // upper-triangular tiles
+	static constexpr int TPW = (NT + kWaves - 1) / kWaves; // tiles per wave
+	static constexpr int OWN = (T + kWaves - 1) / kWaves;  // column blocks owned per wave
+};
+
+// One wave's share of a chunk: 4 slabs of MFMAs + the VALU side sums.  WAVE is a compile-time constant so
+// that the tile list unrolls into straight-line MFMAs.  `img` is the chunk's LDS image.
+template <int T, int WAVE, bool WEIGHTED, bool CENTER>
+__device__ __forceinline__ void compute_chunk(const double *img, int p, int lane, unsigned rowmask,
+                                              const double (&first)[T], double first_y, unsigned colmask,
+                                              dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
+                                              double (&sxy)[WideCfg<T>::OWN], unsigned &ncmask, double &sy,
+                                              double &syy, double &sw) {
+	const int k = lane >> 4;
+	const int i = lane & 15;
+#pragma unroll
+	for (int t = 0; t < kChunkRows / 4; ++t) {
+		const int row = 4 * t + k;
+		const bool rv = (rowmask >> row) & 1u;
+		double d[T];
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			const double raw = img[(16 * I + i) * kLdsStride + row];
+			const bool use = rv && ((colmask >> I) & 1u);
+			const double dev = use ? raw - first[I] : 0.0; // deviation from the first valid row
+			d[I] = CENTER ? dev : (use ? raw : 0.0);
+			if (I % kWaves == WAVE) {
+				// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row
+				ncmask |= !(fabs(dev) < 1e-10) ? (1u << I) : 0u;
+			}
+		}
+		const double yraw = img[p * kLdsStride + row];
+		const double dy = rv ? (CENTER ? yraw - first_y : yraw) : 0.0;
+		double w = rv ? 1.0 : 0.0;
+		if (WEIGHTED) {
+			const double wraw = img[(p + 1) * kLdsStride + row];
+			w = rv ? wraw : 0.0;
+		}
+		double a[T];
+#pragma unroll
+		for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? w * d[I] : d[I];
+
+		int tile = 0;
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+#pragma unroll
+			for (int J = I; J < T; ++J) {
+				if (tile % kWaves == WAVE)
+					acc[tile / kWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[J], acc[tile / kWaves], 0, 0, 0);
+				++tile;
+			}
+		}
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			if (I % kWaves == WAVE) {
+				sx[I / kWaves] += a[I];
+				sxy[I / kWaves] = fma(a[I], dy, sxy[I / kWaves]);
+			}
+		}
+		if (WAVE == 0) {
+			const double wdy = WEIGHTED ? w * dy : dy;
+			sy += wdy;
+			syy = fma(wdy, dy, syy);
+			sw += w;
+		}
+	}
+}
+
+template <int T, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) {
+	using Cfg = WideCfg<T>;
+	constexpr int P16 = 16 * T;
+	const int p = args.p;
+	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int64_t g = blockIdx.x;
+	const int64_t lo = args.row_offsets[args.group_base + g];
+	const int64_t hi = args.row_offsets[args.group_base + g + 1];
+	const int64_t nrows = hi - lo;
+
+	extern __shared__ double lds[];
+	// layout: image[2][ncol_pad][18] | colbase[ncol_pad] (as pointers) | rowmask partials [2][4]
+	const int ncol_pad = wide_ncol_pad(p, WEIGHTED);
+	double *image = lds;
+	const double **colbase = reinterpret_cast<const double **>(lds + 2 * ncol_pad * kLdsStride);
+	unsigned *maskslot = reinterpret_cast<unsigned *>(colbase + ncol_pad);
+
+	for (int c = threadIdx.x; c < ncol_pad; c += 256) {
+		const double *b = nullptr;
+		if (c < p) b = args.x_table[c];
+		else if (c == p) b = args.y;
+		else if (WEIGHTED && c == p + 1) b = args.w;
+		colbase[c] = b ? b + lo : nullptr;
+	}
+	__syncthreads();
+
+	// staging assignment: load instruction q of this wave covers columns 8*(wave + 4q) .. +7; lane -> (col, row pair)
+	constexpr int kMaxLoads = (P16 + 2 + 7) / 8 / kWaves + 1;
+	const int colsub = lane >> 3;
+	const int rp = lane & 7;
+	const int n_loads_total = ncol_pad / 8;
+
+	dbl4 acc[Cfg::TPW];
+#pragma unroll
+	for (int t = 0; t < Cfg::TPW; ++t) acc[t] = (dbl4){0.0, 0.0, 0.0, 0.0};
+	double sx[Cfg::OWN], sxy[Cfg::OWN];
+#pragma unroll
+	for (int o = 0; o < Cfg::OWN; ++o) sx[o] = sxy[o] = 0.0;
+	unsigned ncmask = 0;
+	double sy = 0.0, syy = 0.0, sw = 0.0;
+	double first[T]; // x at the first valid row (the shift when CENTER, and the reference point of the constant test)
+#pragma unroll
+	for (int I = 0; I < T; ++I) first[I] = 0.0;
+	double first_y = 0.0;
+	bool have_first = false;
+	int cnt = 0;
+	unsigned colmask = 0;
+#pragma unroll
+	for (int I = 0; I < T; ++I) colmask |= ((16 * I + (lane & 15)) < p) ? (1u << I) : 0u;
+
+	const int64_t n_chunks = (nrows + kChunkRows - 1) / kChunkRows;
+	double v0[kMaxLoads], v1[kMaxLoads]; // staging registers: rows 2*rp, 2*rp+1 of this lane's columns
+
+	// issue the loads of one chunk (global -> registers); consumed by stage_store
+	auto stage_load = [&](int64_t chunk) {
+		const int64_t r0 = chunk * kChunkRows + 2 * rp; // row within the group
+#pragma unroll
+		for (int q = 0; q < kMaxLoads; ++q) {
+			const int li = wave + kWaves * q;
+			v0[q] = v1[q] = 0.0;
+			if (li < n_loads_total) {
+				const double *b = colbase[8 * li + colsub];
+				if (b != nullptr) {
+					if (r0 + 1 < nrows) {
+						const dbl2u v = *reinterpret_cast<const dbl2u *>(b + r0);
+						v0[q] = v.x;
+						v1[q] = v.y;
+					} else if (r0 < nrows) {
+						v0[q] = b[r0];
+					}
+				}
+			}
+		}
+	};
+	// registers -> LDS image `buf`, plus this wave's partial row-validity mask (ols.rs:59-66, wls.rs:76-86)
+	auto stage_store = [&](int64_t chunk, int buf) {
+		bool ok0 = true, ok1 = true;
+		double *img = image + buf * ncol_pad * kLdsStride;
+#pragma unroll
+		for (int q = 0; q < kMaxLoads; ++q) {
+			const int li = wave + kWaves * q;
+			if (li < n_loads_total) {
+				const int col = 8 * li + colsub;
+				if (col < ncol) {
+					bool f0 = isfinite(v0[q]), f1 = isfinite(v1[q]);
+					if (WEIGHTED && col == p + 1) {
+						f0 = f0 && v0[q] > 0.0;
+						f1 = f1 && v1[q] > 0.0;
+					}
+					ok0 = ok0 && f0;
+					ok1 = ok1 && f1;
+				}
+				double *dst = img + col * kLdsStride + 2 * rp;
+				dst[0] = v0[q];
+				dst[1] = v1[q];
+			}
+		}
+		// fold the 8 column sub-groups: bit m = rows 2m / 2m+1 valid in every column this wave staged
+		unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
+		b0 &= b0 >> 32; b0 &= b0 >> 16; b0 &= b0 >> 8;
+		b1 &= b1 >> 32; b1 &= b1 >> 16; b1 &= b1 >> 8;
+		unsigned m = 0;
+#pragma unroll
+		for (int r = 0; r < 8; ++r) {
+			m |= ((unsigned)(b0 >> r) & 1u) << (2 * r);
+			m |= ((unsigned)(b1 >> r) & 1u) << (2 * r + 1);
+		}
+		const int64_t left = nrows - chunk * kChunkRows; // rows past the end of the group are invalid
+		if (left < kChunkRows) m &= (left <= 0) ? 0u : ((1u << left) - 1u);
+		if (lane == 0) maskslot[buf * kWaves + wave] = m;
+	};
+
+	if (n_chunks > 0) {
+		stage_load(0);
+		stage_store(0, 0);
+	}
+	__syncthreads();
+
+	for (int64_t c = 0; c < n_chunks; ++c) {
+		const int buf = (int)(c & 1);
+		const double *img = image + buf * ncol_pad * kLdsStride;
+		unsigned rowmask = maskslot[buf * kWaves + 0] & maskslot[buf * kWaves + 1] & maskslot[buf * kWaves + 2] &
+		                   maskslot[buf * kWaves + 3];
+		rowmask = __builtin_amdgcn_readfirstlane(rowmask);
+		const bool more = c + 1 < n_chunks;
+		if (more) stage_load(c + 1); // in flight while this chunk's MFMAs run
+
+		if (rowmask != 0u) {
+			if (!have_first) {
+				const int r = __ffs((int)rowmask) - 1;
+#pragma unroll
+				for (int I = 0; I < T; ++I) {
+					const int col = 16 * I + (lane & 15);
+					first[I] = (col < p) ? img[col * kLdsStride + r] : 0.0;
+				}
+				first_y = img[p * kLdsStride + r];
+				have_first = true;
+			}
+			cnt += __popc(rowmask);
+			switch (wave) {
+			case 0: compute_chunk<T, 0, WEIGHTED, CENTER>(img, p, lane, rowmask, first, first_y, colmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			case 1: compute_chunk<T, 1, WEIGHTED, CENTER>(img, p, lane, rowmask, first, first_y, colmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			case 2: compute_chunk<T, 2, WEIGHTED, CENTER>(img, p, lane, rowmask, first, first_y, colmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			default: compute_chunk<T, 3, WEIGHTED, CENTER>(img, p, lane, rowmask, first, first_y, colmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			}
+		}
+		if (more) stage_store(c + 1, buf ^ 1);
+		__syncthreads();
+	}
+
+	// ---- write the moment record ----
+	double *rec = args.moments + g * (int64_t)wide_record_len(T);
+	// tiles: tile-major, 256 doubles each, element (row, col) at row*16 + col
+	{
+		int tile = 0;
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+#pragma unroll
+			for (int J = I; J < T; ++J) {
+				if (tile % kWaves == wave) {
+					double *tp = rec + (int64_t)tile * 256;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) tp[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[tile / kWaves][r];
+				}
+				++tile;
+			}
+		}
+	}
+	double *vec = rec + (int64_t)Cfg::NT * 256;
+	// column sums: reduce over the four k-groups (lanes l, l^16, l^32, l^48)
+#pragma unroll
+	for (int I = 0; I < T; ++I) {
+		if (I % kWaves == wave) {
+			double a = sx[I / kWaves], b = sxy[I / kWaves];
+			a += shfl_xor_d(a, 16); a += shfl_xor_d(a, 32);
+			b += shfl_xor_d(b, 16); b += shfl_xor_d(b, 32);
+			unsigned nc = (ncmask >> I) & 1u;
+			nc |= __shfl_xor((int)nc, 16, 64);
+			nc |= __shfl_xor((int)nc, 32, 64);
+			if (lane < 16) {
+				vec[0 * P16 + 16 * I + lane] = a;
+				vec[1 * P16 + 16 * I + lane] = b;
+				vec[2 * P16 + 16 * I + lane] = first[I];
+				vec[3 * P16 + 16 * I + lane] = (double)nc;
+			}
+		}
+	}
+	if (wave == 0) {
+		// every lane of a k-group holds the same partial: take lanes 0, 16, 32, 48
+		double a = sy, b = syy, c2 = sw;
+		a += shfl_xor_d(a, 16); a += shfl_xor_d(a, 32);
+		b += shfl_xor_d(b, 16); b += shfl_xor_d(b, 32);
+		c2 += shfl_xor_d(c2, 16); c2 += shfl_xor_d(c2, 32);
+		if (lane == 0) {
+			double *sc = vec + 4 * P16;
+			sc[0] = a;
+			sc[1] = b;
+			sc[2] = c2;
+			sc[3] = (double)cnt;
+			sc[4] = first_y;
+		}
+	}
+}
+
+template <int T>
+hipError_t launch_T(const WideArgs &a, hipStream_t stream) {
+	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
+	const bool center = a.fit_intercept != 0;
+	const int ncol_pad = wide_ncol_pad(a.p, weighted);
+	const size_t lds = (size_t)2 * ncol_pad * kLdsStride * sizeof(double) + (size_t)ncol_pad * sizeof(double *) + 64;
+	const dim3 grid((unsigned)a.n_groups), block(256);
+	if (weighted) {
+		if (center) hipLaunchKernelGGL((accumulate_wide_kernel<T, true, true>), grid, block, lds, stream, a);
+		else hipLaunchKernelGGL((accumulate_wide_kernel<T, true, false>), grid, block, lds, stream, a);
+	} else {
+		if (center) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true>), grid, block, lds, stream, a);
+		else hipLaunchKernelGGL((accumulate_wide_kernel<T, false, false>), grid, block, lds, stream, a);
+	}
+	return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	switch (wide_tiles(a.p)) {
+	case 1: return launch_T<1>(a, stream);
+	case 2: return launch_T<2>(a, stream);
+	case 3: return launch_T<3>(a, stream);
+	case 4: return launch_T<4>(a, stream);
+	case 5: return launch_T<5>(a, stream);
+	case 6: return launch_T<6>(a, stream);
+	case 7: return launch_T<7>(a, stream);
+	case 8: return launch_T<8>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+} // namespace anofox

@@ -64,12 +64,55 @@ struct BatchArgs {
 	double *inference;    // [G * (5p+2)] or nullptr
 	int32_t *refine_list; // [G]   groups whose RSS must be recomputed from residuals
 	int32_t *refine_count; // [1]
-	double *rss_direct;   // [G]
+	double *refine_vec;   // [G * (p+2)]  {sum w r^2, sum w r, X'Wr} of the queued groups
 };
+
+// ---- wide path (8 < p <= kWideMaxP): FP64-MFMA accumulation, LDS Cholesky ----
+constexpr int kWideMaxP = 128;
+
+inline __host__ __device__ int wide_tiles(int p) { return (p + 15) / 16; }
+// moment record of the wide path: [NT tiles x 256] | sx[P16] | sxy[P16] | first[P16] | nonconst[P16] | scalars[8]
+//   tile (I <= J) number I*T - I(I-1)/2 + (J-I), element (r, c) at r*16 + c  =  M[16I + r][16J + c]
+//   scalars: sy, syy, sw, cnt, first_y
+inline __host__ __device__ int wide_record_len(int T) { return T * (T + 1) / 2 * 256 + 4 * 16 * T + 8; }
+inline __host__ __device__ int wide_ncol_pad(int p, bool weighted) {
+	const int ncol = p + 1 + (weighted ? 1 : 0);
+	const int a = (ncol + 7) & ~7;
+	const int b = 16 * wide_tiles(p);
+	return a > b ? a : b;
+}
+
+struct WideArgs {
+	const int64_t *row_offsets; // [G_total + 1]
+	const double *y;
+	const double *x_table[kWideMaxP]; // column pointers, by value in the kernel arguments
+	const double *w;
+	int64_t group_base; // first group of this launch
+	int64_t n_groups;   // groups in this launch
+	int p;
+	int model;
+	int fit_intercept;
+	int compute_inference;
+	int lambda_scaling;
+	double confidence_level;
+	double alpha;
+	double *moments;      // [n_groups * wide_record_len(T)] (this launch)
+	double *core;         // [G_total * (p+6)]
+	double *inference;    // [G_total * (5p+2)] or nullptr
+	int32_t *refine_list; // [G_total]
+	int32_t *refine_count;
+	double *refine_vec;   // [G_total * (p+2)]
+};
+
+hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
+hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);
+hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);
 
 // launchers implemented in the .hip translation units
 hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream);
-hipError_t launch_solve_narrow(const BatchArgs &a, bool refine_pass, hipStream_t stream);
-hipError_t launch_residual_rss(const BatchArgs &a, hipStream_t stream);
+// mode: 0 = primary solve of every group; 1 = iterative-refinement update of the queued groups;
+//       2 = final statistics of the queued groups from the directly summed RSS
+hipError_t launch_solve_narrow(const BatchArgs &a, int mode, hipStream_t stream);
+hipError_t launch_residual_grad(const BatchArgs &a, hipStream_t stream);
 
 } // namespace anofox

@@ -59,6 +59,8 @@ bool hip_fail(hipError_t rc, const char *what, AnofoxError *e) {
 	return true;
 }
 
+constexpr int kRefineSteps = 2; // iterative-refinement updates applied to queued groups
+
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 bool ensure_buffer(void **buf, size_t *cap, size_t need, const char *what, AnofoxError *e) {
@@ -92,7 +94,7 @@ hipEvent_t get_event(AnofoxHipContext *ctx) {
 
 struct Workspace {
 	double *moments;
-	double *rss_direct;
+	double *refine_vec;
 	int32_t *refine_list;
 	int32_t *refine_count;
 };
@@ -100,15 +102,82 @@ struct Workspace {
 bool carve_workspace(AnofoxHipContext *ctx, int64_t G, int p, Workspace *out, AnofoxError *e) {
 	const size_t rec = (size_t)moment_record_len(p);
 	const size_t b_mom = align_up((size_t)G * rec * sizeof(double), 256);
-	const size_t b_rss = align_up((size_t)G * sizeof(double), 256);
+	const size_t b_rss = align_up((size_t)G * (size_t)(p + 2) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)G * sizeof(int32_t), 256);
 	const size_t total = b_mom + b_rss + b_lst + 256;
 	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, total, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 	out->moments = (double *)base;
-	out->rss_direct = (double *)(base + b_mom);
+	out->refine_vec = (double *)(base + b_mom);
 	out->refine_list = (int32_t *)(base + b_mom + b_rss);
 	out->refine_count = (int32_t *)(base + b_mom + b_rss + b_lst);
+	return true;
+}
+
+// Wide designs (8 < p <= 128): the same four stages on the MFMA / LDS kernels, slab by slab.
+bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const int64_t *d_off,
+                    const double *d_y, const double *const *x_cols, const double *d_w,
+                    const AnofoxHipBatchOptions &opt, double *d_core, double *d_inf, AnofoxError *e) {
+	(void)n_rows;
+	const int T = wide_tiles((int)p);
+	const size_t rec_bytes = (size_t)wide_record_len(T) * sizeof(double);
+	// the moment scratch is reused by slabs of groups: at most ~1 GiB of it is live
+	int64_t slab = (int64_t)((size_t)1 << 30) / (int64_t)rec_bytes;
+	if (slab < 256) slab = 256;
+	if (slab > G) slab = G;
+	const size_t b_mom = align_up((size_t)slab * rec_bytes, 256);
+	const size_t b_rss = align_up((size_t)G * (p + 2) * sizeof(double), 256);
+	const size_t b_lst = align_up((size_t)slab * sizeof(int32_t), 256);
+	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256, "workspace", e)) return false;
+	char *base = (char *)ctx->ws;
+
+	WideArgs a;
+	memset(&a, 0, sizeof a);
+	a.row_offsets = d_off;
+	a.y = d_y;
+	for (size_t j = 0; j < p; ++j) a.x_table[j] = x_cols[j];
+	a.w = d_w;
+	a.p = (int)p;
+	a.model = (int)opt.model;
+	a.fit_intercept = opt.fit_intercept ? 1 : 0;
+	a.compute_inference = opt.compute_inference ? 1 : 0;
+	a.lambda_scaling = (int)opt.lambda_scaling;
+	a.confidence_level = opt.confidence_level;
+	a.alpha = opt.alpha;
+	a.moments = (double *)base;
+	a.refine_vec = (double *)(base + b_mom);
+	a.refine_list = (int32_t *)(base + b_mom + b_rss);
+	a.refine_count = (int32_t *)(base + b_mom + b_rss + b_lst);
+	a.core = d_core;
+	a.inference = opt.compute_inference ? d_inf : nullptr;
+
+	hipStream_t st = ctx->stream;
+	for (int64_t g0 = 0; g0 < G; g0 += slab) {
+		a.group_base = g0;
+		a.n_groups = (G - g0 < slab) ? G - g0 : slab;
+		if (hip_fail(hipMemsetAsync(a.refine_count, 0, sizeof(int32_t), st), "hipMemsetAsync", e)) return false;
+		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+		if (ctx->timing) {
+			e0 = get_event(ctx);
+			e1 = get_event(ctx);
+			e2 = get_event(ctx);
+			(void)hipEventRecord(e0, st);
+		}
+		if (hip_fail(launch_accumulate_wide(a, st), "wide accumulate kernel launch", e)) return false;
+		if (ctx->timing) (void)hipEventRecord(e1, st);
+		if (hip_fail(launch_solve_wide(a, 0, st), "wide solve kernel launch", e)) return false;
+		for (int it = 0; it < kRefineSteps; ++it) { // queued groups only: b += (X'WX)^-1 X'Wr
+			if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
+			if (hip_fail(launch_solve_wide(a, 1, st), "wide refine kernel launch", e)) return false;
+		}
+		if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
+		if (hip_fail(launch_solve_wide(a, 2, st), "wide final kernel launch", e)) return false;
+		if (ctx->timing) {
+			(void)hipEventRecord(e2, st);
+			ctx->acc_events.emplace_back(e0, e1);
+			ctx->solve_events.emplace_back(e1, e2);
+		}
+	}
 	return true;
 }
 
@@ -118,6 +187,7 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
                       const double *d_y, const double *const *x_cols, const double *d_w,
                       const AnofoxHipBatchOptions &opt, double *d_core, double *d_inf, AnofoxError *e) {
 	if (G == 0) return true;
+	if (p > (size_t)kNarrowMaxP) return run_wide_batch(ctx, G, p, n_rows, d_off, d_y, x_cols, d_w, opt, d_core, d_inf, e);
 	Workspace ws;
 	if (!carve_workspace(ctx, G, (int)p, &ws, e)) return false;
 
@@ -141,7 +211,7 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	a.inference = opt.compute_inference ? d_inf : nullptr;
 	a.refine_list = ws.refine_list;
 	a.refine_count = ws.refine_count;
-	a.rss_direct = ws.rss_direct;
+	a.refine_vec = ws.refine_vec;
 
 	hipStream_t st = ctx->stream;
 	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, sizeof(int32_t), st), "hipMemsetAsync", e)) return false;
@@ -155,9 +225,13 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	}
 	if (hip_fail(launch_accumulate_narrow(a, st), "accumulate kernel launch", e)) return false;
 	if (ctx->timing) (void)hipEventRecord(e1, st);
-	if (hip_fail(launch_solve_narrow(a, false, st), "solve kernel launch", e)) return false;
-	if (hip_fail(launch_residual_rss(a, st), "residual kernel launch", e)) return false;
-	if (hip_fail(launch_solve_narrow(a, true, st), "refine kernel launch", e)) return false;
+	if (hip_fail(launch_solve_narrow(a, 0, st), "solve kernel launch", e)) return false;
+	for (int it = 0; it < kRefineSteps; ++it) { // queued groups only: b += (X'WX)^-1 X'Wr
+		if (hip_fail(launch_residual_grad(a, st), "residual kernel launch", e)) return false;
+		if (hip_fail(launch_solve_narrow(a, 1, st), "refine kernel launch", e)) return false;
+	}
+	if (hip_fail(launch_residual_grad(a, st), "residual kernel launch", e)) return false;
+	if (hip_fail(launch_solve_narrow(a, 2, st), "final kernel launch", e)) return false;
 	if (ctx->timing) {
 		(void)hipEventRecord(e2, st);
 		ctx->acc_events.emplace_back(e0, e1);   // owns e0 and e1
@@ -172,9 +246,9 @@ bool validate_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
 	if (G < 0 || n_rows < 0) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "negative n_groups or n_rows"); return false; }
 	if (p == 0 || !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x is NULL or empty"); return false; }
-	if (p > (size_t)kNarrowMaxP) {
+	if (p > (size_t)kWideMaxP) {
 		set_error(e, ANOFOX_ERROR_INVALID_INPUT,
-		          "n_features = " + std::to_string(p) + " exceeds the supported maximum of " + std::to_string(kNarrowMaxP));
+		          "n_features = " + std::to_string(p) + " exceeds the supported maximum of " + std::to_string(kWideMaxP));
 		return false;
 	}
 	if (G > 0 && (!off || !y || !core)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "row_offsets, y or core is NULL"); return false; }
@@ -212,7 +286,7 @@ const char *anofox_hip_version(void) { return "anofox_stats_hip 0.1 gfx950"; }
 
 size_t anofox_hip_core_record_len(size_t p) { return p + 6; }
 size_t anofox_hip_inference_record_len(size_t p) { return 5 * p + 2; }
-size_t anofox_hip_max_features(void) { return (size_t)kNarrowMaxP; }
+size_t anofox_hip_max_features(void) { return (size_t)kWideMaxP; }
 
 bool anofox_hip_context_create(int device_id, AnofoxHipContext **out_ctx, AnofoxError *out_error) {
 	reset_error(out_error);
@@ -365,7 +439,7 @@ bool anofox_hip_fit_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n
 		char *cur = base + b_off;
 		hipStream_t st = ctx->stream;
 		if (hip_fail(hipMemcpyAsync(d_off, off.data(), ((size_t)G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D offsets", out_error)) return false;
-		const double *d_x[kNarrowMaxP];
+		const double *d_x[kWideMaxP];
 		for (size_t j = 0; j < p; ++j) {
 			if (R > 0 && hip_fail(hipMemcpyAsync(cur, x_cols[j] + r0, (size_t)R * sizeof(double), hipMemcpyHostToDevice, st), "H2D x", out_error)) return false;
 			d_x[j] = (const double *)cur;
@@ -448,8 +522,8 @@ bool fit_single(const char *what, AnofoxDataArray y, const AnofoxDataArray *x, s
 		}
 	}
 	const size_t p = x_count, n = y.len;
-	if (p > (size_t)kNarrowMaxP) {
-		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, std::string(what) + ": more than " + std::to_string(kNarrowMaxP) + " features are not supported by the GPU path yet");
+	if (p > (size_t)kWideMaxP) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, std::string(what) + ": more than " + std::to_string(kWideMaxP) + " features are not supported by the GPU path");
 		return false;
 	}
 	// The kernels apply the aggregate's "< 2 rows -> NULL" rule from row_offsets; a single-group call has no

@@ -9,9 +9,14 @@
 //     (shifted) moment matrix with aliased-pivot detection, two triangular solves, and the closed forms for
 //     R^2, adjusted R^2, sigma, SE, t, p, CI and F
 //   - NaN re-expansion at dropped columns: ols.rs:167-171,191-206
-// Groups whose residual sum of squares is too small relative to the total to be trusted from the moment
-// identity (RSS = Syy - b'Sxy) are queued for residual_rss_kernel, which re-reads the group's rows and sums
-// squared residuals directly; the solve then runs a second time for those groups only.
+//
+// Normal equations square the condition number, and RSS = Syy - b'Sxy cancels when R^2 -> 1.  Groups where
+// either matters (smallest Cholesky pivot ratio < 1e-3, or RSS/TSS < 1e-7) are queued on the device; for
+// those groups only, residual_grad_kernel re-reads the rows and forms the residuals r = y - b0 - x'b, their
+// weighted sum of squares and the gradient X'Wr directly from the data, and the solve runs again in
+//   MODE 1: one step of iterative refinement  b += (X'WX)^-1 X'Wr   (twice), then
+//   MODE 2: final statistics from the directly summed RSS.
+// This restores the accuracy of a QR on the design (the reference's algorithm class) for the queued groups.
 #include "common.h"
 #include "device_math.h"
 
@@ -19,13 +24,16 @@ namespace anofox {
 
 namespace {
 
-constexpr double kAliasTol = 1e-11;  // pivot / original diagonal below this => column aliased (collinear)
-constexpr double kRefineTol = 1e-7;  // RSS / TSS below this => recompute RSS from residuals
+constexpr double kAliasTol = 1e-11;   // pivot / original diagonal below this => column aliased (collinear)
+constexpr double kRefineTol = 1e-7;   // RSS / TSS below this => recompute RSS from residuals
+constexpr double kPivotWarn = 1e-3;   // smallest pivot ratio below this => iterative refinement
 
 __device__ __forceinline__ double nan64() { return __builtin_nan(""); }
 
-template <int P>
-__device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, double rss_in) {
+enum { MODE_PRIMARY = 0, MODE_UPDATE = 1, MODE_FINAL = 2 };
+
+template <int P, int MODE>
+__device__ void solve_one(const BatchArgs &args, int64_t g) {
 	using L = MomentLayout<P>;
 	constexpr int Z = L::Z;
 	const int p = P;
@@ -34,8 +42,8 @@ __device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, doubl
 
 	double *core = args.core + g * (int64_t)(p + 6);
 	double *inf = (args.inference && args.compute_inference) ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
+	const double *rv = args.refine_vec + g * (int64_t)(p + 2); // [rss, sum w r, X'Wr] from residual_grad_kernel
 
-	// default: NULL record
 	int status = ANOFOX_ERROR_SUCCESS;
 	double coef[P];
 	double se[P], tv[P], pv[P], cl[P], cu[P];
@@ -107,6 +115,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, doubl
 		double diag0[P];
 #pragma unroll
 		for (int j = 0; j < P; ++j) diag0[j] = A[j][j];
+		double min_ratio = 1.0;
 #pragma unroll
 		for (int j = 0; j < P; ++j) {
 			double d = A[j][j];
@@ -114,6 +123,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, doubl
 			for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
 			const bool ok = active[j] && (d > kAliasTol * diag0[j]) && (d > 0.0);
 			active[j] = ok;
+			if (ok) min_ratio = fmin(min_ratio, d / diag0[j]);
 			const double ljj = ok ? sqrt(d) : 1.0;
 			A[j][j] = ljj;
 			const double inv = 1.0 / ljj;
@@ -133,37 +143,58 @@ __device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, doubl
 #pragma unroll
 		for (int j = 0; j < P; ++j) rank += active[j] ? 1 : 0;
 
-		// forward solve L zf = c, back solve L' beta = zf
-		double zf[P], beta[P];
-		double zz = 0.0;
+		// L zf = rhs, L' x = zf
+		auto solve_llt = [&](const double (&rhs)[P], double (&zf)[P], double (&x)[P]) {
 #pragma unroll
-		for (int i = 0; i < P; ++i) {
-			double t = c[i];
+			for (int i = 0; i < P; ++i) {
+				double t = rhs[i];
 #pragma unroll
-			for (int k = 0; k < i; ++k) t -= A[i][k] * zf[k];
-			zf[i] = active[i] ? t / A[i][i] : 0.0;
-			zz += zf[i] * zf[i];
-		}
+				for (int k = 0; k < i; ++k) t -= A[i][k] * zf[k];
+				zf[i] = active[i] ? t / A[i][i] : 0.0;
+			}
 #pragma unroll
-		for (int i = P - 1; i >= 0; --i) {
-			double t = zf[i];
+			for (int i = P - 1; i >= 0; --i) {
+				double t = zf[i];
 #pragma unroll
-			for (int k = i + 1; k < P; ++k) t -= A[k][i] * beta[k];
-			beta[i] = active[i] ? t / A[i][i] : 0.0;
+				for (int k = i + 1; k < P; ++k) t -= A[k][i] * x[k];
+				x[i] = active[i] ? t / A[i][i] : 0.0;
+			}
+		};
+
+		double beta[P];
+		double rss;
+		if (MODE == MODE_PRIMARY) {
+			double zf[P];
+			solve_llt(c, zf, beta);
+			double zz = 0.0, bc = 0.0, bb = 0.0;
+#pragma unroll
+			for (int i = 0; i < P; ++i) { zz += zf[i] * zf[i]; bc += beta[i] * c[i]; bb += beta[i] * beta[i]; }
+			rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
+			refine = !(rss > kRefineTol * tss) || (min_ratio < kPivotWarn);
+		} else {
+			// current coefficients come from the record; residual_grad_kernel used exactly these
+#pragma unroll
+			for (int i = 0; i < P; ++i) {
+				const double b = core[i];
+				beta[i] = active[i] ? b : 0.0;
+			}
+			rss = rv[0];
 		}
 
-		double rss;
-		if (have_rss) {
-			rss = rss_in;
-		} else if (model == ANOFOX_HIP_MODEL_RIDGE) {
-			double bc = 0.0, bb = 0.0;
+		if (MODE == MODE_UPDATE) {
+			// gradient of the (penalised) objective at beta, in centred coordinates
+			const double gs = rv[1];
+			double gc[P], u[P], delta[P];
 #pragma unroll
-			for (int i = 0; i < P; ++i) { bc += beta[i] * c[i]; bb += beta[i] * beta[i]; }
-			rss = tss - bc - lam * bb;
-		} else {
-			rss = tss - zz;
+			for (int i = 0; i < P; ++i) {
+				double gi = rv[2 + i];
+				if (icpt) gi -= (s[i] / sw) * gs;
+				gc[i] = active[i] ? gi - lam * beta[i] : 0.0;
+			}
+			solve_llt(gc, u, delta);
+#pragma unroll
+			for (int i = 0; i < P; ++i) beta[i] += delta[i];
 		}
-		if (!have_rss && !(rss > kRefineTol * tss)) refine = true;
 
 		const int n_par = rank + (icpt ? 1 : 0);
 		const double df = cnt - (double)n_par;
@@ -178,6 +209,12 @@ __device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, doubl
 		}
 #pragma unroll
 		for (int i = 0; i < P; ++i) coef[i] = active[i] ? beta[i] : nan64();
+		if (MODE == MODE_UPDATE) { // only the coefficients change in this pass
+#pragma unroll
+			for (int j = 0; j < P; ++j) core[j] = coef[j];
+			core[p] = intercept;
+			return;
+		}
 		r2 = 1.0 - rss / tss;
 		adj = 1.0 - (1.0 - r2) * (cnt - (icpt ? 1.0 : 0.0)) / df;
 		rse = sqrt(rss / df);
@@ -213,6 +250,8 @@ __device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, doubl
 		}
 	} while (false);
 
+	if (MODE == MODE_UPDATE) return; // queued groups always have status 0; nothing else to write
+
 	if (status != ANOFOX_ERROR_SUCCESS) {
 #pragma unroll
 		for (int j = 0; j < P; ++j) coef[j] = nan64();
@@ -243,7 +282,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g, bool have_rss, doubl
 		inf[5 * p] = fstat;
 		inf[5 * p + 1] = fp;
 	}
-	if (refine && status == ANOFOX_ERROR_SUCCESS) {
+	if (MODE == MODE_PRIMARY && refine && status == ANOFOX_ERROR_SUCCESS) {
 		const int slot = atomicAdd(args.refine_count, 1);
 		args.refine_list[slot] = (int32_t)g;
 	}
@@ -253,91 +292,124 @@ template <int P>
 __global__ __launch_bounds__(64) void solve_narrow_kernel(BatchArgs args) {
 	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (g >= args.n_groups) return;
-	solve_one<P>(args, g, false, 0.0);
+	solve_one<P, MODE_PRIMARY>(args, g);
 }
 
-// second pass over the queued groups only, with the directly summed RSS
-template <int P>
+// passes over the queued groups only
+template <int P, int MODE>
 __global__ __launch_bounds__(64) void solve_refine_kernel(BatchArgs args) {
 	const int n = *args.refine_count;
 	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const int64_t g = args.refine_list[i];
-		solve_one<P>(args, g, true, args.rss_direct[g]);
+		solve_one<P, MODE>(args, g);
 	}
 }
 
-// One wavefront per queued group: RSS = sum w (y - b0 - x'b)^2 over the valid rows, from the data.
-__global__ __launch_bounds__(256) void residual_rss_kernel(BatchArgs args) {
+// One wavefront per queued group, straight from the data with the record's current coefficients:
+//   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ... },  r = y - b0 - x'b
+// over the valid rows (same row filter as the accumulate kernel); shift = first valid row when an intercept
+// is fitted (the shift of the moment record), 0 otherwise.
+__global__ __launch_bounds__(256) void residual_grad_kernel(BatchArgs args) {
 	const int lane = threadIdx.x & 63;
 	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const int n_waves = (gridDim.x * blockDim.x) >> 6;
 	const int n = *args.refine_count;
 	const int p = args.p;
 	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
+	const int Z = p + 1;
+	const int off_first = Z + Z * (Z + 1) / 2 + 1;
+	const int rec_len = moment_record_len(p);
 	for (int i = wave; i < n; i += n_waves) {
 		const int64_t g = args.refine_list[i];
 		const double *core = args.core + g * (int64_t)(p + 6);
-		double b[kNarrowMaxP];
-		for (int j = 0; j < p; ++j) {
-			const double bj = core[j];
-			b[j] = isnan(bj) ? 0.0 : bj; // dropped / aliased columns do not enter the fit
+		const double *rec = args.moments + g * (int64_t)rec_len;
+		double b[kNarrowMaxP], sh[kNarrowMaxP], acc[kNarrowMaxP + 2];
+#pragma unroll
+		for (int j = 0; j < kNarrowMaxP; ++j) {
+			b[j] = sh[j] = 0.0;
+			if (j < p) {
+				const double bj = core[j];
+				b[j] = isnan(bj) ? 0.0 : bj; // dropped / aliased columns do not enter the fit
+				sh[j] = args.fit_intercept ? rec[off_first + j] : 0.0;
+			}
 		}
+#pragma unroll
+		for (int k = 0; k < kNarrowMaxP + 2; ++k) acc[k] = 0.0;
 		const double b0 = args.fit_intercept ? core[p] : 0.0;
 		const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
-		double acc = 0.0;
 		for (int64_t r = lo + lane; r < hi; r += 64) {
 			const double yv = args.y[r];
 			bool ok = isfinite(yv);
 			double fit = b0;
-			for (int j = 0; j < p; ++j) {
-				const double xv = args.x[j][r];
-				ok = ok && isfinite(xv);
-				fit = fma(b[j], xv, fit);
+			double xv[kNarrowMaxP];
+#pragma unroll
+			for (int j = 0; j < kNarrowMaxP; ++j) {
+				xv[j] = 0.0;
+				if (j < p) {
+					xv[j] = args.x[j][r];
+					ok = ok && isfinite(xv[j]);
+					fit = fma(b[j], xv[j], fit);
+				}
 			}
 			double wv = 1.0;
 			if (weighted) {
 				wv = args.w[r];
 				ok = ok && (wv > 0.0) && isfinite(wv);
 			}
-			const double e = yv - fit;
-			if (ok) acc = fma(wv * e, e, acc);
+			if (ok) {
+				const double e = yv - fit;
+				const double we = wv * e;
+				acc[0] = fma(we, e, acc[0]);
+				acc[1] += we;
+#pragma unroll
+				for (int j = 0; j < kNarrowMaxP; ++j)
+					if (j < p) acc[2 + j] = fma(we, xv[j] - sh[j], acc[2 + j]);
+			}
 		}
-		for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-		if (lane == 0) args.rss_direct[g] = acc;
+#pragma unroll
+		for (int k = 0; k < kNarrowMaxP + 2; ++k)
+			for (int m = 32; m >= 1; m >>= 1) acc[k] += __shfl_xor(acc[k], m, 64);
+		double *out = args.refine_vec + g * (int64_t)(p + 2);
+		double mine = 0.0;
+#pragma unroll
+		for (int k = 0; k < kNarrowMaxP + 2; ++k) mine = (lane == k) ? acc[k] : mine;
+		if (lane < p + 2) out[lane] = mine;
 	}
 }
 
 template <int P>
-hipError_t launch_solve_p(const BatchArgs &a, bool refine_pass, hipStream_t stream) {
-	if (refine_pass) {
-		hipLaunchKernelGGL((solve_refine_kernel<P>), dim3(256), dim3(64), 0, stream, a);
-	} else {
+hipError_t launch_solve_p(const BatchArgs &a, int mode, hipStream_t stream) {
+	if (mode == MODE_PRIMARY) {
 		const unsigned grid = (unsigned)((a.n_groups + 63) / 64);
 		hipLaunchKernelGGL((solve_narrow_kernel<P>), dim3(grid), dim3(64), 0, stream, a);
+	} else if (mode == MODE_UPDATE) {
+		hipLaunchKernelGGL((solve_refine_kernel<P, MODE_UPDATE>), dim3(256), dim3(64), 0, stream, a);
+	} else {
+		hipLaunchKernelGGL((solve_refine_kernel<P, MODE_FINAL>), dim3(256), dim3(64), 0, stream, a);
 	}
 	return hipGetLastError();
 }
 
 } // namespace
 
-hipError_t launch_solve_narrow(const BatchArgs &a, bool refine_pass, hipStream_t stream) {
+hipError_t launch_solve_narrow(const BatchArgs &a, int mode, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
 	switch (a.p) {
-	case 1: return launch_solve_p<1>(a, refine_pass, stream);
-	case 2: return launch_solve_p<2>(a, refine_pass, stream);
-	case 3: return launch_solve_p<3>(a, refine_pass, stream);
-	case 4: return launch_solve_p<4>(a, refine_pass, stream);
-	case 5: return launch_solve_p<5>(a, refine_pass, stream);
-	case 6: return launch_solve_p<6>(a, refine_pass, stream);
-	case 7: return launch_solve_p<7>(a, refine_pass, stream);
-	case 8: return launch_solve_p<8>(a, refine_pass, stream);
+	case 1: return launch_solve_p<1>(a, mode, stream);
+	case 2: return launch_solve_p<2>(a, mode, stream);
+	case 3: return launch_solve_p<3>(a, mode, stream);
+	case 4: return launch_solve_p<4>(a, mode, stream);
+	case 5: return launch_solve_p<5>(a, mode, stream);
+	case 6: return launch_solve_p<6>(a, mode, stream);
+	case 7: return launch_solve_p<7>(a, mode, stream);
+	case 8: return launch_solve_p<8>(a, mode, stream);
 	default: return hipErrorInvalidValue;
 	}
 }
 
-hipError_t launch_residual_rss(const BatchArgs &a, hipStream_t stream) {
+hipError_t launch_residual_grad(const BatchArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
-	hipLaunchKernelGGL(residual_rss_kernel, dim3(512), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(residual_grad_kernel, dim3(512), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 
