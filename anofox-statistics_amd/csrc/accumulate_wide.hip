@@ -27,6 +27,11 @@ namespace anofox {
 
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
 typedef double dbl4 __attribute__((ext_vector_type(4)));
+// column base pointers are parked in LDS as integers and turned back into *global* pointers, so that the
+// loads through them are global_load (a generic pointer read from memory would give flat_load, whose
+// s_waitcnt vmcnt(0) lgkmcnt(0) serialises every load behind the previous one)
+typedef const double __attribute__((address_space(1))) *gptr_t;
+typedef const dbl2u __attribute__((address_space(1))) *gptr2_t;
 
 namespace {
 
@@ -48,39 +53,40 @@ struct WideCfg {
 	static constexpr int OWN = (T + kWaves - 1) / kWaves;  // column blocks owned per wave
 };
 
+__device__ __forceinline__ double mask_f64(double v, long long m) {
+	return __longlong_as_double(__double_as_longlong(v) & m);
+}
+
 // One wave's share of a chunk: 4 slabs of MFMAs + the VALU side sums.  WAVE is a compile-time constant so
-// that the tile list unrolls into straight-line MFMAs.  `img` is the chunk's LDS image.
+// that the tile list unrolls into straight-line MFMAs.  `img` is the chunk's LDS image; every LDS read is
+// unconditional (padding columns hold zeros) and invalid rows are removed with a bit mask, so the slab is
+// branch-free.
 template <int T, int WAVE, bool WEIGHTED, bool CENTER>
-__device__ __forceinline__ void compute_chunk(const double *img, int p, int lane, unsigned rowmask,
-                                              const double (&first)[T], double first_y, unsigned colmask,
+__device__ __forceinline__ void compute_chunk(const double *img, int ycol, int lane, unsigned rowmask,
+                                              const double (&first)[T], double first_y,
                                               dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
                                               double (&sxy)[WideCfg<T>::OWN], unsigned &ncmask, double &sy,
                                               double &syy, double &sw) {
 	const int k = lane >> 4;
 	const int i = lane & 15;
-#pragma unroll
+#pragma unroll 1
 	for (int t = 0; t < kChunkRows / 4; ++t) {
 		const int row = 4 * t + k;
-		const bool rv = (rowmask >> row) & 1u;
+		const long long rm = -(long long)((rowmask >> row) & 1u); // all ones when the row is valid
 		double d[T];
 #pragma unroll
 		for (int I = 0; I < T; ++I) {
 			const double raw = img[(16 * I + i) * kLdsStride + row];
-			const bool use = rv && ((colmask >> I) & 1u);
-			const double dev = use ? raw - first[I] : 0.0; // deviation from the first valid row
-			d[I] = CENTER ? dev : (use ? raw : 0.0);
+			const double dev = mask_f64(raw - first[I], rm); // deviation from the first valid row
+			d[I] = CENTER ? dev : mask_f64(raw, rm);
 			if (I % kWaves == WAVE) {
 				// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row
 				ncmask |= !(fabs(dev) < 1e-10) ? (1u << I) : 0u;
 			}
 		}
-		const double yraw = img[p * kLdsStride + row];
-		const double dy = rv ? (CENTER ? yraw - first_y : yraw) : 0.0;
-		double w = rv ? 1.0 : 0.0;
-		if (WEIGHTED) {
-			const double wraw = img[(p + 1) * kLdsStride + row];
-			w = rv ? wraw : 0.0;
-		}
+		const double yraw = img[ycol * kLdsStride + row];
+		const double dy = mask_f64(CENTER ? yraw - first_y : yraw, rm);
+		const double w = mask_f64(WEIGHTED ? img[(ycol + 1) * kLdsStride + row] : 1.0, rm);
 		double a[T];
 #pragma unroll
 		for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? w * d[I] : d[I];
@@ -126,17 +132,25 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 
 	extern __shared__ double lds[];
 	// layout: image[2][ncol_pad][18] | colbase[ncol_pad] (as pointers) | rowmask partials [2][4]
+	// image columns: x_0..x_{p-1} | zeros up to 16T | y | w | padding to a multiple of 8
 	const int ncol_pad = wide_ncol_pad(p, WEIGHTED);
+	const int ycol = P16;
 	double *image = lds;
-	const double **colbase = reinterpret_cast<const double **>(lds + 2 * ncol_pad * kLdsStride);
+	unsigned long long *colbase = reinterpret_cast<unsigned long long *>(lds + 2 * ncol_pad * kLdsStride);
 	unsigned *maskslot = reinterpret_cast<unsigned *>(colbase + ncol_pad);
 
+	// source column c (x_0.., y, w) is staged by load slot c; slot -> image column: x in place, y/w after 16T
 	for (int c = threadIdx.x; c < ncol_pad; c += 256) {
-		const double *b = nullptr;
+		const double *b = args.y; // unused slots read y again and are dropped at the store
 		if (c < p) b = args.x_table[c];
-		else if (c == p) b = args.y;
 		else if (WEIGHTED && c == p + 1) b = args.w;
-		colbase[c] = b ? b + lo : nullptr;
+		colbase[c] = reinterpret_cast<unsigned long long>(b + lo);
+	}
+	// zero the padding columns p .. 16T-1 of both buffers once; nothing writes them afterwards
+	for (int idx = threadIdx.x; idx < 2 * (P16 - p) * kLdsStride; idx += 256) {
+		const int bufi = idx / ((P16 - p) * kLdsStride);
+		const int rem = idx - bufi * (P16 - p) * kLdsStride;
+		image[bufi * ncol_pad * kLdsStride + p * kLdsStride + rem] = 0.0;
 	}
 	__syncthreads();
 
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 	constexpr int kMaxLoads = (P16 + 2 + 7) / 8 / kWaves + 1;
 	const int colsub = lane >> 3;
 	const int rp = lane & 7;
-	const int n_loads_total = ncol_pad / 8;
+	const int n_loads_total = (ncol + 7) / 8; // load slots: 8 source columns each
 
 	dbl4 acc[Cfg::TPW];
 #pragma unroll
@@ -160,9 +174,6 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 	double first_y = 0.0;
 	bool have_first = false;
 	int cnt = 0;
-	unsigned colmask = 0;
-#pragma unroll
-	for (int I = 0; I < T; ++I) colmask |= ((16 * I + (lane & 15)) < p) ? (1u << I) : 0u;
 
 	const int64_t n_chunks = (nrows + kChunkRows - 1) / kChunkRows;
 	double v0[kMaxLoads], v1[kMaxLoads]; // staging registers: rows 2*rp, 2*rp+1 of this lane's columns
@@ -170,20 +181,20 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 	// issue the loads of one chunk (global -> registers); consumed by stage_store
 	auto stage_load = [&](int64_t chunk) {
 		const int64_t r0 = chunk * kChunkRows + 2 * rp; // row within the group
+		const bool full = (chunk + 1) * kChunkRows <= nrows; // wave-uniform: every row of the chunk exists
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
 			const int li = wave + kWaves * q;
 			v0[q] = v1[q] = 0.0;
-			if (li < n_loads_total) {
-				const double *b = colbase[8 * li + colsub];
-				if (b != nullptr) {
-					if (r0 + 1 < nrows) {
-						const dbl2u v = *reinterpret_cast<const dbl2u *>(b + r0);
-						v0[q] = v.x;
-						v1[q] = v.y;
-					} else if (r0 < nrows) {
-						v0[q] = b[r0];
-					}
+			if (li < n_loads_total) { // wave-uniform
+				const gptr_t b = reinterpret_cast<gptr_t>(colbase[8 * li + colsub]);
+				if (full) {
+					const dbl2u v = *reinterpret_cast<gptr2_t>(b + r0);
+					v0[q] = v.x;
+					v1[q] = v.y;
+				} else {
+					if (r0 < nrows) v0[q] = b[r0];
+					if (r0 + 1 < nrows) v1[q] = b[r0 + 1];
 				}
 			}
 		}
@@ -196,19 +207,20 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 		for (int q = 0; q < kMaxLoads; ++q) {
 			const int li = wave + kWaves * q;
 			if (li < n_loads_total) {
-				const int col = 8 * li + colsub;
-				if (col < ncol) {
+				const int src = 8 * li + colsub;
+				if (src < ncol) {
 					bool f0 = isfinite(v0[q]), f1 = isfinite(v1[q]);
-					if (WEIGHTED && col == p + 1) {
+					if (WEIGHTED && src == p + 1) {
 						f0 = f0 && v0[q] > 0.0;
 						f1 = f1 && v1[q] > 0.0;
 					}
 					ok0 = ok0 && f0;
 					ok1 = ok1 && f1;
+					const int col = src < p ? src : ycol + (src - p);
+					double *dst = img + col * kLdsStride + 2 * rp;
+					dst[0] = v0[q];
+					dst[1] = v1[q];
 				}
-				double *dst = img + col * kLdsStride + 2 * rp;
-				dst[0] = v0[q];
-				dst[1] = v1[q];
 			}
 		}
 		// fold the 8 column sub-groups: bit m = rows 2m / 2m+1 valid in every column this wave staged
@@ -245,19 +257,16 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 			if (!have_first) {
 				const int r = __ffs((int)rowmask) - 1;
 #pragma unroll
-				for (int I = 0; I < T; ++I) {
-					const int col = 16 * I + (lane & 15);
-					first[I] = (col < p) ? img[col * kLdsStride + r] : 0.0;
-				}
-				first_y = img[p * kLdsStride + r];
+				for (int I = 0; I < T; ++I) first[I] = img[(16 * I + (lane & 15)) * kLdsStride + r]; // padding: 0
+				first_y = img[ycol * kLdsStride + r];
 				have_first = true;
 			}
 			cnt += __popc(rowmask);
 			switch (wave) {
-			case 0: compute_chunk<T, 0, WEIGHTED, CENTER>(img, p, lane, rowmask, first, first_y, colmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			case 1: compute_chunk<T, 1, WEIGHTED, CENTER>(img, p, lane, rowmask, first, first_y, colmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			case 2: compute_chunk<T, 2, WEIGHTED, CENTER>(img, p, lane, rowmask, first, first_y, colmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			default: compute_chunk<T, 3, WEIGHTED, CENTER>(img, p, lane, rowmask, first, first_y, colmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			case 0: compute_chunk<T, 0, WEIGHTED, CENTER>(img, ycol, lane, rowmask, first, first_y, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			case 1: compute_chunk<T, 1, WEIGHTED, CENTER>(img, ycol, lane, rowmask, first, first_y, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			case 2: compute_chunk<T, 2, WEIGHTED, CENTER>(img, ycol, lane, rowmask, first, first_y, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			default: compute_chunk<T, 3, WEIGHTED, CENTER>(img, ycol, lane, rowmask, first, first_y, acc, sx, sxy, ncmask, sy, syy, sw); break;
 			}
 		}
 		if (more) stage_store(c + 1, buf ^ 1);

@@ -75,11 +75,10 @@ inline __host__ __device__ int wide_tiles(int p) { return (p + 15) / 16; }
 //   tile (I <= J) number I*T - I(I-1)/2 + (J-I), element (r, c) at r*16 + c  =  M[16I + r][16J + c]
 //   scalars: sy, syy, sw, cnt, first_y
 inline __host__ __device__ int wide_record_len(int T) { return T * (T + 1) / 2 * 256 + 4 * 16 * T + 8; }
+// columns of the accumulate kernel's LDS image: 16T (x, zero padded) + y + w, rounded up to 8
 inline __host__ __device__ int wide_ncol_pad(int p, bool weighted) {
-	const int ncol = p + 1 + (weighted ? 1 : 0);
-	const int a = (ncol + 7) & ~7;
-	const int b = 16 * wide_tiles(p);
-	return a > b ? a : b;
+	(void)weighted;
+	return (16 * wide_tiles(p) + 2 + 7) & ~7;
 }
 
 struct WideArgs {

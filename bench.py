@@ -30,11 +30,21 @@ import torch.distributed as dist
 
 PKG = "anofox-statistics_amd"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+# FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak.  The guide lists the FP32 matrix peak (157.3 TFLOP/s = the
+# vector rate); FP64 MFMA runs at half of it on MI355X (AMD datasheet: 78.6 TFLOP/s FP64 matrix = FP64 vector).
+FP64_MFMA_PEAK_TFLOPS = 78.6
 
 
 def algorithmic_bytes_per_fit(n: int, p: int, weighted: bool, inference: bool) -> int:
     """8 n (p+1) [+ 8 n weights] input + 8 (p+6) core record [+ 8 (5p+2) inference]."""
     return 8 * n * (p + 1) + (8 * n if weighted else 0) + 8 * (p + 6) + (8 * (5 * p + 2) if inference else 0)
+
+
+def algorithmic_flops_per_fit(n: int, p: int) -> float:
+    """2 n (p'(p'+1)/2 + p' + 1) for the moment accumulation, p' = p + 1 (the O(p'^3) solve is
+    not counted)."""
+    pp = p + 1
+    return 2.0 * n * (pp * (pp + 1) / 2 + pp + 1)
 
 
 def parity_gate(pkg, core, inf, offs, y, x_cols, w, model, kw, p, sample):
@@ -124,7 +134,7 @@ def main():
     if need > 0.9 * free:
         raise SystemExit(f"rank {rank}: workload needs {need / 1e9:.1f} GB, only {free / 1e9:.1f} GB free")
     offs, y, x_cols, w = synth.make_grouped(G_local, n, p, group_start=lo, weights=weighted, device=dev,
-                                            chunk_groups=32768)
+                                            chunk_groups=max(1, min(32768, (1 << 25) // n)))
     kw = {"compute_inference": args.inference}
     if args.model == "ridge":
         kw["alpha"] = 1.0
@@ -173,15 +183,21 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         fits_per_s = G * args.steps / elapsed
         bytes_fit = algorithmic_bytes_per_fit(n, p, weighted, args.inference)
-        acc_ms = kt["accumulate_ms"] / max(kt["accumulate_count"], 1)
-        achieved = (G_local * bytes_fit) / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-        traffic = None
+        acc_ms = kt["accumulate_ms"] / max(kt["accumulate_count"], 1)   # per launch (wide designs: per slab)
+        acc_step_ms = kt["accumulate_ms"] / args.steps                      # all launches of one step
+        if p <= 8:
+            kernel, bound, unit, peak = "accumulate_narrow_kernel", "hbm", "GB/s", HBM_PEAK_GBS
+            per_step = G_local * bytes_fit
+            achieved = per_step / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0
+        else:
+            kernel, bound, unit, peak = "accumulate_wide_kernel", "mfma", "TFLOP/s", FP64_MFMA_PEAK_TFLOPS
+            per_step = G_local * algorithmic_flops_per_fit(n, p)
+            achieved = per_step / (acc_step_ms * 1e-3) / 1e12 if acc_step_ms > 0 else 0.0
+        traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (profiles/hbm_traffic.json), if recorded
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                t = json.load(open(tpath))
-                key = f"{args.model}_G{G_local}_n{n}_p{p}"
-                traffic = t.get(key)
+                traffic = json.load(open(tpath)).get(f"{args.model}_G{G_local}_n{n}_p{p}")
             except Exception:
                 traffic = None
         out = {
@@ -196,11 +212,13 @@ def main():
                        "partition": f"contiguous key ranges over {world} rank(s); all-gather of {p + 6}-double records"},
             "parity": {"ok": ok, "sample_groups_per_rank": min(args.parity_sample, G_local),
                        "max_coef_rel_err": cerr, "max_diag_rel_err": derr},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "accumulate_narrow_kernel", "avg_launch_ms": acc_ms,
-                         "algorithmic_bytes_per_launch": G_local * bytes_fit,
-                         "solve_avg_ms": kt["solve_ms"] / max(kt["solve_count"], 1)},
+            "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": kernel, "avg_launch_ms": acc_ms, "launches_per_step": kt["accumulate_count"] / args.steps,
+                         "kernel_ms_per_step": acc_step_ms,
+                         ("algorithmic_bytes_per_step" if bound == "hbm" else "algorithmic_flops_per_step"): per_step,
+                         "hbm_GBps_algorithmic": G_local * bytes_fit / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0,
+                         "solve_ms_per_step": kt["solve_ms"] / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(offs, y, x_cols, w, args.model, kw, n, p)
