@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libanofox_stats_hip.so")
+# ANOFOX_STATS_HIP_LIB selects another build of the same ABI (used for the diagnostic build with stamps)
+LIB_PATH = os.environ.get("ANOFOX_STATS_HIP_LIB") or os.path.join(_HERE, "libanofox_stats_hip.so")
 
 # --- enums (anofox_stats_hip.h) ------------------------------------------------
 ERROR_SUCCESS = 0

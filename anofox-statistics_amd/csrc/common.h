@@ -65,6 +65,7 @@ struct BatchArgs {
 	int32_t *refine_list; // [G]   groups whose RSS must be recomputed from residuals
 	int32_t *refine_count; // [1]
 	double *refine_vec;   // [G * (p+2)]  {sum w r^2, sum w r, X'Wr} of the queued groups
+	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
 };
 
 // ---- wide path (8 < p <= kWideMaxP): FP64-MFMA accumulation, LDS Cholesky ----
@@ -101,6 +102,7 @@ struct WideArgs {
 	int32_t *refine_list; // [G_total]
 	int32_t *refine_count;
 	double *refine_vec;   // [G_total * (p+2)]
+	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
 };
 
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);

@@ -12,35 +12,34 @@
 
 namespace anofox {
 
+// Continued fraction of the incomplete beta function, evaluated with the forward (Wallis) recurrence on the
+// convergents, renormalised every step: two divisions per iteration (the modified-Lentz form needs six, and
+// f64 division is a ~15-instruction dependent chain on the VALU).
 __device__ __forceinline__ double dm_betacf(double a, double b, double x) {
-	const double tiny = 1e-300;
 	const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
-	double c = 1.0;
-	double d = 1.0 - qab * x / qap;
-	if (fabs(d) < tiny) d = tiny;
-	d = 1.0 / d;
-	double h = d;
-	for (int m = 1; m <= 2000; ++m) {
-		const double dm = (double)m;
-		const double m2 = 2.0 * dm;
-		double aa = dm * (b - dm) * x / ((qam + m2) * (a + m2));
-		d = 1.0 + aa * d;
-		if (fabs(d) < tiny) d = tiny;
-		c = 1.0 + aa / c;
-		if (fabs(c) < tiny) c = tiny;
-		d = 1.0 / d;
-		h *= d * c;
-		aa = -(a + dm) * (qab + dm) * x / ((a + m2) * (qap + m2));
-		d = 1.0 + aa * d;
-		if (fabs(d) < tiny) d = tiny;
-		c = 1.0 + aa / c;
-		if (fabs(c) < tiny) c = tiny;
-		d = 1.0 / d;
-		const double del = d * c;
-		h *= del;
-		if (fabs(del - 1.0) < 2e-16) break;
+	double am = 1.0, bm = 1.0, az = 1.0;
+	double bz = 1.0 - qab * x / qap;
+	for (int m = 1; m <= 3000; ++m) {
+		const double em = (double)m;
+		const double tem = em + em;
+		const double a2 = a + tem;
+		// d_even = em (b - em) x / ((qam + tem)(a + tem)),  d_odd = -(a + em)(qab + em) x / ((a + tem)(qap + tem))
+		const double rden = 1.0 / ((qam + tem) * a2 * (qap + tem));
+		const double de = em * (b - em) * x * (qap + tem) * rden;
+		const double dod = -(a + em) * (qab + em) * x * (qam + tem) * rden;
+		const double ap = az + de * am;
+		const double bp = bz + de * bm;
+		const double app = ap + dod * az;
+		const double bpp = bp + dod * bz;
+		const double r = 1.0 / bpp;
+		const double aold = az;
+		am = ap * r;
+		bm = bp * r;
+		az = app * r;
+		bz = 1.0;
+		if (fabs(az - aold) <= 4e-16 * fabs(az)) break;
 	}
-	return h;
+	return az;
 }
 
 // I_x(a, b)
@@ -73,19 +72,14 @@ __device__ __forceinline__ double dm_t_upper(double t, double df) {
 	return 0.5 * dm_betainc(0.5 * df, 0.5, df / (df + t * t));
 }
 
-// Student-t quantile for prob in (0.5, 1): safeguarded Newton on the upper tail.
-static __device__ __attribute__((noinline)) double dm_t_quantile_upper(double prob, double df) {
-	if (!(prob > 0.5 && prob < 1.0) || !(df > 0.0)) {
-		if (prob == 0.5) return 0.0;
-		return __builtin_nan("");
-	}
+// Student-t quantile for prob in (0.5, 1), robust version: bracketing + safeguarded Newton on the upper tail.
+static __device__ __attribute__((noinline)) double dm_t_quantile_upper_slow(double prob, double df) {
 	const double tail = 1.0 - prob; // target upper-tail mass
 	double lo = 0.0, hi = 1.0;
 	for (int i = 0; i < 1100 && dm_t_upper(hi, df) > tail; ++i) {
 		lo = hi;
 		hi *= 2.0;
 	}
-	// log of the density's normalising constant
 	const double lnc = lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * 3.14159265358979323846);
 	double t = 0.5 * (lo + hi);
 	for (int it = 0; it < 100; ++it) {
@@ -101,6 +95,58 @@ static __device__ __attribute__((noinline)) double dm_t_quantile_upper(double pr
 		}
 		t = tn;
 	}
+	return t;
+}
+
+// Student-t quantile for prob in (0.5, 1): Cornish-Fisher start from the normal quantile
+// (Abramowitz & Stegun 26.7.5), polished by Newton steps on the exact tail; closed forms for df = 1, 2.
+static __device__ __attribute__((noinline)) double dm_t_quantile_upper(double prob, double df) {
+	if (!(prob > 0.5 && prob < 1.0) || !(df > 0.0)) {
+		if (prob == 0.5) return 0.0;
+		return __builtin_nan("");
+	}
+	if (df == 1.0) return tan(3.14159265358979323846 * (prob - 0.5));
+	if (df == 2.0) return (2.0 * prob - 1.0) / sqrt(2.0 * prob * (1.0 - prob));
+	const double tail = 1.0 - prob;
+	const double z = normcdfinv(prob);
+	const double z2 = z * z;
+	const double r = 1.0 / df;
+	const double g1 = z * (z2 + 1.0) * 0.25;
+	const double g2 = z * ((5.0 * z2 + 16.0) * z2 + 3.0) * (1.0 / 96.0);
+	const double g3 = z * (((3.0 * z2 + 19.0) * z2 + 17.0) * z2 - 15.0) * (1.0 / 384.0);
+	const double g4 = z * ((((79.0 * z2 + 776.0) * z2 + 1482.0) * z2 - 1920.0) * z2 - 945.0) * (1.0 / 92160.0);
+	double t = z + r * (g1 + r * (g2 + r * (g3 + r * g4)));
+	if (!(t > 0.0)) return dm_t_quantile_upper_slow(prob, df);
+	const double lnc = lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * 3.14159265358979323846);
+	for (int it = 0; it < 12; ++it) {
+		const double u = dm_t_upper(t, df);
+		const double pdf = exp(lnc - 0.5 * (df + 1.0) * log1p(t * t * r));
+		const double tn = t + (u - tail) / pdf;
+		if (!(tn > 0.0) || !isfinite(tn)) return dm_t_quantile_upper_slow(prob, df);
+		const bool done = fabs(tn - t) <= 1e-14 * fabs(tn);
+		t = tn;
+		if (done) return t;
+	}
+	return dm_t_quantile_upper_slow(prob, df);
+}
+
+// The critical value depends only on (confidence level, df): groups of one batch usually share df, so the
+// value is memoised in a small direct-mapped table in device memory (zeroed at the start of every batch call).
+struct TcritSlot {
+	unsigned long long key; // bits of df
+	double value;
+};
+constexpr int kTcritSlots = 64;
+
+static __device__ __forceinline__ double dm_tcrit_cached(TcritSlot *table, double prob, double df) {
+	if (!(df > 0.0)) return __builtin_nan("");
+	const unsigned long long key = (unsigned long long)__double_as_longlong(df);
+	TcritSlot *slot = table + (int)((key * 0x9E3779B97F4A7C15ull) >> 58); // top 6 bits
+	const unsigned long long seen = __hip_atomic_load(&slot->key, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+	if (seen == key) return __hip_atomic_load(&slot->value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const double t = dm_t_quantile_upper(prob, df);
+	__hip_atomic_store(&slot->value, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(&slot->key, key, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	return t;
 }
 

@@ -97,6 +97,7 @@ struct Workspace {
 	double *refine_vec;
 	int32_t *refine_list;
 	int32_t *refine_count;
+	void *tcrit_table;
 };
 
 bool carve_workspace(AnofoxHipContext *ctx, int64_t G, int p, Workspace *out, AnofoxError *e) {
@@ -104,13 +105,14 @@ bool carve_workspace(AnofoxHipContext *ctx, int64_t G, int p, Workspace *out, An
 	const size_t b_mom = align_up((size_t)G * rec * sizeof(double), 256);
 	const size_t b_rss = align_up((size_t)G * (size_t)(p + 2) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)G * sizeof(int32_t), 256);
-	const size_t total = b_mom + b_rss + b_lst + 256;
+	const size_t total = b_mom + b_rss + b_lst + 256 + 1024;
 	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, total, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 	out->moments = (double *)base;
 	out->refine_vec = (double *)(base + b_mom);
 	out->refine_list = (int32_t *)(base + b_mom + b_rss);
 	out->refine_count = (int32_t *)(base + b_mom + b_rss + b_lst);
+	out->tcrit_table = base + b_mom + b_rss + b_lst + 256;
 	return true;
 }
 
@@ -128,7 +130,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	const size_t b_mom = align_up((size_t)slab * rec_bytes, 256);
 	const size_t b_rss = align_up((size_t)G * (p + 2) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)slab * sizeof(int32_t), 256);
-	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256, "workspace", e)) return false;
+	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256 + 1024, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 
 	WideArgs a;
@@ -148,10 +150,12 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.refine_vec = (double *)(base + b_mom);
 	a.refine_list = (int32_t *)(base + b_mom + b_rss);
 	a.refine_count = (int32_t *)(base + b_mom + b_rss + b_lst);
+	a.tcrit_table = base + b_mom + b_rss + b_lst + 256;
 	a.core = d_core;
 	a.inference = opt.compute_inference ? d_inf : nullptr;
 
 	hipStream_t st = ctx->stream;
+	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, 1024, st), "hipMemsetAsync", e)) return false;
 	for (int64_t g0 = 0; g0 < G; g0 += slab) {
 		a.group_base = g0;
 		a.n_groups = (G - g0 < slab) ? G - g0 : slab;
@@ -212,9 +216,10 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	a.refine_list = ws.refine_list;
 	a.refine_count = ws.refine_count;
 	a.refine_vec = ws.refine_vec;
+	a.tcrit_table = ws.tcrit_table;
 
 	hipStream_t st = ctx->stream;
-	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, sizeof(int32_t), st), "hipMemsetAsync", e)) return false;
+	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, 256 + 1024, st), "hipMemsetAsync", e)) return false; // counter + t table
 
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 	if (ctx->timing) {

@@ -225,7 +225,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 			has_inf = true;
 			fp = dm_f_sf(fstat, dfm, df);
 			const double sigma2 = rss / df;
-			const double tcrit = dm_t_quantile_upper(0.5 * (1.0 + args.confidence_level), df);
+			const double tcrit = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
 			// diag of (L L')^-1 through the columns of L^-1
 #pragma unroll
 			for (int j = 0; j < P; ++j) {

@@ -16,6 +16,18 @@ namespace anofox {
 
 namespace {
 
+// Diagnostic build only (-DANOFOX_SOLVE_STAMPS, csrc/Makefile target `diag`): workgroup 0 records s_memtime at
+// the phase boundaries of its first group into a buffer nothing else reads.  Not compiled into the product.
+#ifdef ANOFOX_SOLVE_STAMPS
+__device__ unsigned long long g_solve_stamps[32];
+#define SOLVE_STAMP(k)                                                                  \
+	do {                                                                                \
+		if (blockIdx.x == 0 && threadIdx.x == 0 && item == 0) g_solve_stamps[k] = __builtin_amdgcn_s_memtime(); \
+	} while (0)
+#else
+#define SOLVE_STAMP(k) do { } while (0)
+#endif
+
 constexpr double kAliasTolW = 1e-11;
 constexpr double kRefineTolW = 1e-7;
 constexpr double kPivotWarnW = 1e-3;
@@ -23,40 +35,281 @@ enum { MODE_PRIMARY = 0, MODE_UPDATE = 1, MODE_FINAL = 2 };
 
 __device__ __forceinline__ double nan64w() { return __builtin_nan(""); }
 
+// LDS layout of one group (doubles): A[(P16+1) x LD] | sv | fx | diag0 | ldiag | linv | zv | bv | tmp[(T-1) x 256] | red[16]
+//   then ints: active[P16] | live[P16]
+// A rows 0..P16-1 are the (zero padded) x columns, row P16 is the y row of the augmented matrix
+//   [ Sxx  Sxy ]      Cholesky of the leading block leaves  z = L^-1 Sxy  in the y row, so the forward solve
+//   [ Sxy' Syy ]      is free and RSS = Syy - |z|^2.
+// Lower triangle: L.  Upper triangle: W = L^-1 stored transposed (W[i][j] at A[j][i], i > j), diag of W in linv.
+struct WideLds {
+	int P16, LD, T;
+	double *A, *sv, *fx, *diag0, *ldiag, *linv, *zv, *bv, *tmp, *red;
+	int *active, *live;
+};
+
+__device__ __forceinline__ WideLds carve_lds(double *sm, int p) {
+	WideLds l;
+	l.T = wide_tiles(p);
+	l.P16 = 16 * l.T;
+	l.LD = l.P16 + 1;
+	l.A = sm;
+	l.sv = l.A + (size_t)(l.P16 + 1) * l.LD;
+	l.fx = l.sv + l.P16;
+	l.diag0 = l.fx + l.P16;
+	l.ldiag = l.diag0 + l.P16;
+	l.linv = l.ldiag + l.P16;
+	l.zv = l.linv + l.P16;
+	l.bv = l.zv + l.P16;
+	l.tmp = l.bv + l.P16;
+	l.red = l.tmp + (l.T > 1 ? (l.T - 1) * 256 : 0);
+	l.active = reinterpret_cast<int *>(l.red + 16);
+	l.live = l.active + l.P16;
+	return l;
+}
+
+__device__ __forceinline__ double rl_f64(double v, int src_lane) {
+	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+	                        __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
+// sum over the 256 threads of a workgroup; every thread gets the result.  `slot` = 4 doubles of LDS scratch.
+__device__ __forceinline__ double block_sum(double v, double *slot, int tid) {
+	for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+	if ((tid & 63) == 0) slot[tid >> 6] = v;
+	__syncthreads();
+	const double tot = slot[0] + slot[1] + slot[2] + slot[3];
+	__syncthreads();
+	return tot;
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+	// orders the LDS traffic of the lanes of ONE wavefront (used where a single wave works on a 16x16 block)
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// W[kk][jj] for kk >= jj
+__device__ __forceinline__ double getW(const WideLds &l, int kk, int jj) {
+	return kk > jj ? l.A[(size_t)jj * l.LD + kk] : (kk == jj ? l.linv[kk] : 0.0);
+}
+
+// Blocked right-looking Cholesky of the augmented matrix in LDS (block size 16), deactivating constant and
+// aliased columns in place.  Returns (to every thread) the smallest accepted pivot ratio.
+__device__ double blocked_cholesky(const WideLds &l, int tid) {
+	const int P16 = l.P16, LD = l.LD, T = l.T;
+	double *A = l.A;
+	const int lane = tid & 63;
+	const int wave = tid >> 6;
+	if (tid == 0) l.red[7] = 1.0;
+	for (int kb = 0; kb < T; ++kb) {
+		const int k0 = 16 * kb;
+		__syncthreads();
+#ifdef ANOFOX_SOLVE_STAMPS
+		if (blockIdx.x == 0 && tid == 0 && kb == 0) g_solve_stamps[8] = __builtin_amdgcn_s_memtime();
+#endif
+		if (wave == 0) {
+			// (a) factor the 16x16 diagonal block in registers: lane r (mod 16) owns row r; column j is finished
+			// left-looking with the already final columns k < j, whose row-j entries are broadcast by readlane.
+			const int r = lane & 15;
+			double arow[16], lrow[16];
+#pragma unroll
+			for (int c = 0; c < 16; ++c) arow[c] = A[(size_t)(k0 + r) * LD + k0 + c];
+			double min_ratio = l.red[7];
+			const double d0 = l.diag0[k0 + r];
+			const int act = l.active[k0 + r];
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				double t = arow[j];
+#pragma unroll
+				for (int k = 0; k < j; ++k) t -= lrow[k] * rl_f64(lrow[k], j); // L[r][k] * L[j][k]
+				const double d = rl_f64(t, j);
+				const double dj0 = rl_f64(d0, j);
+				const bool ok = (__builtin_amdgcn_readlane(act, j) != 0) && (d > kAliasTolW * dj0) && (d > 0.0);
+				const double inv = ok ? rsqrt(d) : 0.0;
+				const double ljj = ok ? d * inv : 1.0;
+				if (ok) min_ratio = fmin(min_ratio, d / dj0);
+				lrow[j] = (r > j) ? t * inv : ((r == j) ? ljj : 0.0); // aliased / constant: column := 0
+				if (lane == j) {
+					l.ldiag[k0 + j] = ljj;
+					l.linv[k0 + j] = inv;
+					l.live[k0 + j] = ok ? 1 : 0;
+				}
+			}
+			if (lane < 16) {
+#pragma unroll
+				for (int c = 0; c < 16; ++c)
+					if (c < r) A[(size_t)(k0 + r) * LD + k0 + c] = lrow[c];
+			}
+			if (lane == 0) l.red[7] = min_ratio;
+		}
+		__syncthreads();
+#ifdef ANOFOX_SOLVE_STAMPS
+		if (blockIdx.x == 0 && tid == 0 && kb == 0) g_solve_stamps[9] = __builtin_amdgcn_s_memtime();
+#endif
+		// (b) panel: rows below the block (and the y row): X := X L_kk^-T, one thread per row
+		const int n_below = P16 - k0 - 16 + 1;
+		if (tid < n_below) {
+			const int i = k0 + 16 + tid;
+			double x[16];
+#pragma unroll
+			for (int c = 0; c < 16; ++c) x[c] = A[(size_t)i * LD + k0 + c];
+#pragma unroll
+			for (int c = 0; c < 16; ++c) {
+				double sacc = x[c];
+#pragma unroll
+				for (int m = 0; m < c; ++m) sacc -= x[m] * A[(size_t)(k0 + c) * LD + k0 + m];
+				x[c] = sacc * l.linv[k0 + c];
+			}
+#pragma unroll
+			for (int c = 0; c < 16; ++c) A[(size_t)i * LD + k0 + c] = x[c];
+		}
+		__syncthreads();
+#ifdef ANOFOX_SOLVE_STAMPS
+		if (blockIdx.x == 0 && tid == 0 && kb == 0) g_solve_stamps[10] = __builtin_amdgcn_s_memtime();
+#endif
+		// (c) trailing update with the 16 new columns, 4x4 register tiles over the lower triangle
+		const int mrem = P16 - k0 - 16; // remaining x rows (multiple of 16)
+		const int nt = mrem >> 2;
+		const int ta = tid >> 4, tb = tid & 15;
+		for (int a4 = ta; a4 < nt; a4 += 16) {
+			for (int b4 = tb; b4 <= a4; b4 += 16) {
+				const int i0 = k0 + 16 + 4 * a4, c0 = k0 + 16 + 4 * b4;
+				double acc[4][4];
+#pragma unroll
+				for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+					for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = 0.0;
+#pragma unroll 4
+				for (int m = 0; m < 16; ++m) {
+					double xa[4], xb[4];
+#pragma unroll
+					for (int rr = 0; rr < 4; ++rr) xa[rr] = A[(size_t)(i0 + rr) * LD + k0 + m];
+#pragma unroll
+					for (int cc = 0; cc < 4; ++cc) xb[cc] = A[(size_t)(c0 + cc) * LD + k0 + m];
+#pragma unroll
+					for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+						for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = fma(xa[rr], xb[cc], acc[rr][cc]);
+				}
+#pragma unroll
+				for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+					for (int cc = 0; cc < 4; ++cc)
+						if (c0 + cc <= i0 + rr) A[(size_t)(i0 + rr) * LD + c0 + cc] -= acc[rr][cc];
+			}
+		}
+		// y row: 1 x 4 tiles
+		for (int b4 = tid; b4 < nt; b4 += 256) {
+			const int c0 = k0 + 16 + 4 * b4;
+			double acc[4] = {0.0, 0.0, 0.0, 0.0};
+			for (int m = 0; m < 16; ++m) {
+				const double xa = A[(size_t)P16 * LD + k0 + m];
+#pragma unroll
+				for (int cc = 0; cc < 4; ++cc) acc[cc] = fma(xa, A[(size_t)(c0 + cc) * LD + k0 + m], acc[cc]);
+			}
+#pragma unroll
+			for (int cc = 0; cc < 4; ++cc) A[(size_t)P16 * LD + c0 + cc] -= acc[cc];
+		}
+#ifdef ANOFOX_SOLVE_STAMPS
+		__syncthreads();
+		if (blockIdx.x == 0 && tid == 0 && kb == 0) g_solve_stamps[11] = __builtin_amdgcn_s_memtime();
+#endif
+	}
+	__syncthreads();
+	return l.red[7];
+}
+
+// W = L^-1 by 16x16 blocks: diagonal blocks first (16 lanes per block), then the off-diagonal blocks along
+// anti-diagonals (block (ib, jb) needs only blocks (kb, jb), kb < ib).
+__device__ void blocked_tri_inverse(const WideLds &l, int tid) {
+	const int LD = l.LD, T = l.T;
+	double *A = l.A;
+	// diagonal blocks: quarter-wave q handles block q, lane c its column c
+	{
+		const int q = tid >> 4, c = tid & 15;
+		if (q < T) {
+			const int k0 = 16 * q;
+			double w[16];
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				double sacc = 0.0;
+#pragma unroll
+				for (int m = 0; m < r; ++m) sacc = fma(A[(size_t)(k0 + r) * LD + k0 + m], (m >= c) ? w[m] : 0.0, sacc);
+				w[r] = (r == c) ? l.linv[k0 + r] : ((r > c) ? -sacc * l.linv[k0 + r] : 0.0);
+			}
+#pragma unroll
+			for (int r = 1; r < 16; ++r)
+				if (r > c) A[(size_t)(k0 + c) * LD + k0 + r] = w[r];
+		}
+	}
+	__syncthreads();
+	const int r = tid >> 4, c = tid & 15;
+	for (int s = 1; s < T; ++s) {
+		const int nblk = T - s;
+		// stage 1: S = sum_kb L[ib][kb] W[kb][jb]   (all LDS reads unconditional; selects on the values)
+		for (int blk = 0; blk < nblk; ++blk) {
+			const int jb = blk, ib = blk + s;
+			const int i0 = 16 * ib, j0 = 16 * jb;
+			const double *lrow = A + (size_t)(i0 + r) * LD; // L[i0+r][*]
+			const double *wrow = A + (size_t)(j0 + c) * LD; // W[*][j0+c] stored transposed
+			double sacc = 0.0;
+			{ // kb == jb: W's diagonal block is lower triangular with diagonal linv
+				const double wd = l.linv[j0 + c];
+#pragma unroll
+				for (int m = 0; m < 16; ++m) {
+					const double raw = wrow[j0 + m];
+					const double wv = (m > c) ? raw : ((m == c) ? wd : 0.0);
+					sacc = fma(lrow[j0 + m], wv, sacc);
+				}
+			}
+			for (int kb = jb + 1; kb < ib; ++kb) {
+				const int q0 = 16 * kb;
+#pragma unroll
+				for (int m = 0; m < 16; ++m) sacc = fma(lrow[q0 + m], wrow[q0 + m], sacc);
+			}
+			l.tmp[blk * 256 + r * 16 + c] = sacc;
+		}
+		__syncthreads();
+		// stage 2: W[ib][jb] = -W[ib][ib] S
+		for (int blk = 0; blk < nblk; ++blk) {
+			const int jb = blk, ib = blk + s;
+			const int i0 = 16 * ib, j0 = 16 * jb;
+			const double wd = l.linv[i0 + r];
+			double sacc = 0.0;
+#pragma unroll
+			for (int m = 0; m < 16; ++m) {
+				const double raw = A[(size_t)(i0 + m) * LD + i0 + r]; // W[i0+r][i0+m] for m < r
+				const double wv = (m < r) ? raw : ((m == r) ? wd : 0.0);
+				sacc = fma(wv, l.tmp[blk * 256 + m * 16 + c], sacc);
+			}
+			A[(size_t)(j0 + c) * LD + i0 + r] = -sacc;
+		}
+		__syncthreads();
+	}
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
-	constexpr bool REFINE = MODE != MODE_PRIMARY;
 	extern __shared__ double sm[];
 	const int p = args.p;
-	const int T = wide_tiles(p);
-	const int P16 = 16 * T;
-	const int NT = T * (T + 1) / 2;
-	const int LD = p | 1; // odd leading dimension: walks down a column hit distinct banks
 	const int tid = threadIdx.x;
 	const bool icpt = args.fit_intercept != 0;
 	const int model = args.model;
+	const WideLds l = carve_lds(sm, p);
+	const int T = l.T, P16 = l.P16, LD = l.LD;
+	const int NT = T * (T + 1) / 2;
+	double *A = l.A;
 
-	// LDS: A[p][LD] | cv[p] | zf[p] | sv[p] | fx[p] | diag0[p] | ldiag[p] | active[p], live[p] (int) | red[8]
-	double *A = sm;
-	double *cv = A + (size_t)p * LD; // right-hand side c, later the coefficients
-	double *zf = cv + p;             // forward-solve result
-	double *sv = zf + p;             // column sums of the shifted data
-	double *fx = sv + p;             // x at the first valid row
-	double *diag0 = fx + p;
-	double *ldiag = diag0 + p;       // diagonal of L
-	int *active = reinterpret_cast<int *>(ldiag + p); // not constant (from the accumulate kernel)
-	int *live = active + p;                           // active and not aliased
-	double *red = reinterpret_cast<double *>(live + p); // 2p ints = 8p bytes: stays 8-byte aligned
-
-	const int n_items = REFINE ? *args.refine_count : (int)args.n_groups;
+	const int n_items = (MODE == MODE_PRIMARY) ? (int)args.n_groups : *args.refine_count;
 	for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-		const int64_t gl = REFINE ? (int64_t)args.refine_list[item] : (int64_t)item; // group within this launch
-		const int64_t g = args.group_base + gl;                                       // global group
+		const int64_t gl = (MODE == MODE_PRIMARY) ? (int64_t)item : (int64_t)args.refine_list[item]; // group within this launch
+		const int64_t g = args.group_base + gl;                                                       // global group
 		const double *rec = args.moments + gl * (int64_t)wide_record_len(T);
 		const double *vec = rec + (int64_t)NT * 256;
 		const double *sc = vec + 4 * P16;
 		double *core = args.core + g * (int64_t)(p + 6);
 		double *inf = (args.inference && args.compute_inference) ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
+		const double *rvec = args.refine_vec + g * (int64_t)(p + 2); // {sum w r^2, sum w r, X'Wr}
 		const int64_t nrows = args.row_offsets[g + 1] - args.row_offsets[g];
 
 		// a record whose fit failed (or has no inference block): everything NaN, status in the last slot
@@ -68,6 +321,7 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 		};
 
 		__syncthreads(); // the previous item's LDS contents are dead
+		SOLVE_STAMP(0);
 		const double sy = sc[0], syy = sc[1], sw = sc[2], cnt = sc[3], first_y = sc[4];
 		int status = ANOFOX_ERROR_SUCCESS;
 		if (nrows < 2) status = ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS;                                       // ols_aggregate.cpp:263-267
@@ -78,19 +332,15 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 			continue;
 		}
 
-		if (tid < 8) red[tid] = 0.0;
-		__syncthreads();
 		int mine = 0;
-		for (int j = tid; j < p; j += 256) {
-			const int a = vec[3 * P16 + j] != 0.0 ? 1 : 0;
-			active[j] = a;
-			sv[j] = vec[0 * P16 + j];
-			fx[j] = vec[2 * P16 + j];
+		for (int j = tid; j < P16; j += 256) {
+			const int a = (j < p && vec[3 * P16 + j] != 0.0) ? 1 : 0;
+			l.active[j] = a;
+			l.sv[j] = j < p ? vec[0 * P16 + j] : 0.0;
+			l.fx[j] = j < p ? vec[2 * P16 + j] : 0.0;
 			mine += a;
 		}
-		if (mine) atomicAdd(&red[0], (double)mine);
-		__syncthreads();
-		const int peff = (int)red[0];
+		const int peff = (int)block_sum((double)mine, l.red + 12, tid);
 
 		const double cyy_c = syy - sy * sy / sw;
 		const double ymean = (icpt ? first_y : 0.0) + sy / sw;
@@ -122,115 +372,114 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 		}
 		const double tss = icpt ? cyy_c : syy;
 
-		// moment matrix (lower triangle), centred when an intercept is fitted
-		for (int idx = tid; idx < p * p; idx += 256) {
-			const int i = idx / p, j = idx - i * p;
-			if (j > i) continue;
-			const int I = j >> 4, J = i >> 4; // M[j][i] lives in the upper-triangular tile (I <= J)
-			const int tile = I * T - I * (I - 1) / 2 + (J - I);
-			double v = rec[(int64_t)tile * 256 + (j & 15) * 16 + (i & 15)];
-			if (icpt) v -= sv[i] * sv[j] / sw;
-			if (i == j) v += lam;
-			A[(size_t)i * LD + j] = v;
-		}
-		for (int j = tid; j < p; j += 256) {
-			const double q = vec[1 * P16 + j];
-			cv[j] = icpt ? q - sv[j] * sy / sw : q;
-		}
-		__syncthreads();
-		for (int j = tid; j < p; j += 256) diag0[j] = A[(size_t)j * LD + j];
-		__syncthreads();
-
-		// ---- Cholesky, right-looking; the diagonal of L goes to ldiag, A[j][j] keeps the pivot ----
-		const int ti = tid >> 4, tk = tid & 15;
-		double min_ratio = 1.0;
-		for (int j = 0; j < p; ++j) {
-			const double d = A[(size_t)j * LD + j];
-			const bool ok = active[j] && (d > kAliasTolW * diag0[j]) && (d > 0.0);
-			if (ok) min_ratio = fmin(min_ratio, d / diag0[j]);
-			const double inv = ok ? 1.0 / sqrt(d) : 0.0;
-			for (int i = j + 1 + tid; i < p; i += 256) A[(size_t)i * LD + j] *= inv; // aliased / constant: column := 0
-			if (tid == 0) {
-				ldiag[j] = ok ? sqrt(d) : 1.0;
-				live[j] = ok ? 1 : 0;
-			}
-			__syncthreads();
-			if (ok) {
-				for (int i = j + 1 + ti; i < p; i += 16) {
-					const double lij = A[(size_t)i * LD + j];
-					for (int k = j + 1 + tk; k <= i; k += 16) A[(size_t)i * LD + k] -= lij * A[(size_t)k * LD + j];
+		// augmented moment matrix, lower triangle; centred when an intercept is fitted; padding rows/cols zero.
+		// The record is tile-major (256 contiguous doubles per 16x16 tile): thread t reads element t of each tile.
+		{
+			const int tr = tid >> 4, tc = tid & 15; // element (tr, tc) of an upper-triangular tile = M[16I+tr][16J+tc]
+			int tile = 0;
+			for (int I = 0; I < T; ++I) {
+				for (int J = I; J < T; ++J, ++tile) {
+					const int jj = 16 * I + tr, ii = 16 * J + tc; // jj <= ii except inside diagonal tiles
+					if (jj > ii) continue;
+					double v = 0.0;
+					if (ii < p) {
+						v = rec[(int64_t)tile * 256 + tid];
+						if (icpt) v -= l.sv[ii] * l.sv[jj] / sw;
+						if (ii == jj) v += lam;
+					}
+					A[(size_t)ii * LD + jj] = v;
 				}
 			}
-			__syncthreads();
+			for (int j = tid; j < P16; j += 256) { // y row: centred Sxy
+				double v = 0.0;
+				if (j < p) {
+					const double q = vec[1 * P16 + j];
+					v = icpt ? q - l.sv[j] * sy / sw : q;
+				}
+				A[(size_t)P16 * LD + j] = v;
+			}
 		}
+		__syncthreads();
+		for (int j = tid; j < P16; j += 256) l.diag0[j] = j < p ? A[(size_t)j * LD + j] : 1.0;
+		// blocked_cholesky starts with a barrier
+		SOLVE_STAMP(1);
+		const double min_ratio = blocked_cholesky(l, tid);
+		SOLVE_STAMP(2);
+		blocked_tri_inverse(l, tid);
+		SOLVE_STAMP(3);
 
-		// cv := (L L')^-1 cv
-		auto tri_solve = [&]() {
-			for (int j = 0; j < p; ++j) { // forward: L zf = cv
-				const bool lj = live[j] != 0;
-				const double zj = lj ? cv[j] / ldiag[j] : 0.0;
-				if (tid == 0) zf[j] = zj;
-				if (lj) for (int i = j + 1 + tid; i < p; i += 256) cv[i] -= A[(size_t)i * LD + j] * zj;
-				__syncthreads();
-			}
-			for (int j = p - 1; j >= 0; --j) { // back: L' x = zf, x -> cv
-				const bool lj = live[j] != 0;
-				const double bj = lj ? zf[j] / ldiag[j] : 0.0;
-				if (tid == 0) cv[j] = bj;
-				if (lj) for (int k = tid; k < j; k += 256) zf[k] -= A[(size_t)j * LD + k] * bj;
-				__syncthreads();
-			}
-		};
-		const double *rvec = args.refine_vec + g * (int64_t)(p + 2); // {sum w r^2, sum w r, X'Wr}
-		if (MODE == MODE_PRIMARY) {
-			tri_solve(); // cv = beta
-		} else if (MODE == MODE_UPDATE) {
-			// gradient of the (penalised) objective at the record's coefficients, centred coordinates
+		// z = y row; current / new coefficients
+		for (int j = tid; j < P16; j += 256) l.zv[j] = A[(size_t)P16 * LD + j];
+		__syncthreads();
+		if (MODE == MODE_UPDATE) {
+			// gradient of the (penalised) objective at the record's coefficients, centred: zv := W gc
 			const double gs = rvec[1];
-			for (int j = tid; j < p; j += 256) {
-				double gj = rvec[2 + j];
-				if (icpt) gj -= (sv[j] / sw) * gs;
-				const double bcur = live[j] ? core[j] : 0.0;
-				cv[j] = live[j] ? gj - lam * bcur : 0.0;
+			for (int j = tid; j < P16; j += 256) {
+				double gj = 0.0;
+				if (j < p && l.live[j]) {
+					gj = rvec[2 + j];
+					if (icpt) gj -= (l.sv[j] / sw) * gs;
+					gj -= lam * core[j];
+				}
+				l.bv[j] = gj;
 			}
 			__syncthreads();
-			tri_solve(); // cv = delta
-			for (int j = tid; j < p; j += 256) cv[j] += live[j] ? core[j] : 0.0;
-			__syncthreads();
-		} else {
-			for (int j = tid; j < p; j += 256) cv[j] = live[j] ? core[j] : 0.0;
+			for (int i = tid; i < P16; i += 256) {
+				double u = 0.0;
+				for (int j = 0; j <= i; ++j) u = fma(getW(l, i, j), l.bv[j], u);
+				l.zv[i] = u;
+			}
 			__syncthreads();
 		}
+		// bv_j = sum_{i >= j} W[i][j] zv_i  (= beta, or the refinement step delta);  dsum_j = sum_i W[i][j]^2
+		for (int j = tid; j < P16; j += 256) {
+			const double wjj = l.linv[j];
+			double bj = wjj * l.zv[j], dj = wjj * wjj;
+			for (int i = j + 1; i < P16; ++i) {
+				const double wv = A[(size_t)j * LD + i];
+				bj = fma(wv, l.zv[i], bj);
+				dj = fma(wv, wv, dj);
+			}
+			if (MODE == MODE_PRIMARY) l.bv[j] = bj;
+			else if (MODE == MODE_UPDATE) l.bv[j] = (j < p && l.live[j] ? core[j] : 0.0) + bj;
+			else l.bv[j] = (j < p && l.live[j]) ? core[j] : 0.0;
+			l.diag0[j] = dj; // diag0 is dead after the factorisation: reuse for diag((LL')^-1)
+		}
+		__syncthreads();
 
-		// block sums: rank, b'c, b'b, mean correction of the intercept
-		double rk = 0.0, bc = 0.0, bb = 0.0, xb = 0.0;
+		SOLVE_STAMP(4);
+		// block sums: rank, b'c, b'b, mean correction of the intercept, |z|^2
+		double rk = 0.0, bc = 0.0, bb = 0.0, xb = 0.0, zz = 0.0;
 		for (int j = tid; j < p; j += 256) {
-			if (live[j]) {
+			if (l.live[j]) {
 				rk += 1.0;
 				const double q = vec[1 * P16 + j];
-				const double cj = icpt ? q - sv[j] * sy / sw : q;
-				const double bj = cv[j];
+				const double cj = icpt ? q - l.sv[j] * sy / sw : q;
+				const double bj = l.bv[j];
 				bc += bj * cj;
 				bb += bj * bj;
-				xb += bj * ((icpt ? fx[j] : 0.0) + sv[j] / sw);
+				xb += bj * ((icpt ? l.fx[j] : 0.0) + l.sv[j] / sw);
+				const double zj = A[(size_t)P16 * LD + j];
+				zz += zj * zj;
 			}
 		}
-		atomicAdd(&red[2], rk);
-		atomicAdd(&red[3], bc);
-		atomicAdd(&red[4], bb);
-		atomicAdd(&red[5], xb);
-		__syncthreads();
-		const int rank = (int)red[2];
+		const double rk_t = block_sum(rk, l.red + 12, tid);
+		const double bc_t = block_sum(bc, l.red + 12, tid);
+		const double bb_t = block_sum(bb, l.red + 12, tid);
+		const double xb_t = block_sum(xb, l.red + 12, tid);
+		const double zz_t = block_sum(zz, l.red + 12, tid);
+		const int rank = (int)rk_t;
 		if (MODE == MODE_UPDATE) { // only the coefficients change in this pass
 			for (int k = tid; k <= p; k += 256) {
-				if (k < p) core[k] = live[k] ? cv[k] : nan64w();
-				else core[k] = icpt ? ymean - red[5] : nan64w();
+				if (k < p) core[k] = l.live[k] ? l.bv[k] : nan64w();
+				else core[k] = icpt ? ymean - xb_t : nan64w();
 			}
 			continue;
 		}
 		double rss;
 		if (MODE == MODE_FINAL) rss = rvec[0];
-		else rss = tss - red[3] - lam * red[4]; // = Syy - b'Sxy (- lam |b|^2 for ridge)
+		else if (model == ANOFOX_HIP_MODEL_RIDGE) rss = tss - bc_t - lam * bb_t;
+		else rss = tss - zz_t; // Syy - |L^-1 Sxy|^2
 		const bool refine = (MODE == MODE_PRIMARY) && (!(rss > kRefineTolW * tss) || min_ratio < kPivotWarnW);
 		const int n_par = rank + (icpt ? 1 : 0);
 		const double df = cnt - (double)n_par;
@@ -240,8 +489,8 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 
 		for (int k = tid; k < p + 6; k += 256) {
 			double v;
-			if (k < p) v = live[k] ? cv[k] : nan64w();
-			else if (k == p) v = icpt ? ymean - red[5] : nan64w();
+			if (k < p) v = l.live[k] ? l.bv[k] : nan64w();
+			else if (k == p) v = icpt ? ymean - xb_t : nan64w();
 			else if (k == p + 1) v = r2;
 			else if (k == p + 2) v = 1.0 - (1.0 - r2) * (cnt - (icpt ? 1.0 : 0.0)) / df;
 			else if (k == p + 3) v = sqrt(rss / df);
@@ -253,30 +502,18 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 			const int slot = atomicAdd(args.refine_count, 1);
 			args.refine_list[slot] = (int32_t)gl;
 		}
+		SOLVE_STAMP(5);
 
 		if (inf) {
-			if (tid == 0) red[6] = dm_t_quantile_upper(0.5 * (1.0 + args.confidence_level), df);
+			if (tid == 0) l.red[8] = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
 			__syncthreads();
-			const double tcrit = red[6];
+			const double tcrit = l.red[8];
 			const double sigma2 = rss / df;
-			// column j of L^-1, stored transposed in the upper triangle (W[i][j] -> A[j][i], i > j); one thread per column
 			for (int j = tid; j < p; j += 256) {
 				double se = nan64w(), tval = nan64w(), pval = nan64w(), lo = nan64w(), hi = nan64w();
-				if (live[j]) {
-					const double wjj = 1.0 / ldiag[j];
-					double dj = wjj * wjj;
-					for (int i = j + 1; i < p; ++i) {
-						double t = 0.0;
-						if (live[i]) {
-							t = A[(size_t)i * LD + j] * wjj;
-							for (int k = j + 1; k < i; ++k) t += A[(size_t)i * LD + k] * A[(size_t)j * LD + k];
-							t = -t / ldiag[i];
-						}
-						A[(size_t)j * LD + i] = t;
-						dj += t * t;
-					}
-					const double b = cv[j];
-					se = sqrt(sigma2 * dj);
+				if (l.live[j]) {
+					const double b = l.bv[j];
+					se = sqrt(sigma2 * l.diag0[j]);
 					tval = b / se;
 					pval = dm_t_two_sided_p(tval, df);
 					lo = b - tcrit * se;
@@ -293,6 +530,7 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 				inf[5 * p + 1] = dm_f_sf(fstat, dfm, df);
 			}
 		}
+		SOLVE_STAMP(6);
 	}
 }
 
@@ -379,8 +617,9 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 }
 
 size_t solve_wide_lds_bytes(int p) {
-	const int LD = p | 1;
-	return ((size_t)p * LD + 6 * (size_t)p + 8) * sizeof(double) + (2 * (size_t)p + 2) * sizeof(int);
+	const int T = wide_tiles(p), P16 = 16 * T, LD = P16 + 1;
+	const size_t dbl = (size_t)(P16 + 1) * LD + 7 * (size_t)P16 + (T > 1 ? (size_t)(T - 1) * 256 : 0) + 16;
+	return dbl * sizeof(double) + 2 * (size_t)P16 * sizeof(int);
 }
 
 } // namespace
@@ -408,6 +647,12 @@ hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream) {
 	}
 	return hipGetLastError();
 }
+
+#ifdef ANOFOX_SOLVE_STAMPS
+extern "C" __attribute__((visibility("default"))) int anofox_hip_diag_solve_stamps(unsigned long long *out32) {
+	return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_solve_stamps), 32 * sizeof(unsigned long long));
+}
+#endif
 
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
