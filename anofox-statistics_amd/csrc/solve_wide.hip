@@ -82,6 +82,14 @@ __device__ __forceinline__ double block_sum(double v, double *slot, int tid) {
 	return tot;
 }
 
+// t -> (a, b) with b <= a, t = a(a+1)/2 + b
+__device__ __forceinline__ void tri_decode(int t, int &a, int &b) {
+	a = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+	while (a * (a + 1) / 2 > t) --a;
+	while ((a + 1) * (a + 2) / 2 <= t) ++a;
+	b = t - a * (a + 1) / 2;
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
 	// orders the LDS traffic of the lanes of ONE wavefront (used where a single wave works on a 16x16 block)
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -111,30 +119,38 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 			// (a) factor the 16x16 diagonal block in registers: lane r (mod 16) owns row r; column j is finished
 			// left-looking with the already final columns k < j, whose row-j entries are broadcast by readlane.
 			const int r = lane & 15;
-			double arow[16], lrow[16];
+			double arow[16]; // row r of the block; column j becomes L[r][j] at step j (right-looking: the
+			                 // 15-j updates of a step are independent, the only chain is pivot -> rsqrt -> scale)
 #pragma unroll
 			for (int c = 0; c < 16; ++c) arow[c] = A[(size_t)(k0 + r) * LD + k0 + c];
 			double min_ratio = l.red[7];
 			const double d0 = l.diag0[k0 + r];
+			const double d0inv = 1.0 / d0;
 			const int act = l.active[k0 + r];
 #pragma unroll
 			for (int j = 0; j < 16; ++j) {
-				double t = arow[j];
+				// The pivot is wave-uniform, but it is deliberately laundered into a vector register: with a scalar
+				// condition the compiler emits ~8 scalar branches per pivot, with a vector one plain selects.
+				double d = rl_f64(arow[j], j);
+				double dj0 = rl_f64(d0, j);
+				int actj = __builtin_amdgcn_readlane(act, j);
+				asm volatile("" : "+v"(d), "+v"(dj0), "+v"(actj));
+				const bool ok = (actj != 0) && (d > kAliasTolW * dj0) && (d > 0.0);
+				const double inv0 = rsqrt(ok ? d : 1.0);
+				const double inv = ok ? inv0 : 0.0;
+				const double ljj = ok ? d * inv0 : 1.0;
+				min_ratio = ok ? fmin(min_ratio, d * rl_f64(d0inv, j)) : min_ratio;
+				const double lrj = (r > j) ? arow[j] * inv : 0.0; // aliased / constant: column := 0
+				arow[j] = (r == j) ? ljj : lrj;
 #pragma unroll
-				for (int k = 0; k < j; ++k) t -= lrow[k] * rl_f64(lrow[k], j); // L[r][k] * L[j][k]
-				const double d = rl_f64(t, j);
-				const double dj0 = rl_f64(d0, j);
-				const bool ok = (__builtin_amdgcn_readlane(act, j) != 0) && (d > kAliasTolW * dj0) && (d > 0.0);
-				const double inv = ok ? rsqrt(d) : 0.0;
-				const double ljj = ok ? d * inv : 1.0;
-				if (ok) min_ratio = fmin(min_ratio, d / dj0);
-				lrow[j] = (r > j) ? t * inv : ((r == j) ? ljj : 0.0); // aliased / constant: column := 0
+				for (int c = j + 1; c < 16; ++c) arow[c] -= lrj * rl_f64(lrj, c); // L[r][j] * L[c][j]
 				if (lane == j) {
 					l.ldiag[k0 + j] = ljj;
 					l.linv[k0 + j] = inv;
 					l.live[k0 + j] = ok ? 1 : 0;
 				}
 			}
+			double (&lrow)[16] = arow;
 			if (lane < 16) {
 #pragma unroll
 				for (int c = 0; c < 16; ++c)
@@ -170,33 +186,39 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 		// (c) trailing update with the 16 new columns, 4x4 register tiles over the lower triangle
 		const int mrem = P16 - k0 - 16; // remaining x rows (multiple of 16)
 		const int nt = mrem >> 2;
-		const int ta = tid >> 4, tb = tid & 15;
-		for (int a4 = ta; a4 < nt; a4 += 16) {
-			for (int b4 = tb; b4 <= a4; b4 += 16) {
-				const int i0 = k0 + 16 + 4 * a4, c0 = k0 + 16 + 4 * b4;
-				double acc[4][4];
+		const int ntri = nt * (nt + 1) / 2;
+		for (int t = tid; t < ntri; t += 256) {
+			int a4, b4;
+			tri_decode(t, a4, b4);
+			const int i0 = k0 + 16 + 4 * a4, c0 = k0 + 16 + 4 * b4;
+			double acc[4][4];
 #pragma unroll
-				for (int rr = 0; rr < 4; ++rr)
+			for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-					for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = 0.0;
+				for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = 0.0;
 #pragma unroll 4
-				for (int m = 0; m < 16; ++m) {
-					double xa[4], xb[4];
+			for (int m = 0; m < 16; ++m) {
+				double xa[4], xb[4];
 #pragma unroll
-					for (int rr = 0; rr < 4; ++rr) xa[rr] = A[(size_t)(i0 + rr) * LD + k0 + m];
+				for (int rr = 0; rr < 4; ++rr) xa[rr] = A[(size_t)(i0 + rr) * LD + k0 + m];
 #pragma unroll
-					for (int cc = 0; cc < 4; ++cc) xb[cc] = A[(size_t)(c0 + cc) * LD + k0 + m];
-#pragma unroll
-					for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-						for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = fma(xa[rr], xb[cc], acc[rr][cc]);
-				}
+				for (int cc = 0; cc < 4; ++cc) xb[cc] = A[(size_t)(c0 + cc) * LD + k0 + m];
 #pragma unroll
 				for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-					for (int cc = 0; cc < 4; ++cc)
-						if (c0 + cc <= i0 + rr) A[(size_t)(i0 + rr) * LD + c0 + cc] -= acc[rr][cc];
+					for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = fma(xa[rr], xb[cc], acc[rr][cc]);
 			}
+			// unconditional read-modify-write: the above-diagonal entries of diagonal tiles land in the (still
+			// unused) upper triangle
+			double old[4][4];
+#pragma unroll
+			for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+				for (int cc = 0; cc < 4; ++cc) old[rr][cc] = A[(size_t)(i0 + rr) * LD + c0 + cc];
+#pragma unroll
+			for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+				for (int cc = 0; cc < 4; ++cc) A[(size_t)(i0 + rr) * LD + c0 + cc] = old[rr][cc] - acc[rr][cc];
 		}
 		// y row: 1 x 4 tiles
 		for (int b4 = tid; b4 < nt; b4 += 256) {
@@ -219,70 +241,111 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 	return l.red[7];
 }
 
-// W = L^-1 by 16x16 blocks: diagonal blocks first (16 lanes per block), then the off-diagonal blocks along
-// anti-diagonals (block (ib, jb) needs only blocks (kb, jb), kb < ib).
+// W = L^-1, right-looking by 16-row blocks, solving L W = I:  block row kb of W is finished by a triangular
+// solve with L_kk (one thread per column), then the rows below receive the rank-16 update
+// RHS[i][j] -= sum_m L[i][k0+m] W[k0+m][j] in 4x4 register tiles.  W[i][j], i > j, lives at A[j][i].
 __device__ void blocked_tri_inverse(const WideLds &l, int tid) {
-	const int LD = l.LD, T = l.T;
+	const int P16 = l.P16, LD = l.LD, T = l.T;
 	double *A = l.A;
-	// diagonal blocks: quarter-wave q handles block q, lane c its column c
-	{
-		const int q = tid >> 4, c = tid & 15;
-		if (q < T) {
-			const int k0 = 16 * q;
-			double w[16];
-#pragma unroll
-			for (int r = 0; r < 16; ++r) {
-				double sacc = 0.0;
-#pragma unroll
-				for (int m = 0; m < r; ++m) sacc = fma(A[(size_t)(k0 + r) * LD + k0 + m], (m >= c) ? w[m] : 0.0, sacc);
-				w[r] = (r == c) ? l.linv[k0 + r] : ((r > c) ? -sacc * l.linv[k0 + r] : 0.0);
-			}
-#pragma unroll
-			for (int r = 1; r < 16; ++r)
-				if (r > c) A[(size_t)(k0 + c) * LD + k0 + r] = w[r];
-		}
+	// RHS = I: clear the strictly upper triangle (the transposed strictly lower part of the RHS)
+	for (int idx = tid; idx < P16 * P16; idx += 256) {
+		const int j = idx / P16, i = idx - j * P16;
+		if (i > j) A[(size_t)j * LD + i] = 0.0;
 	}
 	__syncthreads();
-	const int r = tid >> 4, c = tid & 15;
-	for (int s = 1; s < T; ++s) {
-		const int nblk = T - s;
-		// stage 1: S = sum_kb L[ib][kb] W[kb][jb]   (all LDS reads unconditional; selects on the values)
-		for (int blk = 0; blk < nblk; ++blk) {
-			const int jb = blk, ib = blk + s;
-			const int i0 = 16 * ib, j0 = 16 * jb;
-			const double *lrow = A + (size_t)(i0 + r) * LD; // L[i0+r][*]
-			const double *wrow = A + (size_t)(j0 + c) * LD; // W[*][j0+c] stored transposed
-			double sacc = 0.0;
-			{ // kb == jb: W's diagonal block is lower triangular with diagonal linv
-				const double wd = l.linv[j0 + c];
+	for (int kb = 0; kb < T; ++kb) {
+		const int k0 = 16 * kb;
+		// (i) block row kb: x = L_kk^-1 rhs, one thread per column j <= k0 + 15
+		if (tid < k0 + 16) {
+			const int j = tid;
+			double x[16];
 #pragma unroll
-				for (int m = 0; m < 16; ++m) {
-					const double raw = wrow[j0 + m];
-					const double wv = (m > c) ? raw : ((m == c) ? wd : 0.0);
-					sacc = fma(lrow[j0 + m], wv, sacc);
-				}
+			for (int r = 0; r < 16; ++r) {
+				const double raw = A[(size_t)j * LD + k0 + r];         // accumulated RHS (columns left of the block)
+				x[r] = (k0 + r > j) ? raw : ((k0 + r == j) ? 1.0 : 0.0); // identity inside the block
 			}
-			for (int kb = jb + 1; kb < ib; ++kb) {
-				const int q0 = 16 * kb;
 #pragma unroll
-				for (int m = 0; m < 16; ++m) sacc = fma(lrow[q0 + m], wrow[q0 + m], sacc);
+			for (int r = 0; r < 16; ++r) {
+				double sacc = x[r];
+#pragma unroll
+				for (int m = 0; m < r; ++m) sacc -= A[(size_t)(k0 + r) * LD + k0 + m] * x[m];
+				x[r] = sacc * l.linv[k0 + r];
 			}
-			l.tmp[blk * 256 + r * 16 + c] = sacc;
+#pragma unroll
+			for (int r = 0; r < 16; ++r)
+				if (k0 + r > j) A[(size_t)j * LD + k0 + r] = x[r];
 		}
 		__syncthreads();
-		// stage 2: W[ib][jb] = -W[ib][ib] S
-		for (int blk = 0; blk < nblk; ++blk) {
-			const int jb = blk, ib = blk + s;
-			const int i0 = 16 * ib, j0 = 16 * jb;
-			const double wd = l.linv[i0 + r];
-			double sacc = 0.0;
+		// (ii) rows below: 4x4 tiles over (P16 - k0 - 16) x (k0 + 16)
+		const int nr = (P16 - k0 - 16) >> 2, nc = (k0 + 16) >> 2;
+		for (int t = tid; t < nr * nc; t += 256) {
+			const int a4 = t / nc, b4 = t - a4 * nc;
+			const int i0 = k0 + 16 + 4 * a4, j0 = 4 * b4;
+			const bool inblock = j0 >= k0; // columns of the current block: W's block is lower triangular
+			double acc[4][4];
 #pragma unroll
+			for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+				for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = 0.0;
+#pragma unroll 4
 			for (int m = 0; m < 16; ++m) {
-				const double raw = A[(size_t)(i0 + m) * LD + i0 + r]; // W[i0+r][i0+m] for m < r
-				const double wv = (m < r) ? raw : ((m == r) ? wd : 0.0);
-				sacc = fma(wv, l.tmp[blk * 256 + m * 16 + c], sacc);
+				double xa[4], xb[4];
+#pragma unroll
+				for (int rr = 0; rr < 4; ++rr) xa[rr] = A[(size_t)(i0 + rr) * LD + k0 + m];
+#pragma unroll
+				for (int cc = 0; cc < 4; ++cc) {
+					const double raw = A[(size_t)(j0 + cc) * LD + k0 + m];
+					const int kk = k0 + m, jj = j0 + cc;
+					xb[cc] = (!inblock || kk > jj) ? raw : ((kk == jj) ? l.linv[jj] : 0.0);
+				}
+#pragma unroll
+				for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+					for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = fma(xa[rr], xb[cc], acc[rr][cc]);
 			}
-			A[(size_t)(j0 + c) * LD + i0 + r] = -sacc;
+#pragma unroll
+			for (int cc = 0; cc < 4; ++cc) {
+				double old[4];
+#pragma unroll
+				for (int rr = 0; rr < 4; ++rr) old[rr] = A[(size_t)(j0 + cc) * LD + i0 + rr];
+#pragma unroll
+				for (int rr = 0; rr < 4; ++rr) A[(size_t)(j0 + cc) * LD + i0 + rr] = old[rr] - acc[rr][cc];
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// beta = L^-T z by 16-column blocks from the bottom: wave 0 finishes the 16 unknowns of a block with readlane
+// broadcasts, then every thread removes their contribution from the rows above.  zv is consumed, bv := beta.
+__device__ void blocked_back_solve(const WideLds &l, int tid) {
+	const int LD = l.LD, T = l.T;
+	const double *A = l.A;
+	const int lane = tid & 63;
+	for (int kb = T - 1; kb >= 0; --kb) {
+		const int k0 = 16 * kb;
+		if (tid < 64) {
+			const int r = lane & 15;
+			double zr = l.zv[k0 + r];
+			const double inv = l.linv[k0 + r];
+			double col[16]; // L[k0+m][k0+r], m > r: column r of the block = coefficients of beta_m in equation r
+#pragma unroll
+			for (int m = 0; m < 16; ++m) col[m] = A[(size_t)(k0 + m) * LD + k0 + r];
+			double br = 0.0;
+#pragma unroll
+			for (int m = 15; m >= 0; --m) {
+				const double bm = rl_f64(zr * inv, m); // beta_m once every later unknown has been removed from z_m
+				if (r == m) br = bm;
+				zr -= (r < m) ? col[m] * bm : 0.0;
+			}
+			if (lane < 16) l.bv[k0 + r] = br;
+		}
+		__syncthreads();
+		for (int i = tid; i < k0; i += 256) {
+			double zi = l.zv[i];
+#pragma unroll
+			for (int m = 0; m < 16; ++m) zi -= A[(size_t)(k0 + m) * LD + i] * l.bv[k0 + m];
+			l.zv[i] = zi;
 		}
 		__syncthreads();
 	}
@@ -375,16 +438,26 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 		// augmented moment matrix, lower triangle; centred when an intercept is fitted; padding rows/cols zero.
 		// The record is tile-major (256 contiguous doubles per 16x16 tile): thread t reads element t of each tile.
 		{
+			const double inv_sw = 1.0 / sw;
 			const int tr = tid >> 4, tc = tid & 15; // element (tr, tc) of an upper-triangular tile = M[16I+tr][16J+tc]
-			int tile = 0;
-			for (int I = 0; I < T; ++I) {
-				for (int J = I; J < T; ++J, ++tile) {
+			// four tiles per trip so that four independent 2 KiB loads are in flight (the record comes from HBM / L2)
+			for (int t0 = 0; t0 < NT; t0 += 4) {
+				double v4[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) v4[u] = rec[(int64_t)((t0 + u < NT) ? t0 + u : NT - 1) * 256 + tid];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const int tile = t0 + u;
+					if (tile >= NT) break;
+					int I = 0;
+					while ((I + 1) * T - (I + 1) * I / 2 <= tile) ++I; // first tile of block row I+1 is past `tile`
+					const int J = I + (tile - (I * T - I * (I - 1) / 2));
 					const int jj = 16 * I + tr, ii = 16 * J + tc; // jj <= ii except inside diagonal tiles
 					if (jj > ii) continue;
 					double v = 0.0;
 					if (ii < p) {
-						v = rec[(int64_t)tile * 256 + tid];
-						if (icpt) v -= l.sv[ii] * l.sv[jj] / sw;
+						v = v4[u];
+						if (icpt) v -= l.sv[ii] * l.sv[jj] * inv_sw;
 						if (ii == jj) v += lam;
 					}
 					A[(size_t)ii * LD + jj] = v;
@@ -405,48 +478,53 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 		SOLVE_STAMP(1);
 		const double min_ratio = blocked_cholesky(l, tid);
 		SOLVE_STAMP(2);
-		blocked_tri_inverse(l, tid);
-		SOLVE_STAMP(3);
-
-		// z = y row; current / new coefficients
-		for (int j = tid; j < P16; j += 256) l.zv[j] = A[(size_t)P16 * LD + j];
+		// W = L^-1 is needed for the standard errors (diag of the inverse) and for the refinement passes; the
+		// plain primary solve only needs beta = L^-T z
+		const bool need_w = (MODE != MODE_PRIMARY) || (inf != nullptr);
+		for (int j = tid; j < P16; j += 256) l.zv[j] = A[(size_t)P16 * LD + j]; // z = y row
 		__syncthreads();
-		if (MODE == MODE_UPDATE) {
-			// gradient of the (penalised) objective at the record's coefficients, centred: zv := W gc
-			const double gs = rvec[1];
-			for (int j = tid; j < P16; j += 256) {
-				double gj = 0.0;
-				if (j < p && l.live[j]) {
-					gj = rvec[2 + j];
-					if (icpt) gj -= (l.sv[j] / sw) * gs;
-					gj -= lam * core[j];
+		if (!need_w) {
+			blocked_back_solve(l, tid);
+			SOLVE_STAMP(3);
+		} else {
+			blocked_tri_inverse(l, tid);
+			SOLVE_STAMP(3);
+			if (MODE == MODE_UPDATE) {
+				// gradient of the (penalised) objective at the record's coefficients, centred: zv := W gc
+				const double gs = rvec[1];
+				for (int j = tid; j < P16; j += 256) {
+					double gj = 0.0;
+					if (j < p && l.live[j]) {
+						gj = rvec[2 + j];
+						if (icpt) gj -= (l.sv[j] / sw) * gs;
+						gj -= lam * core[j];
+					}
+					l.bv[j] = gj;
 				}
-				l.bv[j] = gj;
+				__syncthreads();
+				for (int i = tid; i < P16; i += 256) {
+					double u = 0.0;
+					for (int j = 0; j <= i; ++j) u = fma(getW(l, i, j), l.bv[j], u);
+					l.zv[i] = u;
+				}
+				__syncthreads();
 			}
-			__syncthreads();
-			for (int i = tid; i < P16; i += 256) {
-				double u = 0.0;
-				for (int j = 0; j <= i; ++j) u = fma(getW(l, i, j), l.bv[j], u);
-				l.zv[i] = u;
+			// bv_j = sum_{i >= j} W[i][j] zv_i  (= beta, or the refinement step delta);  diag_j = sum_i W[i][j]^2
+			for (int j = tid; j < P16; j += 256) {
+				const double wjj = l.linv[j];
+				double bj = wjj * l.zv[j], dj = wjj * wjj;
+				for (int i = j + 1; i < P16; ++i) {
+					const double wv = A[(size_t)j * LD + i];
+					bj = fma(wv, l.zv[i], bj);
+					dj = fma(wv, wv, dj);
+				}
+				if (MODE == MODE_PRIMARY) l.bv[j] = bj;
+				else if (MODE == MODE_UPDATE) l.bv[j] = (j < p && l.live[j] ? core[j] : 0.0) + bj;
+				else l.bv[j] = (j < p && l.live[j]) ? core[j] : 0.0;
+				l.diag0[j] = dj; // diag0 is dead after the factorisation: reuse for diag((LL')^-1)
 			}
 			__syncthreads();
 		}
-		// bv_j = sum_{i >= j} W[i][j] zv_i  (= beta, or the refinement step delta);  dsum_j = sum_i W[i][j]^2
-		for (int j = tid; j < P16; j += 256) {
-			const double wjj = l.linv[j];
-			double bj = wjj * l.zv[j], dj = wjj * wjj;
-			for (int i = j + 1; i < P16; ++i) {
-				const double wv = A[(size_t)j * LD + i];
-				bj = fma(wv, l.zv[i], bj);
-				dj = fma(wv, wv, dj);
-			}
-			if (MODE == MODE_PRIMARY) l.bv[j] = bj;
-			else if (MODE == MODE_UPDATE) l.bv[j] = (j < p && l.live[j] ? core[j] : 0.0) + bj;
-			else l.bv[j] = (j < p && l.live[j]) ? core[j] : 0.0;
-			l.diag0[j] = dj; // diag0 is dead after the factorisation: reuse for diag((LL')^-1)
-		}
-		__syncthreads();
-
 		SOLVE_STAMP(4);
 		// block sums: rank, b'c, b'b, mean correction of the intercept, |z|^2
 		double rk = 0.0, bc = 0.0, bb = 0.0, xb = 0.0, zz = 0.0;

@@ -75,7 +75,9 @@ def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=12.0):
     import oracle
     cores = len(os.sched_getaffinity(0))
     G = offs.numel() - 1
-    S = int(min(G, 256 * cores, 65536))
+    # sample size: about one second of work per pass at ~1 GFLOP/s per core of dense QR (2 n p'^2 flops per fit)
+    t_fit = 2.0 * n * (p + 1) ** 2 / 1e9
+    S = int(max(min(G, cores), min(G, 65536, cores / max(t_fit, 1e-9))))
     n_rows = int(offs[S].item())
     ys = y[:n_rows].cpu().numpy()
     xs = [c[:n_rows].cpu().numpy() for c in x_cols]
