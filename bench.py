@@ -116,11 +116,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ANOFOX_BENCH_REHEARSAL=1: several ranks share cuda:0 over gloo (to rehearse the N > 1 path on a 1-GPU box)
+    rehearsal = os.environ.get("ANOFOX_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     pkg = importlib.import_module(PKG)
     synth = importlib.import_module(PKG + ".synth")
@@ -141,7 +147,7 @@ def main():
     if args.model == "ridge":
         kw["alpha"] = 1.0
     opts = pkg.RegressionOptions(**kw).batch_options(args.model)
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(dev_index)
     sharded = dmod.ShardedBatchFit(ctx, G)
 
     def step():
@@ -149,6 +155,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    sharded.finish()
     torch.cuda.synchronize()
     ctx.enable_timing(True)
     ctx.collect_timing()
@@ -158,6 +165,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         core_all, inf_all = step()
+    sharded.finish()          # every all-gather issued inside the timed region completes inside it
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -166,7 +174,7 @@ def main():
     kt = ctx.collect_timing()
     ctx.enable_timing(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -177,7 +185,7 @@ def main():
         mine_inf = inf_all[lo:hi] if inf_all is not None else None
         ok, cerr, derr = parity_gate(pkg, mine, mine_inf, offs, y, x_cols, w, args.model, kw, p, args.parity_sample)
         if world > 1:
-            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            flag = torch.tensor([1.0 if ok else 0.0], device="cpu" if rehearsal else dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item() > 0.5)
 
