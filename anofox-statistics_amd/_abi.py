@@ -80,7 +80,11 @@ class AnofoxHipBatchOptions(C.Structure):
 
 class AnofoxHipKernelTimes(C.Structure):
     _fields_ = [("accumulate_ms", C.c_double), ("accumulate_count", C.c_int64), ("solve_ms", C.c_double),
-                ("solve_count", C.c_int64)]
+                ("solve_count", C.c_int64), ("predict_ms", C.c_double), ("predict_count", C.c_int64)]
+
+
+class AnofoxPredictionResult(C.Structure):
+    _fields_ = [("yhat", C.c_double), ("yhat_lower", C.c_double), ("yhat_upper", C.c_double)]
 
 
 # every symbol include/anofox_stats_hip.h declares: name -> (restype, argtypes)
@@ -110,6 +114,20 @@ SYMBOLS = {
                                                C.c_void_p, _ERRP]),
     "anofox_hip_fit_batch_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), _DP,
                                              C.POINTER(_DP), _DP, AnofoxHipBatchOptions, _DP, _DP, _ERRP]),
+    "anofox_t_critical": (C.c_double, [C.c_double, C.c_size_t]),
+    "anofox_predict_with_interval": (C.c_bool, [_DP, C.c_size_t, C.c_double, _DP, C.c_size_t, C.c_double, C.c_size_t,
+                                                C.c_double, C.POINTER(AnofoxPredictionResult)]),
+    "anofox_predict": (C.c_bool, [C.POINTER(AnofoxDataArray), C.c_size_t, _DP, C.c_size_t, C.c_double,
+                                  C.POINTER(_DP), C.POINTER(C.c_size_t), _ERRP]),
+    "anofox_free_predictions": (None, [_DP]),
+    "anofox_hip_fit_predict_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p,
+                                                       C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                                       AnofoxHipBatchOptions, C.c_void_p, C.c_void_p, _ERRP]),
+    "anofox_hip_fit_predict_batch_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), _DP,
+                                                     C.POINTER(_DP), _DP, C.POINTER(C.c_int64), AnofoxHipBatchOptions,
+                                                     _DP, _DP, _ERRP]),
+    "anofox_hip_predict_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p,
+                                                   C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_void_p, _ERRP]),
     "anofox_hip_context_enable_timing": (C.c_bool, [_CTX, C.c_bool, _ERRP]),
     "anofox_hip_context_collect_timing": (C.c_bool, [_CTX, C.POINTER(AnofoxHipKernelTimes), _ERRP]),
     "anofox_hip_version": (C.c_char_p, []),

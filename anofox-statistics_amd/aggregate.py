@@ -249,3 +249,172 @@ SQL_FUNCTIONS = {
     "anofox_stats_ridge_fit_agg": ridge_fit_agg, "ridge_fit_agg": ridge_fit_agg,
     "anofox_stats_wls_fit_agg": wls_fit_agg, "wls_fit_agg": wls_fit_agg,
 }
+
+
+# ------------------------------------------------------------------------------------------------------
+# *_fit_predict_agg(y, x [, options]): fit on the training rows of each group, predict every row
+# (src/aggregate_functions/{ols,ridge,wls}_predict_aggregate.cpp)
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class FitPredictAggResult:
+    """Per group: LIST(STRUCT(y, yhat, yhat_lower, yhat_upper, is_training)) (ols_predict_aggregate.cpp:93-104)."""
+    keys: np.ndarray
+    row_offsets: np.ndarray           # rows of group i = [row_offsets[i], row_offsets[i+1])
+    y: np.ndarray                     # NaN where y was NULL
+    y_is_null: np.ndarray
+    yhat: np.ndarray                  # NaN = SQL NULL
+    yhat_lower: np.ndarray
+    yhat_upper: np.ndarray
+    is_training: np.ndarray
+    is_null: np.ndarray               # per group: the whole LIST is NULL
+    core: np.ndarray                  # fit records [G, p+6]
+
+    def rows(self, i: int) -> Optional[list]:
+        if self.is_null[i]:
+            return None
+        lo, hi = int(self.row_offsets[i]), int(self.row_offsets[i + 1])
+        out = []
+        for r in range(lo, hi):
+            nn = lambda v: None if np.isnan(v) else float(v)  # noqa: E731
+            out.append({"y": None if self.y_is_null[r] else float(self.y[r]), "yhat": nn(self.yhat[r]),
+                        "yhat_lower": nn(self.yhat_lower[r]), "yhat_upper": nn(self.yhat_upper[r]),
+                        "is_training": bool(self.is_training[r])})
+        return out
+
+
+class _FitPredictAgg:
+    """Bind / Update / Combine / Finalize of the predict aggregates.  Update keeps ALL rows whose x list is not
+    NULL; a row trains iff its y is not NULL and no feature is NULL (ols_predict_aggregate.cpp:150-250), or iff the
+    optional split column says 'train'/'training' and y is not NULL."""
+    model = "ols"
+    sql_name = "anofox_stats_ols_fit_predict_agg"
+    has_weights = False
+
+    def __init__(self, options: Optional[Mapping[str, Any]] = None, context: Optional[Context] = None):
+        self.options: RegressionOptions = parse_options(options)
+        self._ctx = context
+        self.n_features: Optional[int] = None
+        self._chunks: List[tuple] = []
+        self._seen_keys: List[np.ndarray] = []
+
+    def update(self, group_keys, y, x, weights=None, split=None):
+        keys = np.asarray(group_keys)
+        yv, ynull = _null_mask_1d(y)
+        n = len(yv)
+        rows = [None if r is None else list(r) for r in (x.tolist() if isinstance(x, np.ndarray) else x)]
+        if len(rows) != n or len(keys) != n:
+            raise InvalidInputException("group_keys, y and x differ in length")
+        xnull = np.array([r is None for r in rows], dtype=bool)
+        keep = ~xnull                                            # rows with a NULL x list are skipped entirely
+        lens = {len(r) for r in rows if r is not None}
+        for ln in sorted(lens):
+            if self.n_features is None:
+                self.n_features = next(len(r) for r in rows if r is not None)
+            if ln != self.n_features:
+                raise InvalidInputException(f"Inconsistent feature count: expected {self.n_features}, got {ln}")
+        p = self.n_features or 0
+        X = np.full((n, p), np.nan)
+        feat_null = np.zeros(n, dtype=bool)
+        for i, r in enumerate(rows):
+            if r is not None:
+                for j, v in enumerate(r):
+                    if v is None:
+                        feat_null[i] = True
+                    else:
+                        X[i, j] = float(v)
+        if split is not None:
+            sp = [None if s is None else str(s).lower() for s in split]
+            train = np.array([s in ("train", "training") for s in sp], dtype=bool) & ~ynull
+        else:
+            train = ~ynull
+        train &= ~feat_null
+        if self.options.null_policy == "drop_y_zero_x":          # ols_predict_aggregate.cpp:241-249
+            train &= ~np.any(X == 0.0, axis=1)
+        wv = None
+        if self.has_weights:
+            if weights is None:
+                raise InvalidInputException(f"{self.sql_name} needs a weight argument")
+            wv, wnull = _null_mask_1d(weights)
+            train &= ~wnull
+        self._seen_keys.append(keys)
+        if keep.any():
+            self._chunks.append((keys[keep], yv[keep], ynull[keep], X[keep], train[keep],
+                                 None if wv is None else wv[keep]))
+        return self
+
+    def combine(self, other: "_FitPredictAgg"):
+        if other.n_features is not None:
+            if self.n_features is None:
+                self.n_features = other.n_features
+            elif self.n_features != other.n_features:
+                raise InvalidInputException(
+                    f"Cannot combine states with different feature counts: {self.n_features} vs {other.n_features}")
+        self._chunks.extend(other._chunks)
+        self._seen_keys.extend(other._seen_keys)
+        return self
+
+    def finalize(self) -> FitPredictAggResult:
+        from .runtime import fit_predict_batch_host
+        ukeys = np.unique(np.concatenate(self._seen_keys)) if self._seen_keys else np.empty(0)
+        G = len(ukeys)
+        p = self.n_features or 0
+        if not self._chunks:
+            z = np.empty(0)
+            return FitPredictAggResult(ukeys, np.zeros(G + 1, dtype=np.int64), z, z.astype(bool), z, z, z,
+                                       z.astype(bool), np.ones(G, dtype=bool), np.full((G, p + 6), np.nan))
+        keys = np.concatenate([c[0] for c in self._chunks])
+        gid = np.searchsorted(ukeys, keys)
+        order = np.argsort(gid, kind="stable")
+        counts = np.bincount(gid, minlength=G)
+        offsets = np.zeros(G + 1, dtype=np.int64)
+        np.cumsum(counts, out=offsets[1:])
+        y = np.concatenate([c[1] for c in self._chunks])[order]
+        ynull = np.concatenate([c[2] for c in self._chunks])[order]
+        X = np.concatenate([c[3] for c in self._chunks], axis=0)[order]
+        train = np.concatenate([c[4] for c in self._chunks])[order]
+        w = np.concatenate([c[5] for c in self._chunks])[order] if self.has_weights else None
+        # non-training rows must not enter the fit: their y goes in as NaN (the batch ABI's NULL)
+        y_fit = np.where(train, y, np.nan)
+        train_counts = np.bincount(gid[order], weights=train.astype(np.float64), minlength=G).astype(np.int64)
+        x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+        opts = self.options.batch_options(self.model)
+        core, pred = fit_predict_batch_host(offsets, y_fit, x_cols, w, opts, train_counts=train_counts, ctx=self._ctx)
+        is_null = core[:, p + 5] != 0
+        return FitPredictAggResult(ukeys, offsets, np.where(ynull, np.nan, y), ynull, pred[:, 0], pred[:, 1],
+                                   pred[:, 2], train, is_null, core)
+
+
+class OlsFitPredictAgg(_FitPredictAgg):
+    model = "ols"
+    sql_name = "anofox_stats_ols_fit_predict_agg"
+
+
+class RidgeFitPredictAgg(_FitPredictAgg):
+    model = "ridge"
+    sql_name = "anofox_stats_ridge_fit_predict_agg"
+
+
+class WlsFitPredictAgg(_FitPredictAgg):
+    model = "wls"
+    sql_name = "anofox_stats_wls_fit_predict_agg"
+    has_weights = True
+
+
+def ols_fit_predict_agg(group_keys, y, x, options=None, context=None, split=None) -> FitPredictAggResult:
+    return OlsFitPredictAgg(options, context).update(group_keys, y, x, split=split).finalize()
+
+
+def ridge_fit_predict_agg(group_keys, y, x, options=None, context=None, split=None) -> FitPredictAggResult:
+    return RidgeFitPredictAgg(options, context).update(group_keys, y, x, split=split).finalize()
+
+
+def wls_fit_predict_agg(group_keys, y, x, weights, options=None, context=None, split=None) -> FitPredictAggResult:
+    return WlsFitPredictAgg(options, context).update(group_keys, y, x, weights, split=split).finalize()
+
+
+SQL_FUNCTIONS.update({
+    "anofox_stats_ols_fit_predict_agg": ols_fit_predict_agg, "ols_fit_predict_agg": ols_fit_predict_agg,
+    "ols_predict_agg": ols_fit_predict_agg, "anofox_stats_ols_predict_agg": ols_fit_predict_agg,  # deprecated aliases
+    "anofox_stats_ridge_fit_predict_agg": ridge_fit_predict_agg, "ridge_fit_predict_agg": ridge_fit_predict_agg,
+    "anofox_stats_wls_fit_predict_agg": wls_fit_predict_agg, "wls_fit_predict_agg": wls_fit_predict_agg,
+})

@@ -66,6 +66,7 @@ struct BatchArgs {
 	int32_t *refine_count; // [1]
 	double *refine_vec;   // [G * (p+2)]  {sum w r^2, sum w r, X'Wr} of the queued groups
 	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
+	const int64_t *rule_counts; // optional [G]: the count the "< 2 rows -> NULL" rule looks at (default: rows of the group)
 };
 
 // ---- wide path (8 < p <= kWideMaxP): FP64-MFMA accumulation, LDS Cholesky ----
@@ -103,7 +104,21 @@ struct WideArgs {
 	int32_t *refine_count;
 	double *refine_vec;   // [G_total * (p+2)]
 	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
+	const int64_t *rule_counts; // optional [G_total], see BatchArgs
 };
+
+// per-row predictions (predict.hip), any p <= kWideMaxP
+struct PredictArgs {
+	const int64_t *row_offsets;
+	const double *x_table[kWideMaxP];
+	const double *core; // [G * (p+6)] fit records
+	double *pred;       // [N * 3] {yhat, yhat_lower, yhat_upper}
+	int64_t n_groups;
+	int p;
+	double confidence_level;
+	void *tcrit_table;
+};
+hipError_t launch_predict(const PredictArgs &a, hipStream_t stream);
 
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);

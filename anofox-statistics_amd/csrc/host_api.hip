@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.h"
+#include "host_math.h"
 
 using namespace anofox;
 
@@ -31,10 +32,13 @@ struct AnofoxHipContext {
 	// device staging for the host-pointer entry points
 	void *stage = nullptr;
 	size_t stage_bytes = 0;
+	// small auxiliary device buffer (t-quantile memo of the predict kernel)
+	void *aux = nullptr;
+	size_t aux_bytes = 0;
 	// timing
 	bool timing = false;
 	std::vector<hipEvent_t> free_events;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_events, solve_events;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_events, solve_events, predict_events;
 };
 
 namespace {
@@ -119,7 +123,8 @@ bool carve_workspace(AnofoxHipContext *ctx, int64_t G, int p, Workspace *out, An
 // Wide designs (8 < p <= 128): the same four stages on the MFMA / LDS kernels, slab by slab.
 bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const int64_t *d_off,
                     const double *d_y, const double *const *x_cols, const double *d_w,
-                    const AnofoxHipBatchOptions &opt, double *d_core, double *d_inf, AnofoxError *e) {
+                    const AnofoxHipBatchOptions &opt, double *d_core, double *d_inf, const int64_t *d_rule_counts,
+                    AnofoxError *e) {
 	(void)n_rows;
 	const int T = wide_tiles((int)p);
 	const size_t rec_bytes = (size_t)wide_record_len(T) * sizeof(double);
@@ -153,6 +158,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.tcrit_table = base + b_mom + b_rss + b_lst + 256;
 	a.core = d_core;
 	a.inference = opt.compute_inference ? d_inf : nullptr;
+	a.rule_counts = d_rule_counts;
 
 	hipStream_t st = ctx->stream;
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, 1024, st), "hipMemsetAsync", e)) return false;
@@ -189,9 +195,11 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 // Everything is enqueued on the context's stream; no host synchronisation.
 bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const int64_t *d_off,
                       const double *d_y, const double *const *x_cols, const double *d_w,
-                      const AnofoxHipBatchOptions &opt, double *d_core, double *d_inf, AnofoxError *e) {
+                      const AnofoxHipBatchOptions &opt, double *d_core, double *d_inf, AnofoxError *e,
+                      const int64_t *d_rule_counts = nullptr) {
 	if (G == 0) return true;
-	if (p > (size_t)kNarrowMaxP) return run_wide_batch(ctx, G, p, n_rows, d_off, d_y, x_cols, d_w, opt, d_core, d_inf, e);
+	if (p > (size_t)kNarrowMaxP)
+		return run_wide_batch(ctx, G, p, n_rows, d_off, d_y, x_cols, d_w, opt, d_core, d_inf, d_rule_counts, e);
 	Workspace ws;
 	if (!carve_workspace(ctx, G, (int)p, &ws, e)) return false;
 
@@ -217,6 +225,7 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	a.refine_count = ws.refine_count;
 	a.refine_vec = ws.refine_vec;
 	a.tcrit_table = ws.tcrit_table;
+	a.rule_counts = d_rule_counts;
 
 	hipStream_t st = ctx->stream;
 	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, 256 + 1024, st), "hipMemsetAsync", e)) return false; // counter + t table
@@ -330,6 +339,8 @@ void anofox_hip_context_destroy(AnofoxHipContext *ctx) {
 	for (auto ev : ctx->free_events) (void)hipEventDestroy(ev);
 	if (ctx->ws) (void)hipFree(ctx->ws);
 	if (ctx->stage) (void)hipFree(ctx->stage);
+	if (ctx->aux) (void)hipFree(ctx->aux);
+	for (auto &pr : ctx->predict_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
 }
@@ -373,10 +384,17 @@ bool anofox_hip_context_collect_timing(AnofoxHipContext *ctx, AnofoxHipKernelTim
 		float ms = 0.f;
 		if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { out->solve_ms += ms; out->solve_count++; }
 	}
+	for (auto &pr : ctx->predict_events) {
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { out->predict_ms += ms; out->predict_count++; }
+		ctx->free_events.push_back(pr.first);
+		ctx->free_events.push_back(pr.second);
+	}
 	for (auto &pr : ctx->acc_events) { ctx->free_events.push_back(pr.first); ctx->free_events.push_back(pr.second); }
 	for (auto &pr : ctx->solve_events) { ctx->free_events.push_back(pr.second); }
 	ctx->acc_events.clear();
 	ctx->solve_events.clear();
+	ctx->predict_events.clear();
 	return true;
 }
 
@@ -392,6 +410,152 @@ bool anofox_hip_fit_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t
 	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
 	return run_device_batch(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, options, d_core,
 	                        d_inference, out_error);
+}
+
+
+namespace {
+
+// per-row predictions from fit records; uses (and zeroes) the t table at the end of the workspace
+bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *const *x_cols,
+                 const double *d_core, double confidence, double *d_pred, AnofoxError *e) {
+	if (G == 0) return true;
+	if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, 1024, "t table", e)) return false;
+	PredictArgs a;
+	memset(&a, 0, sizeof a);
+	a.row_offsets = d_off;
+	for (size_t j = 0; j < p; ++j) a.x_table[j] = x_cols[j];
+	a.core = d_core;
+	a.pred = d_pred;
+	a.n_groups = G;
+	a.p = (int)p;
+	a.confidence_level = confidence;
+	a.tcrit_table = ctx->aux;
+	if (hip_fail(hipMemsetAsync(ctx->aux, 0, 1024, ctx->stream), "hipMemsetAsync", e)) return false;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (ctx->timing) {
+		e0 = get_event(ctx);
+		e1 = get_event(ctx);
+		(void)hipEventRecord(e0, ctx->stream);
+	}
+	if (hip_fail(launch_predict(a, ctx->stream), "predict kernel launch", e)) return false;
+	if (ctx->timing) {
+		(void)hipEventRecord(e1, ctx->stream);
+		ctx->predict_events.emplace_back(e0, e1);
+	}
+	return true;
+}
+
+} // namespace
+
+bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                     const int64_t *d_row_offsets, const double *const *x_cols, const double *d_core,
+                                     double confidence_level, double *d_pred, AnofoxError *out_error) {
+	reset_error(out_error);
+	(void)n_rows;
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (n_groups < 0 || n_features == 0 || n_features > (size_t)kWideMaxP || !x_cols) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "invalid n_groups / n_features / x");
+		return false;
+	}
+	if (n_groups > 0 && (!d_row_offsets || !d_core || !d_pred)) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets, core or pred is NULL");
+		return false;
+	}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	return run_predict(ctx, n_groups, n_features, d_row_offsets, x_cols, d_core, confidence_level, d_pred, out_error);
+}
+
+bool anofox_hip_fit_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                         const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
+                                         const double *d_w, const int64_t *d_train_counts, AnofoxHipBatchOptions options,
+                                         double *d_core, double *d_pred, AnofoxError *out_error) {
+	reset_error(out_error);
+	options.compute_inference = false; // ols_predict_aggregate.cpp:353
+	if (!validate_batch(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, options, d_core, nullptr,
+	                    out_error))
+		return false;
+	if (n_groups > 0 && !d_pred) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "pred is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	if (!run_device_batch(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, options, d_core, nullptr,
+	                      out_error, d_train_counts))
+		return false;
+	return run_predict(ctx, n_groups, n_features, d_row_offsets, x_cols, d_core, options.confidence_level, d_pred,
+	                   out_error);
+}
+
+bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                       const int64_t *row_offsets, const double *y, const double *const *x_cols,
+                                       const double *w, const int64_t *train_counts, AnofoxHipBatchOptions options,
+                                       double *core, double *pred, AnofoxError *out_error) {
+	reset_error(out_error);
+	options.compute_inference = false;
+	if (!ctx) {
+		ctx = default_context(out_error);
+		if (!ctx) return false;
+	}
+	if (!validate_batch(ctx, n_groups, n_features, n_rows, row_offsets, y, x_cols, w, options, core, nullptr, out_error))
+		return false;
+	if (n_groups == 0) return true;
+	if (!pred) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "pred is NULL"); return false; }
+	if (row_offsets[0] != 0 || row_offsets[n_groups] != n_rows) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must start at 0 and end at n_rows");
+		return false;
+	}
+	for (int64_t g = 0; g < n_groups; ++g)
+		if (row_offsets[g + 1] < row_offsets[g]) {
+			set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must be non-decreasing");
+			return false;
+		}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	const size_t p = n_features;
+	const bool weighted = options.model == ANOFOX_HIP_MODEL_WLS;
+	const size_t ncol = p + 1 + (weighted ? 1 : 0);
+	const size_t core_len = p + 6;
+	const size_t R = (size_t)n_rows, G = (size_t)n_groups;
+	const size_t b_off = align_up((G + 1) * sizeof(int64_t), 256);
+	const size_t b_cnt = train_counts ? align_up(G * sizeof(int64_t), 256) : 0;
+	const size_t b_col = align_up((R + 2) * sizeof(double), 256);
+	const size_t b_core = align_up(G * core_len * sizeof(double), 256);
+	const size_t b_pred = align_up(R * 3 * sizeof(double) + 8, 256);
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_off + b_cnt + ncol * b_col + b_core + b_pred, "staging", out_error))
+		return false;
+	char *cur = (char *)ctx->stage;
+	hipStream_t st = ctx->stream;
+	int64_t *d_off = (int64_t *)cur;
+	cur += b_off;
+	if (hip_fail(hipMemcpyAsync(d_off, row_offsets, (G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D offsets", out_error)) return false;
+	int64_t *d_cnt = nullptr;
+	if (train_counts) {
+		d_cnt = (int64_t *)cur;
+		cur += b_cnt;
+		if (hip_fail(hipMemcpyAsync(d_cnt, train_counts, G * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D counts", out_error)) return false;
+	}
+	const double *d_x[kWideMaxP];
+	for (size_t j = 0; j < p; ++j) {
+		if (R > 0 && hip_fail(hipMemcpyAsync(cur, x_cols[j], R * sizeof(double), hipMemcpyHostToDevice, st), "H2D x", out_error)) return false;
+		d_x[j] = (const double *)cur;
+		cur += b_col;
+	}
+	if (R > 0 && hip_fail(hipMemcpyAsync(cur, y, R * sizeof(double), hipMemcpyHostToDevice, st), "H2D y", out_error)) return false;
+	const double *d_y = (const double *)cur;
+	cur += b_col;
+	const double *d_w = nullptr;
+	if (weighted) {
+		if (R > 0 && hip_fail(hipMemcpyAsync(cur, w, R * sizeof(double), hipMemcpyHostToDevice, st), "H2D w", out_error)) return false;
+		d_w = (const double *)cur;
+		cur += b_col;
+	}
+	double *d_core = (double *)cur;
+	cur += b_core;
+	double *d_pred = (double *)cur;
+	if (!run_device_batch(ctx, n_groups, p, n_rows, d_off, d_y, d_x, d_w, options, d_core, nullptr, out_error, d_cnt)) return false;
+	if (!run_predict(ctx, n_groups, p, d_off, d_x, d_core, options.confidence_level, d_pred, out_error)) return false;
+	if (hip_fail(hipMemcpyAsync(core, d_core, G * core_len * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;
+	if (R > 0 && hip_fail(hipMemcpyAsync(pred, d_pred, R * 3 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H pred", out_error)) return false;
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
 }
 
 bool anofox_hip_fit_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
@@ -698,6 +862,107 @@ bool anofox_compute_bic(double rss, size_t n, size_t k, double *out_bic, AnofoxE
 	if (rss < 0.0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Invalid input: RSS must be non-negative"); return false; }
 	*out_bic = rss == 0.0 ? -INFINITY : (double)n * log(rss / (double)n) + (double)k * log((double)n);
 	return true;
+}
+
+double anofox_t_critical(double confidence_level, size_t df) {
+	if (df == 0 || !(confidence_level > 0.0) || !(confidence_level < 1.0)) return NAN; // lib.rs:2218-2220
+	return hostmath::t_quantile_upper(0.5 * (1.0 + confidence_level), (double)df);
+}
+
+bool anofox_predict_with_interval(const double *coefficients, size_t coefficients_len, double intercept,
+                                  const double *x_new, size_t x_len, double residual_std_error, size_t n_observations,
+                                  double confidence_level, AnofoxPredictionResult *out_result) {
+	if (!out_result) return false;
+	out_result->yhat = out_result->yhat_lower = out_result->yhat_upper = NAN;
+	if (!coefficients || coefficients_len == 0) return false;
+	if (!x_new || x_len != coefficients_len) return false;
+	double yhat = isnan(intercept) ? 0.0 : intercept;
+	for (size_t j = 0; j < coefficients_len; ++j)
+		if (!isnan(coefficients[j])) yhat += coefficients[j] * x_new[j]; // NaN coefficients contribute 0
+	out_result->yhat = out_result->yhat_lower = out_result->yhat_upper = yhat;
+	if (isnan(residual_std_error) || residual_std_error <= 0.0 || n_observations <= coefficients_len + 1) return true;
+	const bool has_icpt = !isnan(intercept);
+	const size_t used = coefficients_len + (has_icpt ? 1 : 0);
+	const size_t df = n_observations > used ? n_observations - used : 0;
+	if (df == 0) return true;
+	const double tcrit = anofox_t_critical(confidence_level, df);
+	if (isnan(tcrit)) return true;
+	const double n = (double)n_observations;
+	const double margin = tcrit * residual_std_error * sqrt(1.0 + 1.0 / n);
+	out_result->yhat_lower = yhat - margin;
+	out_result->yhat_upper = yhat + margin;
+	return true;
+}
+
+bool anofox_predict(const AnofoxDataArray *x, size_t x_count, const double *coefficients, size_t coefficients_len,
+                    double intercept, double **out_predictions, size_t *out_predictions_len, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!x || x_count == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "x is NULL or empty"); return false; }
+	if (!coefficients || coefficients_len == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "coefficients is NULL or empty"); return false; }
+	if (!out_predictions || !out_predictions_len) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "out_predictions or out_predictions_len is NULL");
+		return false;
+	}
+	if (x_count != coefficients_len) {
+		set_error(out_error, ANOFOX_ERROR_DIMENSION_MISMATCH, "Dimension mismatch: y has " + std::to_string(coefficients_len) + " elements, X has " + std::to_string(x_count) + " rows");
+		return false;
+	}
+	const size_t n = x[0].len, p = x_count;
+	for (size_t j = 0; j < p; ++j)
+		if (x[j].len != n) {
+			set_error(out_error, ANOFOX_ERROR_DIMENSION_MISMATCH, "Dimension mismatch: y has " + std::to_string(n) + " elements, X has " + std::to_string(x[j].len) + " rows");
+			return false;
+		}
+	if (p > (size_t)kWideMaxP) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "too many features for the GPU path"); return false; }
+	double *out = (double *)malloc((n ? n : 1) * sizeof(double));
+	if (!out) { set_error(out_error, ANOFOX_ERROR_ALLOCATION_FAILURE, "Failed to allocate predictions"); return false; }
+	if (n > 0) {
+		AnofoxHipContext *ctx = default_context(out_error);
+		if (!ctx) { free(out); return false; }
+		std::lock_guard<std::mutex> lk(ctx->mu);
+		bool ok = !hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error);
+		// one group holding every row; a fit record carrying the coefficients (n_obs = 0 -> no interval)
+		std::vector<std::vector<double>> cols(p);
+		std::vector<double> core(p + 6, 0.0), pred(3 * n);
+		bool nan_coef = false;
+		for (size_t j = 0; j < p; ++j) { expand(x[j], cols[j]); core[j] = coefficients[j]; nan_coef = nan_coef || isnan(coefficients[j]); }
+		core[p] = intercept;
+		core[p + 3] = NAN;
+		const size_t b_col = align_up(n * sizeof(double), 256);
+		const size_t total = 256 + p * b_col + align_up(core.size() * sizeof(double), 256) + 3 * n * sizeof(double);
+		ok = ok && ensure_buffer(&ctx->stage, &ctx->stage_bytes, total, "staging", out_error);
+		if (ok) {
+			char *cur = (char *)ctx->stage;
+			hipStream_t st = ctx->stream;
+			const int64_t off[2] = {0, (int64_t)n};
+			int64_t *d_off = (int64_t *)cur;
+			cur += 256;
+			ok = !hip_fail(hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, st), "H2D", out_error);
+			const double *d_x[kWideMaxP];
+			for (size_t j = 0; ok && j < p; ++j) {
+				ok = !hip_fail(hipMemcpyAsync(cur, cols[j].data(), n * sizeof(double), hipMemcpyHostToDevice, st), "H2D", out_error);
+				d_x[j] = (const double *)cur;
+				cur += b_col;
+			}
+			double *d_core = (double *)cur;
+			cur += align_up(core.size() * sizeof(double), 256);
+			double *d_pred = (double *)cur;
+			ok = ok && !hip_fail(hipMemcpyAsync(d_core, core.data(), core.size() * sizeof(double), hipMemcpyHostToDevice, st), "H2D", out_error);
+			ok = ok && run_predict(ctx, 1, p, d_off, d_x, d_core, 0.95, d_pred, out_error);
+			ok = ok && !hip_fail(hipMemcpyAsync(pred.data(), d_pred, 3 * n * sizeof(double), hipMemcpyDeviceToHost, st), "D2H", out_error);
+			ok = ok && !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
+		}
+		if (!ok) { free(out); return false; }
+		// upstream's plain predict lets a NaN coefficient poison every prediction (predict.rs:55-61)
+		for (size_t i = 0; i < n; ++i) out[i] = nan_coef ? NAN : pred[3 * i];
+	}
+	*out_predictions = out;
+	*out_predictions_len = n;
+	return true;
+}
+
+void anofox_free_predictions(double *predictions) {
+	if (predictions) free(predictions);
 }
 
 } // extern "C"

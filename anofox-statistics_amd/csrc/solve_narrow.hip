@@ -55,7 +55,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 	bool refine = false;
 
 	const double *rec = args.moments + g * (int64_t)L::REC;
-	const int64_t nrows = args.row_offsets[g + 1] - args.row_offsets[g];
+	const int64_t nrows = args.rule_counts ? args.rule_counts[g] : args.row_offsets[g + 1] - args.row_offsets[g];
 
 	do {
 		if (nrows < 2) { status = ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS; break; }           // ols_aggregate.cpp:263-267

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 		double *core = args.core + g * (int64_t)(p + 6);
 		double *inf = (args.inference && args.compute_inference) ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
 		const double *rvec = args.refine_vec + g * (int64_t)(p + 2); // {sum w r^2, sum w r, X'Wr}
-		const int64_t nrows = args.row_offsets[g + 1] - args.row_offsets[g];
+		const int64_t nrows = args.rule_counts ? args.rule_counts[g] : args.row_offsets[g + 1] - args.row_offsets[g];
 
 		// a record whose fit failed (or has no inference block): everything NaN, status in the last slot
 		auto write_null = [&](int status, bool core_too) {

@@ -60,6 +60,7 @@ class RegressionOptions:
     solver: str = "svd"                # ols_aggregate.cpp:51 (accepted, ignored by the GPU path)
     hc_type: str = "none"
     lambda_scaling: str = "raw"
+    null_policy: str = "drop"          # predict aggregates only (ols_predict_aggregate.cpp:68)
 
     def batch_options(self, model: str) -> _abi.AnofoxHipBatchOptions:
         return _abi.AnofoxHipBatchOptions(
@@ -105,6 +106,13 @@ def parse_options(opts: Optional[Mapping[str, Any]]) -> RegressionOptions:
             v = _extract_enum(val, _abi.LAMBDA_SCALING, "lambda_scaling", "'raw', 'glmnet'")
             if v is not None:
                 out.lambda_scaling = v
+        elif key == "null_policy":
+            if val is not None:
+                v = str(val).lower()
+                if v not in ("drop", "drop_y_zero_x"):
+                    raise InvalidInputException(
+                        f"Invalid null_policy: '{v}'. Valid values are 'drop', 'drop_y_zero_x'")
+                out.null_policy = v
         # every other key: ignored, as in the reference
     if alpha is not None:      # GetRegularizationStrength: alpha first, then lambda
         out.alpha = alpha

@@ -54,7 +54,8 @@ class Context:
         t = _abi.AnofoxHipKernelTimes()
         self._check(self._lib.anofox_hip_context_collect_timing(self._h, C.byref(t), C.byref(err)), err)
         return {"accumulate_ms": t.accumulate_ms, "accumulate_count": t.accumulate_count,
-                "solve_ms": t.solve_ms, "solve_count": t.solve_count}
+                "solve_ms": t.solve_ms, "solve_count": t.solve_count,
+                "predict_ms": t.predict_ms, "predict_count": t.predict_count}
 
     # ---- device-resident batch (torch tensors on this context's GPU) -------------------------
     def fit_batch_device(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
@@ -88,6 +89,30 @@ class Context:
         self._check(ok, err)
         return core, (inference if options.compute_inference else None)
 
+    def fit_predict_batch_device(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
+                                 train_counts=None, core=None, pred=None, use_current_torch_stream: bool = True):
+        """fit + per-row predictions, device resident.  Returns (core[G, p+6], pred[N, 3]) CUDA tensors."""
+        import torch
+
+        p = len(x_cols)
+        G = int(row_offsets.numel()) - 1
+        N = int(y.numel())
+        if core is None:
+            core = torch.empty((G, p + 6), dtype=torch.float64, device=y.device)
+        if pred is None:
+            pred = torch.empty((N, 3), dtype=torch.float64, device=y.device)
+        if use_current_torch_stream:
+            self.set_stream(torch.cuda.current_stream(y.device).cuda_stream)
+        cols = (C.c_void_p * p)(*[c.data_ptr() for c in x_cols])
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_fit_predict_batch_device(
+            self._h, G, p, N, C.c_void_p(row_offsets.data_ptr()), C.c_void_p(y.data_ptr()), cols,
+            C.c_void_p(w.data_ptr() if w is not None else 0),
+            C.c_void_p(train_counts.data_ptr() if train_counts is not None else 0), options,
+            C.c_void_p(core.data_ptr()), C.c_void_p(pred.data_ptr()), C.byref(err))
+        self._check(ok, err)
+        return core, pred
+
     # ---- host-resident batch (numpy) ----------------------------------------------------------
     def fit_batch_host(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions):
         return fit_batch_host(row_offsets, y, x_cols, w, options, ctx=self)
@@ -120,3 +145,27 @@ def fit_batch_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipB
     if not ok:
         raise AnofoxStatsError(err.code, err.text())
     return core, inf
+
+
+def fit_predict_batch_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions, train_counts=None,
+                           ctx: Optional[Context] = None):
+    """numpy in, numpy out: (core[G, p+6], pred[N, 3] = yhat / yhat_lower / yhat_upper, NaN = SQL NULL)."""
+    lib = _abi.load()
+    off = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    wv = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    tc = None if train_counts is None else np.ascontiguousarray(train_counts, dtype=np.int64)
+    p, G, N = len(cols), len(off) - 1, len(yv)
+    core = np.empty((G, p + 6), dtype=np.float64)
+    pred = np.empty((N, 3), dtype=np.float64)
+    colp = (_DP * max(p, 1))(*[c.ctypes.data_as(_DP) for c in cols])
+    err = _abi.AnofoxError()
+    ok = lib.anofox_hip_fit_predict_batch_host(
+        ctx._h if ctx is not None else None, G, p, N, off.ctypes.data_as(C.POINTER(C.c_int64)), yv.ctypes.data_as(_DP),
+        colp, None if wv is None else wv.ctypes.data_as(_DP),
+        None if tc is None else tc.ctypes.data_as(C.POINTER(C.c_int64)), options, core.ctypes.data_as(_DP),
+        pred.ctypes.data_as(_DP), C.byref(err))
+    if not ok:
+        raise AnofoxStatsError(err.code, err.text())
+    return core, pred

@@ -117,3 +117,46 @@ def bic(rss: float, n: int, k: int) -> Optional[float]:
     out = C.c_double()
     err = _abi.AnofoxError()
     return out.value if lib.anofox_compute_bic(float(rss), int(n), int(k), C.byref(out), C.byref(err)) else None
+
+
+def t_critical(confidence_level: float, df: int) -> float:
+    """anofox_t_critical (crates/anofox-stats-ffi/src/lib.rs:2217-2231)."""
+    return float(_abi.load().anofox_t_critical(float(confidence_level), int(df)))
+
+
+def predict_with_interval(coefficients, intercept, x_new, residual_std_error, n_observations,
+                          confidence_level=0.95) -> Optional[dict]:
+    """anofox_predict_with_interval (lib.rs:2264-2349); None when the call fails."""
+    lib = _abi.load()
+    c = np.ascontiguousarray(coefficients, dtype=np.float64)
+    xn = np.ascontiguousarray(x_new, dtype=np.float64)
+    out = _abi.AnofoxPredictionResult()
+    ok = lib.anofox_predict_with_interval(c.ctypes.data_as(_DP), len(c), float(intercept), xn.ctypes.data_as(_DP),
+                                          len(xn), float(residual_std_error), int(n_observations),
+                                          float(confidence_level), C.byref(out))
+    return {"yhat": out.yhat, "yhat_lower": out.yhat_lower, "yhat_upper": out.yhat_upper} if ok else None
+
+
+def predict(x, coefficients, intercept=float("nan")):
+    """anofox_stats_predict(x LIST(LIST), coefficients, intercept) (src/table_functions/predict.cpp); x is
+    column-major.  Runs on the GPU."""
+    lib = _abi.load()
+    xs = (_abi.AnofoxDataArray * max(len(x), 1))()
+    keep = []
+    for j, col in enumerate(x):
+        a, k = _data_array(col)
+        xs[j] = a
+        keep.append(k)
+    c = np.ascontiguousarray(coefficients, dtype=np.float64)
+    outp = _DP()
+    outn = C.c_size_t()
+    err = _abi.AnofoxError()
+    if not lib.anofox_predict(xs, len(x), c.ctypes.data_as(_DP), len(c), float(intercept), C.byref(outp),
+                              C.byref(outn), C.byref(err)):
+        e = InvalidInputException(f"Prediction failed: {err.text()}")
+        e.code = err.code
+        raise e
+    try:
+        return [outp[i] for i in range(outn.value)]
+    finally:
+        lib.anofox_free_predictions(outp)

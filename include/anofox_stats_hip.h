@@ -175,6 +175,33 @@ ANOFOX_HIP_API void anofox_free_result_inference(AnofoxFitResultInference *resul
 ANOFOX_HIP_API bool anofox_compute_aic(double rss, size_t n, size_t k, double *out_aic, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_compute_bic(double rss, size_t n, size_t k, double *out_bic, AnofoxError *out_error);
 
+/* ---- prediction helpers of the fit-predict family ---- */
+
+/* replaces anofox_t_critical, anofox_stats_ffi.h:655 (lib.rs:2217-2231): Student-t quantile at (1 + c)/2;
+ * NaN when df == 0 or c is outside (0, 1).  Scalar helper, evaluated on the host. */
+ANOFOX_HIP_API double anofox_t_critical(double confidence_level, size_t df);
+
+/* replaces AnofoxPredictionResult, anofox_stats_ffi.h:660-667 */
+typedef struct {
+	double yhat;
+	double yhat_lower;
+	double yhat_upper;
+} AnofoxPredictionResult;
+
+/* replaces anofox_predict_with_interval, anofox_stats_ffi.h:686-688 (lib.rs:2264-2349): one new observation,
+ * simplified interval yhat -/+ t * rse * sqrt(1 + 1/n); NaN coefficients are skipped; bounds = yhat when no
+ * interval can be formed.  Scalar helper, evaluated on the host. */
+ANOFOX_HIP_API bool anofox_predict_with_interval(const double *coefficients, size_t coefficients_len, double intercept,
+                                  const double *x_new, size_t x_len, double residual_std_error, size_t n_observations,
+                                  double confidence_level, AnofoxPredictionResult *out_result);
+
+/* replaces anofox_predict / anofox_free_predictions, anofox_stats_ffi.h:489-495 (lib.rs:1568-1664,
+ * crates/anofox-stats-core/src/models/predict.rs:17-64): y = intercept (0 when NaN) + sum_j coef_j x_j for every row
+ * (NaN coefficients propagate, as upstream).  Runs on the GPU; *out_predictions is malloc'ed. */
+ANOFOX_HIP_API bool anofox_predict(const AnofoxDataArray *x, size_t x_count, const double *coefficients, size_t coefficients_len,
+                    double intercept, double **out_predictions, size_t *out_predictions_len, AnofoxError *out_error);
+ANOFOX_HIP_API void anofox_free_predictions(double *predictions);
+
 #endif /* ANOFOX_STATS_FFI_H */
 
 /* ------------------------------------------------------------------------ */
@@ -255,6 +282,29 @@ ANOFOX_HIP_API bool anofox_hip_fit_batch_host(AnofoxHipContext *ctx, int64_t n_g
                                const double *w, AnofoxHipBatchOptions options, double *core, double *inference,
                                AnofoxError *out_error);
 
+/*
+ * fit + predict in one batch: the `*_fit_predict_agg` aggregates (src/aggregate_functions/ols_predict_aggregate.cpp:
+ * 322-425, ridge/wls likewise).  Every row of every group gets {yhat, yhat_lower, yhat_upper} (d_pred, [n_rows x 3],
+ * NaN = SQL NULL); rows whose y is NaN (the aggregate's NULL y = "prediction row") or that hold a non-finite
+ * feature do not train.  d_train_counts (optional, [n_groups]) is the number of training rows the aggregate's
+ * "fewer than 2 -> NULL" rule looks at (ols_predict_aggregate.cpp:333); NULL = use the group's row count.
+ * d_core receives the fit records as in anofox_hip_fit_batch_device (compute_inference is ignored: the
+ * aggregates fit with inference off).
+ */
+ANOFOX_HIP_API bool anofox_hip_fit_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                         const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
+                                         const double *d_w, const int64_t *d_train_counts, AnofoxHipBatchOptions options,
+                                         double *d_core, double *d_pred, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                       const int64_t *row_offsets, const double *y, const double *const *x_cols,
+                                       const double *w, const int64_t *train_counts, AnofoxHipBatchOptions options,
+                                       double *core, double *pred, AnofoxError *out_error);
+
+/* Predictions only, from existing fit records (d_core as produced by the fit entry points). */
+ANOFOX_HIP_API bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                     const int64_t *d_row_offsets, const double *const *x_cols, const double *d_core,
+                                     double confidence_level, double *d_pred, AnofoxError *out_error);
+
 /* Measurement hooks (bench.py): when enabled, every accumulate-kernel launch of this context is
  * bracketed by HIP events on the launch stream. */
 typedef struct {
@@ -262,6 +312,8 @@ typedef struct {
 	int64_t accumulate_count; /* launches summed */
 	double solve_ms;          /* summed duration of the per-group solve/diagnostics kernels */
 	int64_t solve_count;
+	double predict_ms;        /* summed duration of the per-row prediction kernel */
+	int64_t predict_count;
 } AnofoxHipKernelTimes;
 ANOFOX_HIP_API bool anofox_hip_context_enable_timing(AnofoxHipContext *ctx, bool enable, AnofoxError *out_error);
 /* synchronises, returns the sums since the last call and resets them */

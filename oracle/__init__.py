@@ -86,6 +86,13 @@ def lib():
         L.oracle_f_sf.argtypes = [C.c_double] * 3
         L.oracle_t_quantile.restype = C.c_double
         L.oracle_t_quantile.argtypes = [C.c_double, C.c_double]
+        L.oracle_t_critical.restype = C.c_double
+        L.oracle_t_critical.argtypes = [C.c_double, C.c_int64]
+        L.oracle_predict_with_interval.restype = C.c_int
+        L.oracle_predict_with_interval.argtypes = [_DP, C.c_size_t, C.c_double, _DP, C.c_double, C.c_int64, C.c_double, _DP]
+        L.oracle_fit_predict_groups.restype = C.c_int
+        L.oracle_fit_predict_groups.argtypes = [_DP, C.POINTER(_DP), _DP, C.POINTER(C.c_int64), C.c_int64, C.c_size_t,
+                                                C.POINTER(OracleOptions), C.POINTER(C.c_int64), _DP, _DP]
         for name in ("oracle_aic", "oracle_bic"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_double, C.c_int64, C.c_int64, _DP]
@@ -159,3 +166,37 @@ def bic(rss, n, k):
     out = C.c_double()
     rc = lib().oracle_bic(rss, n, k, C.byref(out))
     return rc, out.value
+
+
+def t_critical(confidence_level, df):
+    return lib().oracle_t_critical(float(confidence_level), int(df))
+
+
+def predict_with_interval(coef, intercept, x_new, rse, n_obs, confidence_level=0.95):
+    c = np.ascontiguousarray(coef, dtype=np.float64)
+    xn = np.ascontiguousarray(x_new, dtype=np.float64)
+    out = np.empty(3)
+    ok = lib().oracle_predict_with_interval(c.ctypes.data_as(_DP), len(c), float(intercept), xn.ctypes.data_as(_DP),
+                                            float(rse), int(n_obs), float(confidence_level), out.ctypes.data_as(_DP))
+    return bool(ok), out
+
+
+def fit_predict_groups(y, x_cols, offsets, w=None, train_counts=None, **kw):
+    """(core[G, p+6], pred[N, 3]) — y carries NaN at non-training rows."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    p, G = len(cols), len(offsets) - 1
+    wv = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    tc = None if train_counts is None else np.ascontiguousarray(train_counts, dtype=np.int64)
+    o = _opts(**kw)
+    core = np.empty((G, p + 6))
+    pred = np.empty((len(y), 3))
+    rc = lib().oracle_fit_predict_groups(y.ctypes.data_as(_DP), _col_ptrs(cols),
+                                         None if wv is None else wv.ctypes.data_as(_DP),
+                                         offsets.ctypes.data_as(C.POINTER(C.c_int64)), G, p, C.byref(o),
+                                         None if tc is None else tc.ctypes.data_as(C.POINTER(C.c_int64)),
+                                         core.ctypes.data_as(_DP), pred.ctypes.data_as(_DP))
+    if rc != 0:
+        raise RuntimeError(f"oracle_fit_predict_groups failed: {rc}")
+    return core, pred

@@ -559,3 +559,82 @@ ORACLE_EXPORT int oracle_fit_groups(const double *y, const double *const *x, con
 	if (n_threads > 1) for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
 	return ORC_SUCCESS;
 }
+
+/* ------------------------------------------------------------------------- */
+/* Prediction helpers of the fit-predict family.                               */
+/*   oracle_t_critical            crates/anofox-stats-ffi/src/lib.rs:2217-2231  */
+/*   oracle_predict_with_interval lib.rs:2264-2349                              */
+/*   oracle_fit_predict_groups    src/aggregate_functions/ols_predict_aggregate.cpp:322-425 */
+/* ------------------------------------------------------------------------- */
+ORACLE_EXPORT double oracle_t_critical(double confidence_level, int64_t df) {
+	if (df <= 0 || !(confidence_level > 0.0) || !(confidence_level < 1.0)) return NAN;
+	return oracle_t_quantile(0.5 * (1.0 + confidence_level), (double)df);
+}
+
+/* out[3] = {yhat, lower, upper}; returns 1 on success */
+ORACLE_EXPORT int oracle_predict_with_interval(const double *coef, size_t p, double intercept, const double *x_new,
+                                               double rse, int64_t n_obs, double confidence_level, double *out) {
+	out[0] = out[1] = out[2] = NAN;
+	if (!coef || p == 0 || !x_new) return 0;
+	double yhat = isnan(intercept) ? 0.0 : intercept;
+	for (size_t j = 0; j < p; j++)
+		if (!isnan(coef[j])) yhat += coef[j] * x_new[j];
+	out[0] = out[1] = out[2] = yhat;
+	if (isnan(rse) || rse <= 0.0 || n_obs <= (int64_t)p + 1) return 1;
+	int64_t used = (int64_t)p + (isnan(intercept) ? 0 : 1);
+	int64_t df = n_obs > used ? n_obs - used : 0;
+	if (df == 0) return 1;
+	double tc = oracle_t_critical(confidence_level, df);
+	if (isnan(tc)) return 1;
+	double margin = tc * rse * sqrt(1.0 + 1.0 / (double)n_obs);
+	out[1] = yhat - margin;
+	out[2] = yhat + margin;
+	return 1;
+}
+
+/* Grouped fit + predict.  y holds NaN at non-training rows; train_counts[g] (may be NULL) is the number of
+ * training rows the aggregate's "< 2 -> NULL" rule looks at.  pred is [N][3], NaN = SQL NULL. */
+ORACLE_EXPORT int oracle_fit_predict_groups(const double *y, const double *const *x, const double *w,
+                                            const int64_t *offsets, int64_t n_groups, size_t p, const OracleOptions *opt,
+                                            const int64_t *train_counts, double *core, double *pred) {
+	OracleOptions o = *opt;
+	o.compute_inference = 0;
+	const double **xs = (const double **)malloc(p * sizeof(double *));
+	double *tmp = (double *)malloc(p * sizeof(double));
+	double *row = (double *)malloc(p * sizeof(double));
+	for (int64_t g = 0; g < n_groups; g++) {
+		int64_t lo = offsets[g], hi = offsets[g + 1];
+		double *c = core + (size_t)g * (p + 6);
+		for (size_t k = 0; k < p + 6; k++) c[k] = NAN;
+		int status;
+		OracleResult r;
+		memset(&r, 0, sizeof r);
+		int64_t rule = train_counts ? train_counts[g] : hi - lo;
+		if (rule < 2) {
+			status = ORC_STATUS_NULL_TOO_FEW_ROWS;
+		} else {
+			for (size_t j = 0; j < p; j++) xs[j] = x[j] + lo;
+			r.coefficients = tmp;
+			status = oracle_fit(y + lo, xs, w ? w + lo : NULL, (size_t)(hi - lo), p, &o, &r);
+		}
+		if (status == ORC_SUCCESS) {
+			memcpy(c, r.coefficients, p * sizeof(double));
+			c[p] = r.intercept; c[p + 1] = r.r_squared; c[p + 2] = r.adj_r_squared;
+			c[p + 3] = r.residual_std_error; c[p + 4] = (double)r.n_observations;
+		}
+		c[p + 5] = (double)status;
+		for (int64_t i = lo; i < hi; i++) {
+			double *out = pred + (size_t)i * 3;
+			out[0] = out[1] = out[2] = NAN;
+			if (status != ORC_SUCCESS) continue;
+			for (size_t j = 0; j < p; j++) row[j] = x[j][i];
+			double pr[3];
+			if (oracle_predict_with_interval(c, p, c[p], row, c[p + 3], (int64_t)c[p + 4], o.confidence_level, pr) &&
+			    isfinite(pr[0])) {
+				out[0] = pr[0]; out[1] = pr[1]; out[2] = pr[2];
+			}
+		}
+	}
+	free(row); free(tmp); free((void *)xs);
+	return ORC_SUCCESS;
+}

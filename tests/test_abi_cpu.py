@@ -129,3 +129,18 @@ def test_argument_validation_precedes_device_use():
     xs = (abi.AnofoxDataArray * 1)()
     assert not lib.anofox_ridge_fit(y, xs, 1, ropt, C.byref(core), None, C.byref(err))
     assert err.code == abi.ERROR_INVALID_ALPHA
+
+
+def test_host_prediction_helpers_need_no_gpu():
+    """anofox_t_critical / anofox_predict_with_interval are scalar host helpers (like aic / bic)."""
+    from scipy import stats as sps
+    import oracle
+    pkg = import_pkg()
+    for df in (1, 2, 7, 30, 400):
+        assert abs(pkg.t_critical(0.95, df) / sps.t.ppf(0.975, df) - 1.0) < 1e-10
+    got = pkg.predict_with_interval([2.0, float("nan")], 1.0, [3.0, 5.0], 0.5, 20, 0.95)
+    ok, want = oracle.predict_with_interval([2.0, float("nan")], 1.0, [3.0, 5.0], 0.5, 20, 0.95)
+    assert ok and abs(got["yhat_lower"] - want[1]) < 1e-12 and abs(got["yhat_upper"] - want[2]) < 1e-12
+    abi = import_pkg("_abi")
+    assert not abi.load().anofox_predict_with_interval(None, 0, 0.0, None, 0, 1.0, 10, 0.95,
+                                                        C.byref(abi.AnofoxPredictionResult()))

@@ -535,3 +535,108 @@ def test_wide_cfg5_shape_sample_and_properties(pkg, ctx):
     assert np.max(np.abs(c2[:, :p] - want) / np.maximum(np.abs(want), 1e-3 * scale)) < COEF_RTOL
     assert np.max(np.abs(c2[:, p + 3] / (2.0 * ch[:, p + 3]) - 1.0)) < DIAG_RTOL
     assert float(np.max(np.abs(ch[:, p + 3] - 2.0))) < 0.2        # sigma of the generator
+
+
+# --------------------------------------------------------------------------------------------------
+# fit-predict family: *_fit_predict_agg, predict, predict_with_interval, t_critical
+# --------------------------------------------------------------------------------------------------
+def test_predict_agg_reference_structural_tests(pkg, ctx):
+    """test/sql/predict_agg/test_ols_predict_agg.test:8-118: y = 2i + 1 for i <= 7, NULL for i = 8..10."""
+    i = np.arange(1, 11, dtype=np.float64)
+    y = [float(2 * v + 1) if v <= 7 else None for v in i]
+    res = pkg.ols_fit_predict_agg(np.zeros(10, dtype=np.int64), y, [[v] for v in i], context=ctx)
+    rows = res.rows(0)
+    assert len(rows) == 10
+    assert sum(r["is_training"] for r in rows) == 7 and sum(not r["is_training"] for r in rows) == 3
+    assert all(r["yhat"] is not None and r["yhat_upper"] >= r["yhat_lower"] for r in rows)
+    assert all(r["y"] is not None for r in rows if r["is_training"])
+    assert all(r["y"] is None for r in rows if not r["is_training"])
+    assert max(abs(r["yhat"] - (2 * v + 1)) for r, v in zip(rows, i)) < 1e-9
+    # null_policy = drop_y_zero_x: a zero feature value removes the row from training (test :87-107)
+    x2 = [0.0 if v == 3 else v for v in i]
+    res = pkg.SQL_FUNCTIONS["ols_predict_agg"](np.zeros(10, dtype=np.int64), y, [[a, b] for a, b in zip(i, x2)],
+                                               {"null_policy": "drop_y_zero_x"}, context=ctx)
+    assert sum(r["is_training"] for r in res.rows(0)) == 6
+    with pytest.raises(pkg.InvalidInputException, match="Invalid null_policy"):
+        pkg.parse_options({"null_policy": "keep"})
+
+
+@pytest.mark.parametrize("model", ["ols", "ridge", "wls"])
+@pytest.mark.parametrize("p", [2, 8, 20])
+def test_fit_predict_batch_matches_oracle(pkg, ctx, model, p):
+    rng = np.random.default_rng(31 * p + len(model))
+    G = 40
+    offs, y, x_cols, w = _random_groups(rng, G, p, 1, 4 * p + 30)
+    # prediction rows (NULL y), rows with a NULL feature, groups with too few training rows
+    y = y.copy()
+    y[rng.random(len(y)) < 0.25] = np.nan
+    x_cols = [c.copy() for c in x_cols]
+    x_cols[0][rng.random(len(y)) < 0.03] = np.nan
+    train = ~np.isnan(y) & ~np.isnan(x_cols[0])
+    gid = np.repeat(np.arange(G), np.diff(offs))
+    train_counts = np.bincount(gid, weights=train, minlength=G).astype(np.int64)
+    for icpt in (True, False):
+        kw = dict(fit_intercept=icpt, confidence_level=0.9)
+        if model == "ridge":
+            kw["alpha"] = 0.7
+        wv = w if model == "wls" else None
+        core, pred = pkg.fit_predict_batch_host(offs, y, x_cols, wv, _opts(pkg, model, **kw),
+                                                train_counts=train_counts, ctx=ctx)
+        rcore, rpred = oracle.fit_predict_groups(y, x_cols, offs, w=wv, train_counts=train_counts,
+                                                 **_oracle_kw(model, kw))
+        zero_df = [g for g in range(G) if rcore[g, p + 5] == 0 and rcore[g, p + 4] - np.sum(~np.isnan(rcore[g, :p])) - icpt == 0]
+        assert_records_match(core, rcore, p, what=f"fit_predict {model} p={p} icpt={icpt}", skip_diag_groups=zero_df)
+        assert np.array_equal(np.isnan(pred), np.isnan(rpred))
+        m = ~np.isnan(rpred)
+        rowgrp = np.repeat(np.arange(G), np.diff(offs))
+        skip = np.isin(rowgrp, zero_df)
+        m &= ~skip[:, None]
+        scale = np.maximum(np.abs(rpred[m]), 1e-3 * np.abs(rpred[~np.isnan(rpred)]).max())
+        assert np.max(np.abs(pred[m] - rpred[m]) / scale) < 1e-9
+
+
+def test_scalar_prediction_helpers(pkg):
+    from scipy import stats as sps
+    for df in (1, 2, 5, 17, 146, 991):
+        for c in (0.8, 0.95, 0.99):
+            assert rel_err(pkg.t_critical(c, df), sps.t.ppf(0.5 * (1 + c), df)) < 1e-10
+            assert rel_err(pkg.t_critical(c, df), oracle.t_critical(c, df)) < 1e-12
+    assert np.isnan(pkg.t_critical(0.95, 0)) and np.isnan(pkg.t_critical(1.0, 5))
+    for coef, icpt, xn, rse, n in (([2.0, np.nan], 1.0, [3.0, 5.0], 0.5, 20), ([2.0], np.nan, [3.0], 0.5, 20),
+                                   ([2.0], 1.0, [3.0], np.nan, 20), ([2.0], 1.0, [3.0], 0.5, 2)):
+        got = pkg.predict_with_interval(coef, icpt, xn, rse, n, 0.95)
+        ok, want = oracle.predict_with_interval(coef, icpt, xn, rse, n, 0.95)
+        assert ok and max(abs(got[k] - want[i]) for i, k in enumerate(("yhat", "yhat_lower", "yhat_upper"))) < 1e-12
+    # anofox_predict: plain X beta (+ intercept); runs on the GPU
+    x = [[1.0, 2.0, 3.0, None], [0.5, -1.0, 2.0, 4.0]]
+    out = pkg.predict(x, [2.0, -3.0], 0.25)
+    assert out[:3] == [0.25 + 2 * 1 - 3 * 0.5, 0.25 + 4 + 3, 0.25 + 6 - 6] and np.isnan(out[3])
+    assert pkg.predict(x, [2.0, -3.0]) [0] == 2 * 1 - 3 * 0.5           # NaN intercept = none
+    assert all(np.isnan(v) for v in pkg.predict(x, [2.0, float("nan")], 1.0))   # NaN coefficients poison (predict.rs:55-61)
+    with pytest.raises(pkg.InvalidInputException):
+        pkg.predict(x, [1.0, 2.0, 3.0])
+
+
+def test_fit_predict_device_cfg_shape_properties(pkg, ctx):
+    """Device-resident fit + predict at the reference's published 1M-group benchmark shape scaled to fit a test
+    (100k groups x 100 rows x p = 3, examples/performance_1m_groups/benchmark_ols.sql): every 5th row is a
+    prediction row.  yhat of the training rows must reproduce y - residual (mean residual 0 with an intercept),
+    and a sample is checked against the oracle."""
+    import torch
+    synth = import_pkg("synth")
+    G, n, p = 100_000, 100, 3
+    offs, y, x_cols, _ = synth.make_grouped(G, n, p, device="cuda")
+    hold = (torch.arange(G * n, device="cuda") % 5) == 4
+    y_fit = torch.where(hold, torch.full_like(y, float("nan")), y)
+    core, pred = ctx.fit_predict_batch_device(offs, y_fit, x_cols, None, _opts(pkg, "ols"))
+    torch.cuda.synchronize()
+    assert bool((core[:, p + 5] == 0).all()) and bool((core[:, p + 4] == 80).all())
+    assert not bool(torch.isnan(pred).any())
+    resid = torch.where(hold, torch.zeros_like(y), y - pred[:, 0]).reshape(G, n)
+    assert float(resid.sum(dim=1).abs().max()) < 1e-8                      # residuals of the training rows sum to 0
+    assert bool((pred[:, 2] >= pred[:, 1]).all())
+    S = 64
+    rcore, rpred = oracle.fit_predict_groups(y_fit[:S * n].cpu().numpy(), [c[:S * n].cpu().numpy() for c in x_cols],
+                                             offs[:S + 1].cpu().numpy(), model="ols")
+    assert_records_match(core[:S].cpu().numpy(), rcore, p, what="fit_predict device sample")
+    assert np.max(np.abs(pred[:S * n].cpu().numpy() - rpred) / np.maximum(np.abs(rpred), 1.0)) < 1e-9

@@ -272,3 +272,34 @@ def test_error_codes_and_edge_cases():
     m = (1 + 4 + 6) / 4
     assert code == 0 and abs(r["intercept"] - m) < 1e-15
     assert abs(r["residual_std_error"] - np.sqrt(((1 - m) ** 2 + 2 * (2 - m) ** 2 + (6 - m) ** 2) / 4)) < 1e-15
+
+
+def test_t_critical_and_prediction_interval_restatement():
+    # anofox_t_critical (lib.rs:2217-2231): quantile at (1 + c) / 2; NaN for df == 0 or c outside (0, 1)
+    for df in (1, 2, 3, 10, 78, 146, 991):
+        for c in (0.8, 0.9, 0.95, 0.99):
+            assert rel_err(oracle.t_critical(c, df), sps.t.ppf(0.5 * (1 + c), df)) < 1e-10
+    assert np.isnan(oracle.t_critical(0.95, 0)) and np.isnan(oracle.t_critical(1.0, 5)) and np.isnan(oracle.t_critical(0.0, 5))
+    # anofox_predict_with_interval (lib.rs:2264-2349): simplified interval, NaN coefficients skipped
+    ok, out = oracle.predict_with_interval([2.0, np.nan], 1.0, [3.0, 5.0], 0.5, 20, 0.95)
+    want = sps.t.ppf(0.975, 20 - 3) * 0.5 * np.sqrt(1 + 1 / 20)
+    assert ok and out[0] == 7.0 and abs(out[1] - (7.0 - want)) < 1e-12 and abs(out[2] - (7.0 + want)) < 1e-12
+    ok, out = oracle.predict_with_interval([2.0], np.nan, [3.0], 0.5, 20, 0.95)       # no intercept: df = n - p
+    want = sps.t.ppf(0.975, 19) * 0.5 * np.sqrt(1 + 1 / 20)
+    assert ok and out[0] == 6.0 and abs(out[2] - (6.0 + want)) < 1e-12
+    for rse, n in ((np.nan, 20), (0.0, 20), (0.5, 2), (0.5, 1)):                        # no interval: bounds = yhat
+        ok, out = oracle.predict_with_interval([2.0], 1.0, [3.0], rse, n, 0.95)
+        assert ok and out[0] == out[1] == out[2] == 7.0
+    # the fit of the prediction fixture + the simplified interval at its new x values
+    d = load_csv("inference_tests/input/prediction_train.csv")
+    e = load_json("inference_tests/expected/prediction_intervals.json")
+    xn = [n for n in d if n != "y"]
+    _, r = oracle.fit(d["y"], _xcols(d, xn), model="ols")
+    for xv, fit in zip(e["new_x_values"], e["predictions"]["fit"]):
+        ok, out = oracle.predict_with_interval(r["coefficients"], r["intercept"], [xv], r["residual_std_error"],
+                                               r["n_observations"], 0.95)
+        assert ok and rel_err(out[0], fit) < STRICT
+        # R's exact interval has the leverage term; the reference's simplified one is narrower or equal
+        k = e["new_x_values"].index(xv)
+        assert out[1] >= e["predictions"]["prediction_lower"][k] - 1e-9
+        assert out[2] <= e["predictions"]["prediction_upper"][k] + 1e-9
