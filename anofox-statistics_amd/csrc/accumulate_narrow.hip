@@ -104,19 +104,21 @@ __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) 
 				w0 = v.x;
 				w1 = v.y;
 			}
-		} else { // ragged tail: guarded 8-byte loads
+		} else { // ragged tail: unconditional 8-byte loads from clamped (valid) rows; a guarded load per element
+			// would sit behind its own branch and wait.  Rows past the end are masked by in0 / in1 below.
 			in0 = r0 < hi;
 			in1 = r0 + 1 < hi;
+			const int64_t c0 = in0 ? r0 : hi - 1, c1 = in1 ? r0 + 1 : hi - 1;
 #pragma unroll
 			for (int j = 0; j < P; ++j) {
-				z0[j] = in0 ? args.x[j][r0] : 0.0;
-				z1[j] = in1 ? args.x[j][r0 + 1] : 0.0;
+				z0[j] = args.x[j][c0];
+				z1[j] = args.x[j][c1];
 			}
-			z0[P] = in0 ? args.y[r0] : 0.0;
-			z1[P] = in1 ? args.y[r0 + 1] : 0.0;
+			z0[P] = args.y[c0];
+			z1[P] = args.y[c1];
 			if (WEIGHTED) {
-				w0 = in0 ? args.w[r0] : 0.0;
-				w1 = in1 ? args.w[r0 + 1] : 0.0;
+				w0 = args.w[c0];
+				w1 = args.w[c1];
 			}
 		}
 

@@ -113,6 +113,7 @@ struct PredictArgs {
 	const double *x_table[kWideMaxP];
 	const double *core; // [G * (p+6)] fit records
 	double *pred;       // [N * 3] {yhat, yhat_lower, yhat_upper}
+	double *margin;     // [G] scratch: half-width of the interval per group
 	int64_t n_groups;
 	int p;
 	double confidence_level;

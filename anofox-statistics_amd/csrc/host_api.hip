@@ -419,7 +419,7 @@ namespace {
 bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *const *x_cols,
                  const double *d_core, double confidence, double *d_pred, AnofoxError *e) {
 	if (G == 0) return true;
-	if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, 1024, "t table", e)) return false;
+	if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, 1024 + (size_t)G * sizeof(double), "predict scratch", e)) return false;
 	PredictArgs a;
 	memset(&a, 0, sizeof a);
 	a.row_offsets = d_off;
@@ -430,6 +430,7 @@ bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_of
 	a.p = (int)p;
 	a.confidence_level = confidence;
 	a.tcrit_table = ctx->aux;
+	a.margin = (double *)((char *)ctx->aux + 1024);
 	if (hip_fail(hipMemsetAsync(ctx->aux, 0, 1024, ctx->stream), "hipMemsetAsync", e)) return false;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->timing) {

@@ -18,6 +18,31 @@ namespace anofox {
 
 namespace {
 
+// Half-width of the interval per group (0 = bounds equal yhat), one thread per group.  Kept out of the row
+// kernels: the t quantile's call tree needs ~240 VGPRs, the row kernels ~40 — separating them keeps the
+// streaming kernels at full occupancy.
+__global__ __launch_bounds__(256) void predict_margin_kernel(PredictArgs args) {
+	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= args.n_groups) return;
+	const int p = args.p;
+	const double *core = args.core + g * (int64_t)(p + 6);
+	const double icpt = core[p];
+	const double rse = core[p + 3];
+	const double nobs = core[p + 4];
+	const bool is_null = core[p + 5] != 0.0;
+	const bool has_icpt = !isnan(icpt);
+	double margin = 0.0;
+	if (!is_null && !(isnan(rse) || rse <= 0.0 || nobs <= (double)(p + 1))) {
+		const double df = has_icpt ? nobs - (double)(p + 1) : nobs - (double)p;
+		const double c = args.confidence_level;
+		if (df > 0.0 && c > 0.0 && c < 1.0) { // anofox_t_critical: NaN outside (0, 1) -> no interval
+			const double tcrit = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + c), df);
+			if (!isnan(tcrit)) margin = tcrit * rse * sqrt(1.0 + 1.0 / nobs);
+		}
+	}
+	args.margin[g] = margin;
+}
+
 __global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
 	__shared__ double coef_s[4][kWideMaxP];
 	__shared__ int dead_s[4][kWideMaxP];
@@ -34,20 +59,9 @@ __global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
 		dead_s[wv][j] = dead ? 1 : 0;
 	}
 	const double icpt = core[p];
-	const double rse = core[p + 3];
-	const double nobs = core[p + 4];
 	const bool is_null = core[p + 5] != 0.0;
-	const bool has_icpt = !isnan(icpt);
-	const double b0 = has_icpt ? icpt : 0.0;
-	double margin = 0.0; // 0 => bounds equal yhat
-	if (!is_null && !(isnan(rse) || rse <= 0.0 || nobs <= (double)(p + 1))) {
-		const double df = has_icpt ? nobs - (double)(p + 1) : nobs - (double)p;
-		const double c = args.confidence_level;
-		if (df > 0.0 && c > 0.0 && c < 1.0) { // anofox_t_critical: NaN outside (0, 1) -> no interval
-			const double tcrit = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + c), df);
-			if (!isnan(tcrit)) margin = tcrit * rse * sqrt(1.0 + 1.0 / nobs);
-		}
-	}
+	const double b0 = isnan(icpt) ? 0.0 : icpt;
+	const double margin = args.margin[g]; // 0 => bounds equal yhat
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the wave's own LDS writes above
 	__builtin_amdgcn_wave_barrier();
 	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
@@ -65,10 +79,99 @@ __global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
 	}
 }
 
+// p <= 8: coefficients in registers, 128-row tiles with one 16-byte load per column and lane (rows 2l, 2l+1),
+// all loads of a tile in flight together; 48 contiguous output bytes per lane.
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int P>
+__global__ __launch_bounds__(256) void predict_narrow_kernel(PredictArgs args) {
+	const int lane = threadIdx.x & 63;
+	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+	if (g >= args.n_groups) return;
+	const double *core = args.core + g * (int64_t)(P + 6);
+	double coef[P];
+	bool dead[P];
+#pragma unroll
+	for (int j = 0; j < P; ++j) {
+		const double c = core[j];
+		dead[j] = isnan(c);
+		coef[j] = dead[j] ? 0.0 : c;
+	}
+	const double icpt = core[P];
+	const bool is_null = core[P + 5] != 0.0;
+	const double b0 = isnan(icpt) ? 0.0 : icpt;
+	const double margin = args.margin[g];
+	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+	const double nanv = __builtin_nan("");
+	for (int64_t base = lo; base < hi; base += 128) {
+		const int64_t r0 = base + 2 * lane;
+		double x0[P], x1[P];
+		if (base + 128 <= hi) {
+#pragma unroll
+			for (int j = 0; j < P; ++j) {
+				const dbl2u v = *reinterpret_cast<const dbl2u *>(args.x_table[j] + r0);
+				x0[j] = v.x;
+				x1[j] = v.y;
+			}
+		} else {
+			// ragged tail: unconditional loads from clamped (valid) rows — a guarded load per element would put
+			// every load behind its own branch and wait; rows past the end are dropped at the store
+			const int64_t c0 = r0 < hi ? r0 : hi - 1, c1 = r0 + 1 < hi ? r0 + 1 : hi - 1;
+#pragma unroll
+			for (int j = 0; j < P; ++j) {
+				x0[j] = args.x_table[j][c0];
+				x1[j] = args.x_table[j][c1];
+			}
+		}
+		double y0 = b0, y1 = b0;
+#pragma unroll
+		for (int j = 0; j < P; ++j) { // NaN coefficients are skipped whatever x holds (lib.rs:2300-2304)
+			y0 = fma(coef[j], dead[j] ? 0.0 : x0[j], y0);
+			y1 = fma(coef[j], dead[j] ? 0.0 : x1[j], y1);
+		}
+		const bool ok0 = !is_null && isfinite(y0), ok1 = !is_null && isfinite(y1);
+		double *out = args.pred + r0 * 3;
+		if (r0 + 1 < hi) {
+			dbl2u a, b, c;
+			a.x = ok0 ? y0 : nanv;
+			a.y = ok0 ? y0 - margin : nanv;
+			b.x = ok0 ? y0 + margin : nanv;
+			b.y = ok1 ? y1 : nanv;
+			c.x = ok1 ? y1 - margin : nanv;
+			c.y = ok1 ? y1 + margin : nanv;
+			*reinterpret_cast<dbl2u *>(out) = a;
+			*reinterpret_cast<dbl2u *>(out + 2) = b;
+			*reinterpret_cast<dbl2u *>(out + 4) = c;
+		} else if (r0 < hi) {
+			out[0] = ok0 ? y0 : nanv;
+			out[1] = ok0 ? y0 - margin : nanv;
+			out[2] = ok0 ? y0 + margin : nanv;
+		}
+	}
+}
+
+template <int P>
+hipError_t launch_predict_p(const PredictArgs &a, hipStream_t stream) {
+	hipLaunchKernelGGL((predict_narrow_kernel<P>), dim3((unsigned)((a.n_groups + 3) / 4)), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
 } // namespace
 
 hipError_t launch_predict(const PredictArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
+	hipLaunchKernelGGL(predict_margin_kernel, dim3((unsigned)((a.n_groups + 255) / 256)), dim3(256), 0, stream, a);
+	switch (a.p) {
+	case 1: return launch_predict_p<1>(a, stream);
+	case 2: return launch_predict_p<2>(a, stream);
+	case 3: return launch_predict_p<3>(a, stream);
+	case 4: return launch_predict_p<4>(a, stream);
+	case 5: return launch_predict_p<5>(a, stream);
+	case 6: return launch_predict_p<6>(a, stream);
+	case 7: return launch_predict_p<7>(a, stream);
+	case 8: return launch_predict_p<8>(a, stream);
+	default: break;
+	}
 	hipLaunchKernelGGL(predict_kernel, dim3((unsigned)((a.n_groups + 3) / 4)), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }

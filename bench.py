@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--features", type=int, default=8)
     ap.add_argument("--model", default="ols", choices=["ols", "ridge", "wls"])
     ap.add_argument("--inference", action="store_true")
+    ap.add_argument("--predict", action="store_true",
+                    help="fit + per-row predictions (*_fit_predict_agg); every 5th row is a prediction row (NULL y)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-sample", type=int, default=1024)
     args = ap.parse_args()
@@ -143,6 +145,12 @@ def main():
         raise SystemExit(f"rank {rank}: workload needs {need / 1e9:.1f} GB, only {free / 1e9:.1f} GB free")
     offs, y, x_cols, w = synth.make_grouped(G_local, n, p, group_start=lo, weights=weighted, device=dev,
                                             chunk_groups=max(1, min(32768, (1 << 25) // n)))
+    if args.predict:
+        if world > 1:
+            raise SystemExit("--predict is a single-GPU measurement")
+        hold = (torch.arange(y.numel(), device=dev) % 5) == 4
+        y = torch.where(hold, torch.full_like(y, float("nan")), y)
+        del hold
     kw = {"compute_inference": args.inference}
     if args.model == "ridge":
         kw["alpha"] = 1.0
@@ -150,7 +158,13 @@ def main():
     ctx = pkg.Context(dev_index)
     sharded = dmod.ShardedBatchFit(ctx, G)
 
+    pred_buf = torch.empty((y.numel(), 3), dtype=torch.float64, device=dev) if args.predict else None
+    core_buf = torch.empty((G_local, p + 6), dtype=torch.float64, device=dev) if args.predict else None
+
     def step():
+        if args.predict:
+            c, _ = ctx.fit_predict_batch_device(offs, y, x_cols, w, opts, core=core_buf, pred=pred_buf)
+            return c, None
         return sharded.fit(offs, y, x_cols, w, opts)
 
     for _ in range(args.warmup):
@@ -210,13 +224,18 @@ def main():
                 traffic = json.load(open(tpath)).get(f"{args.model}_G{G_local}_n{n}_p{p}")
             except Exception:
                 traffic = None
+        extra = {}
+        if args.predict:
+            extra = {"rows_per_sec": G * n * args.steps / elapsed, "predict_kernel_ms_per_step": kt["predict_ms"] / args.steps,
+                     "predict_GBps": G_local * n * (8 * p + 24) / (kt["predict_ms"] / args.steps * 1e-3) / 1e9
+                     if kt["predict_ms"] > 0 else 0.0}
         out = {
-            "metric": "group_fits_per_sec", "value": fits_per_s if ok else None, "unit": "fits/s",
+            "metric": "group_fits_per_sec", "value": fits_per_s if ok else None, "unit": "fits/s", **extra,
             "ns_per_row": (elapsed / args.steps) * 1e9 / (G * n),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.model}_fit_agg: {G} groups x n={n} x p={p}, device-resident grouped columns, "
+            "config": {"workload": f"{args.model}_fit{'_predict' if args.predict else ''}_agg: {G} groups x n={n} x p={p}, device-resident grouped columns, "
                                    f"fit_intercept=true, compute_inference={str(args.inference).lower()}",
                        "groups_total": G, "groups_per_gpu": G_local, "rows_per_group": n, "features": p,
                        "partition": f"contiguous key ranges over {world} rank(s); all-gather of {p + 6}-double records"},
