@@ -23,7 +23,7 @@ __device__ inline unsigned long long mix64(unsigned long long z) {
 }
 __device__ inline double u01(unsigned long long h) { return ((double)(h >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
 
-struct Cols { double *x[8]; double *y; double *w; };
+struct Cols { double *x[128]; double *y; double *w; };
 
 __global__ void fill_kernel(Cols c, int p, long long n_per, long long n_rows) {
 	const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -55,7 +55,7 @@ int main(int argc, char **argv) {
 	const char *model = argc > 4 ? argv[4] : "ols";
 	const int steps = argc > 5 ? atoi(argv[5]) : 5;
 	const bool inference = argc > 6 && !strcmp(argv[6], "inference");
-	if (p < 1 || p > 8) { fprintf(stderr, "features must be 1..8\n"); return 2; }
+	if (p < 1 || p > 128) { fprintf(stderr, "features must be 1..128\n"); return 2; }
 	const long long N = G * n;
 	const bool weighted = !strcmp(model, "wls");
 
@@ -85,7 +85,7 @@ int main(int argc, char **argv) {
 	opt.confidence_level = 0.95;
 	opt.alpha = 1.0;
 	opt.solver = ANOFOX_SOLVER_SVD;
-	const double *xc[8];
+	const double *xc[128];
 	for (int j = 0; j < p; ++j) xc[j] = c.x[j];
 
 	auto run = [&]() {
