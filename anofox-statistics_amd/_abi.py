@@ -126,6 +126,11 @@ SYMBOLS = {
     "anofox_hip_fit_predict_batch_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), _DP,
                                                      C.POINTER(_DP), _DP, C.POINTER(C.c_int64), AnofoxHipBatchOptions,
                                                      _DP, _DP, _ERRP]),
+    "anofox_hip_fit_predict_expanding_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p,
+                                                           C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p,
+                                                           AnofoxHipBatchOptions, C.c_void_p, _ERRP]),
+    "anofox_hip_fit_predict_expanding_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64),
+                                                         _DP, C.POINTER(_DP), _DP, AnofoxHipBatchOptions, _DP, _ERRP]),
     "anofox_hip_predict_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p,
                                                    C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_void_p, _ERRP]),
     "anofox_hip_context_enable_timing": (C.c_bool, [_CTX, C.c_bool, _ERRP]),

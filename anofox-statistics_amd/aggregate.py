@@ -418,3 +418,68 @@ SQL_FUNCTIONS.update({
     "anofox_stats_ridge_fit_predict_agg": ridge_fit_predict_agg, "ridge_fit_predict_agg": ridge_fit_predict_agg,
     "anofox_stats_wls_fit_predict_agg": wls_fit_predict_agg, "wls_fit_predict_agg": wls_fit_predict_agg,
 })
+
+
+# ------------------------------------------------------------------------------------------------------
+# *_fit_predict(y, x [, options]) OVER (PARTITION BY k ORDER BY o ROWS BETWEEN UNBOUNDED PRECEDING AND
+# CURRENT ROW | 1 PRECEDING): the window functions (src/window_functions/{ols,ridge,wls}_fit_predict.cpp)
+# ------------------------------------------------------------------------------------------------------
+def _fit_predict_window(model, partition_keys, order, y, x, weights, options, context, frame_end):
+    """Returns (yhat, yhat_lower, yhat_upper) per input row, in input order; NaN = SQL NULL.
+    frame_end: "current row" or "1 preceding" (the frame starts UNBOUNDED PRECEDING)."""
+    from .runtime import fit_predict_expanding_host
+    opts = parse_options(options)
+    keys = np.asarray(partition_keys)
+    yv, ynull = _null_mask_1d(y)
+    yv = np.where(ynull, np.nan, yv)
+    rows = [None if r is None else [np.nan if v is None else float(v) for v in r] for r in x]
+    p = max((len(r) for r in rows if r is not None), default=0)
+    Xd = np.full((len(yv), p), np.nan)
+    for i, r in enumerate(rows):
+        if r is None:
+            continue                                             # NULL x list: no current x, no training
+        if len(r) != p:
+            raise InvalidInputException(f"Inconsistent feature count: expected {p}, got {len(r)}")
+        Xd[i] = r
+    if opts.null_policy == "drop_y_zero_x":                      # ols_fit_predict.cpp:171-178
+        yv = np.where(np.any(Xd == 0.0, axis=1), np.nan, yv)
+    ukeys, gid = np.unique(keys, return_inverse=True)
+    perm = np.lexsort((np.asarray(order), gid))                  # PARTITION BY keys ORDER BY order
+    counts = np.bincount(gid, minlength=len(ukeys))
+    offsets = np.zeros(len(ukeys) + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    wv = None
+    if weights is not None:
+        wv, wnull = _null_mask_1d(weights)
+        wv = np.where(wnull, np.nan, wv)[perm]
+    pred_sorted = fit_predict_expanding_host(offsets, yv[perm], [np.ascontiguousarray(Xd[perm, j]) for j in range(p)],
+                                             wv, opts.batch_options(model), ctx=context)
+    if frame_end == "1 preceding":                               # frame ends one row earlier: shift inside partitions
+        shifted = np.full_like(pred_sorted, np.nan)
+        shifted[1:] = pred_sorted[:-1]
+        shifted[offsets[:-1][counts > 0]] = np.nan
+        pred_sorted = shifted
+    elif frame_end != "current row":
+        raise InvalidInputException("frame_end must be 'current row' or '1 preceding'")
+    out = np.empty_like(pred_sorted)
+    out[perm] = pred_sorted
+    return out[:, 0], out[:, 1], out[:, 2]
+
+
+def ols_fit_predict(partition_keys, order, y, x, options=None, context=None, frame_end="current row"):
+    return _fit_predict_window("ols", partition_keys, order, y, x, None, options, context, frame_end)
+
+
+def ridge_fit_predict(partition_keys, order, y, x, options=None, context=None, frame_end="current row"):
+    return _fit_predict_window("ridge", partition_keys, order, y, x, None, options, context, frame_end)
+
+
+def wls_fit_predict(partition_keys, order, y, x, weights, options=None, context=None, frame_end="current row"):
+    return _fit_predict_window("wls", partition_keys, order, y, x, weights, options, context, frame_end)
+
+
+SQL_FUNCTIONS.update({
+    "anofox_stats_ols_fit_predict": ols_fit_predict, "ols_fit_predict": ols_fit_predict,
+    "anofox_stats_ridge_fit_predict": ridge_fit_predict, "ridge_fit_predict": ridge_fit_predict,
+    "anofox_stats_wls_fit_predict": wls_fit_predict, "wls_fit_predict": wls_fit_predict,
+})

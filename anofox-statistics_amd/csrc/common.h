@@ -121,6 +121,26 @@ struct PredictArgs {
 };
 hipError_t launch_predict(const PredictArgs &a, hipStream_t stream);
 
+// expanding-window fit + predict (window_narrow.hip), p <= kNarrowMaxP
+struct WindowArgs {
+	const int64_t *row_offsets;
+	const double *y;
+	const double *x[kNarrowMaxP];
+	const double *w;
+	double *pred; // [N * 3]
+	int64_t n_groups;
+	int p;
+	int model;
+	int fit_intercept;
+	int lambda_scaling;
+	double alpha;
+	const double *tcrit; // [tcrit_cap + 1], see tcrit_table_kernel
+	int tcrit_cap;
+};
+constexpr int kWindowTcritCap = 65536;
+hipError_t launch_tcrit_table(double *table, int cap, double prob, hipStream_t stream);
+hipError_t launch_expanding_predict(const WindowArgs &a, hipStream_t stream);
+
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);

@@ -35,6 +35,10 @@ struct AnofoxHipContext {
 	// small auxiliary device buffer (t-quantile memo of the predict kernel)
 	void *aux = nullptr;
 	size_t aux_bytes = 0;
+	// Student-t critical values for df = 1..kWindowTcritCap at the confidence level of the last window call
+	void *wtab = nullptr;
+	size_t wtab_bytes = 0;
+	double wtab_conf = -1.0;
 	// timing
 	bool timing = false;
 	std::vector<hipEvent_t> free_events;
@@ -340,6 +344,7 @@ void anofox_hip_context_destroy(AnofoxHipContext *ctx) {
 	if (ctx->ws) (void)hipFree(ctx->ws);
 	if (ctx->stage) (void)hipFree(ctx->stage);
 	if (ctx->aux) (void)hipFree(ctx->aux);
+	if (ctx->wtab) (void)hipFree(ctx->wtab);
 	for (auto &pr : ctx->predict_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
@@ -555,6 +560,133 @@ bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int64_t n_groups, 
 	if (!run_device_batch(ctx, n_groups, p, n_rows, d_off, d_y, d_x, d_w, options, d_core, nullptr, out_error, d_cnt)) return false;
 	if (!run_predict(ctx, n_groups, p, d_off, d_x, d_core, options.confidence_level, d_pred, out_error)) return false;
 	if (hip_fail(hipMemcpyAsync(core, d_core, G * core_len * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;
+	if (R > 0 && hip_fail(hipMemcpyAsync(pred, d_pred, R * 3 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H pred", out_error)) return false;
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
+}
+
+
+namespace {
+
+bool run_expanding(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *d_y,
+                   const double *const *x_cols, const double *d_w, const AnofoxHipBatchOptions &opt, double *d_pred,
+                   AnofoxError *e) {
+	if (G == 0) return true;
+	if (!ensure_buffer(&ctx->wtab, &ctx->wtab_bytes, (size_t)(kWindowTcritCap + 1) * sizeof(double), "t table", e)) return false;
+	hipStream_t st = ctx->stream;
+	if (ctx->wtab_conf != opt.confidence_level) {
+		if (hip_fail(launch_tcrit_table((double *)ctx->wtab, kWindowTcritCap, 0.5 * (1.0 + opt.confidence_level), st), "t table kernel launch", e)) return false;
+		ctx->wtab_conf = opt.confidence_level;
+	}
+	WindowArgs a;
+	memset(&a, 0, sizeof a);
+	a.row_offsets = d_off;
+	a.y = d_y;
+	for (size_t j = 0; j < p; ++j) a.x[j] = x_cols[j];
+	a.w = d_w;
+	a.pred = d_pred;
+	a.n_groups = G;
+	a.p = (int)p;
+	a.model = (int)opt.model;
+	a.fit_intercept = opt.fit_intercept ? 1 : 0;
+	a.lambda_scaling = (int)opt.lambda_scaling;
+	a.alpha = opt.alpha;
+	a.tcrit = (const double *)ctx->wtab;
+	a.tcrit_cap = kWindowTcritCap;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (ctx->timing) {
+		e0 = get_event(ctx);
+		e1 = get_event(ctx);
+		(void)hipEventRecord(e0, st);
+	}
+	if (hip_fail(launch_expanding_predict(a, st), "window kernel launch", e)) return false;
+	if (ctx->timing) {
+		(void)hipEventRecord(e1, st);
+		ctx->predict_events.emplace_back(e0, e1);
+	}
+	return true;
+}
+
+bool validate_window(AnofoxHipContext *ctx, int64_t G, size_t p, const void *off, const void *y, const double *const *x_cols,
+                     const void *w, const AnofoxHipBatchOptions &opt, const void *pred, AnofoxError *e) {
+	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (G < 0 || p == 0 || !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "invalid n_groups / n_features / x"); return false; }
+	if (p > (size_t)kNarrowMaxP) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "the window path supports at most " + std::to_string(kNarrowMaxP) + " features");
+		return false;
+	}
+	if (G > 0 && (!off || !y || !pred)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "row_offsets, y or pred is NULL"); return false; }
+	for (size_t j = 0; j < p; ++j)
+		if (G > 0 && !x_cols[j]) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x column pointer is NULL"); return false; }
+	if (opt.model == ANOFOX_HIP_MODEL_WLS && G > 0 && !w) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "weights is NULL"); return false; }
+	if (opt.hc_type != ANOFOX_HC_NONE) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "hc_type other than 'none' is not implemented on the GPU path"); return false; }
+	return true;
+}
+
+} // namespace
+
+bool anofox_hip_fit_predict_expanding_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                             const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
+                                             const double *d_w, AnofoxHipBatchOptions options, double *d_pred,
+                                             AnofoxError *out_error) {
+	reset_error(out_error);
+	(void)n_rows;
+	if (!validate_window(ctx, n_groups, n_features, d_row_offsets, d_y, x_cols, d_w, options, d_pred, out_error)) return false;
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	return run_expanding(ctx, n_groups, n_features, d_row_offsets, d_y, x_cols, d_w, options, d_pred, out_error);
+}
+
+bool anofox_hip_fit_predict_expanding_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                           const int64_t *row_offsets, const double *y, const double *const *x_cols,
+                                           const double *w, AnofoxHipBatchOptions options, double *pred,
+                                           AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) {
+		ctx = default_context(out_error);
+		if (!ctx) return false;
+	}
+	if (!validate_window(ctx, n_groups, n_features, row_offsets, y, x_cols, w, options, pred, out_error)) return false;
+	if (n_groups == 0) return true;
+	if (row_offsets[0] != 0 || row_offsets[n_groups] != n_rows) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must start at 0 and end at n_rows");
+		return false;
+	}
+	for (int64_t g = 0; g < n_groups; ++g)
+		if (row_offsets[g + 1] < row_offsets[g]) {
+			set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must be non-decreasing");
+			return false;
+		}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	const size_t p = n_features, R = (size_t)n_rows, G = (size_t)n_groups;
+	const bool weighted = options.model == ANOFOX_HIP_MODEL_WLS;
+	const size_t ncol = p + 1 + (weighted ? 1 : 0);
+	const size_t b_off = align_up((G + 1) * sizeof(int64_t), 256);
+	const size_t b_col = align_up((R + 2) * sizeof(double), 256);
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_off + ncol * b_col + align_up(R * 3 * sizeof(double) + 8, 256), "staging", out_error))
+		return false;
+	char *cur = (char *)ctx->stage;
+	hipStream_t st = ctx->stream;
+	int64_t *d_off = (int64_t *)cur;
+	cur += b_off;
+	if (hip_fail(hipMemcpyAsync(d_off, row_offsets, (G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D offsets", out_error)) return false;
+	const double *d_x[kNarrowMaxP];
+	for (size_t j = 0; j < p; ++j) {
+		if (R > 0 && hip_fail(hipMemcpyAsync(cur, x_cols[j], R * sizeof(double), hipMemcpyHostToDevice, st), "H2D x", out_error)) return false;
+		d_x[j] = (const double *)cur;
+		cur += b_col;
+	}
+	if (R > 0 && hip_fail(hipMemcpyAsync(cur, y, R * sizeof(double), hipMemcpyHostToDevice, st), "H2D y", out_error)) return false;
+	const double *d_y = (const double *)cur;
+	cur += b_col;
+	const double *d_w = nullptr;
+	if (weighted) {
+		if (R > 0 && hip_fail(hipMemcpyAsync(cur, w, R * sizeof(double), hipMemcpyHostToDevice, st), "H2D w", out_error)) return false;
+		d_w = (const double *)cur;
+		cur += b_col;
+	}
+	double *d_pred = (double *)cur;
+	if (!run_expanding(ctx, n_groups, p, d_off, d_y, d_x, d_w, options, d_pred, out_error)) return false;
 	if (R > 0 && hip_fail(hipMemcpyAsync(pred, d_pred, R * 3 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H pred", out_error)) return false;
 	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
 }

@@ -1,0 +1,351 @@
+// window_narrow.hip — expanding-window fit + predict for the `*_fit_predict` window functions (p <= 8).
+//
+// The reference implements `anofox_stats_{ols,ridge,wls}_fit_predict(y, x [, w] [, opts]) OVER (...)` as a window
+// aggregate (src/window_functions/ols_fit_predict.cpp): the state buffers the frame's training rows (y not NULL,
+// :164-190) and remembers the x of the LAST row of the frame (:157-162); Finalize refits from scratch for every
+// output row — NULL unless more than p + [intercept] training rows (:257-262) — and predicts that x with
+// anofox_predict_with_interval (:296-308).  For the frames of the reference's published benchmark
+// (ROWS BETWEEN UNBOUNDED PRECEDING AND CURRENT ROW / 1 PRECEDING, examples/performance_1m_groups/benchmark_ols.sql)
+// that is O(n) refits of O(n) rows per partition.
+//
+// Here: out[e] = prediction for x_e from the fit on rows 0..e of its partition, for every row e, in ONE pass:
+// one wavefront per partition, lanes = consecutive rows; each lane forms its row's moment contribution, a wave
+// inclusive scan (6 shuffle steps per value) plus a running carry turns them into prefix moments, and every
+// lane then solves its own prefix problem in registers (same semantics as solve_narrow.hip: row filter,
+// constant / aliased columns, intercept-only shortcut, minimum observations).  A frame ending at 1 PRECEDING
+// is the same output shifted by one row (done by the caller).
+// Loads and stores are fully coalesced; the kernel is f64-VALU bound (one p x p solve per row).
+#include "common.h"
+#include "device_math.h"
+
+namespace anofox {
+
+namespace {
+
+constexpr double kAliasTolX = 1e-11;
+
+// table[0] = normal quantile z at prob, table[i] = Student-t quantile at prob for df = i (1 <= i <= cap)
+__global__ __launch_bounds__(256) void tcrit_table_kernel(double *table, int cap, double prob) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > cap) return;
+	const bool valid = prob > 0.5 && prob < 1.0;
+	table[i] = !valid ? __builtin_nan("") : (i == 0 ? normcdfinv(prob) : dm_t_quantile_upper(prob, (double)i));
+}
+
+// critical value for an integer df: table lookup; beyond the table the Cornish-Fisher series
+// (Abramowitz & Stegun 26.7.5) is exact to < 1e-15 relative (df > 65536)
+__device__ __forceinline__ double window_tcrit(const WindowArgs &a, double df) {
+	const int i = (int)df;
+	if (i <= a.tcrit_cap) return a.tcrit[i];
+	const double z = a.tcrit[0], z2 = z * z, r = 1.0 / df;
+	const double g1 = z * (z2 + 1.0) * 0.25;
+	const double g2 = z * ((5.0 * z2 + 16.0) * z2 + 3.0) * (1.0 / 96.0);
+	const double g3 = z * (((3.0 * z2 + 19.0) * z2 + 17.0) * z2 - 15.0) * (1.0 / 384.0);
+	return z + r * (g1 + r * (g2 + r * g3));
+}
+
+template <int P>
+struct PrefixFit {
+	double coef[P]; // NaN = dropped
+	double intercept;
+	double rse;
+	double nobs;
+	bool ok;
+};
+
+// Fit from the moments of one prefix; rec uses the MomentLayout<P> of the accumulate kernel.
+template <int P>
+__device__ __forceinline__ void fit_from_moments(const double (&rec)[MomentLayout<P>::REC], int model, bool icpt, double alpha,
+                                                 int lambda_scaling, PrefixFit<P> &out) {
+	using L = MomentLayout<P>;
+	const double nanv = __builtin_nan("");
+	out.ok = false;
+	out.intercept = out.rse = out.nobs = nanv;
+#pragma unroll
+	for (int j = 0; j < P; ++j) out.coef[j] = nanv;
+	if (model == ANOFOX_HIP_MODEL_RIDGE && alpha < 0.0) return;       // ridge.rs:38-40
+	const double cnt = rec[L::OFF_CNT];
+	if (!(cnt > 0.0)) return;                                          // ols.rs:68-70
+	const double sw = rec[L::OFF_SW];
+	const unsigned mask = (unsigned)rec[L::OFF_MASK];
+	const int p_eff = __popc(mask);
+	const double sy = rec[L::OFF_S + P];
+	const double qyy = rec[L::q_index(P, P)];
+	const double cyy_c = qyy - sy * sy / sw;
+	const double ymean = (icpt ? rec[L::OFF_FIRST + P] : 0.0) + sy / sw;
+	if (p_eff == 0) {                                                   // ols.rs:101-130, wls.rs:119-150
+		if (!icpt) return;
+		out.ok = true;
+		out.intercept = ymean;
+		out.rse = (model == ANOFOX_HIP_MODEL_WLS) ? sqrt(cyy_c / sw) : sqrt(cyy_c / (cnt - 1.0));
+		out.nobs = cnt;
+		return;
+	}
+	if (cnt < (double)(p_eff + (icpt ? 1 : 0))) return;                 // ols.rs:132-139
+	double A[P][P], c[P];
+	bool active[P];
+#pragma unroll
+	for (int i = 0; i < P; ++i) {
+		active[i] = (mask >> i) & 1u;
+		const double si = rec[L::OFF_S + i];
+#pragma unroll
+		for (int j = 0; j <= i; ++j) {
+			const double qij = rec[L::q_index(j, i)];
+			A[i][j] = icpt ? qij - si * rec[L::OFF_S + j] / sw : qij;
+		}
+		const double qiy = rec[L::q_index(i, P)];
+		c[i] = icpt ? qiy - si * sy / sw : qiy;
+	}
+	const double tss = icpt ? cyy_c : qyy;
+	double lam = 0.0;
+	if (model == ANOFOX_HIP_MODEL_RIDGE) {
+		lam = alpha;
+		if (lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) lam = cnt * alpha / sqrt(cyy_c / cnt);
+#pragma unroll
+		for (int i = 0; i < P; ++i) A[i][i] += lam;
+	}
+	double diag0[P];
+#pragma unroll
+	for (int j = 0; j < P; ++j) diag0[j] = A[j][j];
+#pragma unroll
+	for (int j = 0; j < P; ++j) {
+		double d = A[j][j];
+#pragma unroll
+		for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+		const bool ok = active[j] && (d > kAliasTolX * diag0[j]) && (d > 0.0);
+		active[j] = ok;
+		const double ljj = ok ? sqrt(d) : 1.0;
+		A[j][j] = ljj;
+		const double inv = 1.0 / ljj;
+#pragma unroll
+		for (int i = j + 1; i < P; ++i) {
+			double t = A[i][j];
+#pragma unroll
+			for (int k = 0; k < j; ++k) t -= A[i][k] * A[j][k];
+			A[i][j] = ok ? t * inv : 0.0;
+		}
+	}
+	int rank = 0;
+#pragma unroll
+	for (int j = 0; j < P; ++j) rank += active[j] ? 1 : 0;
+	double zf[P], beta[P];
+	double zz = 0.0, bc = 0.0, bb = 0.0;
+#pragma unroll
+	for (int i = 0; i < P; ++i) {
+		double t = c[i];
+#pragma unroll
+		for (int k = 0; k < i; ++k) t -= A[i][k] * zf[k];
+		zf[i] = active[i] ? t / A[i][i] : 0.0;
+		zz += zf[i] * zf[i];
+	}
+#pragma unroll
+	for (int i = P - 1; i >= 0; --i) {
+		double t = zf[i];
+#pragma unroll
+		for (int k = i + 1; k < P; ++k) t -= A[k][i] * beta[k];
+		beta[i] = active[i] ? t / A[i][i] : 0.0;
+		bc += beta[i] * c[i];
+		bb += beta[i] * beta[i];
+	}
+	double rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
+	if (rss < 0.0) rss = 0.0; // exact fits: the moment identity can round below zero (no residual pass here)
+	const double df = cnt - (double)(rank + (icpt ? 1 : 0));
+	double b0 = nanv;
+	if (icpt) {
+		b0 = ymean;
+#pragma unroll
+		for (int i = 0; i < P; ++i) b0 -= beta[i] * (rec[L::OFF_FIRST + i] + rec[L::OFF_S + i] / sw);
+	}
+	out.ok = true;
+	out.intercept = b0;
+#pragma unroll
+	for (int i = 0; i < P; ++i) out.coef[i] = active[i] ? beta[i] : nanv;
+	out.rse = sqrt(rss / df);
+	out.nobs = cnt;
+}
+
+__device__ __forceinline__ double scan_incl(double v, int lane) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const double u = __shfl_up(v, d, 64);
+		v += (lane >= d) ? u : 0.0;
+	}
+	return v;
+}
+
+__device__ __forceinline__ unsigned scan_or(unsigned v, int lane) {
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const unsigned u = (unsigned)__shfl_up((int)v, d, 64);
+		v |= (lane >= d) ? u : 0u;
+	}
+	return v;
+}
+
+__device__ __forceinline__ double rl64(double v, int src) {
+	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+	                        __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+template <int P, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args) {
+	using L = MomentLayout<P>;
+	constexpr int Z = L::Z;
+	constexpr int ZZ = L::ZZ;
+	const int lane = threadIdx.x & 63;
+	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+	if (g >= args.n_groups) return;
+	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+	const bool icpt = CENTER;
+	const double nanv = __builtin_nan("");
+
+	// running totals of the rows of all previous tiles (wave-uniform)
+	double car_s[Z], car_q[ZZ], car_w = 0.0, car_n = 0.0, car_ny = 0.0;
+	unsigned car_mask = 0;
+#pragma unroll
+	for (int a = 0; a < Z; ++a) car_s[a] = 0.0;
+#pragma unroll
+	for (int k = 0; k < ZZ; ++k) car_q[k] = 0.0;
+	double first[Z];
+#pragma unroll
+	for (int a = 0; a < Z; ++a) first[a] = 0.0;
+	bool have_first = false;
+
+	for (int64_t base = lo; base < hi; base += 64) {
+		const int64_t r = base + lane;
+		const bool in = r < hi;
+		const int64_t rc = in ? r : hi - 1; // clamped: unconditional loads
+		double z[Z];
+#pragma unroll
+		for (int j = 0; j < P; ++j) z[j] = args.x[j][rc];
+		z[P] = args.y[rc];
+		double w = 1.0;
+		if (WEIGHTED) w = args.w[rc];
+		bool xfinite = true;
+#pragma unroll
+		for (int j = 0; j < P; ++j) xfinite = xfinite && isfinite(z[j]);
+		bool valid = in && xfinite && isfinite(z[P]);
+		if (WEIGHTED) valid = valid && (w > 0.0) && isfinite(w);
+		const unsigned long long bv = __ballot(valid);
+		// the window aggregate counts every row whose y is not NULL (NaN here) as a training row for its
+		// "enough rows" rule, before the fit drops the non-finite ones (ols_fit_predict.cpp:164-190,257-262)
+		const unsigned long long by = __ballot(in && !isnan(z[P]));
+		const double n_y = car_ny + (double)__popcll(by & ((2ull << lane) - 1ull));
+		if (!have_first && bv != 0ull) {
+			const int fl = __ffsll((long long)bv) - 1;
+#pragma unroll
+			for (int a = 0; a < Z; ++a) first[a] = rl64(z[a], fl);
+			have_first = true;
+		}
+		// this row's contribution (zero when it does not train), then inclusive prefix over the tile + carry
+		double rec[L::REC];
+		const double ww = valid ? w : 0.0;
+		double d[Z];
+		unsigned m = 0;
+#pragma unroll
+		for (int a = 0; a < Z; ++a) {
+			const double dev = valid ? z[a] - first[a] : 0.0;
+			d[a] = CENTER ? dev : (valid ? z[a] : 0.0);
+			if (a < P) m |= !(fabs(dev) < 1e-10) ? (1u << a) : 0u;
+		}
+#pragma unroll
+		for (int a = 0; a < Z; ++a) {
+			const double wd = WEIGHTED ? ww * d[a] : d[a];
+			rec[L::OFF_S + a] = car_s[a] + scan_incl(wd, lane);
+#pragma unroll
+			for (int b = a; b < Z; ++b) {
+				const int k = a * Z - a * (a - 1) / 2 + (b - a);
+				rec[L::OFF_Q + k] = car_q[k] + scan_incl(wd * d[b], lane);
+			}
+		}
+		rec[L::OFF_SW] = car_w + scan_incl(ww, lane);
+		const double cnt = car_n + (double)__popcll(bv & ((2ull << lane) - 1ull));
+		rec[L::OFF_CNT] = cnt;
+		const unsigned mask = car_mask | scan_or(m, lane);
+		rec[L::OFF_MASK] = (double)mask;
+#pragma unroll
+		for (int a = 0; a < Z; ++a) rec[L::OFF_FIRST + a] = first[a];
+
+		// carry for the next tile = lane 63's inclusive prefix
+#pragma unroll
+		for (int a = 0; a < Z; ++a) car_s[a] = rl64(rec[L::OFF_S + a], 63);
+#pragma unroll
+		for (int k = 0; k < ZZ; ++k) car_q[k] = rl64(rec[L::OFF_Q + k], 63);
+		car_w = rl64(rec[L::OFF_SW], 63);
+		car_n += (double)__popcll(bv);
+		car_ny += (double)__popcll(by);
+		car_mask = (unsigned)__builtin_amdgcn_readlane((int)mask, 63);
+
+		// Finalize of the window aggregate for the frame ending at this row
+		double yhat = nanv, ylo = nanv, yhi = nanv;
+		if (in && xfinite && n_y > (double)(P + (icpt ? 1 : 0))) {       // ols_fit_predict.cpp:257-262 (strictly more)
+			PrefixFit<P> f;
+			fit_from_moments<P>(rec, args.model, icpt, args.alpha, args.lambda_scaling, f);
+			if (f.ok) {
+				double v = isnan(f.intercept) ? 0.0 : f.intercept;
+#pragma unroll
+				for (int j = 0; j < P; ++j) v = fma(isnan(f.coef[j]) ? 0.0 : f.coef[j], isnan(f.coef[j]) ? 0.0 : z[j], v);
+				if (isfinite(v)) {
+					yhat = ylo = yhi = v;
+					// anofox_predict_with_interval: lib.rs:2306-2347
+					if (!(isnan(f.rse) || f.rse <= 0.0 || f.nobs <= (double)(P + 1))) {
+						const double df = f.nobs - (double)(P + (icpt ? 1 : 0));
+						if (df > 0.0) {
+							const double tcrit = window_tcrit(args, df);
+							if (!isnan(tcrit)) {
+								const double margin = tcrit * f.rse * sqrt(1.0 + 1.0 / f.nobs);
+								ylo = v - margin;
+								yhi = v + margin;
+							}
+						}
+					}
+				}
+			}
+		}
+		if (in) {
+			double *out = args.pred + r * 3;
+			out[0] = yhat;
+			out[1] = ylo;
+			out[2] = yhi;
+		}
+	}
+}
+
+template <int P>
+hipError_t launch_window_p(const WindowArgs &a, hipStream_t stream) {
+	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
+	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
+	const bool center = a.fit_intercept != 0;
+	if (weighted) {
+		if (center) hipLaunchKernelGGL((expanding_predict_kernel<P, true, true>), grid, block, 0, stream, a);
+		else hipLaunchKernelGGL((expanding_predict_kernel<P, true, false>), grid, block, 0, stream, a);
+	} else {
+		if (center) hipLaunchKernelGGL((expanding_predict_kernel<P, false, true>), grid, block, 0, stream, a);
+		else hipLaunchKernelGGL((expanding_predict_kernel<P, false, false>), grid, block, 0, stream, a);
+	}
+	return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_tcrit_table(double *table, int cap, double prob, hipStream_t stream) {
+	hipLaunchKernelGGL(tcrit_table_kernel, dim3((unsigned)((cap + 256) / 256)), dim3(256), 0, stream, table, cap, prob);
+	return hipGetLastError();
+}
+
+hipError_t launch_expanding_predict(const WindowArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	switch (a.p) {
+	case 1: return launch_window_p<1>(a, stream);
+	case 2: return launch_window_p<2>(a, stream);
+	case 3: return launch_window_p<3>(a, stream);
+	case 4: return launch_window_p<4>(a, stream);
+	case 5: return launch_window_p<5>(a, stream);
+	case 6: return launch_window_p<6>(a, stream);
+	case 7: return launch_window_p<7>(a, stream);
+	case 8: return launch_window_p<8>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+} // namespace anofox

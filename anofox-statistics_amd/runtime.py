@@ -113,6 +113,26 @@ class Context:
         self._check(ok, err)
         return core, pred
 
+    def fit_predict_expanding_device(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
+                                     pred=None, use_current_torch_stream: bool = True):
+        """Expanding-window fit + predict, device resident.  Returns pred[N, 3] (CUDA tensor)."""
+        import torch
+
+        p = len(x_cols)
+        G = int(row_offsets.numel()) - 1
+        N = int(y.numel())
+        if pred is None:
+            pred = torch.empty((N, 3), dtype=torch.float64, device=y.device)
+        if use_current_torch_stream:
+            self.set_stream(torch.cuda.current_stream(y.device).cuda_stream)
+        cols = (C.c_void_p * p)(*[c.data_ptr() for c in x_cols])
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_fit_predict_expanding_device(
+            self._h, G, p, N, C.c_void_p(row_offsets.data_ptr()), C.c_void_p(y.data_ptr()), cols,
+            C.c_void_p(w.data_ptr() if w is not None else 0), options, C.c_void_p(pred.data_ptr()), C.byref(err))
+        self._check(ok, err)
+        return pred
+
     # ---- host-resident batch (numpy) ----------------------------------------------------------
     def fit_batch_host(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions):
         return fit_batch_host(row_offsets, y, x_cols, w, options, ctx=self)
@@ -169,3 +189,23 @@ def fit_predict_batch_host(row_offsets, y, x_cols: Sequence, w, options: _abi.An
     if not ok:
         raise AnofoxStatsError(err.code, err.text())
     return core, pred
+
+
+def fit_predict_expanding_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
+                               ctx: Optional[Context] = None):
+    """numpy in, numpy out: pred[N, 3] — prediction of x_e from the fit on rows 0..e of its partition."""
+    lib = _abi.load()
+    off = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    wv = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    p, G, N = len(cols), len(off) - 1, len(yv)
+    pred = np.empty((N, 3), dtype=np.float64)
+    colp = (_DP * max(p, 1))(*[c.ctypes.data_as(_DP) for c in cols])
+    err = _abi.AnofoxError()
+    ok = lib.anofox_hip_fit_predict_expanding_host(
+        ctx._h if ctx is not None else None, G, p, N, off.ctypes.data_as(C.POINTER(C.c_int64)), yv.ctypes.data_as(_DP),
+        colp, None if wv is None else wv.ctypes.data_as(_DP), options, pred.ctypes.data_as(_DP), C.byref(err))
+    if not ok:
+        raise AnofoxStatsError(err.code, err.text())
+    return pred

@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--features", type=int, default=8)
     ap.add_argument("--model", default="ols", choices=["ols", "ridge", "wls"])
     ap.add_argument("--inference", action="store_true")
+    ap.add_argument("--window", action="store_true",
+                    help="expanding-window fit + predict (*_fit_predict OVER ...): one fit per ROW")
     ap.add_argument("--predict", action="store_true",
                     help="fit + per-row predictions (*_fit_predict_agg); every 5th row is a prediction row (NULL y)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -161,7 +163,15 @@ def main():
     pred_buf = torch.empty((y.numel(), 3), dtype=torch.float64, device=dev) if args.predict else None
     core_buf = torch.empty((G_local, p + 6), dtype=torch.float64, device=dev) if args.predict else None
 
+    if args.window:
+        if world > 1:
+            raise SystemExit("--window is a single-GPU measurement")
+        pred_buf = torch.empty((y.numel(), 3), dtype=torch.float64, device=dev)
+
     def step():
+        if args.window:
+            ctx.fit_predict_expanding_device(offs, y, x_cols, w, opts, pred=pred_buf)
+            return None, None
         if args.predict:
             c, _ = ctx.fit_predict_batch_device(offs, y, x_cols, w, opts, core=core_buf, pred=pred_buf)
             return c, None
@@ -193,6 +203,20 @@ def main():
         elapsed = float(tmax.item())
 
     ok, cerr, derr = True, 0.0, 0.0
+    if args.window:
+        # parity gate of the window path: a few partitions against the oracle's O(n^2) refits
+        import oracle
+        S = min(8, G_local)
+        nr = int(offs[S].item())
+        ref = oracle.fit_predict_expanding(y[:nr].cpu().numpy(), [c[:nr].cpu().numpy() for c in x_cols],
+                                           offs[:S + 1].cpu().numpy(), w=w[:nr].cpu().numpy() if w is not None else None,
+                                           model=args.model, **{k: v for k, v in kw.items() if k != "compute_inference"})
+        got = pred_buf[:nr].cpu().numpy()
+        m = ~np.isnan(ref[:, 0])
+        ok = bool(np.array_equal(np.isnan(got[:, 0]), ~m))
+        cerr = float(np.quantile(np.abs(got[m, 0] - ref[m, 0]) / np.maximum(np.abs(ref[m, 0]), 1.0), 0.98)) if m.any() else 0.0
+        ok = ok and cerr < 1e-9
+        args.parity_sample = 0
     if args.parity_sample > 0:
         # every rank checks the head of its own shard (the gathered block [lo:hi] must be its own records)
         mine = core_all[lo:hi]
@@ -225,6 +249,9 @@ def main():
             except Exception:
                 traffic = None
         extra = {}
+        if args.window:
+            extra = {"rows_per_sec": G * n * args.steps / elapsed, "row_fits_per_sec": G * n * args.steps / elapsed,
+                     "window_kernel_ms_per_step": kt["predict_ms"] / args.steps}
         if args.predict:
             extra = {"rows_per_sec": G * n * args.steps / elapsed, "predict_kernel_ms_per_step": kt["predict_ms"] / args.steps,
                      "predict_GBps": G_local * n * (8 * p + 24) / (kt["predict_ms"] / args.steps * 1e-3) / 1e9
@@ -235,7 +262,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.model}_fit{'_predict' if args.predict else ''}_agg: {G} groups x n={n} x p={p}, device-resident grouped columns, "
+            "config": {"workload": f"{args.model}_fit{'_predict' if (args.predict or args.window) else ''}{' OVER (expanding window)' if args.window else '_agg'}: {G} groups x n={n} x p={p}, device-resident grouped columns, "
                                    f"fit_intercept=true, compute_inference={str(args.inference).lower()}",
                        "groups_total": G, "groups_per_gpu": G_local, "rows_per_group": n, "features": p,
                        "partition": f"contiguous key ranges over {world} rank(s); all-gather of {p + 6}-double records"},

@@ -300,6 +300,24 @@ ANOFOX_HIP_API bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int
                                        const double *w, const int64_t *train_counts, AnofoxHipBatchOptions options,
                                        double *core, double *pred, AnofoxError *out_error);
 
+/*
+ * Expanding-window fit + predict: the `*_fit_predict(y, x [, w] [, opts]) OVER (PARTITION BY .. ORDER BY ..
+ * ROWS BETWEEN UNBOUNDED PRECEDING AND CURRENT ROW)` window functions (src/window_functions/ols_fit_predict.cpp:
+ * 110-324, ridge_fit_predict.cpp, wls_fit_predict.cpp).  Partitions = groups, rows already in window order.
+ * d_pred[3*e .. 3*e+2] = {yhat, yhat_lower, yhat_upper} of x_e from the fit on rows 0..e of e's partition
+ * (rows with NaN y — the window's NULL y — or non-finite features do not train); NaN = SQL NULL (at most
+ * p + [intercept] training rows so far, failed fit, or non-finite prediction).  A frame ending at 1 PRECEDING is
+ * this output shifted down by one row within the partition.  n_features <= 8.
+ */
+ANOFOX_HIP_API bool anofox_hip_fit_predict_expanding_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                             const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
+                                             const double *d_w, AnofoxHipBatchOptions options, double *d_pred,
+                                             AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_fit_predict_expanding_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                           const int64_t *row_offsets, const double *y, const double *const *x_cols,
+                                           const double *w, AnofoxHipBatchOptions options, double *pred,
+                                           AnofoxError *out_error);
+
 /* Predictions only, from existing fit records (d_core as produced by the fit entry points). */
 ANOFOX_HIP_API bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                      const int64_t *d_row_offsets, const double *const *x_cols, const double *d_core,

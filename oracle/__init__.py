@@ -93,6 +93,9 @@ def lib():
         L.oracle_fit_predict_groups.restype = C.c_int
         L.oracle_fit_predict_groups.argtypes = [_DP, C.POINTER(_DP), _DP, C.POINTER(C.c_int64), C.c_int64, C.c_size_t,
                                                 C.POINTER(OracleOptions), C.POINTER(C.c_int64), _DP, _DP]
+        L.oracle_fit_predict_expanding.restype = C.c_int
+        L.oracle_fit_predict_expanding.argtypes = [_DP, C.POINTER(_DP), _DP, C.POINTER(C.c_int64), C.c_int64, C.c_size_t,
+                                                   C.POINTER(OracleOptions), _DP]
         for name in ("oracle_aic", "oracle_bic"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_double, C.c_int64, C.c_int64, _DP]
@@ -200,3 +203,20 @@ def fit_predict_groups(y, x_cols, offsets, w=None, train_counts=None, **kw):
     if rc != 0:
         raise RuntimeError(f"oracle_fit_predict_groups failed: {rc}")
     return core, pred
+
+
+def fit_predict_expanding(y, x_cols, offsets, w=None, **kw):
+    """pred[N, 3]: prediction of x_e from the fit on rows 0..e of its partition (window functions)."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    wv = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    o = _opts(**kw)
+    pred = np.empty((len(y), 3))
+    rc = lib().oracle_fit_predict_expanding(y.ctypes.data_as(_DP), _col_ptrs(cols),
+                                            None if wv is None else wv.ctypes.data_as(_DP),
+                                            offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(offsets) - 1, len(cols),
+                                            C.byref(o), pred.ctypes.data_as(_DP))
+    if rc != 0:
+        raise RuntimeError(f"oracle_fit_predict_expanding failed: {rc}")
+    return pred

@@ -638,3 +638,52 @@ ORACLE_EXPORT int oracle_fit_predict_groups(const double *y, const double *const
 	free(row); free(tmp); free((void *)xs);
 	return ORC_SUCCESS;
 }
+
+/* Expanding-window fit + predict (src/window_functions/ols_fit_predict.cpp:110-324): for every row e of a
+ * partition, fit on the rows 0..e whose y is not NULL (NaN here), predict x_e.  NULL (NaN) unless MORE than
+ * p + [intercept] such rows exist (:257-262), the fit succeeds and the prediction is finite.  O(n^2) per
+ * partition: test sizes only. */
+ORACLE_EXPORT int oracle_fit_predict_expanding(const double *y, const double *const *x, const double *w,
+                                               const int64_t *offsets, int64_t n_groups, size_t p,
+                                               const OracleOptions *opt, double *pred) {
+	OracleOptions o = *opt;
+	o.compute_inference = 0;
+	double *coef = (double *)malloc(p * sizeof(double));
+	double *row = (double *)malloc(p * sizeof(double));
+	const double **xs = (const double **)malloc(p * sizeof(double *));
+	for (int64_t g = 0; g < n_groups; g++) {
+		int64_t lo = offsets[g], hi = offsets[g + 1];
+		size_t cap = (size_t)(hi - lo);
+		double *ty = (double *)malloc((cap + 1) * sizeof(double));
+		double *tw = (double *)malloc((cap + 1) * sizeof(double));
+		double **tx = (double **)malloc(p * sizeof(double *));
+		for (size_t j = 0; j < p; j++) tx[j] = (double *)malloc((cap + 1) * sizeof(double));
+		size_t nt = 0;
+		for (int64_t e = lo; e < hi; e++) {
+			double *out = pred + (size_t)e * 3;
+			out[0] = out[1] = out[2] = NAN;
+			if (!isnan(y[e])) { /* training row of the frame */
+				ty[nt] = y[e];
+				if (w) tw[nt] = w[e];
+				for (size_t j = 0; j < p; j++) tx[j][nt] = x[j][e];
+				nt++;
+			}
+			if (nt <= p + (size_t)(o.fit_intercept ? 1 : 0)) continue;
+			OracleResult r;
+			memset(&r, 0, sizeof r);
+			r.coefficients = coef;
+			for (size_t j = 0; j < p; j++) xs[j] = tx[j];
+			if (oracle_fit(ty, xs, w ? tw : NULL, nt, p, &o, &r) != ORC_SUCCESS) continue;
+			for (size_t j = 0; j < p; j++) row[j] = x[j][e];
+			double pr[3];
+			if (oracle_predict_with_interval(coef, p, r.intercept, row, r.residual_std_error, r.n_observations,
+			                                 o.confidence_level, pr) && isfinite(pr[0])) {
+				out[0] = pr[0]; out[1] = pr[1]; out[2] = pr[2];
+			}
+		}
+		for (size_t j = 0; j < p; j++) free(tx[j]);
+		free(tx); free(tw); free(ty);
+	}
+	free((void *)xs); free(row); free(coef);
+	return ORC_SUCCESS;
+}

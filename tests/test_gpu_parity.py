@@ -640,3 +640,89 @@ def test_fit_predict_device_cfg_shape_properties(pkg, ctx):
                                              offs[:S + 1].cpu().numpy(), model="ols")
     assert_records_match(core[:S].cpu().numpy(), rcore, p, what="fit_predict device sample")
     assert np.max(np.abs(pred[:S * n].cpu().numpy() - rpred) / np.maximum(np.abs(rpred), 1.0)) < 1e-9
+
+
+# --------------------------------------------------------------------------------------------------
+# *_fit_predict window functions (expanding frames)
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["ols", "ridge", "wls"])
+@pytest.mark.parametrize("p", [1, 3, 8])
+def test_expanding_window_matches_oracle(pkg, ctx, model, p):
+    rng = np.random.default_rng(17 * p + len(model))
+    G = 24
+    offs, y, x_cols, w = _random_groups(rng, G, p, 1, 180)
+    y = y.copy()
+    y[rng.random(len(y)) < 0.15] = np.nan                       # prediction rows (NULL y)
+    x_cols = [c.copy() for c in x_cols]
+    x_cols[0][rng.random(len(y)) < 0.02] = np.nan               # NULL feature: no prediction, no training
+    if p >= 3:                                                  # a column that only starts to vary late
+        lo, hi = offs[3], offs[4]
+        x_cols[1][lo:hi] = 2.5
+        if hi - lo > 20:
+            x_cols[1][lo + 15:hi] = rng.uniform(-1, 1, hi - lo - 15)
+    for icpt in (True, False):
+        kw = dict(fit_intercept=icpt, confidence_level=0.9)
+        if model == "ridge":
+            kw["alpha"] = 0.5
+        wv = w if model == "wls" else None
+        pred = pkg.fit_predict_expanding_host(offs, y, x_cols, wv, _opts(pkg, model, **kw), ctx=ctx)
+        ref = oracle.fit_predict_expanding(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
+        assert np.array_equal(np.isnan(pred[:, 0]), np.isnan(ref[:, 0])), f"NULL pattern {model} p={p} icpt={icpt}"
+        m = ~np.isnan(ref[:, 0])
+        scale = np.maximum(np.abs(ref[m, 0]), 1.0)
+        # early prefixes (n barely above p) are ill-conditioned: the window kernel has no refinement pass
+        err = np.abs(pred[m, 0] - ref[m, 0]) / scale
+        assert np.quantile(err, 0.98) < 1e-9 and err.max() < 1e-5, (model, p, icpt, err.max())
+        wid_ref = ref[m, 2] - ref[m, 1]
+        wid = pred[m, 2] - pred[m, 1]
+        ok = np.isfinite(wid_ref) & (wid_ref > 1e-6 * scale)
+        assert np.quantile(np.abs(wid[ok] / wid_ref[ok] - 1.0), 0.98) < 1e-6
+
+
+def test_window_function_mirror_and_frames(pkg, ctx):
+    """ols_fit_predict OVER (PARTITION BY g ORDER BY t): unsorted input, NULL y rows are predicted, and the
+    '1 preceding' frame of the reference's benchmark (examples/performance_1m_groups/benchmark_ols.sql:16-19) is
+    the 'current row' result shifted by one row inside each partition."""
+    rng = np.random.default_rng(4)
+    n = 60
+    keys = np.array(["a"] * n + ["b"] * n)
+    t = np.concatenate([rng.permutation(n), rng.permutation(n)])
+    X = rng.uniform(-5, 5, (2 * n, 2))
+    y = 1.5 + X @ np.array([2.0, -1.0]) + 0.1 * rng.standard_normal(2 * n)
+    yl = [None if (ti % 7 == 6) else float(v) for v, ti in zip(y, t)]
+    yh, lo, hi = pkg.ols_fit_predict(keys, t, yl, X.tolist(), {"confidence_level": 0.9}, context=ctx)
+    yh1, _, _ = pkg.ols_fit_predict(keys, t, yl, X.tolist(), {"confidence_level": 0.9}, context=ctx, frame_end="1 preceding")
+    for k in ("a", "b"):
+        sel = np.nonzero(keys == k)[0]
+        order = sel[np.argsort(t[sel])]
+        assert np.all(np.isnan(yh[order[:3]]))                 # needs more than p + 1 = 3 training rows
+        assert np.all(np.isfinite(yh[order[8:]])) and np.all(hi[order[8:]] >= lo[order[8:]])
+        assert np.isnan(yh1[order[0]])
+        # shifted: row i of the '1 preceding' frame = prediction made at row i-1 (with x of row i-1)
+        assert np.array_equal(yh1[order[1:]], yh[order[:-1]], equal_nan=True)
+        late = order[30:]
+        assert np.max(np.abs(yh[late] - (1.5 + X[late] @ np.array([2.0, -1.0])))) < 0.3
+
+
+def test_expanding_window_device_reference_benchmark_shape(pkg, ctx):
+    """The reference's published window benchmark shape (1M partitions x 100 rows x p = 3,
+    examples/performance_1m_groups/benchmark_ols.sql) at 200k partitions, device resident: a sample against the
+    oracle, and the last row of every partition against the whole-partition fit."""
+    import torch
+    synth = import_pkg("synth")
+    G, n, p = 200_000, 100, 3
+    offs, y, x_cols, _ = synth.make_grouped(G, n, p, device="cuda")
+    pred = ctx.fit_predict_expanding_device(offs, y, x_cols, None, _opts(pkg, "ols"))
+    core, pall = ctx.fit_predict_batch_device(offs, y, x_cols, None, _opts(pkg, "ols"))
+    torch.cuda.synchronize()
+    last = (offs[1:] - 1)
+    assert float((pred[last] - pall[last]).abs().max() / pall[last].abs().max()) < 1e-9
+    first_rows = pred.reshape(G, n, 3)[:, :4, 0]
+    assert bool(torch.isnan(first_rows).all()) and not bool(torch.isnan(pred.reshape(G, n, 3)[:, 4:, :]).any())
+    S = 16
+    ref = oracle.fit_predict_expanding(y[:S * n].cpu().numpy(), [c[:S * n].cpu().numpy() for c in x_cols],
+                                       offs[:S + 1].cpu().numpy(), model="ols")
+    got = pred[:S * n].cpu().numpy()
+    m = ~np.isnan(ref[:, 0])
+    assert np.array_equal(np.isnan(got[:, 0]), ~m)
+    assert np.quantile(np.abs(got[m] - ref[m]) / np.maximum(np.abs(ref[m]), 1.0), 0.98) < 1e-9
