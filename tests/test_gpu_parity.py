@@ -726,3 +726,40 @@ def test_expanding_window_device_reference_benchmark_shape(pkg, ctx):
     m = ~np.isnan(ref[:, 0])
     assert np.array_equal(np.isnan(got[:, 0]), ~m)
     assert np.quantile(np.abs(got[m] - ref[m]) / np.maximum(np.abs(ref[m]), 1.0), 0.98) < 1e-9
+
+
+def test_entry_points_are_reentrant_across_threads(pkg):
+    """DuckDB calls Update/Finalize from its worker pool (SURVEY.md §8b 'Threading'): the single-group symbols use a
+    per-thread default context and must be safe to call concurrently; so must batch calls on separate contexts."""
+    import threading
+    rng = np.random.default_rng(8)
+    problems = []
+    for k in range(16):
+        n = 30 + 5 * k
+        X = rng.uniform(-5, 5, (n, 3))
+        y = 0.5 * k + X @ np.array([1.0, -2.0, 0.25 * k]) + 0.01 * rng.standard_normal(n)
+        problems.append((y.tolist(), [X[:, j].tolist() for j in range(3)]))
+    expected = [oracle.fit(p[0], p[1])[1] for p in problems]
+    errors = []
+
+    def worker(tid):
+        try:
+            ctx = pkg.Context()
+            for rep in range(5):
+                for k in range(tid, len(problems), 4):
+                    r = pkg.ols_fit(problems[k][0], problems[k][1], {"compute_inference": True})
+                    assert np.allclose(r["coefficients"], expected[k]["coefficients"], rtol=1e-9)
+                    off, yy, xc, _ = _random_groups(np.random.default_rng(100 * tid + rep), 8, 2, 10, 40)
+                    core, _ = pkg.fit_batch_host(off, yy, xc, None, pkg.RegressionOptions().batch_options("ols"), ctx=ctx)
+                    ref, _ = oracle.fit_groups(yy, xc, off)
+                    assert np.allclose(core[:, :3], ref[:, :3], rtol=1e-9)
+            ctx.close()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
