@@ -17,11 +17,20 @@
 //
 // Roofline: HBM-bound.  Algorithmic bytes per row 8(p+1) (+8 with weights); 63 f64 VALU ops per row at
 // p = 8 (~20 % of the f64 vector rate at the HBM-bound row rate).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace anofox {
 
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+
+// 16-byte streaming load; NT = non-temporal (the rows are read exactly once, keep them out of the caches' LRU)
+template <bool NT>
+__device__ __forceinline__ dbl2u load2(const double *p) {
+	if (NT) return __builtin_nontemporal_load(reinterpret_cast<const dbl2u *>(p));
+	return *reinterpret_cast<const dbl2u *>(p);
+}
 
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 	const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
@@ -53,7 +62,7 @@ __device__ __forceinline__ double fold_shfl(double a, double b, int lane) {
 	return keep + __shfl_xor(send, M, 64);
 }
 
-template <int P, bool WEIGHTED, bool CENTER>
+template <int P, bool WEIGHTED, bool CENTER, bool NT>
 __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) {
 	using L = MomentLayout<P>;
 	constexpr int Z = L::Z;
@@ -90,17 +99,17 @@ __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) 
 			in0 = in1 = true;
 #pragma unroll
 			for (int j = 0; j < P; ++j) {
-				const dbl2u v = *reinterpret_cast<const dbl2u *>(args.x[j] + r0);
+				const dbl2u v = load2<NT>(args.x[j] + r0);
 				z0[j] = v.x;
 				z1[j] = v.y;
 			}
 			{
-				const dbl2u v = *reinterpret_cast<const dbl2u *>(args.y + r0);
+				const dbl2u v = load2<NT>(args.y + r0);
 				z0[P] = v.x;
 				z1[P] = v.y;
 			}
 			if (WEIGHTED) {
-				const dbl2u v = *reinterpret_cast<const dbl2u *>(args.w + r0);
+				const dbl2u v = load2<NT>(args.w + r0);
 				w0 = v.x;
 				w1 = v.y;
 			}
@@ -213,20 +222,27 @@ __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) 
 	if (lane < Z + 2) rec[L::KRED + lane] = e;
 }
 
-template <int P>
-static hipError_t launch_p(const BatchArgs &a, hipStream_t stream) {
+template <int P, bool NT>
+static hipError_t launch_pn(const BatchArgs &a, hipStream_t stream) {
 	const dim3 block(256);
 	const dim3 grid((unsigned)((a.n_groups + 3) / 4));
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
 	if (weighted) {
-		if (center) hipLaunchKernelGGL((accumulate_narrow_kernel<P, true, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((accumulate_narrow_kernel<P, true, false>), grid, block, 0, stream, a);
+		if (center) hipLaunchKernelGGL((accumulate_narrow_kernel<P, true, true, NT>), grid, block, 0, stream, a);
+		else hipLaunchKernelGGL((accumulate_narrow_kernel<P, true, false, NT>), grid, block, 0, stream, a);
 	} else {
-		if (center) hipLaunchKernelGGL((accumulate_narrow_kernel<P, false, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((accumulate_narrow_kernel<P, false, false>), grid, block, 0, stream, a);
+		if (center) hipLaunchKernelGGL((accumulate_narrow_kernel<P, false, true, NT>), grid, block, 0, stream, a);
+		else hipLaunchKernelGGL((accumulate_narrow_kernel<P, false, false, NT>), grid, block, 0, stream, a);
 	}
 	return hipGetLastError();
+}
+
+template <int P>
+static hipError_t launch_p(const BatchArgs &a, hipStream_t stream) {
+	// ANOFOX_ACC_NT=0/1 overrides the load policy (A/B measurements)
+	static const int nt = [] { const char *e = getenv("ANOFOX_ACC_NT"); return e ? atoi(e) : 0; }();
+	return nt ? launch_pn<P, true>(a, stream) : launch_pn<P, false>(a, stream);
 }
 
 hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream) {
