@@ -11,6 +11,9 @@ namespace anofox {
 // (p+1)(p+2)/2 moment triangle in VGPRs.  Above this the LDS/MFMA ("wide") path takes over.
 constexpr int kNarrowMaxP = 8;
 
+// bytes of the t critical value memo (device_math.h: TcritSlot[kTcritSlots]) at the end of a workspace
+constexpr size_t kTcritTableBytes = 4096;
+
 // Per-group moment record written by the accumulate kernel and read by the solve kernel.
 // z = (x_1 .. x_p, y), Z = p + 1 columns, shifted by the group's first valid row ("first") when an
 // intercept is fitted (shift 0 otherwise):  d = z - shift.
@@ -56,6 +59,7 @@ struct BatchArgs {
 	int fit_intercept;
 	int compute_inference;
 	int lambda_scaling;
+	int hc_type; // AnofoxHcType; acted on by launch_hc_narrow only
 	double confidence_level;
 	double alpha;
 	// workspace / outputs
@@ -151,5 +155,8 @@ hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream);
 //       2 = final statistics of the queued groups from the directly summed RSS
 hipError_t launch_solve_narrow(const BatchArgs &a, int mode, hipStream_t stream);
 hipError_t launch_residual_grad(const BatchArgs &a, hipStream_t stream);
+// hc_narrow.hip: HC0..HC3 standard errors over the finished fit (rewrites se/t/p/ci of the inference records)
+size_t hc_prep_bytes(int64_t n_groups, int p); // scratch the pass needs (prep records)
+hipError_t launch_hc_narrow(const BatchArgs &a, double *prep, hipStream_t stream);
 
 } // namespace anofox

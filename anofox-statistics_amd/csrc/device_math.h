@@ -131,22 +131,42 @@ static __device__ __attribute__((noinline)) double dm_t_quantile_upper(double pr
 }
 
 // The critical value depends only on (confidence level, df): groups of one batch usually share df, so the
-// value is memoised in a small direct-mapped table in device memory (zeroed at the start of every batch call).
+// value is memoised in a small open-addressed table in device memory (zeroed at the start of every batch call).
+// A slot is written once: it is claimed by a compare-and-swap of its key from 0 to kTcritBusy, the value is
+// stored, then the key is published with release order; readers that find their key (acquire) may read the
+// value.  A df that finds its probe window taken by other keys is simply computed every time.
 struct TcritSlot {
-	unsigned long long key; // bits of df
+	unsigned long long key; // bits of df (0 = empty, 1 = being written)
 	double value;
 };
-constexpr int kTcritSlots = 64;
+constexpr int kTcritSlots = 256; // kTcritTableBytes / sizeof(TcritSlot)
+constexpr int kTcritProbes = 4;
+constexpr unsigned long long kTcritBusy = 1ull;
 
 static __device__ __forceinline__ double dm_tcrit_cached(TcritSlot *table, double prob, double df) {
 	if (!(df > 0.0)) return __builtin_nan("");
 	const unsigned long long key = (unsigned long long)__double_as_longlong(df);
-	TcritSlot *slot = table + (int)((key * 0x9E3779B97F4A7C15ull) >> 58); // top 6 bits
-	const unsigned long long seen = __hip_atomic_load(&slot->key, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-	if (seen == key) return __hip_atomic_load(&slot->value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const int home = (int)((key * 0x9E3779B97F4A7C15ull) >> 56); // top 8 bits
+	TcritSlot *empty = nullptr;
+	for (int i = 0; i < kTcritProbes; ++i) {
+		TcritSlot *slot = table + ((home + i) & (kTcritSlots - 1));
+		const unsigned long long seen = __hip_atomic_load(&slot->key, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+		if (seen == key) return __hip_atomic_load(&slot->value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (seen == 0ull) { empty = slot; break; }
+	}
 	const double t = dm_t_quantile_upper(prob, df);
-	__hip_atomic_store(&slot->value, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	__hip_atomic_store(&slot->key, key, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+	// one lane per wavefront publishes, and only into a slot that is still empty: a batch whose groups share df
+	// would otherwise start with ~10^5 lanes queueing on the same compare-and-swap
+	const unsigned long long missed = __ballot(1);
+	const bool leader = (int)__lane_id() == __ffsll((unsigned long long)missed) - 1;
+	if (empty && leader && __hip_atomic_load(&empty->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
+		unsigned long long expect = 0ull;
+		if (__hip_atomic_compare_exchange_strong(&empty->key, &expect, kTcritBusy, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+		                                         __HIP_MEMORY_SCOPE_AGENT)) {
+			__hip_atomic_store(&empty->value, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&empty->key, key, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
 	return t;
 }
 

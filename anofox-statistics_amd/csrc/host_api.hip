@@ -113,7 +113,7 @@ bool carve_workspace(AnofoxHipContext *ctx, int64_t G, int p, Workspace *out, An
 	const size_t b_mom = align_up((size_t)G * rec * sizeof(double), 256);
 	const size_t b_rss = align_up((size_t)G * (size_t)(p + 2) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)G * sizeof(int32_t), 256);
-	const size_t total = b_mom + b_rss + b_lst + 256 + 1024;
+	const size_t total = b_mom + b_rss + b_lst + 256 + kTcritTableBytes;
 	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, total, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 	out->moments = (double *)base;
@@ -139,7 +139,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	const size_t b_mom = align_up((size_t)slab * rec_bytes, 256);
 	const size_t b_rss = align_up((size_t)G * (p + 2) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)slab * sizeof(int32_t), 256);
-	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256 + 1024, "workspace", e)) return false;
+	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256 + kTcritTableBytes, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 
 	WideArgs a;
@@ -165,7 +165,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.rule_counts = d_rule_counts;
 
 	hipStream_t st = ctx->stream;
-	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, 1024, st), "hipMemsetAsync", e)) return false;
+	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
 	for (int64_t g0 = 0; g0 < G; g0 += slab) {
 		a.group_base = g0;
 		a.n_groups = (G - g0 < slab) ? G - g0 : slab;
@@ -220,6 +220,7 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	a.fit_intercept = opt.fit_intercept ? 1 : 0;
 	a.compute_inference = opt.compute_inference ? 1 : 0;
 	a.lambda_scaling = (int)opt.lambda_scaling;
+	a.hc_type = (int)opt.hc_type;
 	a.confidence_level = opt.confidence_level;
 	a.alpha = opt.alpha;
 	a.moments = ws.moments;
@@ -232,7 +233,7 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	a.rule_counts = d_rule_counts;
 
 	hipStream_t st = ctx->stream;
-	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, 256 + 1024, st), "hipMemsetAsync", e)) return false; // counter + t table
+	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, 256 + kTcritTableBytes, st), "hipMemsetAsync", e)) return false; // counter + t table
 
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 	if (ctx->timing) {
@@ -250,6 +251,11 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	}
 	if (hip_fail(launch_residual_grad(a, st), "residual kernel launch", e)) return false;
 	if (hip_fail(launch_solve_narrow(a, 2, st), "final kernel launch", e)) return false;
+	// ols.rs:209-231, wls.rs:230-252: HC errors replace the classical ones; ridge has no such branch
+	if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE) {
+		if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, hc_prep_bytes(G, (int)p), "hc scratch", e)) return false;
+		if (hip_fail(launch_hc_narrow(a, (double *)ctx->aux, st), "hc kernel launch", e)) return false;
+	}
 	if (ctx->timing) {
 		(void)hipEventRecord(e2, st);
 		ctx->acc_events.emplace_back(e0, e1);   // owns e0 and e1
@@ -278,8 +284,14 @@ bool validate_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	}
 	if (opt.model == ANOFOX_HIP_MODEL_WLS && G > 0 && !w) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "weights is NULL"); return false; }
 	if (opt.compute_inference && G > 0 && !inf) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "inference buffer is NULL"); return false; }
-	if (opt.hc_type != ANOFOX_HC_NONE) {
-		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "hc_type other than 'none' is not implemented on the GPU path");
+	if ((int)opt.hc_type < ANOFOX_HC_NONE || (int)opt.hc_type > ANOFOX_HC_HC3) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "unknown hc_type");
+		return false;
+	}
+	if (opt.hc_type != ANOFOX_HC_NONE && opt.compute_inference && opt.model != ANOFOX_HIP_MODEL_RIDGE &&
+	    p > (size_t)kNarrowMaxP) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT,
+		          "hc_type other than 'none' needs n_features <= " + std::to_string(kNarrowMaxP) + " on the GPU path");
 		return false;
 	}
 	return true;
@@ -424,7 +436,7 @@ namespace {
 bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *const *x_cols,
                  const double *d_core, double confidence, double *d_pred, AnofoxError *e) {
 	if (G == 0) return true;
-	if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, 1024 + (size_t)G * sizeof(double), "predict scratch", e)) return false;
+	if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, kTcritTableBytes + (size_t)G * sizeof(double), "predict scratch", e)) return false;
 	PredictArgs a;
 	memset(&a, 0, sizeof a);
 	a.row_offsets = d_off;
@@ -435,8 +447,8 @@ bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_of
 	a.p = (int)p;
 	a.confidence_level = confidence;
 	a.tcrit_table = ctx->aux;
-	a.margin = (double *)((char *)ctx->aux + 1024);
-	if (hip_fail(hipMemsetAsync(ctx->aux, 0, 1024, ctx->stream), "hipMemsetAsync", e)) return false;
+	a.margin = (double *)((char *)ctx->aux + kTcritTableBytes);
+	if (hip_fail(hipMemsetAsync(ctx->aux, 0, kTcritTableBytes, ctx->stream), "hipMemsetAsync", e)) return false;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->timing) {
 		e0 = get_event(ctx);
@@ -618,7 +630,6 @@ bool validate_window(AnofoxHipContext *ctx, int64_t G, size_t p, const void *off
 	for (size_t j = 0; j < p; ++j)
 		if (G > 0 && !x_cols[j]) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x column pointer is NULL"); return false; }
 	if (opt.model == ANOFOX_HIP_MODEL_WLS && G > 0 && !w) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "weights is NULL"); return false; }
-	if (opt.hc_type != ANOFOX_HC_NONE) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "hc_type other than 'none' is not implemented on the GPU path"); return false; }
 	return true;
 }
 

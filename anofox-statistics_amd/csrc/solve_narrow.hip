@@ -22,6 +22,8 @@
 
 namespace anofox {
 
+static_assert(sizeof(TcritSlot) * kTcritSlots == kTcritTableBytes, "t memo does not fill its workspace slice");
+
 namespace {
 
 constexpr double kAliasTol = 1e-11;   // pivot / original diagonal below this => column aliased (collinear)

@@ -54,7 +54,8 @@ int main(int argc, char **argv) {
 	const int p = argc > 3 ? atoi(argv[3]) : 8;
 	const char *model = argc > 4 ? argv[4] : "ols";
 	const int steps = argc > 5 ? atoi(argv[5]) : 5;
-	const bool inference = argc > 6 && !strcmp(argv[6], "inference");
+	const bool inference = argc > 6 && (!strcmp(argv[6], "inference") || !strncmp(argv[6], "hc", 2));
+	const int hc = (argc > 6 && !strncmp(argv[6], "hc", 2)) ? 1 + atoi(argv[6] + 2) : 0; // hc0..hc3
 	if (p < 1 || p > 128) { fprintf(stderr, "features must be 1..128\n"); return 2; }
 	const long long N = G * n;
 	const bool weighted = !strcmp(model, "wls");
@@ -85,6 +86,7 @@ int main(int argc, char **argv) {
 	opt.confidence_level = 0.95;
 	opt.alpha = 1.0;
 	opt.solver = ANOFOX_SOLVER_SVD;
+	opt.hc_type = (AnofoxHcType)hc;
 	const double *xc[128];
 	for (int j = 0; j < p; ++j) xc[j] = c.x[j];
 

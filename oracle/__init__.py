@@ -26,6 +26,8 @@ class OracleOptions(C.Structure):
         ("lambda_scaling", C.c_int32),
         ("confidence_level", C.c_double),
         ("alpha", C.c_double),
+        ("hc_type", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -104,9 +106,10 @@ def lib():
 
 
 def _opts(model="ols", fit_intercept=True, compute_inference=False, confidence_level=0.95, alpha=1.0,
-          lambda_scaling="raw") -> OracleOptions:
+          lambda_scaling="raw", hc_type="none") -> OracleOptions:
     return OracleOptions(MODEL[model], int(bool(fit_intercept)), int(bool(compute_inference)),
-                         {"raw": 0, "glmnet": 1}[lambda_scaling], float(confidence_level), float(alpha))
+                         {"raw": 0, "glmnet": 1}[lambda_scaling], float(confidence_level), float(alpha),
+                         {"none": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}[hc_type], 0)
 
 
 def _col_ptrs(cols):

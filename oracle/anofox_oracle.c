@@ -65,6 +65,8 @@ typedef struct {
 	int32_t lambda_scaling;    /* 0 raw, 1 glmnet */
 	double confidence_level;
 	double alpha; /* ridge penalty */
+	int32_t hc_type; /* AnofoxHcType: 0 none, 1..4 = HC0..HC3 (anofox_stats_ffi.h:119-125); OLS and WLS only */
+	int32_t reserved;
 } OracleOptions;
 
 typedef struct {
@@ -471,6 +473,65 @@ ORACLE_EXPORT int oracle_fit(const double *y, const double *const *x, const doub
 			if (res->p_values) res->p_values[feat] = oracle_t_two_sided_p(t, df);
 			if (res->ci_lower) res->ci_lower[feat] = bc - tcrit * se;
 			if (res->ci_upper) res->ci_upper[feat] = bc + tcrit * se;
+		}
+		/* Heteroscedasticity-consistent errors replace SE/t/p/CI, F stays classical (ols.rs:209-231,
+		 * wls.rs:230-252).  The estimator itself lives in the un-vendored anofox-regression crate
+		 * (inference::compute_hc_inference) and the reference's tests only assert "finite, positive, differs
+		 * from classical" (ols.rs:402-453): PARITY UNPINNED.  Restated from the published definition
+		 * (MacKinnon & White 1985; R sandwich::vcovHC): on the sqrt(w)-scaled design a_i with residual e_i,
+		 *   V = B (sum_i omega_i a_i a_i') B,  B = (A'A)^-1,  h_i = a_i' B a_i,
+		 *   omega_i = e_i^2 (HC0), e_i^2 n/(n-k) (HC1), e_i^2/(1-h_i) (HC2), e_i^2/(1-h_i)^2 (HC3),
+		 * t distribution with n-k degrees of freedom. */
+		if (opt->hc_type != 0 && model != ORC_MODEL_RIDGE) {
+			double *ai = (double *)calloc(3 * (size_t)rank + 1, sizeof(double));
+			double *vdiag = (double *)calloc((size_t)rank + 1, sizeof(double));
+			if (!ai || !vdiag) { free(ai); free(vdiag); rc = ORC_ALLOC; goto done; }
+			double *tt = ai + rank, *uu = ai + 2 * rank;
+			for (size_t r = 0; r < nv; r++) {
+				size_t i = rows[r];
+				double swi = (model == ORC_MODEL_WLS) ? sqrt(w[i]) : 1.0;
+				double fit = icpt ? b0 : 0.0;
+				for (size_t c = 0; c < pe; c++) {
+					double bc = res->coefficients[keep[c]];
+					if (!isnan(bc)) fit += bc * x[keep[c]][i];
+				}
+				double e = swi * (y[i] - fit);
+				for (int l = 0; l < rank; l++) {
+					int col = piv[l];
+					ai[l] = (icpt && col == 0) ? swi : swi * x[keep[col - icpt]][i];
+				}
+				double h = 0.0;
+				for (int c = 0; c < rank; c++) {
+					double s = 0.0;
+					for (int k = 0; k <= c; k++) s += Rinv[(size_t)c * qd + k] * ai[k];
+					tt[c] = s;
+					h += s * s;
+				}
+				for (int k = 0; k < rank; k++) {
+					double s = 0.0;
+					for (int c = k; c < rank; c++) s += Rinv[(size_t)c * qd + k] * tt[c];
+					uu[k] = s;
+				}
+				double om = e * e;
+				if (opt->hc_type == 2) om *= (double)nv / df;
+				else if (opt->hc_type == 3) om /= (1.0 - h);
+				else if (opt->hc_type == 4) om /= (1.0 - h) * (1.0 - h);
+				for (int k = 0; k < rank; k++) vdiag[k] += om * uu[k] * uu[k];
+			}
+			for (int k = 0; k < rank; k++) {
+				int col = piv[k];
+				if (icpt && col == 0) continue;
+				int feat = keep[col - icpt];
+				double se = sqrt(vdiag[k]);
+				double bc = res->coefficients[feat];
+				double t = bc / se;
+				if (res->std_errors) res->std_errors[feat] = se;
+				if (res->t_values) res->t_values[feat] = t;
+				if (res->p_values) res->p_values[feat] = oracle_t_two_sided_p(t, df);
+				if (res->ci_lower) res->ci_lower[feat] = bc - tcrit * se;
+				if (res->ci_upper) res->ci_upper[feat] = bc + tcrit * se;
+			}
+			free(ai); free(vdiag);
 		}
 	}
 

@@ -323,6 +323,48 @@ def test_edge_cases_match_oracle(pkg, ctx):
                     assert abs(core[g, p + 1] - 1.0) < 1e-12
 
 
+@pytest.mark.parametrize("hc", ["hc0", "hc1", "hc2", "hc3"])
+@pytest.mark.parametrize("model", ["ols", "wls"])
+def test_hc_standard_errors_match_oracle(pkg, ctx, model, hc):
+    """hc_type replaces se / t / p / ci and keeps the classical F (ols.rs:209-231, wls.rs:230-252).  The
+    estimator is upstream's un-vendored compute_hc_inference: parity is UNPINNED, the oracle restates the
+    published sandwich estimator (checked against a dense numpy sandwich in tests/test_oracle_golden.py)."""
+    for p, icpt in ((1, True), (3, True), (3, False), (8, True), (8, False)):
+        rng = np.random.default_rng(31 * p + len(hc) + ord(hc[2]) + (5 if icpt else 0))
+        offs, y, x_cols, w = _random_groups(rng, 96, p, p + 5, 700)
+        y = y + np.abs(x_cols[0]) * rng.standard_normal(len(y))         # variance grows with |x_1|
+        y[offs[5]:offs[6]:9] = np.nan                                   # invalid rows inside a group
+        if p >= 3:
+            x_cols[1][offs[7]:offs[8]] = 2.5                            # constant column -> NaN slot
+            x_cols[2][offs[9]:offs[10]] = 3.0 * x_cols[0][offs[9]:offs[10]] - 1.0   # aliased column
+        kw = dict(fit_intercept=icpt, compute_inference=True, confidence_level=0.9, hc_type=hc)
+        wv = w if model == "wls" else None
+        core, inf = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+        rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
+        assert_records_match(core, rcore, p, inf, rinf, what=f"{hc} {model} p={p} icpt={icpt}")
+        kw["hc_type"] = "none"
+        _, inf_classical = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+        assert np.array_equal(inf[:, 5 * p:], inf_classical[:, 5 * p:], equal_nan=True)   # F, F p-value
+        assert not np.allclose(inf[:, :p], inf_classical[:, :p], equal_nan=True)
+
+
+def test_hc_is_ignored_where_the_reference_ignores_it(pkg, ctx):
+    rng = np.random.default_rng(8)
+    offs, y, x_cols, w = _random_groups(rng, 16, 3, 10, 50)
+    base = _host_fit(pkg, ctx, "ridge", offs, y, x_cols, alpha=1.0, compute_inference=True)
+    hc = _host_fit(pkg, ctx, "ridge", offs, y, x_cols, alpha=1.0, compute_inference=True, hc_type="hc3")
+    assert np.array_equal(base[1], hc[1], equal_nan=True)              # ridge has no HC branch (ridge.rs)
+    core_a, inf_a = _host_fit(pkg, ctx, "ols", offs, y, x_cols, hc_type="hc1")       # no inference requested
+    core_b, _ = _host_fit(pkg, ctx, "ols", offs, y, x_cols)
+    assert inf_a is None and np.array_equal(core_a, core_b, equal_nan=True)
+    r = pkg.ols_fit(y[:40], [c[:40] for c in x_cols], {"compute_inference": True, "hc_type": "hc1"})
+    code, d = oracle.fit(y[:40], [c[:40] for c in x_cols], compute_inference=True, hc_type="hc1")
+    assert code == 0 and np.allclose(r["std_errors"], d["std_errors"], rtol=1e-8)
+    wide = [rng.standard_normal(len(y)) for _ in range(9)]
+    with pytest.raises(Exception, match="n_features <= 8"):
+        _host_fit(pkg, ctx, "ols", offs, y, wide, compute_inference=True, hc_type="hc1")
+
+
 def test_alpha_negative_and_bad_arguments(pkg, ctx):
     a = import_pkg("_abi")
     rng = np.random.default_rng(2)
@@ -331,8 +373,6 @@ def test_alpha_negative_and_bad_arguments(pkg, ctx):
     assert np.all(core[:, 2 + 5] == a.ERROR_INVALID_ALPHA) and np.all(np.isnan(core[:, :7]))
     with pytest.raises(pkg.AnofoxStatsError):
         _host_fit(pkg, ctx, "wls", offs, y, x_cols, None)                    # weights missing
-    with pytest.raises(pkg.AnofoxStatsError):
-        _host_fit(pkg, ctx, "ols", offs, y, x_cols, hc_type="hc1")           # not implemented on the GPU path
     with pytest.raises(pkg.AnofoxStatsError):
         _host_fit(pkg, ctx, "ols", offs[::-1].copy(), y, x_cols)             # decreasing offsets
     with pytest.raises(pkg.AnofoxStatsError):

@@ -303,3 +303,40 @@ def test_t_critical_and_prediction_interval_restatement():
         k = e["new_x_values"].index(xv)
         assert out[1] >= e["predictions"]["prediction_lower"][k] - 1e-9
         assert out[2] <= e["predictions"]["prediction_upper"][k] + 1e-9
+
+
+def test_hc_sandwich_matches_dense_numpy():
+    """HC0..HC3 of the oracle (parity unpinned upstream) against the dense textbook sandwich
+    B (Z' diag(omega) Z) B on the sqrt(w)-scaled design, plus the reference's own unit-test assertions
+    (crates/anofox-stats-core/src/models/ols.rs:402-453: finite, positive, differs from classical)."""
+    rng = np.random.default_rng(3)
+    n, p = 40, 3
+    X = rng.normal(size=(n, p))
+    y = 1 + X @ [1.0, -2.0, 0.5] + rng.normal(size=n) * (1 + np.abs(X[:, 0]))
+    w = rng.uniform(0.5, 2, size=n)
+    for model, wv in (("ols", None), ("wls", w)):
+        for icpt in (True, False):
+            Z = np.column_stack([np.ones(n), X]) if icpt else X
+            ww = wv if wv is not None else np.ones(n)
+            B = np.linalg.inv(Z.T @ (Z * ww[:, None]))
+            b = B @ Z.T @ (ww * y)
+            e = y - Z @ b
+            h = ww * np.einsum("ij,jk,ik->i", Z, B, Z)
+            k = Z.shape[1]
+            for hc in ("hc0", "hc1", "hc2", "hc3"):
+                om = (ww * e) ** 2
+                om = {"hc0": om, "hc1": om * n / (n - k), "hc2": om / (1 - h), "hc3": om / (1 - h) ** 2}[hc]
+                se = np.sqrt(np.diag(B @ (Z.T * om) @ Z @ B))[(1 if icpt else 0):]
+                code, d = oracle.fit(y, [X[:, j] for j in range(p)], w=wv, model=model, fit_intercept=icpt,
+                                     compute_inference=True, hc_type=hc)
+                assert code == 0
+                assert np.allclose(d["std_errors"], se, rtol=1e-12)
+                assert np.allclose(d["t_values"], d["coefficients"] / se, rtol=1e-12)
+    x = np.arange(1.0, 11.0)
+    yy = np.array([2.1, 4.0, 5.9, 8.1, 10.0, 11.9, 14.1, 16.0, 17.9, 20.1])
+    _, classical = oracle.fit(yy, [x], compute_inference=True)
+    for hc in ("hc1", "hc3"):
+        _, d = oracle.fit(yy, [x], compute_inference=True, hc_type=hc)
+        assert np.isfinite(d["std_errors"][0]) and d["std_errors"][0] > 0 and d["p_values"][0] < 0.05
+        assert abs(d["std_errors"][0] - classical["std_errors"][0]) > 1e-15
+        assert d["f_statistic"] == classical["f_statistic"]
