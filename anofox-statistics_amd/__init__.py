@@ -17,7 +17,7 @@ from .aggregate import (FitAggResult, FitPredictAggResult, OlsFitAgg, OlsFitPred
                         ols_fit_predict_agg, ridge_fit_agg, ridge_fit_predict_agg, wls_fit_agg, wls_fit_predict_agg,
                         result_from_records, ols_fit_predict, ridge_fit_predict, wls_fit_predict)
 from .options import InvalidInputException, RegressionOptions, parse_options  # noqa: E402
-from .runtime import Context, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host  # noqa: E402
+from .runtime import Context, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host, fit_predict_window_host  # noqa: E402
 from .scalar import aic, bic, ols_fit, predict, predict_with_interval, ridge_fit, t_critical, wls_fit  # noqa: E402
 
 __all__ = [
@@ -26,7 +26,7 @@ __all__ = [
     "parse_options", "result_from_records", "ridge_fit", "ridge_fit_agg", "wls_fit", "wls_fit_agg",
     "FitPredictAggResult", "OlsFitPredictAgg", "RidgeFitPredictAgg", "WlsFitPredictAgg", "fit_predict_batch_host",
     "ols_fit_predict_agg", "ridge_fit_predict_agg", "wls_fit_predict_agg", "predict", "predict_with_interval",
-    "t_critical", "fit_predict_expanding_host", "ols_fit_predict", "ridge_fit_predict", "wls_fit_predict",
+    "t_critical", "fit_predict_expanding_host", "fit_predict_window_host", "ols_fit_predict", "ridge_fit_predict", "wls_fit_predict",
 ]
 
 

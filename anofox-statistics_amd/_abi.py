@@ -83,6 +83,11 @@ class AnofoxHipKernelTimes(C.Structure):
                 ("solve_count", C.c_int64), ("predict_ms", C.c_double), ("predict_count", C.c_int64)]
 
 
+class AnofoxHipWindowFrame(C.Structure):
+    """ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING; start_preceding < 0 = UNBOUNDED."""
+    _fields_ = [("start_preceding", C.c_int64), ("end_preceding", C.c_int64)]
+
+
 class AnofoxPredictionResult(C.Structure):
     _fields_ = [("yhat", C.c_double), ("yhat_lower", C.c_double), ("yhat_upper", C.c_double)]
 
@@ -131,6 +136,12 @@ SYMBOLS = {
                                                            AnofoxHipBatchOptions, C.c_void_p, _ERRP]),
     "anofox_hip_fit_predict_expanding_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64),
                                                          _DP, C.POINTER(_DP), _DP, AnofoxHipBatchOptions, _DP, _ERRP]),
+    "anofox_hip_fit_predict_window_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p,
+                                                        C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p,
+                                                        AnofoxHipWindowFrame, AnofoxHipBatchOptions, C.c_void_p, _ERRP]),
+    "anofox_hip_fit_predict_window_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64),
+                                                      _DP, C.POINTER(_DP), _DP, AnofoxHipWindowFrame,
+                                                      AnofoxHipBatchOptions, _DP, _ERRP]),
     "anofox_hip_predict_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p,
                                                    C.POINTER(C.c_void_p), C.c_void_p, C.c_double, C.c_void_p, _ERRP]),
     "anofox_hip_context_enable_timing": (C.c_bool, [_CTX, C.c_bool, _ERRP]),

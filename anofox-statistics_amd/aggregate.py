@@ -422,13 +422,37 @@ SQL_FUNCTIONS.update({
 
 # ------------------------------------------------------------------------------------------------------
 # *_fit_predict(y, x [, options]) OVER (PARTITION BY k ORDER BY o ROWS BETWEEN UNBOUNDED PRECEDING AND
-# CURRENT ROW | 1 PRECEDING): the window functions (src/window_functions/{ols,ridge,wls}_fit_predict.cpp)
+# CURRENT ROW | k PRECEDING, or any ROWS BETWEEN a PRECEDING AND b PRECEDING): the window functions (src/window_functions/{ols,ridge,wls}_fit_predict.cpp)
 # ------------------------------------------------------------------------------------------------------
-def _fit_predict_window(model, partition_keys, order, y, x, weights, options, context, frame_end):
+def _parse_frame(frame, frame_end):
+    """(start_preceding or None, end_preceding) from `frame` = (start, end) with start in {None, "unbounded", k}
+    and end in {"current row", k}; `frame_end` is the older spelling for UNBOUNDED frames."""
+    def bound(v, what):
+        if isinstance(v, str):
+            t = v.strip().lower()
+            if t in ("current row", "current"):
+                return 0
+            if t in ("unbounded", "unbounded preceding"):
+                return None
+            if t.endswith(" preceding") and t[:-10].strip().isdigit():
+                return int(t[:-10])
+            raise InvalidInputException(f"{what} must be 'unbounded', 'current row' or '<k> preceding'")
+        return v if v is None else int(v)
+    if frame is None:
+        frame = (None, frame_end)
+    start, end = bound(frame[0], "frame start"), bound(frame[1], "frame end")
+    if end is None or end < 0 or (start is not None and start < end):
+        raise InvalidInputException("the frame must end at or before the current row and start at or before its end")
+    return start, end
+
+
+def _fit_predict_window(model, partition_keys, order, y, x, weights, options, context, frame_end, frame=None):
     """Returns (yhat, yhat_lower, yhat_upper) per input row, in input order; NaN = SQL NULL.
-    frame_end: "current row" or "1 preceding" (the frame starts UNBOUNDED PRECEDING)."""
-    from .runtime import fit_predict_expanding_host
+    ROWS BETWEEN frame[0] PRECEDING AND frame[1] PRECEDING; the default frame starts UNBOUNDED PRECEDING and
+    ends at `frame_end` ("current row" or "<k> preceding")."""
+    from .runtime import fit_predict_window_host
     opts = parse_options(options)
+    start, end = _parse_frame(frame, frame_end)
     keys = np.asarray(partition_keys)
     yv, ynull = _null_mask_1d(y)
     yv = np.where(ynull, np.nan, yv)
@@ -452,30 +476,23 @@ def _fit_predict_window(model, partition_keys, order, y, x, weights, options, co
     if weights is not None:
         wv, wnull = _null_mask_1d(weights)
         wv = np.where(wnull, np.nan, wv)[perm]
-    pred_sorted = fit_predict_expanding_host(offsets, yv[perm], [np.ascontiguousarray(Xd[perm, j]) for j in range(p)],
-                                             wv, opts.batch_options(model), ctx=context)
-    if frame_end == "1 preceding":                               # frame ends one row earlier: shift inside partitions
-        shifted = np.full_like(pred_sorted, np.nan)
-        shifted[1:] = pred_sorted[:-1]
-        shifted[offsets[:-1][counts > 0]] = np.nan
-        pred_sorted = shifted
-    elif frame_end != "current row":
-        raise InvalidInputException("frame_end must be 'current row' or '1 preceding'")
+    pred_sorted = fit_predict_window_host(offsets, yv[perm], [np.ascontiguousarray(Xd[perm, j]) for j in range(p)],
+                                          wv, opts.batch_options(model), (start, end), ctx=context)
     out = np.empty_like(pred_sorted)
     out[perm] = pred_sorted
     return out[:, 0], out[:, 1], out[:, 2]
 
 
-def ols_fit_predict(partition_keys, order, y, x, options=None, context=None, frame_end="current row"):
-    return _fit_predict_window("ols", partition_keys, order, y, x, None, options, context, frame_end)
+def ols_fit_predict(partition_keys, order, y, x, options=None, context=None, frame_end="current row", frame=None):
+    return _fit_predict_window("ols", partition_keys, order, y, x, None, options, context, frame_end, frame)
 
 
-def ridge_fit_predict(partition_keys, order, y, x, options=None, context=None, frame_end="current row"):
-    return _fit_predict_window("ridge", partition_keys, order, y, x, None, options, context, frame_end)
+def ridge_fit_predict(partition_keys, order, y, x, options=None, context=None, frame_end="current row", frame=None):
+    return _fit_predict_window("ridge", partition_keys, order, y, x, None, options, context, frame_end, frame)
 
 
-def wls_fit_predict(partition_keys, order, y, x, weights, options=None, context=None, frame_end="current row"):
-    return _fit_predict_window("wls", partition_keys, order, y, x, weights, options, context, frame_end)
+def wls_fit_predict(partition_keys, order, y, x, weights, options=None, context=None, frame_end="current row", frame=None):
+    return _fit_predict_window("wls", partition_keys, order, y, x, weights, options, context, frame_end, frame)
 
 
 SQL_FUNCTIONS.update({

@@ -140,10 +140,13 @@ struct WindowArgs {
 	double alpha;
 	const double *tcrit; // [tcrit_cap + 1], see tcrit_table_kernel
 	int tcrit_cap;
+	// ROWS BETWEEN frame_start PRECEDING AND frame_end PRECEDING; frame_start < 0 = UNBOUNDED PRECEDING
+	int64_t frame_start;
+	int64_t frame_end;
 };
 constexpr int kWindowTcritCap = 65536;
 hipError_t launch_tcrit_table(double *table, int cap, double prob, hipStream_t stream);
-hipError_t launch_expanding_predict(const WindowArgs &a, hipStream_t stream);
+hipError_t launch_window_predict(const WindowArgs &a, hipStream_t stream);
 
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);

@@ -579,9 +579,9 @@ bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int64_t n_groups, 
 
 namespace {
 
-bool run_expanding(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *d_y,
-                   const double *const *x_cols, const double *d_w, const AnofoxHipBatchOptions &opt, double *d_pred,
-                   AnofoxError *e) {
+bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *d_y,
+                const double *const *x_cols, const double *d_w, const AnofoxHipWindowFrame &frame,
+                const AnofoxHipBatchOptions &opt, double *d_pred, AnofoxError *e) {
 	if (G == 0) return true;
 	if (!ensure_buffer(&ctx->wtab, &ctx->wtab_bytes, (size_t)(kWindowTcritCap + 1) * sizeof(double), "t table", e)) return false;
 	hipStream_t st = ctx->stream;
@@ -604,13 +604,15 @@ bool run_expanding(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_
 	a.alpha = opt.alpha;
 	a.tcrit = (const double *)ctx->wtab;
 	a.tcrit_cap = kWindowTcritCap;
+	a.frame_start = frame.start_preceding < 0 ? -1 : frame.start_preceding;
+	a.frame_end = frame.end_preceding;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->timing) {
 		e0 = get_event(ctx);
 		e1 = get_event(ctx);
 		(void)hipEventRecord(e0, st);
 	}
-	if (hip_fail(launch_expanding_predict(a, st), "window kernel launch", e)) return false;
+	if (hip_fail(launch_window_predict(a, st), "window kernel launch", e)) return false;
 	if (ctx->timing) {
 		(void)hipEventRecord(e1, st);
 		ctx->predict_events.emplace_back(e0, e1);
@@ -619,8 +621,13 @@ bool run_expanding(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_
 }
 
 bool validate_window(AnofoxHipContext *ctx, int64_t G, size_t p, const void *off, const void *y, const double *const *x_cols,
-                     const void *w, const AnofoxHipBatchOptions &opt, const void *pred, AnofoxError *e) {
+                     const void *w, const AnofoxHipWindowFrame &frame, const AnofoxHipBatchOptions &opt, const void *pred,
+                     AnofoxError *e) {
 	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (frame.end_preceding < 0 || (frame.start_preceding >= 0 && frame.start_preceding < frame.end_preceding)) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "window frame must end at or before the current row and start at or before its end");
+		return false;
+	}
 	if (G < 0 || p == 0 || !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "invalid n_groups / n_features / x"); return false; }
 	if (p > (size_t)kNarrowMaxP) {
 		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "the window path supports at most " + std::to_string(kNarrowMaxP) + " features");
@@ -635,28 +642,46 @@ bool validate_window(AnofoxHipContext *ctx, int64_t G, size_t p, const void *off
 
 } // namespace
 
+bool anofox_hip_fit_predict_window_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                          const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
+                                          const double *d_w, AnofoxHipWindowFrame frame, AnofoxHipBatchOptions options,
+                                          double *d_pred, AnofoxError *out_error) {
+	reset_error(out_error);
+	(void)n_rows;
+	if (!validate_window(ctx, n_groups, n_features, d_row_offsets, d_y, x_cols, d_w, frame, options, d_pred, out_error)) return false;
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	return run_window(ctx, n_groups, n_features, d_row_offsets, d_y, x_cols, d_w, frame, options, d_pred, out_error);
+}
+
 bool anofox_hip_fit_predict_expanding_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                              const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
                                              const double *d_w, AnofoxHipBatchOptions options, double *d_pred,
                                              AnofoxError *out_error) {
-	reset_error(out_error);
-	(void)n_rows;
-	if (!validate_window(ctx, n_groups, n_features, d_row_offsets, d_y, x_cols, d_w, options, d_pred, out_error)) return false;
-	std::lock_guard<std::mutex> lk(ctx->mu);
-	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
-	return run_expanding(ctx, n_groups, n_features, d_row_offsets, d_y, x_cols, d_w, options, d_pred, out_error);
+	const AnofoxHipWindowFrame frame = {-1, 0}; // UNBOUNDED PRECEDING .. CURRENT ROW
+	return anofox_hip_fit_predict_window_device(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, frame,
+	                                            options, d_pred, out_error);
 }
 
 bool anofox_hip_fit_predict_expanding_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                            const int64_t *row_offsets, const double *y, const double *const *x_cols,
                                            const double *w, AnofoxHipBatchOptions options, double *pred,
                                            AnofoxError *out_error) {
+	const AnofoxHipWindowFrame frame = {-1, 0}; // UNBOUNDED PRECEDING .. CURRENT ROW
+	return anofox_hip_fit_predict_window_host(ctx, n_groups, n_features, n_rows, row_offsets, y, x_cols, w, frame, options, pred,
+	                                          out_error);
+}
+
+bool anofox_hip_fit_predict_window_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                        const int64_t *row_offsets, const double *y, const double *const *x_cols,
+                                        const double *w, AnofoxHipWindowFrame frame, AnofoxHipBatchOptions options,
+                                        double *pred, AnofoxError *out_error) {
 	reset_error(out_error);
 	if (!ctx) {
 		ctx = default_context(out_error);
 		if (!ctx) return false;
 	}
-	if (!validate_window(ctx, n_groups, n_features, row_offsets, y, x_cols, w, options, pred, out_error)) return false;
+	if (!validate_window(ctx, n_groups, n_features, row_offsets, y, x_cols, w, frame, options, pred, out_error)) return false;
 	if (n_groups == 0) return true;
 	if (row_offsets[0] != 0 || row_offsets[n_groups] != n_rows) {
 		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must start at 0 and end at n_rows");
@@ -697,7 +722,7 @@ bool anofox_hip_fit_predict_expanding_host(AnofoxHipContext *ctx, int64_t n_grou
 		cur += b_col;
 	}
 	double *d_pred = (double *)cur;
-	if (!run_expanding(ctx, n_groups, p, d_off, d_y, d_x, d_w, options, d_pred, out_error)) return false;
+	if (!run_window(ctx, n_groups, p, d_off, d_y, d_x, d_w, frame, options, d_pred, out_error)) return false;
 	if (R > 0 && hip_fail(hipMemcpyAsync(pred, d_pred, R * 3 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H pred", out_error)) return false;
 	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
 }

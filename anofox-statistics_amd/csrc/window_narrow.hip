@@ -12,9 +12,16 @@
 // one wavefront per partition, lanes = consecutive rows; each lane forms its row's moment contribution, a wave
 // inclusive scan (6 shuffle steps per value) plus a running carry turns them into prefix moments, and every
 // lane then solves its own prefix problem in registers (same semantics as solve_narrow.hip: row filter,
-// constant / aliased columns, intercept-only shortcut, minimum observations).  A frame ending at 1 PRECEDING
-// is the same output shifted by one row (done by the caller).
-// Loads and stores are fully coalesced; the kernel is f64-VALU bound (one p x p solve per row).
+// constant / aliased columns, intercept-only shortcut, minimum observations).  A frame ending b PRECEDING is the
+// same output written b rows further down (the x that is predicted is the LAST row of the frame, not the current
+// row: ols_fit_predict.cpp:157-162).  Loads and stores are fully coalesced; the kernel is f64-VALU bound (one
+// p x p solve per row).
+//
+// Rolling frames (ROWS BETWEEN a PRECEDING AND b PRECEDING, a finite) are summed directly: lane = output row,
+// a wave-uniform loop walks the a - b + 1 frame offsets and every lane accumulates the moments of ITS frame,
+// shifted by the first training row of that frame.  Differences of prefix moments would be cheaper but cancel
+// (a 10-row frame at row 1000 of a trending regressor loses ~9 digits); the loads of neighbouring lanes are
+// consecutive rows and hit L1/L2 after the first touch, so the direct sum costs O(frame) cached loads per row.
 #include "common.h"
 #include "device_math.h"
 
@@ -303,7 +310,127 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 			}
 		}
 		if (in) {
-			double *out = args.pred + r * 3;
+			const int64_t b = args.frame_end; // frame ends b rows before the current row: row r + b gets this result
+			if (r + b < hi) {
+				double *out = args.pred + (r + b) * 3;
+				out[0] = yhat;
+				out[1] = ylo;
+				out[2] = yhi;
+			}
+			if (r - lo < b) { // empty frame: the aggregate state was never initialised (ols_fit_predict.cpp:253-256)
+				double *out = args.pred + r * 3;
+				out[0] = out[1] = out[2] = nanv;
+			}
+		}
+	}
+}
+
+// Shared tail of both kernels: Finalize of the window aggregate for one frame (moments in rec), predicting z.
+template <int P>
+__device__ __forceinline__ void predict_from_moments(const WindowArgs &args, const double (&rec)[MomentLayout<P>::REC], bool icpt,
+                                                     const double (&z)[P + 1], double &yhat, double &ylo, double &yhi) {
+	PrefixFit<P> f;
+	fit_from_moments<P>(rec, args.model, icpt, args.alpha, args.lambda_scaling, f);
+	if (!f.ok) return;
+	double v = isnan(f.intercept) ? 0.0 : f.intercept;
+#pragma unroll
+	for (int j = 0; j < P; ++j) v = fma(isnan(f.coef[j]) ? 0.0 : f.coef[j], isnan(f.coef[j]) ? 0.0 : z[j], v);
+	if (!isfinite(v)) return;
+	yhat = ylo = yhi = v;
+	// anofox_predict_with_interval: lib.rs:2306-2347
+	if (isnan(f.rse) || f.rse <= 0.0 || f.nobs <= (double)(P + 1)) return;
+	const double df = f.nobs - (double)(P + (icpt ? 1 : 0));
+	if (!(df > 0.0)) return;
+	const double tcrit = window_tcrit(args, df);
+	if (isnan(tcrit)) return;
+	const double margin = tcrit * f.rse * sqrt(1.0 + 1.0 / f.nobs);
+	ylo = v - margin;
+	yhi = v + margin;
+}
+
+template <int P, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
+	using L = MomentLayout<P>;
+	constexpr int Z = L::Z;
+	constexpr int ZZ = L::ZZ;
+	const int lane = threadIdx.x & 63;
+	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+	if (g >= args.n_groups) return;
+	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+	const int64_t fa = args.frame_start, fb = args.frame_end; // fa >= fb >= 0
+	const bool icpt = CENTER;
+	const double nanv = __builtin_nan("");
+
+	for (int64_t base = lo; base < hi; base += 64) {
+		const int64_t e = base + lane;
+		const bool in = e < hi;
+		double s[Z], q[ZZ], first[Z], z[Z];
+#pragma unroll
+		for (int a = 0; a < Z; ++a) s[a] = first[a] = z[a] = 0.0;
+#pragma unroll
+		for (int k = 0; k < ZZ; ++k) q[k] = 0.0;
+		double sw = 0.0, cnt = 0.0, n_y = 0.0;
+		unsigned mask = 0;
+		bool have_first = false, live = false, xfinite = false;
+
+		// offsets beyond the start of the partition hold no row for any lane of this tile
+		int64_t k_hi = base + 63 - lo;
+		if (k_hi > fa) k_hi = fa;
+		for (int64_t k = k_hi; k >= fb; --k) {
+			const int64_t r = e - k;
+			live = in && r >= lo;
+			const int64_t rc = r < lo ? lo : (r >= hi ? hi - 1 : r); // clamped: unconditional loads
+#pragma unroll
+			for (int j = 0; j < P; ++j) z[j] = args.x[j][rc];
+			z[P] = args.y[rc];
+			double w = 1.0;
+			if (WEIGHTED) w = args.w[rc];
+			xfinite = true;
+#pragma unroll
+			for (int j = 0; j < P; ++j) xfinite = xfinite && isfinite(z[j]);
+			bool valid = live && xfinite && isfinite(z[P]);
+			if (WEIGHTED) valid = valid && (w > 0.0) && isfinite(w);
+			n_y += (live && !isnan(z[P])) ? 1.0 : 0.0; // ols_fit_predict.cpp:164-190: y not NULL makes a training row
+			const bool take = valid && !have_first;
+#pragma unroll
+			for (int a = 0; a < Z; ++a) first[a] = take ? z[a] : first[a];
+			have_first = have_first || valid;
+			const double ww = valid ? w : 0.0;
+			double d[Z];
+#pragma unroll
+			for (int a = 0; a < Z; ++a) {
+				const double dev = valid ? z[a] - first[a] : 0.0;
+				d[a] = CENTER ? dev : (valid ? z[a] : 0.0);
+				if (a < P) mask |= !(fabs(dev) < 1e-10) ? (1u << a) : 0u;
+			}
+#pragma unroll
+			for (int a = 0; a < Z; ++a) {
+				const double wd = WEIGHTED ? ww * d[a] : d[a];
+				s[a] += wd;
+#pragma unroll
+				for (int b = a; b < Z; ++b) {
+					const int kk = a * Z - a * (a - 1) / 2 + (b - a);
+					q[kk] = fma(wd, d[b], q[kk]);
+				}
+			}
+			sw += ww;
+			cnt += valid ? 1.0 : 0.0;
+		}
+		// after the loop z / live / xfinite describe the LAST row of the frame (offset fb): the x to predict
+		double yhat = nanv, ylo = nanv, yhi = nanv;
+		if (k_hi >= fb && live && xfinite && n_y > (double)(P + (icpt ? 1 : 0))) { // ols_fit_predict.cpp:253-262
+			double rec[L::REC];
+#pragma unroll
+			for (int a = 0; a < Z; ++a) { rec[L::OFF_S + a] = s[a]; rec[L::OFF_FIRST + a] = first[a]; }
+#pragma unroll
+			for (int k = 0; k < ZZ; ++k) rec[L::OFF_Q + k] = q[k];
+			rec[L::OFF_SW] = sw;
+			rec[L::OFF_CNT] = cnt;
+			rec[L::OFF_MASK] = (double)mask;
+			predict_from_moments<P>(args, rec, icpt, z, yhat, ylo, yhi);
+		}
+		if (in) {
+			double *out = args.pred + e * 3;
 			out[0] = yhat;
 			out[1] = ylo;
 			out[2] = yhi;
@@ -316,13 +443,20 @@ hipError_t launch_window_p(const WindowArgs &a, hipStream_t stream) {
 	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
-	if (weighted) {
-		if (center) hipLaunchKernelGGL((expanding_predict_kernel<P, true, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((expanding_predict_kernel<P, true, false>), grid, block, 0, stream, a);
-	} else {
-		if (center) hipLaunchKernelGGL((expanding_predict_kernel<P, false, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((expanding_predict_kernel<P, false, false>), grid, block, 0, stream, a);
-	}
+	const bool rolling = a.frame_start >= 0;
+#define ANOFOX_WINDOW_LAUNCH(KERNEL)                                                                             \
+	do {                                                                                                         \
+		if (weighted) {                                                                                          \
+			if (center) hipLaunchKernelGGL((KERNEL<P, true, true>), grid, block, 0, stream, a);                  \
+			else hipLaunchKernelGGL((KERNEL<P, true, false>), grid, block, 0, stream, a);                        \
+		} else {                                                                                                 \
+			if (center) hipLaunchKernelGGL((KERNEL<P, false, true>), grid, block, 0, stream, a);                 \
+			else hipLaunchKernelGGL((KERNEL<P, false, false>), grid, block, 0, stream, a);                       \
+		}                                                                                                        \
+	} while (0)
+	if (rolling) ANOFOX_WINDOW_LAUNCH(rolling_predict_kernel);
+	else ANOFOX_WINDOW_LAUNCH(expanding_predict_kernel);
+#undef ANOFOX_WINDOW_LAUNCH
 	return hipGetLastError();
 }
 
@@ -333,8 +467,9 @@ hipError_t launch_tcrit_table(double *table, int cap, double prob, hipStream_t s
 	return hipGetLastError();
 }
 
-hipError_t launch_expanding_predict(const WindowArgs &a, hipStream_t stream) {
+hipError_t launch_window_predict(const WindowArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
+	if (a.frame_end < 0 || (a.frame_start >= 0 && a.frame_start < a.frame_end)) return hipErrorInvalidValue;
 	switch (a.p) {
 	case 1: return launch_window_p<1>(a, stream);
 	case 2: return launch_window_p<2>(a, stream);

@@ -116,6 +116,12 @@ class Context:
     def fit_predict_expanding_device(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
                                      pred=None, use_current_torch_stream: bool = True):
         """Expanding-window fit + predict, device resident.  Returns pred[N, 3] (CUDA tensor)."""
+        return self.fit_predict_window_device(row_offsets, y, x_cols, w, options, (None, 0), pred, use_current_torch_stream)
+
+    def fit_predict_window_device(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
+                                  frame=(None, 0), pred=None, use_current_torch_stream: bool = True):
+        """Window fit + predict over ROWS BETWEEN frame[0] PRECEDING AND frame[1] PRECEDING (frame[0] None =
+        UNBOUNDED), device resident.  Returns pred[N, 3] (CUDA tensor)."""
         import torch
 
         p = len(x_cols)
@@ -127,9 +133,10 @@ class Context:
             self.set_stream(torch.cuda.current_stream(y.device).cuda_stream)
         cols = (C.c_void_p * p)(*[c.data_ptr() for c in x_cols])
         err = _abi.AnofoxError()
-        ok = self._lib.anofox_hip_fit_predict_expanding_device(
+        ok = self._lib.anofox_hip_fit_predict_window_device(
             self._h, G, p, N, C.c_void_p(row_offsets.data_ptr()), C.c_void_p(y.data_ptr()), cols,
-            C.c_void_p(w.data_ptr() if w is not None else 0), options, C.c_void_p(pred.data_ptr()), C.byref(err))
+            C.c_void_p(w.data_ptr() if w is not None else 0), _frame(frame), options, C.c_void_p(pred.data_ptr()),
+            C.byref(err))
         self._check(ok, err)
         return pred
 
@@ -191,9 +198,21 @@ def fit_predict_batch_host(row_offsets, y, x_cols: Sequence, w, options: _abi.An
     return core, pred
 
 
+def _frame(frame) -> _abi.AnofoxHipWindowFrame:
+    start, end = frame
+    return _abi.AnofoxHipWindowFrame(-1 if start is None else int(start), int(end))
+
+
 def fit_predict_expanding_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
                                ctx: Optional[Context] = None):
     """numpy in, numpy out: pred[N, 3] — prediction of x_e from the fit on rows 0..e of its partition."""
+    return fit_predict_window_host(row_offsets, y, x_cols, w, options, (None, 0), ctx=ctx)
+
+
+def fit_predict_window_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
+                            frame=(None, 0), ctx: Optional[Context] = None):
+    """numpy in, numpy out: pred[N, 3] of the window functions over ROWS BETWEEN frame[0] PRECEDING AND frame[1]
+    PRECEDING (frame[0] None = UNBOUNDED PRECEDING, frame[1] 0 = CURRENT ROW)."""
     lib = _abi.load()
     off = np.ascontiguousarray(row_offsets, dtype=np.int64)
     yv = np.ascontiguousarray(y, dtype=np.float64)
@@ -203,9 +222,10 @@ def fit_predict_expanding_host(row_offsets, y, x_cols: Sequence, w, options: _ab
     pred = np.empty((N, 3), dtype=np.float64)
     colp = (_DP * max(p, 1))(*[c.ctypes.data_as(_DP) for c in cols])
     err = _abi.AnofoxError()
-    ok = lib.anofox_hip_fit_predict_expanding_host(
+    ok = lib.anofox_hip_fit_predict_window_host(
         ctx._h if ctx is not None else None, G, p, N, off.ctypes.data_as(C.POINTER(C.c_int64)), yv.ctypes.data_as(_DP),
-        colp, None if wv is None else wv.ctypes.data_as(_DP), options, pred.ctypes.data_as(_DP), C.byref(err))
+        colp, None if wv is None else wv.ctypes.data_as(_DP), _frame(frame), options, pred.ctypes.data_as(_DP),
+        C.byref(err))
     if not ok:
         raise AnofoxStatsError(err.code, err.text())
     return pred

@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--inference", action="store_true")
     ap.add_argument("--window", action="store_true",
                     help="expanding-window fit + predict (*_fit_predict OVER ...): one fit per ROW")
+    ap.add_argument("--frame", default="u,0",
+                    help="with --window: ROWS BETWEEN a PRECEDING AND b PRECEDING as 'a,b' (a = u for UNBOUNDED)")
     ap.add_argument("--predict", action="store_true",
                     help="fit + per-row predictions (*_fit_predict_agg); every 5th row is a prediction row (NULL y)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,10 +169,12 @@ def main():
         if world > 1:
             raise SystemExit("--window is a single-GPU measurement")
         pred_buf = torch.empty((y.numel(), 3), dtype=torch.float64, device=dev)
+    fa, fb = args.frame.split(",")
+    frame = (None if fa.strip().lower().startswith("u") else int(fa), int(fb))
 
     def step():
         if args.window:
-            ctx.fit_predict_expanding_device(offs, y, x_cols, w, opts, pred=pred_buf)
+            ctx.fit_predict_window_device(offs, y, x_cols, w, opts, frame, pred=pred_buf)
             return None, None
         if args.predict:
             c, _ = ctx.fit_predict_batch_device(offs, y, x_cols, w, opts, core=core_buf, pred=pred_buf)
@@ -208,9 +212,10 @@ def main():
         import oracle
         S = min(8, G_local)
         nr = int(offs[S].item())
-        ref = oracle.fit_predict_expanding(y[:nr].cpu().numpy(), [c[:nr].cpu().numpy() for c in x_cols],
-                                           offs[:S + 1].cpu().numpy(), w=w[:nr].cpu().numpy() if w is not None else None,
-                                           model=args.model, **{k: v for k, v in kw.items() if k != "compute_inference"})
+        ref = oracle.fit_predict_window(y[:nr].cpu().numpy(), [c[:nr].cpu().numpy() for c in x_cols],
+                                        offs[:S + 1].cpu().numpy(), w=w[:nr].cpu().numpy() if w is not None else None,
+                                        start_preceding=-1 if frame[0] is None else frame[0], end_preceding=frame[1],
+                                        model=args.model, **{k: v for k, v in kw.items() if k != "compute_inference"})
         got = pred_buf[:nr].cpu().numpy()
         m = ~np.isnan(ref[:, 0])
         ok = bool(np.array_equal(np.isnan(got[:, 0]), ~m))
@@ -262,7 +267,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.model}_fit{'_predict' if (args.predict or args.window) else ''}{' OVER (expanding window)' if args.window else '_agg'}: {G} groups x n={n} x p={p}, device-resident grouped columns, "
+            "config": {"workload": f"{args.model}_fit{'_predict' if (args.predict or args.window) else ''}{(' OVER (ROWS BETWEEN ' + ('UNBOUNDED' if frame[0] is None else str(frame[0])) + ' PRECEDING AND ' + str(frame[1]) + ' PRECEDING)') if args.window else '_agg'}: {G} groups x n={n} x p={p}, device-resident grouped columns, "
                                    f"fit_intercept=true, compute_inference={str(args.inference).lower()}",
                        "groups_total": G, "groups_per_gpu": G_local, "rows_per_group": n, "features": p,
                        "partition": f"contiguous key ranges over {world} rank(s); all-gather of {p + 6}-double records"},

@@ -318,6 +318,27 @@ ANOFOX_HIP_API bool anofox_hip_fit_predict_expanding_host(AnofoxHipContext *ctx,
                                            const double *w, AnofoxHipBatchOptions options, double *pred,
                                            AnofoxError *out_error);
 
+/*
+ * The same window functions over any ROWS frame that ends at or before the current row:
+ *   ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING
+ * (start_preceding < 0 = UNBOUNDED PRECEDING; end_preceding = 0 = CURRENT ROW; start_preceding >= end_preceding).
+ * The aggregate trains on the frame's rows with non-NULL y and predicts the x of the LAST row of the frame
+ * (ols_fit_predict.cpp:157-162), so with end_preceding = b the output of row e uses x of row e - b; rows whose
+ * frame is empty are NULL.  UNBOUNDED frames run the one-pass prefix kernel, finite ones sum each frame directly.
+ */
+typedef struct {
+	int64_t start_preceding;
+	int64_t end_preceding;
+} AnofoxHipWindowFrame;
+ANOFOX_HIP_API bool anofox_hip_fit_predict_window_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                          const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
+                                          const double *d_w, AnofoxHipWindowFrame frame, AnofoxHipBatchOptions options,
+                                          double *d_pred, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_fit_predict_window_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                        const int64_t *row_offsets, const double *y, const double *const *x_cols,
+                                        const double *w, AnofoxHipWindowFrame frame, AnofoxHipBatchOptions options,
+                                        double *pred, AnofoxError *out_error);
+
 /* Predictions only, from existing fit records (d_core as produced by the fit entry points). */
 ANOFOX_HIP_API bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                      const int64_t *d_row_offsets, const double *const *x_cols, const double *d_core,

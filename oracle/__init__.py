@@ -98,6 +98,9 @@ def lib():
         L.oracle_fit_predict_expanding.restype = C.c_int
         L.oracle_fit_predict_expanding.argtypes = [_DP, C.POINTER(_DP), _DP, C.POINTER(C.c_int64), C.c_int64, C.c_size_t,
                                                    C.POINTER(OracleOptions), _DP]
+        L.oracle_fit_predict_window.restype = C.c_int
+        L.oracle_fit_predict_window.argtypes = [_DP, C.POINTER(_DP), _DP, C.POINTER(C.c_int64), C.c_int64, C.c_size_t,
+                                                C.POINTER(OracleOptions), C.c_int64, C.c_int64, _DP]
         for name in ("oracle_aic", "oracle_bic"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_double, C.c_int64, C.c_int64, _DP]
@@ -222,4 +225,22 @@ def fit_predict_expanding(y, x_cols, offsets, w=None, **kw):
                                             C.byref(o), pred.ctypes.data_as(_DP))
     if rc != 0:
         raise RuntimeError(f"oracle_fit_predict_expanding failed: {rc}")
+    return pred
+
+
+def fit_predict_window(y, x_cols, offsets, w=None, start_preceding=-1, end_preceding=0, **kw):
+    """pred[N, 3] of the window functions over ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING
+    (start_preceding < 0 = UNBOUNDED PRECEDING)."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    wv = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    o = _opts(**kw)
+    pred = np.empty((len(y), 3))
+    rc = lib().oracle_fit_predict_window(y.ctypes.data_as(_DP), _col_ptrs(cols),
+                                         None if wv is None else wv.ctypes.data_as(_DP),
+                                         offsets.ctypes.data_as(C.POINTER(C.c_int64)), len(offsets) - 1, len(cols),
+                                         C.byref(o), int(start_preceding), int(end_preceding), pred.ctypes.data_as(_DP))
+    if rc != 0:
+        raise RuntimeError(f"oracle_fit_predict_window failed: {rc}")
     return pred

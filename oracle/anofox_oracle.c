@@ -748,3 +748,60 @@ ORACLE_EXPORT int oracle_fit_predict_expanding(const double *y, const double *co
 	free((void *)xs); free(row); free(coef);
 	return ORC_SUCCESS;
 }
+
+/* The window functions over ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING
+ * (start_preceding < 0 = UNBOUNDED PRECEDING): the aggregate's Update/Finalize applied to every frame from
+ * scratch (src/window_functions/ols_fit_predict.cpp:110-324).  Training rows = frame rows with y not NULL
+ * (:164-190); the x that is predicted is the one of the LAST frame row (:157-162); NULL for an empty frame
+ * (:253-256) and unless MORE than p + [intercept] training rows exist (:257-262).  O(n * frame) fits. */
+ORACLE_EXPORT int oracle_fit_predict_window(const double *y, const double *const *x, const double *w,
+                                            const int64_t *offsets, int64_t n_groups, size_t p,
+                                            const OracleOptions *opt, int64_t start_preceding, int64_t end_preceding,
+                                            double *pred) {
+	if (end_preceding < 0 || (start_preceding >= 0 && start_preceding < end_preceding)) return ORC_INVALID_INPUT;
+	OracleOptions o = *opt;
+	o.compute_inference = 0;
+	double *coef = (double *)malloc(p * sizeof(double));
+	double *row = (double *)malloc(p * sizeof(double));
+	const double **xs = (const double **)malloc(p * sizeof(double *));
+	for (int64_t g = 0; g < n_groups; g++) {
+		int64_t lo = offsets[g], hi = offsets[g + 1];
+		size_t cap = (size_t)(hi - lo);
+		double *ty = (double *)malloc((cap + 1) * sizeof(double));
+		double *tw = (double *)malloc((cap + 1) * sizeof(double));
+		double **tx = (double **)malloc(p * sizeof(double *));
+		for (size_t j = 0; j < p; j++) tx[j] = (double *)malloc((cap + 1) * sizeof(double));
+		for (int64_t e = lo; e < hi; e++) {
+			double *out = pred + (size_t)e * 3;
+			out[0] = out[1] = out[2] = NAN;
+			int64_t last = e - end_preceding;
+			int64_t first = start_preceding < 0 ? lo : e - start_preceding;
+			if (first < lo) first = lo;
+			if (last < first) continue; /* empty frame */
+			size_t nt = 0;
+			for (int64_t r = first; r <= last; r++) {
+				if (isnan(y[r])) continue;
+				ty[nt] = y[r];
+				if (w) tw[nt] = w[r];
+				for (size_t j = 0; j < p; j++) tx[j][nt] = x[j][r];
+				nt++;
+			}
+			if (nt <= p + (size_t)(o.fit_intercept ? 1 : 0)) continue;
+			OracleResult r;
+			memset(&r, 0, sizeof r);
+			r.coefficients = coef;
+			for (size_t j = 0; j < p; j++) xs[j] = tx[j];
+			if (oracle_fit(ty, xs, w ? tw : NULL, nt, p, &o, &r) != ORC_SUCCESS) continue;
+			for (size_t j = 0; j < p; j++) row[j] = x[j][last];
+			double pr[3];
+			if (oracle_predict_with_interval(coef, p, r.intercept, row, r.residual_std_error, r.n_observations,
+			                                 o.confidence_level, pr) && isfinite(pr[0])) {
+				out[0] = pr[0]; out[1] = pr[1]; out[2] = pr[2];
+			}
+		}
+		for (size_t j = 0; j < p; j++) free(tx[j]);
+		free(tx); free(tw); free(ty);
+	}
+	free((void *)xs); free(row); free(coef);
+	return ORC_SUCCESS;
+}
