@@ -15,10 +15,10 @@ from ._abi import AnofoxStatsError  # noqa: E402
 from .aggregate import (FitAggResult, FitPredictAggResult, OlsFitAgg, OlsFitPredictAgg, RidgeFitAgg,  # noqa: E402
                         RidgeFitPredictAgg, WlsFitAgg, WlsFitPredictAgg, SQL_FUNCTIONS, ols_fit_agg,
                         ols_fit_predict_agg, ridge_fit_agg, ridge_fit_predict_agg, wls_fit_agg, wls_fit_predict_agg,
-                        result_from_records, ols_fit_predict, ridge_fit_predict, wls_fit_predict)
+                        result_from_records, ols_fit_predict, ridge_fit_predict, wls_fit_predict, vif_agg)
 from .options import InvalidInputException, RegressionOptions, parse_options  # noqa: E402
-from .runtime import Context, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host, fit_predict_window_host  # noqa: E402
-from .scalar import aic, bic, ols_fit, predict, predict_with_interval, ridge_fit, t_critical, wls_fit  # noqa: E402
+from .runtime import Context, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host, fit_predict_window_host, vif_batch_host  # noqa: E402
+from .scalar import aic, bic, ols_fit, predict, predict_with_interval, ridge_fit, t_critical, vif, wls_fit  # noqa: E402
 
 __all__ = [
     "AnofoxStatsError", "Context", "FitAggResult", "InvalidInputException", "OlsFitAgg", "RegressionOptions",
@@ -27,6 +27,7 @@ __all__ = [
     "FitPredictAggResult", "OlsFitPredictAgg", "RidgeFitPredictAgg", "WlsFitPredictAgg", "fit_predict_batch_host",
     "ols_fit_predict_agg", "ridge_fit_predict_agg", "wls_fit_predict_agg", "predict", "predict_with_interval",
     "t_critical", "fit_predict_expanding_host", "fit_predict_window_host", "ols_fit_predict", "ridge_fit_predict", "wls_fit_predict",
+    "vif", "vif_agg", "vif_batch_host",
 ]
 
 

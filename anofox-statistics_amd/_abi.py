@@ -125,6 +125,14 @@ SYMBOLS = {
     "anofox_predict": (C.c_bool, [C.POINTER(AnofoxDataArray), C.c_size_t, _DP, C.c_size_t, C.c_double,
                                   C.POINTER(_DP), C.POINTER(C.c_size_t), _ERRP]),
     "anofox_free_predictions": (None, [_DP]),
+    "anofox_compute_vif": (C.c_bool, [C.POINTER(AnofoxDataArray), C.c_size_t, C.POINTER(_DP), C.POINTER(C.c_size_t), _ERRP]),
+    "anofox_free_vif": (None, [_DP]),
+    "anofox_hip_vif_record_len": (C.c_size_t, [C.c_size_t]),
+    "anofox_hip_vif_max_features": (C.c_size_t, []),
+    "anofox_hip_vif_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p),
+                                               C.c_void_p, _ERRP]),
+    "anofox_hip_vif_batch_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), C.POINTER(_DP),
+                                             _DP, _ERRP]),
     "anofox_hip_fit_predict_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p,
                                                        C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                                        AnofoxHipBatchOptions, C.c_void_p, C.c_void_p, _ERRP]),

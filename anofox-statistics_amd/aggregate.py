@@ -421,6 +421,53 @@ SQL_FUNCTIONS.update({
 
 
 # ------------------------------------------------------------------------------------------------------
+# vif_agg(x LIST(DOUBLE)) -> LIST(DOUBLE)  (src/aggregate_functions/vif_aggregate.cpp)
+# ------------------------------------------------------------------------------------------------------
+def vif_agg(group_keys, x, context=None):
+    """GROUP BY mirror of vif_agg.  Returns (keys, [list of p VIFs or None per group]).
+
+    Update (vif_aggregate.cpp:50-95): NULL x lists are skipped; every non-NaN value is appended to ITS column, so a
+    NaN shortens only that column.  Finalize (:144-185): NULL unless >= 2 features and >= 3 values in the first
+    column; columns of unequal length make compute_vif fail (vif.rs:40-51) -> NULL."""
+    from .runtime import vif_batch_host
+    keys = np.asarray(group_keys)
+    rows = [None if r is None else [np.nan if v is None else float(v) for v in r] for r in x]
+    ukeys, gid = np.unique(keys, return_inverse=True)
+    per_group = [[] for _ in ukeys]
+    for i, r in enumerate(rows):
+        if r is not None:
+            per_group[gid[i]].append(r)
+    result = [None] * len(ukeys)
+    batch, batch_ids, p_batch = [], [], None
+    for g, rs in enumerate(per_group):
+        if not rs:
+            continue
+        p = len(rs[0])
+        for r in rs:
+            if len(r) != p:
+                raise InvalidInputException(f"Inconsistent feature count: expected {p}, got {len(r)}")
+        cols = [np.array([r[j] for r in rs if not np.isnan(r[j])]) for j in range(p)]
+        if p < 2 or len(cols[0]) < 3 or any(len(c) != len(cols[0]) for c in cols):
+            continue                                             # SQL NULL
+        if p_batch is not None and p != p_batch:
+            raise InvalidInputException("vif_agg: all groups of one call must have the same feature count")
+        p_batch = p
+        batch.append(cols)
+        batch_ids.append(g)
+    if batch:
+        offsets = np.zeros(len(batch) + 1, dtype=np.int64)
+        np.cumsum([len(c[0]) for c in batch], out=offsets[1:])
+        x_cols = [np.concatenate([c[j] for c in batch]) for j in range(p_batch)]
+        out = vif_batch_host(offsets, x_cols, ctx=context)
+        for k, g in enumerate(batch_ids):
+            result[g] = None if out[k, p_batch] != 0 else [float(v) for v in out[k, :p_batch]]
+    return ukeys, result
+
+
+SQL_FUNCTIONS.update({"anofox_stats_vif_agg": vif_agg, "vif_agg": vif_agg})
+
+
+# ------------------------------------------------------------------------------------------------------
 # *_fit_predict(y, x [, options]) OVER (PARTITION BY k ORDER BY o ROWS BETWEEN UNBOUNDED PRECEDING AND
 # CURRENT ROW | k PRECEDING, or any ROWS BETWEEN a PRECEDING AND b PRECEDING): the window functions (src/window_functions/{ols,ridge,wls}_fit_predict.cpp)
 # ------------------------------------------------------------------------------------------------------

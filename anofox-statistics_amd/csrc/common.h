@@ -158,6 +158,11 @@ hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream);
 //       2 = final statistics of the queued groups from the directly summed RSS
 hipError_t launch_solve_narrow(const BatchArgs &a, int mode, hipStream_t stream);
 hipError_t launch_residual_grad(const BatchArgs &a, hipStream_t stream);
+// vif_narrow.hip: out[g] = { vif[p], status }; rows < min_rows -> NULL (status 100)
+hipError_t launch_vif_narrow(const double *moments, const int64_t *row_offsets, int64_t n_groups, int p, int64_t min_rows,
+                             double *out, hipStream_t stream);
+hipError_t launch_vif_from_core(const double *core, const int64_t *row_offsets, int64_t n_groups, int q, int j, int p,
+                                int64_t min_rows, double *out, hipStream_t stream);
 // hc_narrow.hip: HC0..HC3 standard errors over the finished fit (rewrites se/t/p/ci of the inference records)
 size_t hc_prep_bytes(int64_t n_groups, int p); // scratch the pass needs (prep records)
 hipError_t launch_hc_narrow(const BatchArgs &a, double *prep, hipStream_t stream);

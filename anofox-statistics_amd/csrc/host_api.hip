@@ -1135,3 +1135,187 @@ void anofox_free_predictions(double *predictions) {
 }
 
 } // extern "C"
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Variance inflation factors (vif_agg / vif): p OLS fits per group on one Gram matrix                */
+/* ------------------------------------------------------------------------------------------------ */
+
+namespace {
+
+// d_vif[g] = { vif[p], status }.  min_rows = 3 for the aggregate's rule (vif_aggregate.cpp:154), 0 for compute_vif.
+bool run_vif(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const int64_t *d_off, const double *const *x_cols,
+             int64_t min_rows, double *d_vif, AnofoxError *e) {
+	if (G == 0) return true;
+	hipStream_t st = ctx->stream;
+	if (p <= (size_t)kNarrowMaxP) {
+		Workspace ws;
+		if (!carve_workspace(ctx, G, (int)p, &ws, e)) return false;
+		BatchArgs a;
+		memset(&a, 0, sizeof a);
+		a.row_offsets = d_off;
+		a.y = x_cols[0]; // the y slot of the record is not used
+		for (size_t j = 0; j < p; ++j) a.x[j] = x_cols[j];
+		a.n_groups = G;
+		a.n_rows = n_rows;
+		a.p = (int)p;
+		a.model = ANOFOX_HIP_MODEL_OLS;
+		a.fit_intercept = 1;
+		a.moments = ws.moments;
+		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+		if (ctx->timing) {
+			e0 = get_event(ctx);
+			e1 = get_event(ctx);
+			e2 = get_event(ctx);
+			(void)hipEventRecord(e0, st);
+		}
+		if (hip_fail(launch_accumulate_narrow(a, st), "accumulate kernel launch", e)) return false;
+		if (ctx->timing) (void)hipEventRecord(e1, st);
+		if (hip_fail(launch_vif_narrow(ws.moments, d_off, G, (int)p, min_rows, d_vif, st), "vif kernel launch", e)) return false;
+		if (ctx->timing) {
+			(void)hipEventRecord(e2, st);
+			ctx->acc_events.emplace_back(e0, e1);
+			ctx->solve_events.emplace_back(e1, e2);
+		}
+		return true;
+	}
+	// wide designs: one grouped fit per feature (x_j on the others); only R^2 and the status of each fit are used
+	const size_t q = p - 1;
+	if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, (size_t)G * (q + 6) * sizeof(double), "vif scratch", e)) return false;
+	double *d_core = (double *)ctx->aux;
+	AnofoxHipBatchOptions opt;
+	memset(&opt, 0, sizeof opt);
+	opt.model = ANOFOX_HIP_MODEL_OLS;
+	opt.fit_intercept = true;
+	opt.confidence_level = 0.95;
+	std::vector<const double *> others(q);
+	for (size_t j = 0; j < p; ++j) {
+		for (size_t i = 0, k = 0; i < p; ++i)
+			if (i != j) others[k++] = x_cols[i];
+		if (!run_device_batch(ctx, G, q, n_rows, d_off, x_cols[j], others.data(), nullptr, opt, d_core, nullptr, e)) return false;
+		if (hip_fail(launch_vif_from_core(d_core, d_off, G, (int)q, (int)j, (int)p, min_rows, d_vif, st), "vif kernel launch", e)) return false;
+	}
+	return true;
+}
+
+bool validate_vif(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const void *off, const double *const *x_cols,
+                  const void *out, AnofoxError *e) {
+	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (G < 0 || n_rows < 0) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "negative n_groups or n_rows"); return false; }
+	if (p == 0 || !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x is NULL or empty"); return false; }
+	if (p > (size_t)kWideMaxP + 1) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT,
+		          "n_features = " + std::to_string(p) + " exceeds the supported maximum of " + std::to_string(kWideMaxP + 1));
+		return false;
+	}
+	if (G > 0 && (!off || !out)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "row_offsets or output is NULL"); return false; }
+	for (size_t j = 0; j < p; ++j)
+		if (G > 0 && !x_cols[j]) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x column pointer is NULL"); return false; }
+	return true;
+}
+
+bool vif_host(AnofoxHipContext *ctx, int64_t n_groups, size_t p, int64_t n_rows, const int64_t *row_offsets,
+              const double *const *x_cols, int64_t min_rows, double *vif, AnofoxError *out_error) {
+	if (!ctx) {
+		ctx = default_context(out_error);
+		if (!ctx) return false;
+	}
+	if (!validate_vif(ctx, n_groups, p, n_rows, row_offsets, x_cols, vif, out_error)) return false;
+	if (n_groups == 0) return true;
+	if (row_offsets[0] != 0 || row_offsets[n_groups] != n_rows) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must start at 0 and end at n_rows");
+		return false;
+	}
+	for (int64_t g = 0; g < n_groups; ++g)
+		if (row_offsets[g + 1] < row_offsets[g]) {
+			set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must be non-decreasing");
+			return false;
+		}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	const size_t R = (size_t)n_rows, G = (size_t)n_groups;
+	const size_t b_off = align_up((G + 1) * sizeof(int64_t), 256);
+	const size_t b_col = align_up((R + 2) * sizeof(double), 256);
+	const size_t b_out = align_up(G * (p + 1) * sizeof(double), 256);
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_off + p * b_col + b_out, "staging", out_error)) return false;
+	char *cur = (char *)ctx->stage;
+	hipStream_t st = ctx->stream;
+	int64_t *d_off = (int64_t *)cur;
+	cur += b_off;
+	if (hip_fail(hipMemcpyAsync(d_off, row_offsets, (G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D offsets", out_error)) return false;
+	std::vector<const double *> d_x(p);
+	for (size_t j = 0; j < p; ++j) {
+		if (R > 0 && hip_fail(hipMemcpyAsync(cur, x_cols[j], R * sizeof(double), hipMemcpyHostToDevice, st), "H2D x", out_error)) return false;
+		d_x[j] = (const double *)cur;
+		cur += b_col;
+	}
+	double *d_vif = (double *)cur;
+	if (!run_vif(ctx, n_groups, p, n_rows, d_off, d_x.data(), min_rows, d_vif, out_error)) return false;
+	if (hip_fail(hipMemcpyAsync(vif, d_vif, G * (p + 1) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H vif", out_error)) return false;
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
+}
+
+} // namespace
+
+extern "C" {
+
+size_t anofox_hip_vif_record_len(size_t n_features) { return n_features + 1; }
+size_t anofox_hip_vif_max_features(void) { return (size_t)kWideMaxP + 1; }
+
+bool anofox_hip_vif_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                 const int64_t *d_row_offsets, const double *const *x_cols, double *d_vif,
+                                 AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!validate_vif(ctx, n_groups, n_features, n_rows, d_row_offsets, x_cols, d_vif, out_error)) return false;
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	return run_vif(ctx, n_groups, n_features, n_rows, d_row_offsets, x_cols, 3, d_vif, out_error);
+}
+
+bool anofox_hip_vif_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                               const int64_t *row_offsets, const double *const *x_cols, double *vif, AnofoxError *out_error) {
+	reset_error(out_error);
+	return vif_host(ctx, n_groups, n_features, n_rows, row_offsets, x_cols, 3, vif, out_error);
+}
+
+// lib.rs:1688-1739 over vif.rs:23-98
+bool anofox_compute_vif(const AnofoxDataArray *x, size_t x_count, double **out_vif, size_t *out_vif_len, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!x || x_count == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "x is NULL or empty"); return false; }
+	if (!out_vif || !out_vif_len) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "out_vif or out_vif_len is NULL"); return false; }
+	double *res = (double *)malloc(x_count * sizeof(double));
+	if (!res) { set_error(out_error, ANOFOX_ERROR_ALLOCATION_FAILURE, "Failed to allocate VIF array"); return false; }
+	if (x_count == 1) { // vif.rs:30-33
+		res[0] = 1.0;
+		*out_vif = res;
+		*out_vif_len = 1;
+		return true;
+	}
+	const size_t n = x[0].len;
+	if (n == 0) { free(res); set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Invalid input: Empty feature arrays"); return false; }
+	for (size_t j = 0; j < x_count; ++j)
+		if (x[j].len != n) {
+			free(res);
+			set_error(out_error, ANOFOX_ERROR_DIMENSION_MISMATCH, "Dimension mismatch: Feature " + std::to_string(j) + " has " +
+			          std::to_string(x[j].len) + " observations, expected " + std::to_string(n));
+			return false;
+		}
+	std::vector<std::vector<double>> cols(x_count);
+	std::vector<const double *> ptrs(x_count);
+	for (size_t j = 0; j < x_count; ++j) {
+		expand(x[j], cols[j]);
+		ptrs[j] = cols[j].data();
+	}
+	const int64_t off[2] = {0, (int64_t)n};
+	std::vector<double> rec(x_count + 1);
+	if (!vif_host(nullptr, 1, x_count, (int64_t)n, off, ptrs.data(), 0, rec.data(), out_error)) { free(res); return false; }
+	memcpy(res, rec.data(), x_count * sizeof(double));
+	*out_vif = res;
+	*out_vif_len = x_count;
+	return true;
+}
+
+void anofox_free_vif(double *vif) {
+	if (vif) free(vif);
+}
+
+} // extern "C"

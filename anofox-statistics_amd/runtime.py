@@ -140,6 +140,24 @@ class Context:
         self._check(ok, err)
         return pred
 
+    def vif_batch_device(self, row_offsets, x_cols: Sequence, out=None, use_current_torch_stream: bool = True):
+        """Grouped variance inflation factors, device resident.  Returns out[G, p+1] = {vif[p], status}."""
+        import torch
+
+        p = len(x_cols)
+        G = int(row_offsets.numel()) - 1
+        N = int(x_cols[0].numel())
+        if out is None:
+            out = torch.empty((G, p + 1), dtype=torch.float64, device=x_cols[0].device)
+        if use_current_torch_stream:
+            self.set_stream(torch.cuda.current_stream(x_cols[0].device).cuda_stream)
+        cols = (C.c_void_p * p)(*[c.data_ptr() for c in x_cols])
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_vif_batch_device(self._h, G, p, N, C.c_void_p(row_offsets.data_ptr()), cols,
+                                                   C.c_void_p(out.data_ptr()), C.byref(err))
+        self._check(ok, err)
+        return out
+
     # ---- host-resident batch (numpy) ----------------------------------------------------------
     def fit_batch_host(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions):
         return fit_batch_host(row_offsets, y, x_cols, w, options, ctx=self)
@@ -229,3 +247,20 @@ def fit_predict_window_host(row_offsets, y, x_cols: Sequence, w, options: _abi.A
     if not ok:
         raise AnofoxStatsError(err.code, err.text())
     return pred
+
+
+def vif_batch_host(row_offsets, x_cols: Sequence, ctx: Optional[Context] = None):
+    """numpy in, numpy out: out[G, p+1] = {vif[p], status} (status 100 = fewer than 3 rows -> SQL NULL)."""
+    lib = _abi.load()
+    off = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    p, G = len(cols), len(off) - 1
+    N = len(cols[0]) if cols else 0
+    out = np.empty((G, p + 1), dtype=np.float64)
+    colp = (_DP * max(p, 1))(*[c.ctypes.data_as(_DP) for c in cols])
+    err = _abi.AnofoxError()
+    ok = lib.anofox_hip_vif_batch_host(ctx._h if ctx is not None else None, G, p, N, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       colp, out.ctypes.data_as(_DP), C.byref(err))
+    if not ok:
+        raise AnofoxStatsError(err.code, err.text())
+    return out

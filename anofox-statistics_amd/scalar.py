@@ -160,3 +160,26 @@ def predict(x, coefficients, intercept=float("nan")):
         return [outp[i] for i in range(outn.value)]
     finally:
         lib.anofox_free_predictions(outp)
+
+
+def vif(x):
+    """anofox_stats_vif(x LIST(LIST(DOUBLE))) -> LIST(DOUBLE) (src/scalar_functions/vif.cpp:26-76): x is a list of
+    feature COLUMNS; throws on failure like the SQL function.  Runs on the GPU."""
+    lib = _abi.load()
+    xs = (_abi.AnofoxDataArray * max(len(x), 1))()
+    keep = []
+    for j, col in enumerate(x):
+        a, k = _data_array(col)
+        xs[j] = a
+        keep.append(k)
+    outp = _DP()
+    outn = C.c_size_t()
+    err = _abi.AnofoxError()
+    if not lib.anofox_compute_vif(xs, len(x), C.byref(outp), C.byref(outn), C.byref(err)):
+        e = InvalidInputException(f"VIF computation failed: {err.text()}")
+        e.code = err.code
+        raise e
+    try:
+        return [outp[i] for i in range(outn.value)]
+    finally:
+        lib.anofox_free_vif(outp)

@@ -110,6 +110,8 @@ def main():
                     help="expanding-window fit + predict (*_fit_predict OVER ...): one fit per ROW")
     ap.add_argument("--frame", default="u,0",
                     help="with --window: ROWS BETWEEN a PRECEDING AND b PRECEDING as 'a,b' (a = u for UNBOUNDED)")
+    ap.add_argument("--vif", action="store_true",
+                    help="vif_agg: variance inflation factors (p OLS fits per group from one Gram matrix)")
     ap.add_argument("--predict", action="store_true",
                     help="fit + per-row predictions (*_fit_predict_agg); every 5th row is a prediction row (NULL y)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -172,7 +174,14 @@ def main():
     fa, fb = args.frame.split(",")
     frame = (None if fa.strip().lower().startswith("u") else int(fa), int(fb))
 
+    vif_buf = torch.empty((G_local, p + 1), dtype=torch.float64, device=dev) if args.vif else None
+    if args.vif and world > 1:
+        raise SystemExit("--vif is a single-GPU measurement")
+
     def step():
+        if args.vif:
+            ctx.vif_batch_device(offs, x_cols, out=vif_buf)
+            return None, None
         if args.window:
             ctx.fit_predict_window_device(offs, y, x_cols, w, opts, frame, pred=pred_buf)
             return None, None
@@ -207,6 +216,17 @@ def main():
         elapsed = float(tmax.item())
 
     ok, cerr, derr = True, 0.0, 0.0
+    if args.vif:
+        import oracle
+        S = min(512, G_local)
+        nr = int(offs[S].item())
+        ref = oracle.vif_groups([c[:nr].cpu().numpy() for c in x_cols], offs[:S + 1].cpu().numpy())
+        got = vif_buf[:S].cpu().numpy()
+        fin = np.isfinite(ref[:, :p])
+        ok = bool(np.array_equal(np.isfinite(got[:, :p]), fin) and np.array_equal(got[:, p], ref[:, p]))
+        derr = float(np.max(np.abs(got[:, :p][fin] / ref[:, :p][fin] - 1.0))) if fin.any() else 0.0
+        ok = ok and derr < 1e-6
+        args.parity_sample = 0
     if args.window:
         # parity gate of the window path: a few partitions against the oracle's O(n^2) refits
         import oracle
@@ -236,6 +256,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         fits_per_s = G * args.steps / elapsed
         bytes_fit = algorithmic_bytes_per_fit(n, p, weighted, args.inference)
+        if args.vif:
+            bytes_fit = 8 * n * p + 8 * (p + 1)     # the features once, the VIF record out
         acc_ms = kt["accumulate_ms"] / max(kt["accumulate_count"], 1)   # per launch (wide designs: per slab)
         acc_step_ms = kt["accumulate_ms"] / args.steps                      # all launches of one step
         if p <= 8:
@@ -248,12 +270,14 @@ def main():
             achieved = per_step / (acc_step_ms * 1e-3) / 1e12 if acc_step_ms > 0 else 0.0
         traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (profiles/hbm_traffic.json), if recorded
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not args.vif:
             try:
                 traffic = json.load(open(tpath)).get(f"{args.model}_G{G_local}_n{n}_p{p}")
             except Exception:
                 traffic = None
         extra = {}
+        if args.vif:
+            extra = {"equivalent_ols_fits_per_sec": G * p * args.steps / elapsed}
         if args.window:
             extra = {"rows_per_sec": G * n * args.steps / elapsed, "row_fits_per_sec": G * n * args.steps / elapsed,
                      "window_kernel_ms_per_step": kt["predict_ms"] / args.steps}
@@ -267,7 +291,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.model}_fit{'_predict' if (args.predict or args.window) else ''}{(' OVER (ROWS BETWEEN ' + ('UNBOUNDED' if frame[0] is None else str(frame[0])) + ' PRECEDING AND ' + str(frame[1]) + ' PRECEDING)') if args.window else '_agg'}: {G} groups x n={n} x p={p}, device-resident grouped columns, "
+            "config": {"workload": (f"vif_agg: {G} groups x n={n} x p={p}, device-resident grouped columns" if args.vif else "") or f"{args.model}_fit{'_predict' if (args.predict or args.window) else ''}{(' OVER (ROWS BETWEEN ' + ('UNBOUNDED' if frame[0] is None else str(frame[0])) + ' PRECEDING AND ' + str(frame[1]) + ' PRECEDING)') if args.window else '_agg'}: {G} groups x n={n} x p={p}, device-resident grouped columns, "
                                    f"fit_intercept=true, compute_inference={str(args.inference).lower()}",
                        "groups_total": G, "groups_per_gpu": G_local, "rows_per_group": n, "features": p,
                        "partition": f"contiguous key ranges over {world} rank(s); all-gather of {p + 6}-double records"},

@@ -202,6 +202,14 @@ ANOFOX_HIP_API bool anofox_predict(const AnofoxDataArray *x, size_t x_count, con
                     double intercept, double **out_predictions, size_t *out_predictions_len, AnofoxError *out_error);
 ANOFOX_HIP_API void anofox_free_predictions(double *predictions);
 
+/* replaces anofox_compute_vif / anofox_free_vif, anofox_stats_ffi.h:516-522 (lib.rs:1688-1750 over
+ * crates/anofox-stats-core/src/diagnostics/vif.rs:23-98): feature j regressed on all the others by OLS with an
+ * intercept, VIF_j = 1 / (1 - R^2_j); inf when that fit fails or R^2 >= 0.9999, 1 when R^2 < 0; a single feature
+ * gives {1.0}.  Runs on the GPU (one Gram matrix for all p regressions); *out_vif is malloc'ed. */
+ANOFOX_HIP_API bool anofox_compute_vif(const AnofoxDataArray *x, size_t x_count, double **out_vif, size_t *out_vif_len,
+                        AnofoxError *out_error);
+ANOFOX_HIP_API void anofox_free_vif(double *vif);
+
 #endif /* ANOFOX_STATS_FFI_H */
 
 /* ------------------------------------------------------------------------ */
@@ -338,6 +346,22 @@ ANOFOX_HIP_API bool anofox_hip_fit_predict_window_host(AnofoxHipContext *ctx, in
                                         const int64_t *row_offsets, const double *y, const double *const *x_cols,
                                         const double *w, AnofoxHipWindowFrame frame, AnofoxHipBatchOptions options,
                                         double *pred, AnofoxError *out_error);
+
+/*
+ * Grouped variance inflation factors: the Finalize loop of vif_agg (src/aggregate_functions/vif_aggregate.cpp:
+ * 144-185) in one call.  x_cols as in the fit entry points (rows of a group contiguous; the aggregate's Update
+ * has already dropped NULL rows and NaN values, :67-93).  d_vif[g] = { vif[n_features], status }
+ * (anofox_hip_vif_record_len doubles): status 100 = fewer than 3 rows -> SQL NULL (:154), 0 otherwise.
+ * n_features <= 8 uses one pass over the rows; up to anofox_hip_vif_max_features() = 129 one grouped fit per feature.
+ */
+ANOFOX_HIP_API size_t anofox_hip_vif_record_len(size_t n_features);
+ANOFOX_HIP_API size_t anofox_hip_vif_max_features(void);
+ANOFOX_HIP_API bool anofox_hip_vif_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                 const int64_t *d_row_offsets, const double *const *x_cols, double *d_vif,
+                                 AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_vif_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                               const int64_t *row_offsets, const double *const *x_cols, double *vif,
+                               AnofoxError *out_error);
 
 /* Predictions only, from existing fit records (d_core as produced by the fit entry points). */
 ANOFOX_HIP_API bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,

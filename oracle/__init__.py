@@ -101,6 +101,8 @@ def lib():
         L.oracle_fit_predict_window.restype = C.c_int
         L.oracle_fit_predict_window.argtypes = [_DP, C.POINTER(_DP), _DP, C.POINTER(C.c_int64), C.c_int64, C.c_size_t,
                                                 C.POINTER(OracleOptions), C.c_int64, C.c_int64, _DP]
+        L.oracle_vif_groups.restype = C.c_int
+        L.oracle_vif_groups.argtypes = [C.POINTER(_DP), C.POINTER(C.c_int64), C.c_int64, C.c_size_t, C.c_int64, _DP]
         for name in ("oracle_aic", "oracle_bic"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_double, C.c_int64, C.c_int64, _DP]
@@ -244,3 +246,16 @@ def fit_predict_window(y, x_cols, offsets, w=None, start_preceding=-1, end_prece
     if rc != 0:
         raise RuntimeError(f"oracle_fit_predict_window failed: {rc}")
     return pred
+
+
+def vif_groups(x_cols, offsets, min_rows=3):
+    """out[G, p+1] = { vif[p], status } per group (status 100 = fewer than min_rows rows -> NULL)."""
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    p, G = len(cols), len(offsets) - 1
+    out = np.empty((G, p + 1))
+    rc = lib().oracle_vif_groups(_col_ptrs(cols), offsets.ctypes.data_as(C.POINTER(C.c_int64)), G, p, int(min_rows),
+                                 out.ctypes.data_as(_DP))
+    if rc != 0:
+        raise RuntimeError(f"oracle_vif_groups failed: {rc}")
+    return out

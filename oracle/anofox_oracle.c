@@ -805,3 +805,47 @@ ORACLE_EXPORT int oracle_fit_predict_window(const double *y, const double *const
 	free((void *)xs); free(row); free(coef);
 	return ORC_SUCCESS;
 }
+
+/* Variance inflation factors, crates/anofox-stats-core/src/diagnostics/vif.rs:23-98: feature j regressed on all
+ * the others with fit_ols (intercept, no inference), VIF_j = 1/(1 - R^2_j); inf when the fit fails or
+ * R^2 >= 0.9999, 1 when R^2 < 0; one feature -> {1.0}.  Grouped driver = the Finalize loop of vif_agg
+ * (src/aggregate_functions/vif_aggregate.cpp:144-185): fewer than min_rows (3 there) buffered rows -> NULL
+ * (status 100).  out[g] = { vif[p], status }. */
+ORACLE_EXPORT int oracle_vif_groups(const double *const *x, const int64_t *offsets, int64_t n_groups, size_t p,
+                                    int64_t min_rows, double *out) {
+	OracleOptions o;
+	memset(&o, 0, sizeof o);
+	o.model = ORC_MODEL_OLS;
+	o.fit_intercept = 1;
+	o.confidence_level = 0.95;
+	const double **xs = (const double **)malloc((p ? p : 1) * sizeof(double *));
+	double *coef = (double *)malloc((p ? p : 1) * sizeof(double));
+	for (int64_t g = 0; g < n_groups; g++) {
+		int64_t lo = offsets[g], hi = offsets[g + 1];
+		double *rec = out + (size_t)g * (p + 1);
+		if (hi - lo < min_rows) {
+			for (size_t j = 0; j < p; j++) rec[j] = NAN;
+			rec[p] = (double)ORC_STATUS_NULL_TOO_FEW_ROWS;
+			continue;
+		}
+		rec[p] = 0.0;
+		if (p == 1) { rec[0] = 1.0; continue; }
+		for (size_t j = 0; j < p; j++) {
+			size_t k = 0;
+			for (size_t i = 0; i < p; i++) if (i != j) xs[k++] = x[i] + lo;
+			OracleResult r;
+			memset(&r, 0, sizeof r);
+			r.coefficients = coef;
+			int rc = oracle_fit(x[j] + lo, xs, NULL, (size_t)(hi - lo), p - 1, &o, &r);
+			double v;
+			if (rc != ORC_SUCCESS) v = INFINITY;
+			else if (r.tss == 0.0 && r.rank > 1) v = NAN; /* constant x_j: R^2 = 0/0 (upstream's value is unpinned) */
+			else if (r.r_squared >= 0.9999) v = INFINITY;
+			else if (r.r_squared < 0.0) v = 1.0;
+			else v = 1.0 / (1.0 - r.r_squared);
+			rec[j] = v;
+		}
+	}
+	free(coef); free((void *)xs);
+	return ORC_SUCCESS;
+}

@@ -825,6 +825,92 @@ def test_expanding_window_device_reference_benchmark_shape(pkg, ctx):
     assert np.quantile(np.abs(got[m] - ref[m]) / np.maximum(np.abs(ref[m]), 1.0), 0.98) < 1e-9
 
 
+# --------------------------------------------------------------------------------------------------
+# variance inflation factors (vif_agg / vif): p OLS fits per group from one Gram matrix
+# --------------------------------------------------------------------------------------------------
+def _assert_vif_match(got, ref, p, what):
+    assert np.array_equal(got[:, p], ref[:, p]), f"{what}: status"
+    g, r = got[:, :p], ref[:, :p]
+    assert np.array_equal(np.isnan(g), np.isnan(r)), f"{what}: NaN pattern"
+    assert np.array_equal(np.isinf(g), np.isinf(r)), f"{what}: inf pattern"
+    m = np.isfinite(r)
+    # VIF = 1/(1 - R^2): R^2 is a diagnostic (1e-6); the map amplifies its error by VIF <= 1e4
+    assert np.all(np.abs(g[m] - r[m]) <= 1e-6 * r[m] * np.maximum(r[m], 1.0) * 1e-2 + 1e-9 * r[m]), f"{what}: values"
+
+
+@pytest.mark.parametrize("p", [1, 2, 3, 5, 8, 9, 12])
+def test_vif_batch_matches_oracle(pkg, ctx, p):
+    rng = np.random.default_rng(40 + p)
+    offs, _, x_cols, _ = _random_groups(rng, 64, p, 1, 400)
+    x_cols = [c.copy() for c in x_cols]
+    if p >= 2:
+        lo, hi = offs[5], offs[6]
+        x_cols[1][lo:hi] = 0.9 * x_cols[0][lo:hi] + 0.2 * rng.standard_normal(hi - lo)     # strong, not perfect
+        lo, hi = offs[7], offs[8]
+        x_cols[1][lo:hi] = 2.0 * x_cols[0][lo:hi] + 1.0                                    # perfect -> inf
+        lo, hi = offs[9], offs[10]
+        x_cols[0][lo:hi] = 4.0                                                             # constant feature
+        lo, hi = offs[11], offs[12]
+        x_cols[p - 1][lo:hi:5] = np.inf                                                    # rows the fits drop
+    got = pkg.vif_batch_host(offs, x_cols, ctx=ctx)
+    ref = oracle.vif_groups(x_cols, offs)
+    _assert_vif_match(got, ref, p, f"vif p={p}")
+
+
+def test_vif_reference_sql_tests(pkg, ctx):
+    """test/sql/diagnostics/test_vif_agg.test and test/sql/scalar/test_diagnostics_scalar.test:64-83."""
+    low = np.array([[1, 5, 9], [2, 3, 7], [3, 8, 2], [4, 1, 6], [5, 9, 4], [6, 2, 8], [7, 7, 3], [8, 4, 5], [9, 6, 1], [10, 10, 10]], float)
+    high = np.array([[1, 2.1, 5], [2, 4.0, 6], [3, 6.1, 7], [4, 7.9, 8], [5, 10.0, 9], [6, 12.1, 10], [7, 13.9, 11], [8, 16.0, 12],
+                     [9, 18.1, 13], [10, 19.9, 14]], float)
+    keys, res = pkg.vif_agg(["low"] * 10 + ["high"] * 10, np.concatenate([low, high]).tolist(), context=ctx)
+    d = dict(zip(keys.tolist(), res))
+    assert len(d["low"]) == 3 and min(d["low"]) >= 1.0 and max(d["low"]) < 5
+    assert max(d["high"]) > 5
+    _, two = pkg.vif_agg([0] * 10, low[:, :2].tolist(), context=ctx)
+    assert len(two[0]) == 2
+    keys, res = pkg.vif_agg(["low"] * 5 + ["high"] * 5, np.concatenate([low[:5], high[:5]]).tolist(), context=ctx)
+    d = dict(zip(keys.tolist(), res))
+    assert max(d["low"]) < 5 and not max(d["high"]) < 5
+    # NULL rules of the aggregate: one feature, fewer than 3 rows, a NaN that shortens one column
+    assert pkg.vif_agg([0] * 10, low[:, :1].tolist(), context=ctx)[1] == [None]
+    assert pkg.vif_agg([0] * 2, low[:2].tolist(), context=ctx)[1] == [None]
+    bad = low.tolist()
+    bad[3][1] = float("nan")
+    assert pkg.vif_agg([0] * 10, bad, context=ctx)[1] == [None]
+    rows = low.tolist()
+    rows[4] = None                                                              # NULL list: skipped
+    ref = oracle.vif_groups([np.delete(low[:, j], 4) for j in range(3)], [0, 9])[0, :3]
+    assert np.allclose(pkg.vif_agg([0] * 10, rows, context=ctx)[1][0], ref, rtol=1e-8)
+    # scalar: the argument is a list of feature COLUMNS (5 "features" of 2 observations here -> every fit fails)
+    v = pkg.vif([[1.0, 5.0], [2.0, 3.0], [3.0, 8.0], [4.0, 1.0], [5.0, 9.0]])
+    assert len(v) == 5 and min(v) >= 1.0
+    assert pkg.vif([[1.0, 2, 3, 4, 5]]) == [1.0]
+    v = pkg.vif([low[:, 0].tolist(), low[:, 1].tolist(), low[:, 2].tolist()])
+    assert np.allclose(v, oracle.vif_groups([low[:, j] for j in range(3)], [0, 10], min_rows=0)[0, :3], rtol=1e-8)
+    with pytest.raises(pkg.InvalidInputException, match="Feature 1 has 2 observations, expected 3"):
+        pkg.vif([[1.0, 2.0, 3.0], [1.0, 2.0]])
+    with pytest.raises(pkg.InvalidInputException, match="x is NULL or empty"):
+        pkg.vif([])
+
+
+def test_vif_device_full_size_properties(pkg, ctx):
+    """1M groups x 100 rows x p = 3 independent features, device resident: VIF ~ 1, and a sample against the oracle."""
+    import torch
+    synth = import_pkg("synth")
+    dev = torch.device("cuda:0")
+    G, n, p = 1_000_000, 100, 3
+    offs, _, x_cols, _ = synth.make_grouped(G, n, p, device=dev)
+    out = ctx.vif_batch_device(offs, x_cols)
+    torch.cuda.synchronize()
+    assert bool((out[:, p] == 0).all())
+    v = out[:, :p]
+    assert bool(torch.isfinite(v).all()) and float(v.min()) >= 1.0 and float(v.median()) < 1.1
+    S = 512
+    nr = S * n
+    ref = oracle.vif_groups([c[:nr].cpu().numpy() for c in x_cols], offs[:S + 1].cpu().numpy())
+    _assert_vif_match(out[:S].cpu().numpy(), ref, p, "vif device sample")
+
+
 def test_entry_points_are_reentrant_across_threads(pkg):
     """DuckDB calls Update/Finalize from its worker pool (SURVEY.md §8b 'Threading'): the single-group symbols use a
     per-thread default context and must be safe to call concurrently; so must batch calls on separate contexts."""

@@ -340,3 +340,21 @@ def test_hc_sandwich_matches_dense_numpy():
         assert np.isfinite(d["std_errors"][0]) and d["std_errors"][0] > 0 and d["p_values"][0] < 0.05
         assert abs(d["std_errors"][0] - classical["std_errors"][0]) > 1e-15
         assert d["f_statistic"] == classical["f_statistic"]
+
+
+def test_vif_oracle_matches_closed_form_and_reference_unit_tests():
+    """compute_vif = 1/(1 - R^2_j) of x_j on the others (vif.rs:23-98); reference unit tests vif.rs:104-140."""
+    rng = np.random.default_rng(5)
+    n, p = 60, 4
+    X = rng.normal(size=(n, p))
+    X[:, 3] = 0.8 * X[:, 0] + 0.3 * rng.normal(size=n)
+    out = oracle.vif_groups([X[:, j] for j in range(p)], [0, n])
+    R = np.corrcoef(X, rowvar=False)
+    assert np.allclose(out[0, :p], np.diag(np.linalg.inv(R)), rtol=1e-10)      # textbook identity VIF = diag(R^-1)
+    assert out[0, p] == 0
+    assert oracle.vif_groups([[1.0, 2, 3, 4, 5]], [0, 5])[0, 0] == 1.0          # single feature
+    u = oracle.vif_groups([[1.0, 2, 3, 4, 5], [5.0, 3, 1, 4, 2]], [0, 5])[0]
+    assert u[0] < 2.0 and u[1] < 2.0                                            # uncorrelated
+    c = oracle.vif_groups([[1.0, 2, 3, 4, 5], [2.0, 4, 6, 8, 10]], [0, 5])[0]
+    assert np.isinf(c[0]) and np.isinf(c[1])                                    # perfectly correlated
+    assert oracle.vif_groups([[1.0, 2], [2.0, 1]], [0, 2])[0, 2] == 100         # aggregate rule: < 3 rows -> NULL
