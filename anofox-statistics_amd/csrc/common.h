@@ -99,6 +99,7 @@ struct WideArgs {
 	int fit_intercept;
 	int compute_inference;
 	int lambda_scaling;
+	int hc_type; // AnofoxHcType; acted on by launch_hc_wide only
 	double confidence_level;
 	double alpha;
 	double *moments;      // [n_groups * wide_record_len(T)] (this launch)
@@ -151,6 +152,8 @@ hipError_t launch_window_predict(const WindowArgs &a, hipStream_t stream);
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);
+// HC0..HC3 standard errors over the finished fits of this launch's groups (rewrites se/t/p/ci)
+hipError_t launch_hc_wide(const WideArgs &a, hipStream_t stream);
 
 // launchers implemented in the .hip translation units
 hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream);

@@ -153,6 +153,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.fit_intercept = opt.fit_intercept ? 1 : 0;
 	a.compute_inference = opt.compute_inference ? 1 : 0;
 	a.lambda_scaling = (int)opt.lambda_scaling;
+	a.hc_type = (int)opt.hc_type;
 	a.confidence_level = opt.confidence_level;
 	a.alpha = opt.alpha;
 	a.moments = (double *)base;
@@ -186,6 +187,8 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		}
 		if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
 		if (hip_fail(launch_solve_wide(a, 2, st), "wide final kernel launch", e)) return false;
+		if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE)
+			if (hip_fail(launch_hc_wide(a, st), "wide hc kernel launch", e)) return false;
 		if (ctx->timing) {
 			(void)hipEventRecord(e2, st);
 			ctx->acc_events.emplace_back(e0, e1);
@@ -286,12 +289,6 @@ bool validate_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	if (opt.compute_inference && G > 0 && !inf) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "inference buffer is NULL"); return false; }
 	if ((int)opt.hc_type < ANOFOX_HC_NONE || (int)opt.hc_type > ANOFOX_HC_HC3) {
 		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "unknown hc_type");
-		return false;
-	}
-	if (opt.hc_type != ANOFOX_HC_NONE && opt.compute_inference && opt.model != ANOFOX_HIP_MODEL_RIDGE &&
-	    p > (size_t)kNarrowMaxP) {
-		set_error(e, ANOFOX_ERROR_INVALID_INPUT,
-		          "hc_type other than 'none' needs n_features <= " + std::to_string(kNarrowMaxP) + " on the GPU path");
 		return false;
 	}
 	return true;

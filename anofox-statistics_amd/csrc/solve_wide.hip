@@ -35,7 +35,7 @@ enum { MODE_PRIMARY = 0, MODE_UPDATE = 1, MODE_FINAL = 2 };
 
 __device__ __forceinline__ double nan64w() { return __builtin_nan(""); }
 
-// LDS layout of one group (doubles): A[(P16+1) x LD] | sv | fx | diag0 | ldiag | linv | zv | bv | tmp[(T-1) x 256] | red[16]
+// LDS layout of one group (doubles): A[(P16+1) x LD] | sv | fx | diag0 | ldiag | linv | zv | bv | red[16]
 //   then ints: active[P16] | live[P16]
 // A rows 0..P16-1 are the (zero padded) x columns, row P16 is the y row of the augmented matrix
 //   [ Sxx  Sxy ]      Cholesky of the leading block leaves  z = L^-1 Sxy  in the y row, so the forward solve
@@ -43,7 +43,7 @@ __device__ __forceinline__ double nan64w() { return __builtin_nan(""); }
 // Lower triangle: L.  Upper triangle: W = L^-1 stored transposed (W[i][j] at A[j][i], i > j), diag of W in linv.
 struct WideLds {
 	int P16, LD, T;
-	double *A, *sv, *fx, *diag0, *ldiag, *linv, *zv, *bv, *tmp, *red;
+	double *A, *sv, *fx, *diag0, *ldiag, *linv, *zv, *bv, *red;
 	int *active, *live;
 };
 
@@ -60,8 +60,7 @@ __device__ __forceinline__ WideLds carve_lds(double *sm, int p) {
 	l.linv = l.ldiag + l.P16;
 	l.zv = l.linv + l.P16;
 	l.bv = l.zv + l.P16;
-	l.tmp = l.bv + l.P16;
-	l.red = l.tmp + (l.T > 1 ? (l.T - 1) * 256 : 0);
+	l.red = l.bv + l.P16;
 	l.active = reinterpret_cast<int *>(l.red + 16);
 	l.live = l.active + l.P16;
 	return l;
@@ -351,6 +350,49 @@ __device__ void blocked_back_solve(const WideLds &l, int tid) {
 	}
 }
 
+// Augmented moment matrix -> LDS, lower triangle; centred when an intercept is fitted; padding rows / columns zero.
+// The record is tile-major (256 contiguous doubles per 16x16 tile): thread t reads element t of each tile.
+// Needs l.sv (column sums) in place.
+__device__ void load_moment_matrix(const WideLds &l, const double *rec, int p, bool icpt, double lam, double sw, double sy, int tid) {
+	const int T = l.T, P16 = l.P16, LD = l.LD;
+	const int NT = T * (T + 1) / 2;
+	const double *vec = rec + (int64_t)NT * 256;
+	double *A = l.A;
+	const double inv_sw = 1.0 / sw;
+	const int tr = tid >> 4, tc = tid & 15; // element (tr, tc) of an upper-triangular tile = M[16I+tr][16J+tc]
+	// four tiles per trip so that four independent 2 KiB loads are in flight (the record comes from HBM / L2)
+	for (int t0 = 0; t0 < NT; t0 += 4) {
+		double v4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) v4[u] = rec[(int64_t)((t0 + u < NT) ? t0 + u : NT - 1) * 256 + tid];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const int tile = t0 + u;
+			if (tile >= NT) break;
+			int I = 0;
+			while ((I + 1) * T - (I + 1) * I / 2 <= tile) ++I; // first tile of block row I+1 is past `tile`
+			const int J = I + (tile - (I * T - I * (I - 1) / 2));
+			const int jj = 16 * I + tr, ii = 16 * J + tc; // jj <= ii except inside diagonal tiles
+			if (jj > ii) continue;
+			double v = 0.0;
+			if (ii < p) {
+				v = v4[u];
+				if (icpt) v -= l.sv[ii] * l.sv[jj] * inv_sw;
+				if (ii == jj) v += lam;
+			}
+			A[(size_t)ii * LD + jj] = v;
+		}
+	}
+	for (int j = tid; j < P16; j += 256) { // y row: centred Sxy
+		double v = 0.0;
+		if (j < p) {
+			const double q = vec[1 * P16 + j];
+			v = icpt ? q - l.sv[j] * sy / sw : q;
+		}
+		A[(size_t)P16 * LD + j] = v;
+	}
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 	extern __shared__ double sm[];
@@ -435,43 +477,7 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 		}
 		const double tss = icpt ? cyy_c : syy;
 
-		// augmented moment matrix, lower triangle; centred when an intercept is fitted; padding rows/cols zero.
-		// The record is tile-major (256 contiguous doubles per 16x16 tile): thread t reads element t of each tile.
-		{
-			const double inv_sw = 1.0 / sw;
-			const int tr = tid >> 4, tc = tid & 15; // element (tr, tc) of an upper-triangular tile = M[16I+tr][16J+tc]
-			// four tiles per trip so that four independent 2 KiB loads are in flight (the record comes from HBM / L2)
-			for (int t0 = 0; t0 < NT; t0 += 4) {
-				double v4[4];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) v4[u] = rec[(int64_t)((t0 + u < NT) ? t0 + u : NT - 1) * 256 + tid];
-#pragma unroll
-				for (int u = 0; u < 4; ++u) {
-					const int tile = t0 + u;
-					if (tile >= NT) break;
-					int I = 0;
-					while ((I + 1) * T - (I + 1) * I / 2 <= tile) ++I; // first tile of block row I+1 is past `tile`
-					const int J = I + (tile - (I * T - I * (I - 1) / 2));
-					const int jj = 16 * I + tr, ii = 16 * J + tc; // jj <= ii except inside diagonal tiles
-					if (jj > ii) continue;
-					double v = 0.0;
-					if (ii < p) {
-						v = v4[u];
-						if (icpt) v -= l.sv[ii] * l.sv[jj] * inv_sw;
-						if (ii == jj) v += lam;
-					}
-					A[(size_t)ii * LD + jj] = v;
-				}
-			}
-			for (int j = tid; j < P16; j += 256) { // y row: centred Sxy
-				double v = 0.0;
-				if (j < p) {
-					const double q = vec[1 * P16 + j];
-					v = icpt ? q - l.sv[j] * sy / sw : q;
-				}
-				A[(size_t)P16 * LD + j] = v;
-			}
-		}
+		load_moment_matrix(l, rec, p, icpt, lam, sw, sy, tid);
 		__syncthreads();
 		for (int j = tid; j < P16; j += 256) l.diag0[j] = j < p ? A[(size_t)j * LD + j] : 1.0;
 		// blocked_cholesky starts with a barrier
@@ -696,8 +702,241 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 
 size_t solve_wide_lds_bytes(int p) {
 	const int T = wide_tiles(p), P16 = 16 * T, LD = P16 + 1;
-	const size_t dbl = (size_t)(P16 + 1) * LD + 7 * (size_t)P16 + (T > 1 ? (size_t)(T - 1) * 256 : 0) + 16;
+	const size_t dbl = (size_t)(P16 + 1) * LD + 7 * (size_t)P16 + 16;
 	return dbl * sizeof(double) + 2 * (size_t)P16 * sizeof(int);
+}
+
+// Heteroscedasticity-consistent standard errors for wide designs (same estimator and references as
+// hc_narrow.hip).  One workgroup per group: the centred moment matrix is factored again exactly as in the solve
+// (same inputs, same code => same active set), W = L^-1 is expanded to the full symmetric S^-1 = W'W in LDS, and
+// the rows stream through in chunks of 16: c = x - xbar staged in LDS (transposed, [feature][row]), the chunk's
+// U = C S^-1 (16 x p) on the FP64 matrix cores — v_mfma_f64_16x16x4_f64, A fragment = 16 rows x 4 features of C,
+// B fragment = 4 x 16 block of S^-1, both one ds_read_b64 per lane; wave w owns the column blocks w, w + 4 —
+// then h = w (1/sum(w) + c'u), V_jj += omega u_j^2 from the accumulator registers.  The pass costs n p^2 FMAs
+// per group, twice the flops of the accumulate kernel.
+typedef const double __attribute__((address_space(1))) *hc_gptr_t;
+
+typedef double hc_dbl4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void hc_wide_kernel(WideArgs args) {
+	extern __shared__ double sm[];
+	const int p = args.p;
+	const int tid = threadIdx.x;
+	const bool icpt = args.fit_intercept != 0;
+	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
+	const int hc = args.hc_type;
+	const WideLds l = carve_lds(sm, p);
+	const int T = l.T, P16 = l.P16, LD = l.LD;
+	const int NT = T * (T + 1) / 2;
+	double *A = l.A;
+	double *cs = reinterpret_cast<double *>(l.live + P16); // [P16][16]: centred chunk, feature-major
+	double *yv_s = cs + 16 * P16;                          // [16]
+	double *wv_s = yv_s + 16;                              // [16]
+	double *hpart = wv_s + 16;                             // [4][16] per-wave partial c'u of the chunk's rows
+	double *epart = hpart + 64;                            // [4][16] per-wave partial b'c
+	double *vout = cs;                                     // [P16] after the row loop
+
+	const int lane = tid & 63, wave = tid >> 6;
+	const int kk = lane >> 4, lj = lane & 15; // MFMA fragment coordinates of this lane
+	const int ntile = (T - wave + 3) / 4;     // column blocks wave, wave + 4 (T <= 8: at most two)
+	// staging slot of this thread: row (tid & 15) of the chunk, columns (tid >> 4) + 16 m
+	const int srow = tid & 15, scol = tid >> 4;
+	hc_gptr_t colp[kWideMaxP / 16];
+#pragma unroll
+	for (int m = 0; m < kWideMaxP / 16; ++m) {
+		const int j = scol + 16 * m;
+		colp[m] = (hc_gptr_t)(uintptr_t)args.x_table[j < p ? j : p - 1];
+	}
+
+	for (int64_t gl = blockIdx.x; gl < args.n_groups; gl += gridDim.x) {
+		const int64_t g = args.group_base + gl;
+		const double *rec = args.moments + gl * (int64_t)wide_record_len(T);
+		const double *vec = rec + (int64_t)NT * 256;
+		const double *sc = vec + 4 * P16;
+		const double *core = args.core + g * (int64_t)(p + 6);
+		double *inf = args.inference + g * (int64_t)(5 * p + 2);
+		__syncthreads(); // the previous group's LDS contents are dead
+		if (core[p + 5] != 0.0) continue; // NULL group: the inference record is already NaN
+		const double sy = sc[0], sw = sc[2], cnt = sc[3];
+		double mine = 0.0;
+		for (int j = tid; j < P16; j += 256) {
+			l.active[j] = (j < p && vec[3 * P16 + j] != 0.0) ? 1 : 0;
+			l.sv[j] = j < p ? vec[0 * P16 + j] : 0.0;
+			l.fx[j] = j < p ? vec[2 * P16 + j] : 0.0;
+			mine += (j < p && !isnan(core[j])) ? 1.0 : 0.0;
+		}
+		const int rank = (int)block_sum(mine, l.red + 12, tid);
+		if (rank == 0) continue; // intercept-only fit: inference is None (ols.rs:101-130)
+
+		load_moment_matrix(l, rec, p, icpt, 0.0, sw, sy, tid);
+		__syncthreads();
+		for (int j = tid; j < P16; j += 256) l.diag0[j] = j < p ? A[(size_t)j * LD + j] : 1.0;
+		(void)blocked_cholesky(l, tid);
+		blocked_tri_inverse(l, tid);
+		// S^-1 = W'W: entry (i, j), i >= j, = sum_{k >= i} W[k][i] W[k][j]; W[k][i] (k > i) sits at A[i][k], so
+		// these are dot products of row tails of the upper triangle; the results go to the (dead) lower triangle
+		for (int idx = tid; idx < P16 * (P16 + 1) / 2; idx += 256) {
+			int i, j;
+			tri_decode(idx, i, j);
+			double acc = (i == j) ? l.linv[i] * l.linv[i] : l.linv[i] * A[(size_t)j * LD + i];
+			for (int k = i + 1; k < P16; ++k) acc = fma(A[(size_t)i * LD + k], A[(size_t)j * LD + k], acc);
+			A[(size_t)i * LD + j] = acc;
+		}
+		__syncthreads();
+		for (int idx = tid; idx < P16 * P16; idx += 256) { // mirror into the upper triangle
+			const int i = idx / P16, j = idx - i * P16;
+			if (i > j) A[(size_t)j * LD + i] = A[(size_t)i * LD + j];
+		}
+		// coefficients (0 at dropped columns) and column means
+		double yc = 0.0;
+		for (int j = tid; j < P16; j += 256) {
+			const double bj = (j < p && l.live[j]) ? core[j] : 0.0;
+			const double xb = (icpt && j < p) ? l.fx[j] + l.sv[j] / sw : 0.0;
+			l.zv[j] = bj;
+			l.bv[j] = xb;
+			yc = fma(bj, xb, yc);
+		}
+		const double ycen = (icpt ? core[p] : 0.0) + block_sum(yc, l.red + 12, tid); // fitted value at x = xbar
+		const double df = cnt - (double)(rank + (icpt ? 1 : 0));
+		const double hc1 = cnt / df;
+		const double h0 = icpt ? 1.0 / sw : 0.0;
+
+		const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+		// next chunk, prefetched from global memory: raw loads only, issued back to back (the centring and the
+		// marking of rows past the end happen when the values are written to LDS)
+		double pre[kWideMaxP / 16], pre_y = 0.0, pre_w = 1.0;
+		bool pre_in = false;
+		auto prefetch = [&](int64_t base) {
+			pre_in = base + srow < hi;
+			const int64_t r = pre_in ? base + srow : hi - 1; // clamped: loads stay unconditional
+#pragma unroll
+			for (int m = 0; m < kWideMaxP / 16; ++m)
+				if (m < T) pre[m] = colp[m][r];
+			if (tid < 16) {
+				pre_y = ((hc_gptr_t)(uintptr_t)args.y)[r];
+				pre_w = weighted ? ((hc_gptr_t)(uintptr_t)args.w)[r] : 1.0;
+			}
+		};
+		double vacc[2] = {0.0, 0.0};
+		__syncthreads(); // bv / zv / S^-1 visible
+		double bcol[2];
+#pragma unroll
+		for (int t = 0; t < 2; ++t) bcol[t] = t < ntile ? l.zv[16 * (wave + 4 * t) + lj] : 0.0;
+		double xb[kWideMaxP / 16]; // column means of this thread's staging columns
+#pragma unroll
+		for (int m = 0; m < kWideMaxP / 16; ++m) xb[m] = (m < T) ? l.bv[scol + 16 * m] : 0.0;
+		if (lo < hi) prefetch(lo);
+		for (int64_t base = lo; base < hi; base += 16) {
+			__syncthreads(); // the previous chunk (cs, hpart, epart) has been consumed
+#pragma unroll
+			for (int m = 0; m < kWideMaxP / 16; ++m) {
+				if (m < T) { // padding columns are zero, rows past the end are marked invalid
+					const double v = (scol + 16 * m < p) ? pre[m] - xb[m] : 0.0;
+					cs[(scol + 16 * m) * 16 + srow] = pre_in ? v : nan64w(); // = cs[tid + 256 m]
+				}
+			}
+			if (tid < 16) {
+				yv_s[tid] = pre_y;
+				wv_s[tid] = pre_w;
+			}
+			__syncthreads();
+			if (base + 16 < hi) prefetch(base + 16);
+			// U = C S^-1: lane (kk, lj) supplies C[row lj][k0 + kk] and S^-1[k0 + kk][16 J + lj]; afterwards it holds
+			// U[row kk + 4 i][16 J + lj], i = 0..3
+			hc_dbl4 U[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+			const double *srow0 = A + (size_t)kk * LD + 16 * wave + lj;
+			if (ntile == 2) {
+				for (int k0 = 0; k0 < P16; k0 += 4) {
+					const double a = cs[k0 * 16 + lane];
+					const double b0 = srow0[(size_t)k0 * LD], b1 = srow0[(size_t)k0 * LD + 64];
+					U[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, U[0], 0, 0, 0);
+					U[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, U[1], 0, 0, 0);
+				}
+			} else if (ntile == 1) {
+				for (int k0 = 0; k0 < P16; k0 += 4) {
+					const double a = cs[k0 * 16 + lane];
+					const double b0 = srow0[(size_t)k0 * LD];
+					U[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, U[0], 0, 0, 0);
+				}
+			}
+			double hp[4] = {0.0, 0.0, 0.0, 0.0}, ep[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int t = 0; t < 2; ++t) {
+				if (t < ntile) {
+					const double *ccol = cs + (16 * (wave + 4 * t) + lj) * 16 + kk;
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						const double c = ccol[4 * i];
+						hp[i] = fma(c, U[t][i], hp[i]);
+						ep[i] = fma(bcol[t], c, ep[i]);
+					}
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				for (int m = 8; m >= 1; m >>= 1) { // the 16 lanes that share the rows kk + 4 i
+					hp[i] += __shfl_xor(hp[i], m, 64);
+					ep[i] += __shfl_xor(ep[i], m, 64);
+				}
+			}
+			if (lj == 0) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					hpart[wave * 16 + kk + 4 * i] = hp[i];
+					epart[wave * 16 + kk + 4 * i] = ep[i];
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const int r = kk + 4 * i;
+				const double hs = hpart[r] + hpart[16 + r] + hpart[32 + r] + hpart[48 + r];
+				const double es = epart[r] + epart[16 + r] + epart[32 + r] + epart[48 + r];
+				const double yv = yv_s[r], wv = wv_s[r];
+				const double e = yv - ycen - es;
+				const double lev = wv * (h0 + hs);
+				double om = wv * wv * e * e; // w_i e_i^2 of the scaled residual, times the w_i of the scaled row
+				if (hc == ANOFOX_HC_HC1) om *= hc1;
+				else if (hc == ANOFOX_HC_HC2) om /= (1.0 - lev);
+				else if (hc == ANOFOX_HC_HC3) om /= (1.0 - lev) * (1.0 - lev);
+				// rows outside the fit (past the end, non-finite x / y, w <= 0) carry NaN / inf through e or lev
+				const bool ok = isfinite(e) && isfinite(lev) && (!weighted || ((wv > 0.0) && isfinite(wv)));
+				om = ok ? om : 0.0;
+#pragma unroll
+				for (int t = 0; t < 2; ++t) {
+					const double uu = ok ? U[t][i] : 0.0;
+					vacc[t] = fma(om, uu * uu, vacc[t]);
+				}
+			}
+		}
+		__syncthreads(); // cs is dead: reuse as vout
+#pragma unroll
+		for (int t = 0; t < 2; ++t) {
+			vacc[t] += __shfl_xor(vacc[t], 16, 64);
+			vacc[t] += __shfl_xor(vacc[t], 32, 64); // the four row groups of a wavefront
+			if (t < ntile && lane < 16) vout[16 * (wave + 4 * t) + lj] = vacc[t];
+		}
+		if (tid == 0) l.red[8] = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
+		__syncthreads();
+		const double tcrit = l.red[8];
+		for (int j = tid; j < p; j += 256) {
+			if (!l.live[j]) continue;
+			const double v = vout[j];
+			const double b = l.zv[j];
+			const double se = sqrt(v);
+			const double tval = b / se;
+			inf[j] = se;
+			inf[p + j] = tval;
+			inf[2 * p + j] = dm_t_two_sided_p(tval, df);
+			inf[3 * p + j] = b - tcrit * se;
+			inf[4 * p + j] = b + tcrit * se;
+		}
+	}
+}
+
+size_t hc_wide_lds_bytes(int p) {
+	const int P16 = 16 * wide_tiles(p);
+	return solve_wide_lds_bytes(p) + (size_t)(16 * P16 + 32 + 128) * sizeof(double);
 }
 
 } // namespace
@@ -731,6 +970,20 @@ extern "C" __attribute__((visibility("default"))) int anofox_hip_diag_solve_stam
 	return (int)hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_solve_stamps), 32 * sizeof(unsigned long long));
 }
 #endif
+
+hipError_t launch_hc_wide(const WideArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0 || !a.inference) return hipSuccess;
+	const size_t lds = hc_wide_lds_bytes(a.p);
+	if (lds > 160 * 1024) return hipErrorInvalidValue;
+	static bool attr_set = false;
+	if (!attr_set) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		attr_set = true;
+	}
+	const unsigned grid = (unsigned)(a.n_groups < 65535 * 16 ? a.n_groups : 65535 * 16);
+	hipLaunchKernelGGL(hc_wide_kernel, dim3(grid), dim3(256), lds, stream, a);
+	return hipGetLastError();
+}
 
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;

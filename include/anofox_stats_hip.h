@@ -240,7 +240,7 @@ typedef struct {
 	double alpha; /* ridge only; < 0 -> every group fails with ANOFOX_ERROR_INVALID_ALPHA */
 	AnofoxSolverType solver;
 	AnofoxLambdaScaling lambda_scaling;
-	AnofoxHcType hc_type; /* HC0..HC3 replace se/t/p/ci (OLS, WLS; n_features <= 8); ignored for ridge and without inference */
+	AnofoxHcType hc_type; /* HC0..HC3 replace se/t/p/ci (OLS, WLS); ignored for ridge and without inference */
 } AnofoxHipBatchOptions;
 
 /* Per-group status word stored in the core record: an AnofoxErrorCode, or this value for groups the

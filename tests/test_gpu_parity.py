@@ -348,6 +348,28 @@ def test_hc_standard_errors_match_oracle(pkg, ctx, model, hc):
         assert not np.allclose(inf[:, :p], inf_classical[:, :p], equal_nan=True)
 
 
+@pytest.mark.parametrize("hc", ["hc0", "hc1", "hc2", "hc3"])
+@pytest.mark.parametrize("model", ["ols", "wls"])
+def test_hc_standard_errors_wide_match_oracle(pkg, ctx, model, hc):
+    for p, icpt in ((9, True), (20, False), (33, True), (128, True)):
+        rng = np.random.default_rng(77 * p + len(hc) + ord(hc[2]) + (5 if icpt else 0))
+        G = 6 if p == 128 else 12
+        offs, y, x_cols, w = _random_groups(rng, G, p, p + 6, 3 * p + 60)
+        y = y + np.abs(x_cols[0]) * rng.standard_normal(len(y))
+        y[offs[1]:offs[2]:9] = np.nan                                   # invalid rows inside a group
+        x_cols[1][offs[2]:offs[3]] = 2.5                                # constant column -> NaN slot
+        x_cols[2][offs[3]:offs[4]] = 3.0 * x_cols[0][offs[3]:offs[4]] - 1.0   # aliased column
+        kw = dict(fit_intercept=icpt, compute_inference=True, confidence_level=0.9, hc_type=hc)
+        wv = w if model == "wls" else None
+        core, inf = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+        rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
+        assert_records_match(core, rcore, p, inf, rinf, what=f"{hc} {model} p={p} icpt={icpt}")
+        kw["hc_type"] = "none"
+        _, inf_classical = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+        assert np.array_equal(inf[:, 5 * p:], inf_classical[:, 5 * p:], equal_nan=True)   # F, F p-value
+        assert not np.allclose(inf[:, :p], inf_classical[:, :p], equal_nan=True)
+
+
 def test_hc_is_ignored_where_the_reference_ignores_it(pkg, ctx):
     rng = np.random.default_rng(8)
     offs, y, x_cols, w = _random_groups(rng, 16, 3, 10, 50)
@@ -360,9 +382,6 @@ def test_hc_is_ignored_where_the_reference_ignores_it(pkg, ctx):
     r = pkg.ols_fit(y[:40], [c[:40] for c in x_cols], {"compute_inference": True, "hc_type": "hc1"})
     code, d = oracle.fit(y[:40], [c[:40] for c in x_cols], compute_inference=True, hc_type="hc1")
     assert code == 0 and np.allclose(r["std_errors"], d["std_errors"], rtol=1e-8)
-    wide = [rng.standard_normal(len(y)) for _ in range(9)]
-    with pytest.raises(Exception, match="n_features <= 8"):
-        _host_fit(pkg, ctx, "ols", offs, y, wide, compute_inference=True, hc_type="hc1")
 
 
 def test_alpha_negative_and_bad_arguments(pkg, ctx):
