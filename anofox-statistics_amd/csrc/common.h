@@ -110,6 +110,7 @@ struct WideArgs {
 	double *refine_vec;   // [G_total * (p+2)]
 	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
 	const int64_t *rule_counts; // optional [G_total], see BatchArgs
+	double *hc_df;        // [n_groups of this launch] scratch of launch_hc_wide: residual df, NaN = group skipped
 };
 
 // per-row predictions (predict.hip), any p <= kWideMaxP

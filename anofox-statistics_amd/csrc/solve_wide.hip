@@ -709,14 +709,115 @@ size_t solve_wide_lds_bytes(int p) {
 // Heteroscedasticity-consistent standard errors for wide designs (same estimator and references as
 // hc_narrow.hip).  One workgroup per group: the centred moment matrix is factored again exactly as in the solve
 // (same inputs, same code => same active set), W = L^-1 is expanded to the full symmetric S^-1 = W'W in LDS, and
-// the rows stream through in chunks of 16: c = x - xbar staged in LDS (transposed, [feature][row]), the chunk's
-// U = C S^-1 (16 x p) on the FP64 matrix cores — v_mfma_f64_16x16x4_f64, A fragment = 16 rows x 4 features of C,
-// B fragment = 4 x 16 block of S^-1, both one ds_read_b64 per lane; wave w owns the column blocks w, w + 4 —
-// then h = w (1/sum(w) + c'u), V_jj += omega u_j^2 from the accumulator registers.  The pass costs n p^2 FMAs
-// per group, twice the flops of the accumulate kernel.
+// the rows stream through in chunks of 16, one chunk per wavefront at a time (hc_rows): U = C S^-1 (16 x p) on
+// the FP64 matrix cores — v_mfma_f64_16x16x4_f64, A fragment = 16 rows x 4 features of the centred chunk
+// (loaded from global memory in fragment layout, one chunk ahead), B fragment = 4 x 16 block of S^-1 (one
+// ds_read_b64 per lane) — then h = w (1/sum(w) + c'u), V_jj += omega u_j^2 from the accumulator registers.
+// No barrier inside the row pass.  It costs n p^2 FMAs per group, twice the flops of the accumulate kernel.
 typedef const double __attribute__((address_space(1))) *hc_gptr_t;
 
 typedef double hc_dbl4 __attribute__((ext_vector_type(4)));
+
+// Row pass of hc_wide_kernel for one wavefront: chunks of 16 rows, chunk c of the group goes to wave c mod 4.
+// Everything of a chunk stays inside the wave (no barriers): the A fragments of U = C S^-1 are loaded straight
+// from global memory in fragment layout (lane (kk, lj): row lj, feature 4 ks + kk), one chunk ahead; S^-1 comes
+// from LDS; the same rows are read a second time in accumulator layout (row kk + 4 i, feature 16 J + lj, L1 / L2
+// hits) for the row sums c'u and b'c, which are then 16-lane reductions.  vacc[J] = this lane's share of V for
+// column 16 J + lj.
+template <int TT>
+__device__ __forceinline__ void hc_rows(const WideArgs &args, const WideLds &l, const unsigned long long *colptr, int64_t lo,
+                                        int64_t hi, int wave, int kk, int lj, int p, bool weighted, int hc, double ycen, double h0,
+                                        double hc1, double (&vacc)[kWideMaxP / 16]) {
+	constexpr int KS = 4 * TT; // k-steps of 4 features
+	const int LD = l.LD;
+	const double *A = l.A;
+	const hc_gptr_t yp = (hc_gptr_t)(uintptr_t)args.y;
+	const hc_gptr_t wp = (hc_gptr_t)(uintptr_t)args.w;
+	double bD[TT], xbD[TT];
+	hc_gptr_t colD[TT];
+#pragma unroll
+	for (int J = 0; J < TT; ++J) {
+		bD[J] = l.zv[16 * J + lj];
+		xbD[J] = l.bv[16 * J + lj];
+		colD[J] = (hc_gptr_t)colptr[16 * J + lj];
+	}
+	const int64_t first = lo + 16 * (int64_t)wave;
+	for (int64_t R0 = first; R0 < hi; R0 += 64) {
+		const bool a_in = R0 + lj < hi;
+		const int64_t ra = a_in ? R0 + lj : hi - 1; // clamped: loads stay unconditional
+		// the rows in accumulator layout, plus y and w of rows kk + 4 i (consumed after the products)
+		double cD[TT][4], yv[4], wv[4];
+		bool rin[4];
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			rin[i] = R0 + kk + 4 * i < hi;
+			const int64_t r = rin[i] ? R0 + kk + 4 * i : hi - 1;
+#pragma unroll
+			for (int J = 0; J < TT; ++J) cD[J][i] = colD[J][r];
+			yv[i] = yp[r];
+			wv[i] = weighted ? wp[r] : 1.0;
+		}
+		hc_dbl4 U[TT];
+#pragma unroll
+		for (int J = 0; J < TT; ++J) U[J] = hc_dbl4{0.0, 0.0, 0.0, 0.0};
+		// A fragments four k-steps ahead of their use (a rolled loop keeps the live set small)
+		double an[4];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) an[q] = ((hc_gptr_t)colptr[4 * q + kk])[ra];
+#pragma unroll 1
+		for (int k4 = 0; k4 < KS; k4 += 4) {
+			double ac[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q) { // centred, padding features zero, rows past the end marked invalid (NaN)
+				const int j = 4 * (k4 + q) + kk;
+				const double v = j < p ? an[q] - l.bv[j] : 0.0;
+				ac[q] = a_in ? v : nan64w();
+			}
+			if (k4 + 4 < KS) {
+#pragma unroll
+				for (int q = 0; q < 4; ++q) an[q] = ((hc_gptr_t)colptr[4 * (k4 + 4 + q) + kk])[ra];
+			}
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const double *srow = A + (size_t)(4 * (k4 + q) + kk) * LD + lj;
+#pragma unroll
+				for (int J = 0; J < TT; ++J) U[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[q], srow[16 * J], U[J], 0, 0, 0);
+			}
+		}
+		double hp[4] = {0.0, 0.0, 0.0, 0.0}, ep[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+		for (int J = 0; J < TT; ++J) {
+			const bool real = 16 * J + lj < p;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const double c = real ? cD[J][i] - xbD[J] : 0.0;
+				hp[i] = fma(c, U[J][i], hp[i]);
+				ep[i] = fma(bD[J], c, ep[i]);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			for (int m = 8; m >= 1; m >>= 1) { // the 16 lanes that share the rows kk + 4 i
+				hp[i] += __shfl_xor(hp[i], m, 64);
+				ep[i] += __shfl_xor(ep[i], m, 64);
+			}
+			const double e = yv[i] - ycen - ep[i];
+			const double lev = wv[i] * (h0 + hp[i]);
+			double om = wv[i] * wv[i] * e * e; // w_i e_i^2 of the scaled residual, times the w_i of the scaled row
+			if (hc == ANOFOX_HC_HC1) om *= hc1;
+			else if (hc == ANOFOX_HC_HC2) om /= (1.0 - lev);
+			else if (hc == ANOFOX_HC_HC3) om /= (1.0 - lev) * (1.0 - lev);
+			// rows outside the fit (non-finite x / y, w <= 0) carry NaN / inf through e or lev
+			const bool ok = rin[i] && isfinite(e) && isfinite(lev) && (!weighted || ((wv[i] > 0.0) && isfinite(wv[i])));
+			om = ok ? om : 0.0;
+#pragma unroll
+			for (int J = 0; J < TT; ++J) {
+				const double uu = ok ? U[J][i] : 0.0;
+				vacc[J] = fma(om, uu * uu, vacc[J]);
+			}
+		}
+	}
+}
 
 __global__ __launch_bounds__(256) void hc_wide_kernel(WideArgs args) {
 	extern __shared__ double sm[];
@@ -729,24 +830,12 @@ __global__ __launch_bounds__(256) void hc_wide_kernel(WideArgs args) {
 	const int T = l.T, P16 = l.P16, LD = l.LD;
 	const int NT = T * (T + 1) / 2;
 	double *A = l.A;
-	double *cs = reinterpret_cast<double *>(l.live + P16); // [P16][16]: centred chunk, feature-major
-	double *yv_s = cs + 16 * P16;                          // [16]
-	double *wv_s = yv_s + 16;                              // [16]
-	double *hpart = wv_s + 16;                             // [4][16] per-wave partial c'u of the chunk's rows
-	double *epart = hpart + 64;                            // [4][16] per-wave partial b'c
-	double *vout = cs;                                     // [P16] after the row loop
+	unsigned long long *colptr = reinterpret_cast<unsigned long long *>(l.live + P16); // [P16] feature column addresses
+	double *vsum = reinterpret_cast<double *>(colptr + P16);                             // [4][P16] per-wave V
 
 	const int lane = tid & 63, wave = tid >> 6;
 	const int kk = lane >> 4, lj = lane & 15; // MFMA fragment coordinates of this lane
-	const int ntile = (T - wave + 3) / 4;     // column blocks wave, wave + 4 (T <= 8: at most two)
-	// staging slot of this thread: row (tid & 15) of the chunk, columns (tid >> 4) + 16 m
-	const int srow = tid & 15, scol = tid >> 4;
-	hc_gptr_t colp[kWideMaxP / 16];
-#pragma unroll
-	for (int m = 0; m < kWideMaxP / 16; ++m) {
-		const int j = scol + 16 * m;
-		colp[m] = (hc_gptr_t)(uintptr_t)args.x_table[j < p ? j : p - 1];
-	}
+	for (int j = tid; j < P16; j += 256) colptr[j] = (unsigned long long)(uintptr_t)args.x_table[j < p ? j : p - 1];
 
 	for (int64_t gl = blockIdx.x; gl < args.n_groups; gl += gridDim.x) {
 		const int64_t g = args.group_base + gl;
@@ -756,6 +845,7 @@ __global__ __launch_bounds__(256) void hc_wide_kernel(WideArgs args) {
 		const double *core = args.core + g * (int64_t)(p + 6);
 		double *inf = args.inference + g * (int64_t)(5 * p + 2);
 		__syncthreads(); // the previous group's LDS contents are dead
+		if (tid == 0) args.hc_df[gl] = nan64w(); // overwritten below when HC errors are produced
 		if (core[p + 5] != 0.0) continue; // NULL group: the inference record is already NaN
 		const double sy = sc[0], sw = sc[2], cnt = sc[3];
 		double mine = 0.0;
@@ -802,141 +892,62 @@ __global__ __launch_bounds__(256) void hc_wide_kernel(WideArgs args) {
 		const double h0 = icpt ? 1.0 / sw : 0.0;
 
 		const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
-		// next chunk, prefetched from global memory: raw loads only, issued back to back (the centring and the
-		// marking of rows past the end happen when the values are written to LDS)
-		double pre[kWideMaxP / 16], pre_y = 0.0, pre_w = 1.0;
-		bool pre_in = false;
-		auto prefetch = [&](int64_t base) {
-			pre_in = base + srow < hi;
-			const int64_t r = pre_in ? base + srow : hi - 1; // clamped: loads stay unconditional
+		__syncthreads(); // bv / zv / S^-1 / colptr visible
+		double vacc[kWideMaxP / 16];
 #pragma unroll
-			for (int m = 0; m < kWideMaxP / 16; ++m)
-				if (m < T) pre[m] = colp[m][r];
-			if (tid < 16) {
-				pre_y = ((hc_gptr_t)(uintptr_t)args.y)[r];
-				pre_w = weighted ? ((hc_gptr_t)(uintptr_t)args.w)[r] : 1.0;
-			}
-		};
-		double vacc[2] = {0.0, 0.0};
-		__syncthreads(); // bv / zv / S^-1 visible
-		double bcol[2];
-#pragma unroll
-		for (int t = 0; t < 2; ++t) bcol[t] = t < ntile ? l.zv[16 * (wave + 4 * t) + lj] : 0.0;
-		double xb[kWideMaxP / 16]; // column means of this thread's staging columns
-#pragma unroll
-		for (int m = 0; m < kWideMaxP / 16; ++m) xb[m] = (m < T) ? l.bv[scol + 16 * m] : 0.0;
-		if (lo < hi) prefetch(lo);
-		for (int64_t base = lo; base < hi; base += 16) {
-			__syncthreads(); // the previous chunk (cs, hpart, epart) has been consumed
-#pragma unroll
-			for (int m = 0; m < kWideMaxP / 16; ++m) {
-				if (m < T) { // padding columns are zero, rows past the end are marked invalid
-					const double v = (scol + 16 * m < p) ? pre[m] - xb[m] : 0.0;
-					cs[(scol + 16 * m) * 16 + srow] = pre_in ? v : nan64w(); // = cs[tid + 256 m]
-				}
-			}
-			if (tid < 16) {
-				yv_s[tid] = pre_y;
-				wv_s[tid] = pre_w;
-			}
-			__syncthreads();
-			if (base + 16 < hi) prefetch(base + 16);
-			// U = C S^-1: lane (kk, lj) supplies C[row lj][k0 + kk] and S^-1[k0 + kk][16 J + lj]; afterwards it holds
-			// U[row kk + 4 i][16 J + lj], i = 0..3
-			hc_dbl4 U[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-			const double *srow0 = A + (size_t)kk * LD + 16 * wave + lj;
-			if (ntile == 2) {
-				for (int k0 = 0; k0 < P16; k0 += 4) {
-					const double a = cs[k0 * 16 + lane];
-					const double b0 = srow0[(size_t)k0 * LD], b1 = srow0[(size_t)k0 * LD + 64];
-					U[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, U[0], 0, 0, 0);
-					U[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, U[1], 0, 0, 0);
-				}
-			} else if (ntile == 1) {
-				for (int k0 = 0; k0 < P16; k0 += 4) {
-					const double a = cs[k0 * 16 + lane];
-					const double b0 = srow0[(size_t)k0 * LD];
-					U[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, U[0], 0, 0, 0);
-				}
-			}
-			double hp[4] = {0.0, 0.0, 0.0, 0.0}, ep[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-			for (int t = 0; t < 2; ++t) {
-				if (t < ntile) {
-					const double *ccol = cs + (16 * (wave + 4 * t) + lj) * 16 + kk;
-#pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						const double c = ccol[4 * i];
-						hp[i] = fma(c, U[t][i], hp[i]);
-						ep[i] = fma(bcol[t], c, ep[i]);
-					}
-				}
-			}
-#pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				for (int m = 8; m >= 1; m >>= 1) { // the 16 lanes that share the rows kk + 4 i
-					hp[i] += __shfl_xor(hp[i], m, 64);
-					ep[i] += __shfl_xor(ep[i], m, 64);
-				}
-			}
-			if (lj == 0) {
-#pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					hpart[wave * 16 + kk + 4 * i] = hp[i];
-					epart[wave * 16 + kk + 4 * i] = ep[i];
-				}
-			}
-			__syncthreads();
-#pragma unroll
-			for (int i = 0; i < 4; ++i) {
-				const int r = kk + 4 * i;
-				const double hs = hpart[r] + hpart[16 + r] + hpart[32 + r] + hpart[48 + r];
-				const double es = epart[r] + epart[16 + r] + epart[32 + r] + epart[48 + r];
-				const double yv = yv_s[r], wv = wv_s[r];
-				const double e = yv - ycen - es;
-				const double lev = wv * (h0 + hs);
-				double om = wv * wv * e * e; // w_i e_i^2 of the scaled residual, times the w_i of the scaled row
-				if (hc == ANOFOX_HC_HC1) om *= hc1;
-				else if (hc == ANOFOX_HC_HC2) om /= (1.0 - lev);
-				else if (hc == ANOFOX_HC_HC3) om /= (1.0 - lev) * (1.0 - lev);
-				// rows outside the fit (past the end, non-finite x / y, w <= 0) carry NaN / inf through e or lev
-				const bool ok = isfinite(e) && isfinite(lev) && (!weighted || ((wv > 0.0) && isfinite(wv)));
-				om = ok ? om : 0.0;
-#pragma unroll
-				for (int t = 0; t < 2; ++t) {
-					const double uu = ok ? U[t][i] : 0.0;
-					vacc[t] = fma(om, uu * uu, vacc[t]);
-				}
-			}
+		for (int J = 0; J < kWideMaxP / 16; ++J) vacc[J] = 0.0;
+		switch (T) {
+		case 1: hc_rows<1>(args, l, colptr, lo, hi, wave, kk, lj, p, weighted, hc, ycen, h0, hc1, vacc); break;
+		case 2: hc_rows<2>(args, l, colptr, lo, hi, wave, kk, lj, p, weighted, hc, ycen, h0, hc1, vacc); break;
+		case 3: hc_rows<3>(args, l, colptr, lo, hi, wave, kk, lj, p, weighted, hc, ycen, h0, hc1, vacc); break;
+		case 4: hc_rows<4>(args, l, colptr, lo, hi, wave, kk, lj, p, weighted, hc, ycen, h0, hc1, vacc); break;
+		case 5: hc_rows<5>(args, l, colptr, lo, hi, wave, kk, lj, p, weighted, hc, ycen, h0, hc1, vacc); break;
+		case 6: hc_rows<6>(args, l, colptr, lo, hi, wave, kk, lj, p, weighted, hc, ycen, h0, hc1, vacc); break;
+		case 7: hc_rows<7>(args, l, colptr, lo, hi, wave, kk, lj, p, weighted, hc, ycen, h0, hc1, vacc); break;
+		default: hc_rows<8>(args, l, colptr, lo, hi, wave, kk, lj, p, weighted, hc, ycen, h0, hc1, vacc); break;
 		}
-		__syncthreads(); // cs is dead: reuse as vout
 #pragma unroll
-		for (int t = 0; t < 2; ++t) {
-			vacc[t] += __shfl_xor(vacc[t], 16, 64);
-			vacc[t] += __shfl_xor(vacc[t], 32, 64); // the four row groups of a wavefront
-			if (t < ntile && lane < 16) vout[16 * (wave + 4 * t) + lj] = vacc[t];
+		for (int J = 0; J < kWideMaxP / 16; ++J) {
+			vacc[J] += __shfl_xor(vacc[J], 16, 64);
+			vacc[J] += __shfl_xor(vacc[J], 32, 64); // the four row groups of a wavefront
+			if (J < T && lane < 16) vsum[wave * P16 + 16 * J + lj] = vacc[J];
 		}
-		if (tid == 0) l.red[8] = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
 		__syncthreads();
-		const double tcrit = l.red[8];
+		// standard errors only; t, p and the interval follow in hc_wide_finish_kernel (the special functions are
+		// out-of-line calls and would cap this kernel's register budget)
 		for (int j = tid; j < p; j += 256) {
 			if (!l.live[j]) continue;
-			const double v = vout[j];
-			const double b = l.zv[j];
-			const double se = sqrt(v);
-			const double tval = b / se;
-			inf[j] = se;
-			inf[p + j] = tval;
-			inf[2 * p + j] = dm_t_two_sided_p(tval, df);
-			inf[3 * p + j] = b - tcrit * se;
-			inf[4 * p + j] = b + tcrit * se;
+			inf[j] = sqrt(vsum[j] + vsum[P16 + j] + vsum[2 * P16 + j] + vsum[3 * P16 + j]);
 		}
+		if (tid == 0) args.hc_df[gl] = df;
 	}
+}
+
+// one thread per (group, coefficient): t, p-value and interval from the HC standard error
+__global__ __launch_bounds__(256) void hc_wide_finish_kernel(WideArgs args) {
+	const int p = args.p;
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= args.n_groups * (int64_t)p) return;
+	const int64_t gl = e / p;
+	const int j = (int)(e - gl * p);
+	const double df = args.hc_df[gl];
+	if (isnan(df)) return; // no HC errors were computed for this group
+	const int64_t g = args.group_base + gl;
+	double *inf = args.inference + g * (int64_t)(5 * p + 2);
+	const double b = args.core[g * (int64_t)(p + 6) + j];
+	if (isnan(b)) return; // dropped / aliased column
+	const double se = inf[j];
+	const double tcrit = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
+	const double tval = b / se;
+	inf[p + j] = tval;
+	inf[2 * p + j] = dm_t_two_sided_p(tval, df);
+	inf[3 * p + j] = b - tcrit * se;
+	inf[4 * p + j] = b + tcrit * se;
 }
 
 size_t hc_wide_lds_bytes(int p) {
 	const int P16 = 16 * wide_tiles(p);
-	return solve_wide_lds_bytes(p) + (size_t)(16 * P16 + 32 + 128) * sizeof(double);
+	return solve_wide_lds_bytes(p) + (size_t)(5 * P16) * sizeof(double);
 }
 
 } // namespace
@@ -973,6 +984,7 @@ extern "C" __attribute__((visibility("default"))) int anofox_hip_diag_solve_stam
 
 hipError_t launch_hc_wide(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0 || !a.inference) return hipSuccess;
+	if (!a.hc_df) return hipErrorInvalidValue;
 	const size_t lds = hc_wide_lds_bytes(a.p);
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
 	static bool attr_set = false;
@@ -982,6 +994,8 @@ hipError_t launch_hc_wide(const WideArgs &a, hipStream_t stream) {
 	}
 	const unsigned grid = (unsigned)(a.n_groups < 65535 * 16 ? a.n_groups : 65535 * 16);
 	hipLaunchKernelGGL(hc_wide_kernel, dim3(grid), dim3(256), lds, stream, a);
+	const int64_t elems = a.n_groups * (int64_t)a.p;
+	hipLaunchKernelGGL(hc_wide_finish_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 
