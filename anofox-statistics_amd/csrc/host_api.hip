@@ -166,6 +166,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.rule_counts = d_rule_counts;
 
 	hipStream_t st = ctx->stream;
+	const bool mid = solve_mid_supports((int)p);
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
 	for (int64_t g0 = 0; g0 < G; g0 += slab) {
 		a.group_base = g0;
@@ -180,13 +181,15 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		}
 		if (hip_fail(launch_accumulate_wide(a, st), "wide accumulate kernel launch", e)) return false;
 		if (ctx->timing) (void)hipEventRecord(e1, st);
-		if (hip_fail(launch_solve_wide(a, 0, st), "wide solve kernel launch", e)) return false;
+		// moderately wide designs: one lane per group (solve_mid.hip); beyond that one workgroup per group
+		auto solve = [&](int mode) { return mid ? launch_solve_mid(a, mode, st) : launch_solve_wide(a, mode, st); };
+		if (hip_fail(solve(0), "wide solve kernel launch", e)) return false;
 		for (int it = 0; it < kRefineSteps; ++it) { // queued groups only: b += (X'WX)^-1 X'Wr
 			if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
-			if (hip_fail(launch_solve_wide(a, 1, st), "wide refine kernel launch", e)) return false;
+			if (hip_fail(solve(1), "wide refine kernel launch", e)) return false;
 		}
 		if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
-		if (hip_fail(launch_solve_wide(a, 2, st), "wide final kernel launch", e)) return false;
+		if (hip_fail(solve(2), "wide final kernel launch", e)) return false;
 		if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE) {
 			if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, (size_t)slab * sizeof(double), "hc scratch", e)) return false;
 			a.hc_df = (double *)ctx->aux;
