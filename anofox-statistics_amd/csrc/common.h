@@ -153,6 +153,9 @@ hipError_t launch_window_predict(const WindowArgs &a, hipStream_t stream);
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);
+// accumulate_mid.hip: wave-per-group accumulation into the same records for 8 < p <= 32
+bool accumulate_mid_supports(int p);
+hipError_t launch_accumulate_mid(const WideArgs &a, hipStream_t stream);
 // solve_mid.hip: lane-per-group solve on the same records for 8 < p <= 32 (same modes as launch_solve_wide)
 bool solve_mid_supports(int p);
 hipError_t launch_solve_mid(const WideArgs &a, int mode, hipStream_t stream);

@@ -167,6 +167,8 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 
 	hipStream_t st = ctx->stream;
 	const bool mid = solve_mid_supports((int)p);
+	static const bool mid_acc_on = !(getenv("ANOFOX_MID_ACC") && atoi(getenv("ANOFOX_MID_ACC")) == 0); // A/B switch for measurements
+	const bool mid_acc = mid_acc_on && accumulate_mid_supports((int)p);
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
 	for (int64_t g0 = 0; g0 < G; g0 += slab) {
 		a.group_base = g0;
@@ -179,7 +181,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 			e2 = get_event(ctx);
 			(void)hipEventRecord(e0, st);
 		}
-		if (hip_fail(launch_accumulate_wide(a, st), "wide accumulate kernel launch", e)) return false;
+		if (hip_fail(mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st), "wide accumulate kernel launch", e)) return false;
 		if (ctx->timing) (void)hipEventRecord(e1, st);
 		// moderately wide designs: one lane per group (solve_mid.hip); beyond that one workgroup per group
 		auto solve = [&](int mode) { return mid ? launch_solve_mid(a, mode, st) : launch_solve_wide(a, mode, st); };
