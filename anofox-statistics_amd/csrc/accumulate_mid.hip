@@ -7,12 +7,13 @@
 // through LDS behind a barrier per chunk; with one or two column blocks that overhead, not HBM or the matrix
 // pipe, set the pace (1.7-2.8 TB/s at p = 9..32).  Here a wave owns its group and nothing is shared:
 //   * a step is 16 rows; lane (kk, lj) loads rows 4 kk .. 4 kk + 3 of column 16 I + lj straight into MFMA
-//     fragment layout (two 16-byte loads per column block, the 16 lanes of a column cover one 128-byte line),
-//     one step ahead of its use;
+//     fragment layout (two 16-byte loads per column block, the 16 lanes of a column cover one 128-byte line);
+//     a loop trip is 2 or 4 steps and the next trip's loads are in flight while this one computes;
 //   * K-step m of the MFMA takes the lanes' m-th row: A[i = lj][k = kk] = w d[4 kk + m][16 I + lj],
 //     B[k = kk][j = lj] = d[4 kk + m][16 J + lj]  (which rows share a K-step is irrelevant to the sum);
-//   * row validity = 4 ballots per step (the 16 lanes of a kk group hold the 16 columns of a block), invalid
-//     rows are removed with bit masks, so a step is branch-free;
+//   * row validity: one ballot says whether all 16 rows of a step pass (then the step runs without masks);
+//     otherwise 4 ballots give the row mask (the 16 lanes of a kk group hold the 16 columns of a block) and
+//     invalid rows are removed with bit masks;
 //   * four groups per 256-thread workgroup, no LDS, no barrier.
 #include "common.h"
 
@@ -29,15 +30,79 @@ __device__ __forceinline__ double mid_mask(double v, long long m) {
 	return __longlong_as_double(__double_as_longlong(v) & m);
 }
 
-// four consecutive rows r .. r + 3 of one column; rows at or past `hi` are clamped (their values are masked later)
-__device__ __forceinline__ void load4(mid_gptr_t col, int64_t r, int64_t hi, bool full, double (&v)[4]) {
-	if (full) {
-		const mid_dbl2u a = *reinterpret_cast<mid_gptr2_t>(col + r);
-		const mid_dbl2u b = *reinterpret_cast<mid_gptr2_t>(col + r + 2);
-		v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-	} else {
+// four consecutive rows r .. r + 3 of one column, all inside the group: two 16-byte loads
+__device__ __forceinline__ void load4_full(mid_gptr_t col, int64_t r, double (&v)[4]) {
+	const mid_dbl2u a = *reinterpret_cast<mid_gptr2_t>(col + r);
+	const mid_dbl2u b = *reinterpret_cast<mid_gptr2_t>(col + r + 2);
+	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+// the same at the end of a group: rows at or past `hi` are clamped (their values are masked later)
+__device__ __forceinline__ void load4_tail(mid_gptr_t col, int64_t r, int64_t hi, double (&v)[4]) {
 #pragma unroll
-		for (int m = 0; m < 4; ++m) v[m] = col[r + m < hi ? r + m : hi - 1];
+	for (int m = 0; m < 4; ++m) v[m] = col[r + m < hi ? r + m : hi - 1];
+}
+
+template <int T>
+struct MidState {
+	mid_dbl4 acc[T * (T + 1) / 2];
+	double sx[T], sxy[T], first[T];
+	double sy, syy, sw, first_y;
+	unsigned ncmask;
+	int cnt;
+	bool have_first;
+};
+
+// One 16-row step of a wave.  ALLVALID: every row of the step passed the row filter (the common case) — no masks.
+template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID>
+__device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4], const double (&y)[4], const double (&w)[4],
+                                         unsigned rowmask, int kk, int lj) {
+	if (!st.have_first) {
+		const int r = __ffs((int)rowmask) - 1; // first valid row of the group: held by the lanes of kk = r / 4
+		const int src = 16 * (r >> 2) + lj, m = r & 3;
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			const double mine = m == 0 ? x[I][0] : (m == 1 ? x[I][1] : (m == 2 ? x[I][2] : x[I][3]));
+			st.first[I] = __shfl(mine, src, 64);
+		}
+		const double ym = m == 0 ? y[0] : (m == 1 ? y[1] : (m == 2 ? y[2] : y[3]));
+		st.first_y = __shfl(ym, src, 64);
+		st.have_first = true;
+	}
+	st.cnt += ALLVALID ? 16 : __popc(rowmask);
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		const long long rm = ALLVALID ? -1ll : -(long long)((rowmask >> (4 * kk + m)) & 1u); // all ones when the row is valid
+		double d[T], a[T];
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			const double dev = ALLVALID ? x[I][m] - st.first[I] : mid_mask(x[I][m] - st.first[I], rm); // deviation from the first valid row
+			d[I] = CENTER ? dev : (ALLVALID ? x[I][m] : mid_mask(x[I][m], rm));
+			// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row
+			st.ncmask |= !(fabs(dev) < 1e-10) ? (1u << I) : 0u;
+		}
+		const double dy0 = CENTER ? y[m] - st.first_y : y[m];
+		const double dy = ALLVALID ? dy0 : mid_mask(dy0, rm);
+		const double wv = ALLVALID ? w[m] : mid_mask(w[m], rm);
+#pragma unroll
+		for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? wv * d[I] : d[I];
+		int tile = 0;
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+#pragma unroll
+			for (int J = I; J < T; ++J) {
+				st.acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[J], st.acc[tile], 0, 0, 0);
+				++tile;
+			}
+		}
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			st.sx[I] += a[I];
+			st.sxy[I] = fma(a[I], dy, st.sxy[I]);
+		}
+		const double wdy = WEIGHTED ? wv * dy : dy;
+		st.sy += wdy;
+		st.syy = fma(wdy, dy, st.syy);
+		st.sw += wv;
 	}
 }
 
@@ -64,98 +129,91 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const mid_gptr_t ycol = (mid_gptr_t)(uintptr_t)args.y;
 	const mid_gptr_t wcol = (mid_gptr_t)(uintptr_t)args.w;
 
-	mid_dbl4 acc[NT];
+	MidState<T> st;
 #pragma unroll
-	for (int t = 0; t < NT; ++t) acc[t] = mid_dbl4{0.0, 0.0, 0.0, 0.0};
-	double sx[T], sxy[T], first[T];
+	for (int t = 0; t < NT; ++t) st.acc[t] = mid_dbl4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-	for (int I = 0; I < T; ++I) sx[I] = sxy[I] = first[I] = 0.0;
-	unsigned ncmask = 0;
-	double sy = 0.0, syy = 0.0, sw = 0.0, first_y = 0.0;
-	bool have_first = false;
-	int cnt = 0;
+	for (int I = 0; I < T; ++I) st.sx[I] = st.sxy[I] = st.first[I] = 0.0;
+	st.ncmask = 0;
+	st.sy = st.syy = st.sw = st.first_y = 0.0;
+	st.have_first = false;
+	st.cnt = 0;
 
-	double xn[T][4], yn[4], wn[4]; // the next step, in flight
+	// S steps (16 S rows) per loop trip, the next trip's loads in flight: per column a wave asks for 128 S
+	// contiguous bytes at a time (DRAM locality: a single 128-byte line per stream and trip ran at ~4 TB/s)
+	constexpr int S = (T == 1 && !WEIGHTED) ? 2 : 1;
+	double xn[S][T][4], yn[S][4], wn[S][4];
+	// every load of a trip sits in ONE arm of the (wave-uniform) full / tail branch: a join between the x and the
+	// y loads would make the compiler drain the former before issuing the latter
 	auto issue = [&](int64_t r0) {
-		const bool full = r0 + 16 <= hi; // wave-uniform
-		const int64_t r = r0 + 4 * kk;
+		if (r0 + 16 * S <= hi) {
 #pragma unroll
-		for (int I = 0; I < T; ++I) load4(col[I], r, hi, full, xn[I]);
-		load4(ycol, r, hi, full, yn);
-		if (WEIGHTED) load4(wcol, r, hi, full, wn);
+			for (int q = 0; q < S; ++q) {
+				const int64_t r = r0 + 16 * q + 4 * kk;
+#pragma unroll
+				for (int I = 0; I < T; ++I) load4_full(col[I], r, xn[q][I]);
+				load4_full(ycol, r, yn[q]);
+				if (WEIGHTED) load4_full(wcol, r, wn[q]);
+			}
+		} else {
+#pragma unroll
+			for (int q = 0; q < S; ++q) {
+				const int64_t r = r0 + 16 * q + 4 * kk;
+#pragma unroll
+				for (int I = 0; I < T; ++I) load4_tail(col[I], r, hi, xn[q][I]);
+				load4_tail(ycol, r, hi, yn[q]);
+				if (WEIGHTED) load4_tail(wcol, r, hi, wn[q]);
+			}
+		}
 	};
 	if (lo < hi) issue(lo);
-	for (int64_t r0 = lo; r0 < hi; r0 += 16) {
-		double x[T][4], y[4], w[4];
+	for (int64_t t0 = lo; t0 < hi; t0 += 16 * S) {
+		double xs[S][T][4], ys[S][4], ws[S][4];
 #pragma unroll
-		for (int m = 0; m < 4; ++m) {
+		for (int q = 0; q < S; ++q) {
 #pragma unroll
-			for (int I = 0; I < T; ++I) x[I][m] = real[I] ? xn[I][m] : 0.0;
-			y[m] = yn[m];
-			w[m] = WEIGHTED ? wn[m] : 1.0;
+			for (int m = 0; m < 4; ++m) {
+#pragma unroll
+				for (int I = 0; I < T; ++I) xs[q][I][m] = real[I] ? xn[q][I][m] : 0.0;
+				ys[q][m] = yn[q][m];
+				ws[q][m] = WEIGHTED ? wn[q][m] : 1.0;
+			}
 		}
-		if (r0 + 16 < hi) issue(r0 + 16);
-
-		// row validity (ols.rs:59-66, wls.rs:76-86): bit 4 kk + m of rowmask
-		unsigned rowmask = 0;
+		if (t0 + 16 * S < hi) issue(t0 + 16 * S);
 #pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			bool ok = isfinite(y[m]) && (r0 + 4 * kk + m < hi);
-			if (WEIGHTED) ok = ok && isfinite(w[m]) && (w[m] > 0.0);
+		for (int q = 0; q < S; ++q) {
+			const int64_t r0 = t0 + 16 * q;
+			if (r0 >= hi) break; // wave-uniform
+			const double (&x)[T][4] = xs[q];
+			const double (&y)[4] = ys[q];
+			const double (&w)[4] = ws[q];
+			// row validity (ols.rs:59-66, wls.rs:76-86).  Common case first: a full step whose 16 rows all pass
+			bool ok_all = true;
 #pragma unroll
-			for (int I = 0; I < T; ++I) ok = ok && isfinite(x[I][m]);
-			const unsigned long long b = __ballot(ok);
+			for (int m = 0; m < 4; ++m) {
+				ok_all = ok_all && isfinite(y[m]);
+				if (WEIGHTED) ok_all = ok_all && isfinite(w[m]) && (w[m] > 0.0);
 #pragma unroll
-			for (int k = 0; k < 4; ++k) rowmask |= (((b >> (16 * k)) & 0xFFFFull) == 0xFFFFull) ? (1u << (4 * k + m)) : 0u;
-		}
-		rowmask = __builtin_amdgcn_readfirstlane(rowmask);
-		if (rowmask == 0u) continue;
-		if (!have_first) {
-			const int r = __ffs((int)rowmask) - 1; // first valid row of the group: held by the lanes of kk = r / 4
-			const int src = 16 * (r >> 2) + lj, m = r & 3;
-#pragma unroll
-			for (int I = 0; I < T; ++I) {
-				const double mine = m == 0 ? x[I][0] : (m == 1 ? x[I][1] : (m == 2 ? x[I][2] : x[I][3]));
-				first[I] = __shfl(mine, src, 64);
+				for (int I = 0; I < T; ++I) ok_all = ok_all && isfinite(x[I][m]);
 			}
-			const double ym = m == 0 ? y[0] : (m == 1 ? y[1] : (m == 2 ? y[2] : y[3]));
-			first_y = __shfl(ym, src, 64);
-			have_first = true;
-		}
-		cnt += __popc(rowmask);
-#pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			const long long rm = -(long long)((rowmask >> (4 * kk + m)) & 1u); // all ones when the row is valid
-			double d[T], a[T];
-#pragma unroll
-			for (int I = 0; I < T; ++I) {
-				const double dev = mid_mask(x[I][m] - first[I], rm); // deviation from the first valid row
-				d[I] = CENTER ? dev : mid_mask(x[I][m], rm);
-				// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row
-				ncmask |= !(fabs(dev) < 1e-10) ? (1u << I) : 0u;
+			if (r0 + 16 <= hi && __ballot(ok_all) == ~0ull) {
+				mid_step<T, WEIGHTED, CENTER, true>(st, x, y, w, 0xFFFFu, kk, lj);
+				continue;
 			}
-			const double dy = mid_mask(CENTER ? y[m] - first_y : y[m], rm);
-			const double wv = mid_mask(w[m], rm);
+			unsigned rowmask = 0; // bit 4 kk + m
 #pragma unroll
-			for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? wv * d[I] : d[I];
-			int tile = 0;
+			for (int m = 0; m < 4; ++m) {
+				bool ok = isfinite(y[m]) && (r0 + 4 * kk + m < hi);
+				if (WEIGHTED) ok = ok && isfinite(w[m]) && (w[m] > 0.0);
 #pragma unroll
-			for (int I = 0; I < T; ++I) {
+				for (int I = 0; I < T; ++I) ok = ok && isfinite(x[I][m]);
+				const unsigned long long b = __ballot(ok);
 #pragma unroll
-				for (int J = I; J < T; ++J) {
-					acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[J], acc[tile], 0, 0, 0);
-					++tile;
-				}
+				for (int k = 0; k < 4; ++k) rowmask |= (((b >> (16 * k)) & 0xFFFFull) == 0xFFFFull) ? (1u << (4 * k + m)) : 0u;
 			}
-#pragma unroll
-			for (int I = 0; I < T; ++I) {
-				sx[I] += a[I];
-				sxy[I] = fma(a[I], dy, sxy[I]);
-			}
-			const double wdy = WEIGHTED ? wv * dy : dy;
-			sy += wdy;
-			syy = fma(wdy, dy, syy);
-			sw += wv;
+			rowmask = __builtin_amdgcn_readfirstlane(rowmask);
+			if (rowmask == 0u) continue;
+			mid_step<T, WEIGHTED, CENTER, false>(st, x, y, w, rowmask, kk, lj);
 		}
 	}
 
@@ -165,25 +223,26 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	for (int t = 0; t < NT; ++t) {
 		double *tp = rec + (int64_t)t * 256; // tile-major, element (row, col) at row * 16 + col
 #pragma unroll
-		for (int r = 0; r < 4; ++r) tp[(kk + 4 * r) * 16 + lj] = acc[t][r];
+		for (int r = 0; r < 4; ++r) tp[(kk + 4 * r) * 16 + lj] = st.acc[t][r];
 	}
 	double *vec = rec + (int64_t)NT * 256;
 #pragma unroll
 	for (int I = 0; I < T; ++I) { // reduce over the four kk groups (lanes l, l^16, l^32, l^48)
-		double a = sx[I], b = sxy[I];
+		double a = st.sx[I], b = st.sxy[I];
 		a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
 		b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-		unsigned nc = (ncmask >> I) & 1u;
+		unsigned nc = (st.ncmask >> I) & 1u;
 		nc |= (unsigned)__shfl_xor((int)nc, 16, 64);
 		nc |= (unsigned)__shfl_xor((int)nc, 32, 64);
 		if (lane < 16) {
 			vec[0 * P16 + 16 * I + lane] = a;
 			vec[1 * P16 + 16 * I + lane] = b;
-			vec[2 * P16 + 16 * I + lane] = first[I];
+			vec[2 * P16 + 16 * I + lane] = st.first[I];
 			vec[3 * P16 + 16 * I + lane] = (real[I] && nc) ? 1.0 : 0.0;
 		}
 	}
 	// every lane of a kk group holds the same partial of the y moments: lanes 0, 16, 32, 48
+	double sy = st.sy, syy = st.syy, sw = st.sw;
 	sy += __shfl_xor(sy, 16, 64); sy += __shfl_xor(sy, 32, 64);
 	syy += __shfl_xor(syy, 16, 64); syy += __shfl_xor(syy, 32, 64);
 	sw += __shfl_xor(sw, 16, 64); sw += __shfl_xor(sw, 32, 64);
@@ -192,8 +251,8 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 		sc[0] = sy;
 		sc[1] = syy;
 		sc[2] = sw;
-		sc[3] = (double)cnt;
-		sc[4] = first_y;
+		sc[3] = (double)st.cnt;
+		sc[4] = st.first_y;
 	}
 }
 
