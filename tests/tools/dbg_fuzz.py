@@ -1,3 +1,5 @@
+"""Debug helper: re-run one case of tests/test_gpu_fuzz.py and compare against a long-double solve.
+Run from the repo root on a GPU box: python tests/tools/dbg_fuzz.py SEED [wide].  Test infrastructure (uses the oracle)."""
 import sys, importlib
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")

@@ -1,5 +1,5 @@
 import importlib, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # repo root
 import numpy as np
 pkg = importlib.import_module("anofox-statistics_amd")
 import oracle
