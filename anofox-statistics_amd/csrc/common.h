@@ -164,10 +164,10 @@ hipError_t launch_hc_wide(const WideArgs &a, hipStream_t stream);
 
 // launchers implemented in the .hip translation units
 hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream);
-// mode: 0 = primary solve of every group; 1 = iterative-refinement update of the queued groups;
-//       2 = final statistics of the queued groups from the directly summed RSS
-hipError_t launch_solve_narrow(const BatchArgs &a, int mode, hipStream_t stream);
-hipError_t launch_residual_grad(const BatchArgs &a, hipStream_t stream);
+// primary solve of every group (queues the groups that need refinement), then ONE launch that takes every queued
+// group through `steps` iterative-refinement updates and the final statistics from the directly summed RSS
+hipError_t launch_solve_narrow(const BatchArgs &a, hipStream_t stream);
+hipError_t launch_refine_fused_narrow(const BatchArgs &a, int steps, hipStream_t stream);
 // vif_narrow.hip: out[g] = { vif[p], status }; rows < min_rows -> NULL (status 100)
 hipError_t launch_vif_narrow(const double *moments, const int64_t *row_offsets, int64_t n_groups, int p, int64_t min_rows,
                              double *out, hipStream_t stream);

@@ -35,6 +35,7 @@ struct AnofoxHipContext {
 	// small auxiliary device buffer (t-quantile memo of the predict kernel)
 	void *aux = nullptr;
 	size_t aux_bytes = 0;
+	const int32_t *last_refine_count = nullptr; // device address of the most recent launch's queue counter
 	// Student-t critical values for df = 1..kWindowTcritCap at the confidence level of the last window call
 	void *wtab = nullptr;
 	size_t wtab_bytes = 0;
@@ -160,6 +161,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.refine_vec = (double *)(base + b_mom);
 	a.refine_list = (int32_t *)(base + b_mom + b_rss);
 	a.refine_count = (int32_t *)(base + b_mom + b_rss + b_lst);
+	ctx->last_refine_count = a.refine_count;
 	a.tcrit_table = base + b_mom + b_rss + b_lst + 256;
 	a.core = d_core;
 	a.inference = opt.compute_inference ? d_inf : nullptr;
@@ -239,6 +241,7 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	a.inference = opt.compute_inference ? d_inf : nullptr;
 	a.refine_list = ws.refine_list;
 	a.refine_count = ws.refine_count;
+	ctx->last_refine_count = ws.refine_count;
 	a.refine_vec = ws.refine_vec;
 	a.tcrit_table = ws.tcrit_table;
 	a.rule_counts = d_rule_counts;
@@ -255,13 +258,9 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	}
 	if (hip_fail(launch_accumulate_narrow(a, st), "accumulate kernel launch", e)) return false;
 	if (ctx->timing) (void)hipEventRecord(e1, st);
-	if (hip_fail(launch_solve_narrow(a, 0, st), "solve kernel launch", e)) return false;
-	for (int it = 0; it < kRefineSteps; ++it) { // queued groups only: b += (X'WX)^-1 X'Wr
-		if (hip_fail(launch_residual_grad(a, st), "residual kernel launch", e)) return false;
-		if (hip_fail(launch_solve_narrow(a, 1, st), "refine kernel launch", e)) return false;
-	}
-	if (hip_fail(launch_residual_grad(a, st), "residual kernel launch", e)) return false;
-	if (hip_fail(launch_solve_narrow(a, 2, st), "final kernel launch", e)) return false;
+	if (hip_fail(launch_solve_narrow(a, st), "solve kernel launch", e)) return false;
+	// queued groups only: kRefineSteps x (b += (X'WX)^-1 X'Wr), then the statistics from the directly summed RSS
+	if (hip_fail(launch_refine_fused_narrow(a, kRefineSteps, st), "refine kernel launch", e)) return false;
 	// ols.rs:209-231, wls.rs:230-252: HC errors replace the classical ones; ridge has no such branch
 	if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE) {
 		if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, hc_prep_bytes(G, (int)p), "hc scratch", e)) return false;
@@ -388,6 +387,20 @@ bool anofox_hip_context_enable_timing(AnofoxHipContext *ctx, bool enable, Anofox
 	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	ctx->timing = enable;
+	return true;
+}
+
+bool anofox_hip_context_last_refine_count(AnofoxHipContext *ctx, int64_t *out_count, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx || !out_count) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context or out_count is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	*out_count = 0;
+	if (!ctx->last_refine_count) return true;
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	if (hip_fail(hipStreamSynchronize(ctx->stream), "hipStreamSynchronize", out_error)) return false;
+	int32_t v = 0;
+	if (hip_fail(hipMemcpy(&v, ctx->last_refine_count, sizeof v, hipMemcpyDeviceToHost), "hipMemcpy", out_error)) return false;
+	*out_count = v;
 	return true;
 }
 

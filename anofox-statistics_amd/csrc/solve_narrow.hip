@@ -12,8 +12,9 @@
 //
 // Normal equations square the condition number, and RSS = Syy - b'Sxy cancels when R^2 -> 1.  Groups where
 // either matters (smallest Cholesky pivot ratio < 1e-3, or RSS/TSS < 1e-7) are queued on the device; for
-// those groups only, residual_grad_kernel re-reads the rows and forms the residuals r = y - b0 - x'b, their
-// weighted sum of squares and the gradient X'Wr directly from the data, and the solve runs again in
+// those groups only, refine_fused_kernel re-reads the rows (one wavefront per queued group) and forms the
+// residuals r = y - b0 - x'b, their weighted sum of squares and the gradient X'Wr directly from the data, and
+// the solve runs again in
 //   MODE 1: one step of iterative refinement  b += (X'WX)^-1 X'Wr   (twice), then
 //   MODE 2: final statistics from the directly summed RSS.
 // This restores the accuracy of a QR on the design (the reference's algorithm class) for the queued groups.
@@ -297,32 +298,17 @@ __global__ __launch_bounds__(64) void solve_narrow_kernel(BatchArgs args) {
 	solve_one<P, MODE_PRIMARY>(args, g);
 }
 
-// passes over the queued groups only
-template <int P, int MODE>
-__global__ __launch_bounds__(64) void solve_refine_kernel(BatchArgs args) {
-	const int n = *args.refine_count;
-	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const int64_t g = args.refine_list[i];
-		solve_one<P, MODE>(args, g);
-	}
-}
-
 // One wavefront per queued group, straight from the data with the record's current coefficients:
 //   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ... },  r = y - b0 - x'b
 // over the valid rows (same row filter as the accumulate kernel); shift = first valid row when an intercept
 // is fitted (the shift of the moment record), 0 otherwise.
-__global__ __launch_bounds__(256) void residual_grad_kernel(BatchArgs args) {
-	const int lane = threadIdx.x & 63;
-	const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const int n_waves = (gridDim.x * blockDim.x) >> 6;
-	const int n = *args.refine_count;
+__device__ __forceinline__ void residual_grad_wave(const BatchArgs &args, int64_t g, int lane) {
 	const int p = args.p;
 	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
 	const int Z = p + 1;
 	const int off_first = Z + Z * (Z + 1) / 2 + 1;
 	const int rec_len = moment_record_len(p);
-	for (int i = wave; i < n; i += n_waves) {
-		const int64_t g = args.refine_list[i];
+	{
 		const double *core = args.core + g * (int64_t)(p + 6);
 		const double *rec = args.moments + g * (int64_t)rec_len;
 		double b[kNarrowMaxP], sh[kNarrowMaxP], acc[kNarrowMaxP + 2];
@@ -379,40 +365,73 @@ __global__ __launch_bounds__(256) void residual_grad_kernel(BatchArgs args) {
 	}
 }
 
+// The whole refinement of the queued groups in ONE launch: a wavefront takes a queued group through
+//   kRefineSteps x (residual + gradient pass over its rows, iterative-refinement update)  and the final
+//   residual pass + statistics,
+// the row passes on all 64 lanes, the small solves on lane 0.  Groups are independent, so nothing has to be
+// synchronised across waves; six dependent launches (~35 us of dispatch latency each on an otherwise empty
+// queue) become one.
 template <int P>
-hipError_t launch_solve_p(const BatchArgs &a, int mode, hipStream_t stream) {
-	if (mode == MODE_PRIMARY) {
-		const unsigned grid = (unsigned)((a.n_groups + 63) / 64);
-		hipLaunchKernelGGL((solve_narrow_kernel<P>), dim3(grid), dim3(64), 0, stream, a);
-	} else if (mode == MODE_UPDATE) {
-		hipLaunchKernelGGL((solve_refine_kernel<P, MODE_UPDATE>), dim3(256), dim3(64), 0, stream, a);
-	} else {
-		hipLaunchKernelGGL((solve_refine_kernel<P, MODE_FINAL>), dim3(256), dim3(64), 0, stream, a);
+__global__ __launch_bounds__(64) void refine_fused_kernel(BatchArgs args, int steps) {
+	const int lane = threadIdx.x & 63;
+	const int n = *args.refine_count;
+	for (int i = blockIdx.x; i < n; i += gridDim.x) {
+		const int64_t g = args.refine_list[i];
+		for (int it = 0; it <= steps; ++it) {
+			residual_grad_wave(args, g, lane);
+			__threadfence(); // refine_vec[g] written by lanes 0..p+1, read by lane 0
+			if (lane == 0) {
+				if (it < steps) solve_one<P, MODE_UPDATE>(args, g);
+				else solve_one<P, MODE_FINAL>(args, g);
+			}
+			__threadfence(); // the record's coefficients written by lane 0, read by every lane in the next pass
+		}
 	}
+}
+
+template <int P>
+hipError_t launch_solve_p(const BatchArgs &a, hipStream_t stream) {
+	const unsigned grid = (unsigned)((a.n_groups + 63) / 64);
+	hipLaunchKernelGGL((solve_narrow_kernel<P>), dim3(grid), dim3(64), 0, stream, a);
 	return hipGetLastError();
 }
 
 } // namespace
 
-hipError_t launch_solve_narrow(const BatchArgs &a, int mode, hipStream_t stream) {
+hipError_t launch_solve_narrow(const BatchArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
 	switch (a.p) {
-	case 1: return launch_solve_p<1>(a, mode, stream);
-	case 2: return launch_solve_p<2>(a, mode, stream);
-	case 3: return launch_solve_p<3>(a, mode, stream);
-	case 4: return launch_solve_p<4>(a, mode, stream);
-	case 5: return launch_solve_p<5>(a, mode, stream);
-	case 6: return launch_solve_p<6>(a, mode, stream);
-	case 7: return launch_solve_p<7>(a, mode, stream);
-	case 8: return launch_solve_p<8>(a, mode, stream);
+	case 1: return launch_solve_p<1>(a, stream);
+	case 2: return launch_solve_p<2>(a, stream);
+	case 3: return launch_solve_p<3>(a, stream);
+	case 4: return launch_solve_p<4>(a, stream);
+	case 5: return launch_solve_p<5>(a, stream);
+	case 6: return launch_solve_p<6>(a, stream);
+	case 7: return launch_solve_p<7>(a, stream);
+	case 8: return launch_solve_p<8>(a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }
 
-hipError_t launch_residual_grad(const BatchArgs &a, hipStream_t stream) {
-	if (a.n_groups <= 0) return hipSuccess;
-	hipLaunchKernelGGL(residual_grad_kernel, dim3(512), dim3(256), 0, stream, a);
+template <int P>
+hipError_t launch_refine_p(const BatchArgs &a, int steps, hipStream_t stream) {
+	hipLaunchKernelGGL((refine_fused_kernel<P>), dim3(1024), dim3(64), 0, stream, a, steps);
 	return hipGetLastError();
+}
+
+hipError_t launch_refine_fused_narrow(const BatchArgs &a, int steps, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	switch (a.p) {
+	case 1: return launch_refine_p<1>(a, steps, stream);
+	case 2: return launch_refine_p<2>(a, steps, stream);
+	case 3: return launch_refine_p<3>(a, steps, stream);
+	case 4: return launch_refine_p<4>(a, steps, stream);
+	case 5: return launch_refine_p<5>(a, steps, stream);
+	case 6: return launch_refine_p<6>(a, steps, stream);
+	case 7: return launch_refine_p<7>(a, steps, stream);
+	case 8: return launch_refine_p<8>(a, steps, stream);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 } // namespace anofox

@@ -140,6 +140,13 @@ class Context:
         self._check(ok, err)
         return pred
 
+    def last_refine_count(self) -> int:
+        """Groups of the most recent fit launch that took the on-device refinement passes (diagnostic)."""
+        n = C.c_int64()
+        err = _abi.AnofoxError()
+        self._check(self._lib.anofox_hip_context_last_refine_count(self._h, C.byref(n), C.byref(err)), err)
+        return int(n.value)
+
     def vif_batch_device(self, row_offsets, x_cols: Sequence, out=None, use_current_torch_stream: bool = True):
         """Grouped variance inflation factors, device resident.  Returns out[G, p+1] = {vif[p], status}."""
         import torch

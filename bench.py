@@ -210,6 +210,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kt = ctx.collect_timing()
     ctx.enable_timing(False)
+    refined = ctx.last_refine_count() if not (args.window or args.vif) else 0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -300,7 +301,7 @@ def main():
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,
                          "kernel": kernel, "avg_launch_ms": acc_ms, "launches_per_step": kt["accumulate_count"] / args.steps,
-                         "kernel_ms_per_step": acc_step_ms,
+                         "kernel_ms_per_step": acc_step_ms, "groups_refined_last_launch": refined,
                          ("algorithmic_bytes_per_step" if bound == "hbm" else "algorithmic_flops_per_step"): per_step,
                          "hbm_GBps_algorithmic": G_local * bytes_fit / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0,
                          "solve_ms_per_step": kt["solve_ms"] / args.steps},

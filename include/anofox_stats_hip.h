@@ -382,6 +382,10 @@ ANOFOX_HIP_API bool anofox_hip_context_enable_timing(AnofoxHipContext *ctx, bool
 /* synchronises, returns the sums since the last call and resets them */
 ANOFOX_HIP_API bool anofox_hip_context_collect_timing(AnofoxHipContext *ctx, AnofoxHipKernelTimes *out, AnofoxError *out_error);
 
+/* Diagnostic: how many groups of the context's most recent fit launch (narrow path: the whole batch; wide path:
+ * the last slab) were queued for the on-device refinement passes.  Synchronises the context's stream. */
+ANOFOX_HIP_API bool anofox_hip_context_last_refine_count(AnofoxHipContext *ctx, int64_t *out_count, AnofoxError *out_error);
+
 /* Library / build identification, e.g. "anofox_stats_hip 0.1 gfx950". */
 ANOFOX_HIP_API const char *anofox_hip_version(void);
 
