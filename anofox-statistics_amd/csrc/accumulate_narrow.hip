@@ -15,6 +15,11 @@
 // transposing butterfly (v_permlane32_swap / v_permlane16_swap, then 4 shuffle steps) that leaves moment
 // k on lane k, so the record is written with one coalesced store.
 //
+// Very large groups: a single wavefront streams at only ~5 GB/s, so a group with more than seg_rows rows
+// (>= 1/2048 of the batch) is cut into segments, one wavefront each (accumulate_segments_kernel, a second launch
+// that is idle otherwise); the wave that finishes a group's last segment merges the segment records, moving
+// each to the group's shift.  1 x 50M x 8 went from 698 ms to the HBM-bound time.
+//
 // Roofline: HBM-bound.  Algorithmic bytes per row 8(p+1) (+8 with weights); 63 f64 VALU ops per row at
 // p = 8 (~20 % of the f64 vector rate at the HBM-bound row rate).
 #include <stdlib.h>
@@ -62,18 +67,12 @@ __device__ __forceinline__ double fold_shfl(double a, double b, int lane) {
 	return keep + __shfl_xor(send, M, 64);
 }
 
+// The rows [lo, hi) of one group (or of one segment of a very large group) -> one moment record at `rec`.
 template <int P, bool WEIGHTED, bool CENTER, bool NT>
-__global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) {
+__device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t lo, int64_t hi, double *rec, int lane) {
 	using L = MomentLayout<P>;
 	constexpr int Z = L::Z;
 	constexpr int ZZ = L::ZZ;
-
-	const int lane = threadIdx.x & 63;
-	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
-	if (g >= args.n_groups) return;
-
-	const int64_t lo = args.row_offsets[g];
-	const int64_t hi = args.row_offsets[g + 1];
 
 	double s[Z];
 	double q[ZZ];
@@ -210,7 +209,6 @@ __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) 
 	for (int i = 0; i < 2; ++i) v[i] = fold_shfl<2>(v[i], v[i + 2], lane);
 	v[0] = fold_shfl<1>(v[0], v[1], lane);
 
-	double *rec = args.moments + g * (int64_t)L::REC;
 	if (lane < L::KRED) rec[lane] = v[0];
 
 	// wave-uniform extras: first[], cnt, mask
@@ -222,19 +220,142 @@ __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) 
 	if (lane < Z + 2) rec[L::KRED + lane] = e;
 }
 
+__device__ __forceinline__ SegHeader *seg_header(void *t) { return static_cast<SegHeader *>(t); }
+__device__ __forceinline__ SegBigGroup *seg_big(void *t) { return reinterpret_cast<SegBigGroup *>(seg_header(t) + 1); }
+__device__ __forceinline__ SegEntry *seg_entries(void *t) { return reinterpret_cast<SegEntry *>(seg_big(t) + kSegMaxBig); }
+__device__ __forceinline__ double *seg_records(void *t) { return reinterpret_cast<double *>(seg_entries(t) + kSegMaxSegments); }
+
+template <int P, bool WEIGHTED, bool CENTER, bool NT>
+__global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) {
+	using L = MomentLayout<P>;
+	const int lane = threadIdx.x & 63;
+	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+	if (g >= args.n_groups) return;
+	const int64_t lo = args.row_offsets[g];
+	const int64_t hi = args.row_offsets[g + 1];
+	if (args.seg_table && hi - lo > args.seg_rows) {
+		// a single wavefront streams at ~5 GB/s: hand the group to accumulate_segments_kernel in pieces
+		if (lane == 0) {
+			SegHeader *h = seg_header(args.seg_table);
+			const int64_t S = args.seg_rows;
+			const int nseg = (int)((hi - lo + S - 1) / S);
+			const int slot = atomicAdd(&h->big_total, 1);
+			const int base = atomicAdd(&h->seg_total, nseg);
+			if (slot < kSegMaxBig) {
+				SegBigGroup b;
+				b.g = g; b.base = base; b.nseg = nseg; b.done = 0; b.pad = 0;
+				seg_big(args.seg_table)[slot] = b;
+				for (int k = 0; k < nseg && base + k < kSegMaxSegments; ++k) {
+					SegEntry e;
+					e.lo = lo + k * S;
+					e.hi = (e.lo + S < hi) ? e.lo + S : hi;
+					e.slot = slot; e.pad = 0;
+					seg_entries(args.seg_table)[base + k] = e;
+				}
+			}
+		}
+		return;
+	}
+	accumulate_rows<P, WEIGHTED, CENTER, NT>(args, lo, hi, args.moments + g * (int64_t)L::REC, lane);
+}
+
+// Merge the segment records of one group into its moment record: lane k owns moment k.  Segment b was shifted by
+// ITS first valid row; with delta = first_b - first_group:  s += s_b + sw_b delta,
+// q_ij += q_b,ij + delta_i s_b,j + delta_j s_b,i + sw_b delta_i delta_j  (no shift without an intercept).
+template <int P, bool CENTER>
+__device__ void merge_segments(const double *seg_rec, int nseg, double *rec, int lane) {
+	using L = MomentLayout<P>;
+	constexpr int Z = L::Z;
+	// this lane's moment: s_i (lane < Z), q_ij, or sw
+	int mi = 0, mj = 0;
+	const bool is_s = lane < Z, is_q = lane >= L::OFF_Q && lane < L::OFF_SW, is_sw = lane == L::OFF_SW;
+	if (is_s) mi = mj = lane;
+	if (is_q) {
+		int k = lane - L::OFF_Q;
+		for (int a = 0; a < Z; ++a) {
+			if (k < Z - a) { mi = a; mj = a + k; break; }
+			k -= Z - a;
+		}
+	}
+	double total = 0.0, cnt = 0.0, ai = 0.0, aj = 0.0;
+	double a_first = 0.0; // lane a < Z keeps first_group[a]
+	unsigned mask = 0;
+	bool have = false;
+	for (int t = 0; t < nseg; ++t) {
+		const double *rb = seg_rec + (int64_t)t * L::REC;
+		const double cb = rb[L::OFF_CNT];
+		if (!(cb > 0.0)) continue; // wave-uniform
+		if (!have) {
+			ai = rb[L::OFF_FIRST + mi];
+			aj = rb[L::OFF_FIRST + mj];
+			a_first = lane < Z ? rb[L::OFF_FIRST + lane] : 0.0;
+			have = true;
+		}
+		const double swb = rb[L::OFF_SW];
+		const double di = CENTER ? rb[L::OFF_FIRST + mi] - ai : 0.0;
+		const double dj = CENTER ? rb[L::OFF_FIRST + mj] - aj : 0.0;
+		double v = 0.0;
+		if (is_s) v = rb[L::OFF_S + mi] + swb * di;
+		else if (is_q) v = rb[lane] + di * rb[L::OFF_S + mj] + dj * rb[L::OFF_S + mi] + swb * di * dj;
+		else if (is_sw) v = swb;
+		total += v;
+		cnt += cb;
+		// constant-column test against the GROUP's first row: varies inside the segment, or the segment sits elsewhere
+		unsigned m = (unsigned)rb[L::OFF_MASK];
+		const bool moved = lane < P && !(fabs(rb[L::OFF_FIRST + lane] - a_first) < 1e-10);
+		m |= (unsigned)__ballot(moved);
+		mask |= m;
+	}
+	if (lane < L::KRED) rec[lane] = total;
+	double e = a_first;
+	e = (lane == Z) ? cnt : e;
+	e = (lane == Z + 1) ? (double)(mask & ((1u << P) - 1u)) : e;
+	if (lane < Z + 2) rec[L::KRED + lane] = e;
+}
+
+// One wavefront per registered segment; the wave that completes a group's last segment merges them.
+template <int P, bool WEIGHTED, bool CENTER, bool NT>
+__global__ __launch_bounds__(256) void accumulate_segments_kernel(BatchArgs args) {
+	using L = MomentLayout<P>;
+	const int lane = threadIdx.x & 63;
+	const int v = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int)blockIdx.x * 4;
+	SegHeader *h = seg_header(args.seg_table);
+	int total = h->seg_total;
+	if (total > kSegMaxSegments) total = kSegMaxSegments;
+	if (v >= total) return;
+	const SegEntry e = seg_entries(args.seg_table)[v];
+	double *recs = seg_records(args.seg_table);
+	accumulate_rows<P, WEIGHTED, CENTER, NT>(args, e.lo, e.hi, recs + (int64_t)v * L::REC, lane);
+	__threadfence(); // this segment's record before the counter
+	SegBigGroup *b = seg_big(args.seg_table) + e.slot;
+	int old = 0;
+	if (lane == 0) old = atomicAdd(&b->done, 1);
+	old = __builtin_amdgcn_readfirstlane(old);
+	if (old != b->nseg - 1) return;
+	__threadfence(); // every other segment's record after the counter
+	merge_segments<P, CENTER>(recs + (int64_t)b->base * L::REC, b->nseg, args.moments + b->g * (int64_t)L::REC, lane);
+}
+
 template <int P, bool NT>
 static hipError_t launch_pn(const BatchArgs &a, hipStream_t stream) {
 	const dim3 block(256);
 	const dim3 grid((unsigned)((a.n_groups + 3) / 4));
+	const dim3 seg_grid((unsigned)((kSegMaxSegments + 3) / 4)); // idle unless some group exceeded seg_rows
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
+#define ANOFOX_ACC_LAUNCH(W, C)                                                                               \
+	do {                                                                                                      \
+		hipLaunchKernelGGL((accumulate_narrow_kernel<P, W, C, NT>), grid, block, 0, stream, a);               \
+		if (a.seg_table) hipLaunchKernelGGL((accumulate_segments_kernel<P, W, C, NT>), seg_grid, block, 0, stream, a); \
+	} while (0)
 	if (weighted) {
-		if (center) hipLaunchKernelGGL((accumulate_narrow_kernel<P, true, true, NT>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((accumulate_narrow_kernel<P, true, false, NT>), grid, block, 0, stream, a);
+		if (center) ANOFOX_ACC_LAUNCH(true, true);
+		else ANOFOX_ACC_LAUNCH(true, false);
 	} else {
-		if (center) hipLaunchKernelGGL((accumulate_narrow_kernel<P, false, true, NT>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((accumulate_narrow_kernel<P, false, false, NT>), grid, block, 0, stream, a);
+		if (center) ANOFOX_ACC_LAUNCH(false, true);
+		else ANOFOX_ACC_LAUNCH(false, false);
 	}
+#undef ANOFOX_ACC_LAUNCH
 	return hipGetLastError();
 }
 

@@ -71,7 +71,44 @@ struct BatchArgs {
 	double *refine_vec;   // [G * (p+2)]  {sum w r^2, sum w r, X'Wr} of the queued groups
 	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
 	const int64_t *rule_counts; // optional [G]: the count the "< 2 rows -> NULL" rule looks at (default: rows of the group)
+	// row splitting of very large groups (accumulate_narrow.hip): groups with more than seg_rows rows are cut into
+	// segments of seg_rows rows, one wavefront each, and merged; seg_table == nullptr disables it
+	void *seg_table;
+	int64_t seg_rows;
 };
+
+// Segment bookkeeping of the narrow accumulate kernel.  seg_rows >= ceil(n_rows / kSegTargetWaves), so fewer than
+// kSegTargetWaves groups can exceed it and their segments number fewer than 2 kSegTargetWaves: fixed-size tables.
+constexpr int kSegTargetWaves = 2048;
+constexpr int kSegMaxBig = kSegTargetWaves + 8;
+constexpr int kSegMaxSegments = 2 * kSegTargetWaves + 16;
+constexpr int64_t kSegMinRows = 8192;
+struct SegHeader {
+	int32_t seg_total; // segments registered (may exceed what was written if the caller understated n_rows)
+	int32_t big_total; // groups registered
+	int32_t pad[14];
+};
+struct SegBigGroup {
+	int64_t g;
+	int32_t base; // first segment
+	int32_t nseg;
+	int32_t done; // segments finished (the wave that finishes the last one merges)
+	int32_t pad;
+};
+struct SegEntry {
+	int64_t lo, hi; // rows
+	int32_t slot;   // index into the big-group table
+	int32_t pad;
+};
+inline __host__ __device__ size_t seg_table_bytes(int p) {
+	return sizeof(SegHeader) + sizeof(SegBigGroup) * kSegMaxBig + sizeof(SegEntry) * kSegMaxSegments +
+	       sizeof(double) * (size_t)kSegMaxSegments * (size_t)moment_record_len(p);
+}
+inline __host__ __device__ int64_t seg_rows_for(int64_t n_rows) {
+	int64_t s = (n_rows + kSegTargetWaves - 1) / kSegTargetWaves;
+	s = (s + 127) / 128 * 128;
+	return s < kSegMinRows ? kSegMinRows : s;
+}
 
 // ---- wide path (8 < p <= kWideMaxP): FP64-MFMA accumulation, LDS Cholesky ----
 constexpr int kWideMaxP = 128;

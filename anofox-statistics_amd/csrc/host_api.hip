@@ -102,6 +102,7 @@ hipEvent_t get_event(AnofoxHipContext *ctx) {
 }
 
 struct Workspace {
+	void *seg_table; // SegHeader + tables + segment records (common.h)
 	double *moments;
 	double *refine_vec;
 	int32_t *refine_list;
@@ -114,9 +115,11 @@ bool carve_workspace(AnofoxHipContext *ctx, int64_t G, int p, Workspace *out, An
 	const size_t b_mom = align_up((size_t)G * rec * sizeof(double), 256);
 	const size_t b_rss = align_up((size_t)G * (size_t)(p + 2) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)G * sizeof(int32_t), 256);
-	const size_t total = b_mom + b_rss + b_lst + 256 + kTcritTableBytes;
+	const size_t b_seg = align_up(seg_table_bytes(p), 256);
+	const size_t total = b_mom + b_rss + b_lst + 256 + kTcritTableBytes + b_seg;
 	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, total, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
+	out->seg_table = base + b_mom + b_rss + b_lst + 256 + kTcritTableBytes; // its header is zeroed with the counters
 	out->moments = (double *)base;
 	out->refine_vec = (double *)(base + b_mom);
 	out->refine_list = (int32_t *)(base + b_mom + b_rss);
@@ -245,9 +248,12 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	a.refine_vec = ws.refine_vec;
 	a.tcrit_table = ws.tcrit_table;
 	a.rule_counts = d_rule_counts;
+	a.seg_table = ws.seg_table;
+	a.seg_rows = seg_rows_for(n_rows);
 
 	hipStream_t st = ctx->stream;
-	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, 256 + kTcritTableBytes, st), "hipMemsetAsync", e)) return false; // counter + t table
+	// refine counter + t table + the header of the segment table (contiguous)
+	if (hip_fail(hipMemsetAsync(ws.refine_count, 0, 256 + kTcritTableBytes + sizeof(SegHeader), st), "hipMemsetAsync", e)) return false;
 
 	hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 	if (ctx->timing) {
@@ -1179,6 +1185,9 @@ bool run_vif(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const i
 		a.model = ANOFOX_HIP_MODEL_OLS;
 		a.fit_intercept = 1;
 		a.moments = ws.moments;
+		a.seg_table = ws.seg_table;
+		a.seg_rows = seg_rows_for(n_rows);
+		if (hip_fail(hipMemsetAsync(ws.seg_table, 0, sizeof(SegHeader), st), "hipMemsetAsync", e)) return false;
 		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 		if (ctx->timing) {
 			e0 = get_event(ctx);

@@ -384,6 +384,45 @@ def test_hc_is_ignored_where_the_reference_ignores_it(pkg, ctx):
     assert code == 0 and np.allclose(r["std_errors"], d["std_errors"], rtol=1e-8)
 
 
+@pytest.mark.parametrize("model", ["ols", "ridge", "wls"])
+@pytest.mark.parametrize("icpt", [True, False])
+def test_very_large_groups_are_split_and_merged(pkg, ctx, model, icpt):
+    """Groups with more than seg_rows (>= 8192) rows are cut into segments, one wavefront each, and the segment
+    records are merged with a change of shift (accumulate_narrow.hip) — same results as the one-wave path."""
+    rng = np.random.default_rng(91 + len(model) + (1 if icpt else 0))
+    p = 5
+    ns = [50_000, 3, 20_001, 100, 0, 8192, 8193, 30_000, 17_000, 1]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    X = rng.uniform(-10, 10, (N, p)) + np.array([0.0, 100.0, -3.0, 0.5, 1e3])
+    gid = np.repeat(np.arange(len(ns)), ns)
+    pos = np.arange(N) - offs[gid]
+    X[:, 0] += 1e-3 * pos                                        # trend: the segments sit in different places
+    y = 2.0 + X @ np.array([1.5, -0.2, 0.7, 3.0, 0.01]) + rng.standard_normal(N)
+    w = rng.uniform(0.5, 1.5, N)
+    lo = offs[0]
+    y[lo:lo + 9000] = np.nan                                     # group 0: its whole first segment is invalid
+    lo = offs[2]
+    X[lo:lo + 20_001, 2] = 4.0                                   # group 2: constant column over every segment
+    lo = offs[7]
+    X[lo:lo + 30_000, 3] = np.where(np.arange(30_000) < 16_384, 1.0, 2.0)   # constant INSIDE each segment, not overall
+    X[lo + 5:lo + 30_000:977, 1] = np.inf                        # scattered invalid rows
+    lo = offs[8]
+    X[lo:lo + 17_000, 4] = 2.0 * X[lo:lo + 17_000, 1] + 1.0      # aliased column
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    kw = dict(fit_intercept=icpt, compute_inference=True)
+    if model == "ridge":
+        kw["alpha"] = 0.7
+    wv = w if model == "wls" else None
+    core, inf = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+    rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
+    assert_records_match(core, rcore, p, inf, rinf, what=f"split {model} icpt={icpt}")
+    assert np.isnan(core[2, 2]) and core[7, 5 + 5] == 0 and not np.isnan(core[7, 3])
+    v = pkg.vif_batch_host(offs, x_cols[:4], ctx=ctx)            # the same accumulate kernel under vif_agg
+    rv = oracle.vif_groups(x_cols[:4], offs)
+    _assert_vif_match(v, rv, 4, "split vif")
+
+
 def test_alpha_negative_and_bad_arguments(pkg, ctx):
     a = import_pkg("_abi")
     rng = np.random.default_rng(2)
