@@ -14,7 +14,10 @@
 //   * row validity: one ballot says whether all 16 rows of a step pass (then the step runs without masks);
 //     otherwise 4 ballots give the row mask (the 16 lanes of a kk group hold the 16 columns of a block) and
 //     invalid rows are removed with bit masks;
-//   * four groups per 256-thread workgroup, no LDS, no barrier.
+//   * four groups per 256-thread workgroup, no LDS, no barrier;
+//   * a group with more than seg_rows rows (>= 1/2048 of the batch) is cut into segments, one wavefront each
+//     (accumulate_mid_segments_kernel, idle otherwise), all shifted by the group's first valid row, and the wave
+//     that finishes the last segment sums the segment records.
 #include "common.h"
 
 namespace anofox {
@@ -106,17 +109,15 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 	}
 }
 
+// The rows [lo, hi) of one group — or of one segment of a very large group, then with the group's first valid
+// row handed in (`forced_first`: x per column, y at index 16 T) — into one wide moment record at `rec`.
 template <int T, bool WEIGHTED, bool CENTER>
-__global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
+__device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
+                                                    const double *forced_first, int lane) {
 	constexpr int P16 = 16 * T;
 	constexpr int NT = T * (T + 1) / 2;
 	const int p = args.p;
-	const int lane = threadIdx.x & 63;
 	const int kk = lane >> 4, lj = lane & 15;
-	const int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	if (gl >= args.n_groups) return;
-	const int64_t lo = args.row_offsets[args.group_base + gl];
-	const int64_t hi = args.row_offsets[args.group_base + gl + 1];
 
 	mid_gptr_t col[T];
 	bool real[T]; // column 16 I + lj exists (padding columns read column p - 1 and count as zeros)
@@ -138,6 +139,12 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	st.sy = st.syy = st.sw = st.first_y = 0.0;
 	st.have_first = false;
 	st.cnt = 0;
+	if (forced_first) {
+#pragma unroll
+		for (int I = 0; I < T; ++I) st.first[I] = real[I] ? forced_first[16 * I + lj] : 0.0;
+		st.first_y = forced_first[P16];
+		st.have_first = true;
+	}
 
 	// S steps (16 S rows) per loop trip, the next trip's loads in flight: per column a wave asks for 128 S
 	// contiguous bytes at a time (DRAM locality: a single 128-byte line per stream and trip ran at ~4 TB/s)
@@ -218,7 +225,6 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	}
 
 	// ---- the moment record, layout of accumulate_wide.hip ----
-	double *rec = args.moments + gl * (int64_t)wide_record_len(T);
 #pragma unroll
 	for (int t = 0; t < NT; ++t) {
 		double *tp = rec + (int64_t)t * 256; // tile-major, element (row, col) at row * 16 + col
@@ -256,18 +262,132 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	}
 }
 
+__device__ __forceinline__ SegHeader *mseg_header(void *t) { return static_cast<SegHeader *>(t); }
+__device__ __forceinline__ SegBigGroup *mseg_big(void *t) { return reinterpret_cast<SegBigGroup *>(mseg_header(t) + 1); }
+__device__ __forceinline__ SegEntry *mseg_entries(void *t) { return reinterpret_cast<SegEntry *>(mseg_big(t) + kSegMaxBig); }
+__device__ __forceinline__ double *mseg_first(void *t) { return reinterpret_cast<double *>(mseg_entries(t) + kSegMaxSegments); }
+__device__ __forceinline__ double *mseg_records(void *t, int T) { return mseg_first(t) + (size_t)kSegMaxBig * (16 * T + 2); }
+
+// Registration of a very large group by the wave that would have streamed it alone (~5 GB/s): find the group's
+// first valid row (the shift and the reference point of the constant-column test), store it, cut the rows into
+// segments for accumulate_mid_segments_kernel.
+__device__ void mid_register_big_group(const WideArgs &args, int64_t gl, int64_t lo, int64_t hi, int T, int lane) {
+	const int p = args.p;
+	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
+	int64_t rfirst = -1;
+	for (int64_t base = lo; base < hi && rfirst < 0; base += 64) {
+		const int64_t r = base + lane < hi ? base + lane : hi - 1;
+		bool ok = (base + lane < hi) && isfinite(args.y[r]);
+		for (int j = 0; j < p; ++j) ok = ok && isfinite(args.x_table[j][r]);
+		if (weighted) {
+			const double w = args.w[r];
+			ok = ok && isfinite(w) && (w > 0.0);
+		}
+		const unsigned long long b = __ballot(ok);
+		if (b != 0ull) rfirst = base + (__ffsll((long long)b) - 1);
+	}
+	SegHeader *h = mseg_header(args.seg_table);
+	const int64_t S = args.seg_rows;
+	const int nseg = (int)((hi - lo + S - 1) / S);
+	int slot = 0, base = 0;
+	if (lane == 0) {
+		slot = atomicAdd(&h->big_total, 1);
+		base = atomicAdd(&h->seg_total, nseg);
+	}
+	slot = __builtin_amdgcn_readfirstlane(slot);
+	base = __builtin_amdgcn_readfirstlane(base);
+	if (slot >= kSegMaxBig) return;
+	double *ff = mseg_first(args.seg_table) + (size_t)slot * (16 * T + 2);
+	for (int j = lane; j <= 16 * T; j += 64) {
+		double v = 0.0;
+		if (rfirst >= 0) v = j < p ? args.x_table[j][rfirst] : (j == 16 * T ? args.y[rfirst] : 0.0);
+		ff[j] = v;
+	}
+	if (lane == 0) {
+		SegBigGroup b;
+		b.g = gl; b.base = base; b.nseg = nseg; b.done = 0; b.pad = 0;
+		mseg_big(args.seg_table)[slot] = b;
+	}
+	for (int k = lane; k < nseg && base + k < kSegMaxSegments; k += 64) {
+		SegEntry e;
+		e.lo = lo + k * S;
+		e.hi = (e.lo + S < hi) ? e.lo + S : hi;
+		e.slot = slot; e.pad = 0;
+		mseg_entries(args.seg_table)[base + k] = e;
+	}
+}
+
+template <int T, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
+	const int lane = threadIdx.x & 63;
+	const int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (gl >= args.n_groups) return;
+	const int64_t lo = args.row_offsets[args.group_base + gl];
+	const int64_t hi = args.row_offsets[args.group_base + gl + 1];
+	if (args.seg_table && hi - lo > args.seg_rows) {
+		mid_register_big_group(args, gl, lo, hi, T, lane);
+		return;
+	}
+	mid_accumulate_rows<T, WEIGHTED, CENTER>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), nullptr, lane);
+}
+
+// One wavefront per registered segment; every segment of a group uses the group's first valid row as its shift,
+// so the wave that completes the last one merges by plain (ordered) sums.
+template <int T, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256) void accumulate_mid_segments_kernel(WideArgs args) {
+	constexpr int P16 = 16 * T;
+	constexpr int NT = T * (T + 1) / 2;
+	const int reclen = wide_record_len(T);
+	const int lane = threadIdx.x & 63;
+	const int v = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int)blockIdx.x * 4;
+	SegHeader *h = mseg_header(args.seg_table);
+	int total = h->seg_total;
+	if (total > kSegMaxSegments) total = kSegMaxSegments;
+	if (v >= total) return;
+	const SegEntry e = mseg_entries(args.seg_table)[v];
+	SegBigGroup *b = mseg_big(args.seg_table) + e.slot;
+	const double *ff = mseg_first(args.seg_table) + (size_t)e.slot * (P16 + 2);
+	double *recs = mseg_records(args.seg_table, T);
+	mid_accumulate_rows<T, WEIGHTED, CENTER>(args, e.lo, e.hi, recs + (int64_t)v * reclen, ff, lane);
+	__threadfence(); // this segment's record before the counter
+	int old = 0;
+	if (lane == 0) old = atomicAdd(&b->done, 1);
+	old = __builtin_amdgcn_readfirstlane(old);
+	if (old != b->nseg - 1) return;
+	__threadfence(); // every other segment's record after the counter
+	const double *src = recs + (int64_t)b->base * reclen;
+	double *dst = args.moments + b->g * (int64_t)reclen;
+	const int vec0 = NT * 256;
+	for (int k = lane; k < reclen; k += 64) {
+		const bool is_first = (k >= vec0 + 2 * P16 && k < vec0 + 3 * P16) || k == vec0 + 4 * P16 + 4; // first x / first y: shared
+		const bool is_flag = k >= vec0 + 3 * P16 && k < vec0 + 4 * P16;                                   // non-constant flags: OR
+		double acc = 0.0;
+		for (int t = 0; t < b->nseg; ++t) acc += src[(int64_t)t * reclen + k];
+		if (is_first) acc = src[k];
+		if (is_flag) acc = acc > 0.0 ? 1.0 : 0.0;
+		dst[k] = acc;
+	}
+}
+
 template <int T>
 hipError_t launch_mid_T(const WideArgs &a, hipStream_t stream) {
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
 	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
+	const dim3 seg_grid((unsigned)((kSegMaxSegments + 3) / 4)); // idle unless some group exceeded seg_rows
+#define ANOFOX_MID_LAUNCH(W, C)                                                                                  \
+	do {                                                                                                         \
+		hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C>), grid, block, 0, stream, a);                         \
+		if (a.seg_table) hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C>), seg_grid, block, 0, stream, a); \
+	} while (0)
 	if (weighted) {
-		if (center) hipLaunchKernelGGL((accumulate_mid_kernel<T, true, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((accumulate_mid_kernel<T, true, false>), grid, block, 0, stream, a);
+		if (center) ANOFOX_MID_LAUNCH(true, true);
+		else ANOFOX_MID_LAUNCH(true, false);
 	} else {
-		if (center) hipLaunchKernelGGL((accumulate_mid_kernel<T, false, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((accumulate_mid_kernel<T, false, false>), grid, block, 0, stream, a);
+		if (center) ANOFOX_MID_LAUNCH(false, true);
+		else ANOFOX_MID_LAUNCH(false, false);
 	}
+#undef ANOFOX_MID_LAUNCH
 	return hipGetLastError();
 }
 

@@ -148,7 +148,18 @@ struct WideArgs {
 	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
 	const int64_t *rule_counts; // optional [G_total], see BatchArgs
 	double *hc_df;        // [n_groups of this launch] scratch of launch_hc_wide: residual df, NaN = group skipped
+	// row splitting of very large groups, as in BatchArgs (here every segment is accumulated with the GROUP's first
+	// valid row as its shift, found when the group is registered, so that merging is a plain sum)
+	void *seg_table;
+	int64_t seg_rows;
 };
+
+// wide-record segment table: SegHeader | SegBigGroup[kSegMaxBig] | SegEntry[kSegMaxSegments] |
+//   first[kSegMaxBig][16 T + 2] (x at the group's first valid row, then y) | records[kSegMaxSegments][record_len]
+inline __host__ __device__ size_t wide_seg_table_bytes(int T) {
+	return sizeof(SegHeader) + sizeof(SegBigGroup) * kSegMaxBig + sizeof(SegEntry) * kSegMaxSegments +
+	       sizeof(double) * ((size_t)kSegMaxBig * (size_t)(16 * T + 2) + (size_t)kSegMaxSegments * (size_t)wide_record_len(T));
+}
 
 // per-row predictions (predict.hip), any p <= kWideMaxP
 struct PredictArgs {

@@ -133,7 +133,6 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
                     const double *d_y, const double *const *x_cols, const double *d_w,
                     const AnofoxHipBatchOptions &opt, double *d_core, double *d_inf, const int64_t *d_rule_counts,
                     AnofoxError *e) {
-	(void)n_rows;
 	const int T = wide_tiles((int)p);
 	const size_t rec_bytes = (size_t)wide_record_len(T) * sizeof(double);
 	// the moment scratch is reused by slabs of groups: at most ~1 GiB of it is live
@@ -143,7 +142,11 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	const size_t b_mom = align_up((size_t)slab * rec_bytes, 256);
 	const size_t b_rss = align_up((size_t)G * (p + 2) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)slab * sizeof(int32_t), 256);
-	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256 + kTcritTableBytes, "workspace", e)) return false;
+	const bool mid = solve_mid_supports((int)p);
+	static const bool mid_acc_on = !(getenv("ANOFOX_MID_ACC") && atoi(getenv("ANOFOX_MID_ACC")) == 0); // A/B switch for measurements
+	const bool mid_acc = mid_acc_on && accumulate_mid_supports((int)p);
+	const size_t b_seg = mid_acc ? align_up(wide_seg_table_bytes(T), 256) : 0; // very large groups are split (accumulate_mid.hip)
+	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256 + kTcritTableBytes + b_seg, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 
 	WideArgs a;
@@ -171,14 +174,16 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.rule_counts = d_rule_counts;
 
 	hipStream_t st = ctx->stream;
-	const bool mid = solve_mid_supports((int)p);
-	static const bool mid_acc_on = !(getenv("ANOFOX_MID_ACC") && atoi(getenv("ANOFOX_MID_ACC")) == 0); // A/B switch for measurements
-	const bool mid_acc = mid_acc_on && accumulate_mid_supports((int)p);
+	if (mid_acc) {
+		a.seg_table = base + b_mom + b_rss + b_lst + 256 + kTcritTableBytes;
+		a.seg_rows = seg_rows_for(n_rows);
+	}
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
 	for (int64_t g0 = 0; g0 < G; g0 += slab) {
 		a.group_base = g0;
 		a.n_groups = (G - g0 < slab) ? G - g0 : slab;
 		if (hip_fail(hipMemsetAsync(a.refine_count, 0, sizeof(int32_t), st), "hipMemsetAsync", e)) return false;
+		if (a.seg_table && hip_fail(hipMemsetAsync(a.seg_table, 0, sizeof(SegHeader), st), "hipMemsetAsync", e)) return false;
 		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 		if (ctx->timing) {
 			e0 = get_event(ctx);

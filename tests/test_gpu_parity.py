@@ -423,6 +423,36 @@ def test_very_large_groups_are_split_and_merged(pkg, ctx, model, icpt):
     _assert_vif_match(v, rv, 4, "split vif")
 
 
+@pytest.mark.parametrize("model,p", [("ols", 12), ("wls", 20), ("ridge", 32)])
+def test_very_large_groups_are_split_and_merged_mid(pkg, ctx, model, p):
+    """The same for the wave-per-group MFMA path (8 < p <= 32): segments share the group's first valid row."""
+    rng = np.random.default_rng(17 + p)
+    ns = [30_000, 5, 9_000, 0, 8193, 200]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    X = rng.uniform(-10, 10, (N, p)) + rng.uniform(-50, 50, p)
+    gid = np.repeat(np.arange(len(ns)), ns)
+    pos = np.arange(N) - offs[gid]
+    X[:, 0] += 1e-3 * pos
+    y = 2.0 + X @ rng.uniform(-1, 1, p) + rng.standard_normal(N)
+    w = rng.uniform(0.5, 1.5, N)
+    y[0:9000] = np.nan                                           # group 0: first segment entirely invalid
+    lo = offs[2]
+    X[lo:lo + 9000, 3] = 4.0                                     # constant column over both segments
+    X[lo:lo + 9000, 5] = np.where(np.arange(9000) < 8192, 1.0, 2.0)   # constant inside each segment only
+    X[lo + 3:lo + 9000:501, 1] = np.nan
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    for icpt in (True, False):
+        kw = dict(fit_intercept=icpt, compute_inference=True)
+        if model == "ridge":
+            kw["alpha"] = 0.7
+        wv = w if model == "wls" else None
+        core, inf = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+        rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
+        assert_records_match(core, rcore, p, inf, rinf, what=f"split mid {model} p={p} icpt={icpt}")
+        assert np.isnan(core[2, 3]) and not np.isnan(core[2, 5])
+
+
 def test_alpha_negative_and_bad_arguments(pkg, ctx):
     a = import_pkg("_abi")
     rng = np.random.default_rng(2)
