@@ -262,61 +262,6 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 	}
 }
 
-__device__ __forceinline__ SegHeader *mseg_header(void *t) { return static_cast<SegHeader *>(t); }
-__device__ __forceinline__ SegBigGroup *mseg_big(void *t) { return reinterpret_cast<SegBigGroup *>(mseg_header(t) + 1); }
-__device__ __forceinline__ SegEntry *mseg_entries(void *t) { return reinterpret_cast<SegEntry *>(mseg_big(t) + kSegMaxBig); }
-__device__ __forceinline__ double *mseg_first(void *t) { return reinterpret_cast<double *>(mseg_entries(t) + kSegMaxSegments); }
-__device__ __forceinline__ double *mseg_records(void *t, int T) { return mseg_first(t) + (size_t)kSegMaxBig * (16 * T + 2); }
-
-// Registration of a very large group by the wave that would have streamed it alone (~5 GB/s): find the group's
-// first valid row (the shift and the reference point of the constant-column test), store it, cut the rows into
-// segments for accumulate_mid_segments_kernel.
-__device__ void mid_register_big_group(const WideArgs &args, int64_t gl, int64_t lo, int64_t hi, int T, int lane) {
-	const int p = args.p;
-	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
-	int64_t rfirst = -1;
-	for (int64_t base = lo; base < hi && rfirst < 0; base += 64) {
-		const int64_t r = base + lane < hi ? base + lane : hi - 1;
-		bool ok = (base + lane < hi) && isfinite(args.y[r]);
-		for (int j = 0; j < p; ++j) ok = ok && isfinite(args.x_table[j][r]);
-		if (weighted) {
-			const double w = args.w[r];
-			ok = ok && isfinite(w) && (w > 0.0);
-		}
-		const unsigned long long b = __ballot(ok);
-		if (b != 0ull) rfirst = base + (__ffsll((long long)b) - 1);
-	}
-	SegHeader *h = mseg_header(args.seg_table);
-	const int64_t S = args.seg_rows;
-	const int nseg = (int)((hi - lo + S - 1) / S);
-	int slot = 0, base = 0;
-	if (lane == 0) {
-		slot = atomicAdd(&h->big_total, 1);
-		base = atomicAdd(&h->seg_total, nseg);
-	}
-	slot = __builtin_amdgcn_readfirstlane(slot);
-	base = __builtin_amdgcn_readfirstlane(base);
-	if (slot >= kSegMaxBig) return;
-	double *ff = mseg_first(args.seg_table) + (size_t)slot * (16 * T + 2);
-	for (int j = lane; j <= 16 * T; j += 64) {
-		double v = 0.0;
-		if (rfirst >= 0) v = j < p ? args.x_table[j][rfirst] : (j == 16 * T ? args.y[rfirst] : 0.0);
-		ff[j] = v;
-	}
-	if (lane == 0) {
-		SegBigGroup b;
-		b.g = gl; b.base = base; b.nseg = nseg; b.done = 0; b.pad = 0;
-		mseg_big(args.seg_table)[slot] = b;
-	}
-	for (int k = lane; k < nseg && base + k < kSegMaxSegments; k += 64) {
-		SegEntry e;
-		e.lo = lo + k * S;
-		e.hi = (e.lo + S < hi) ? e.lo + S : hi;
-		e.slot = slot; e.pad = 0;
-		mseg_entries(args.seg_table)[base + k] = e;
-	}
-}
-
 template <int T, bool WEIGHTED, bool CENTER>
 __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const int lane = threadIdx.x & 63;
@@ -325,7 +270,7 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const int64_t lo = args.row_offsets[args.group_base + gl];
 	const int64_t hi = args.row_offsets[args.group_base + gl + 1];
 	if (args.seg_table && hi - lo > args.seg_rows) {
-		mid_register_big_group(args, gl, lo, hi, T, lane);
+		wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments);
 		return;
 	}
 	mid_accumulate_rows<T, WEIGHTED, CENTER>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), nullptr, lane);
@@ -340,14 +285,14 @@ __global__ __launch_bounds__(256) void accumulate_mid_segments_kernel(WideArgs a
 	const int reclen = wide_record_len(T);
 	const int lane = threadIdx.x & 63;
 	const int v = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int)blockIdx.x * 4;
-	SegHeader *h = mseg_header(args.seg_table);
+	SegHeader *h = wseg_header(args.seg_table);
 	int total = h->seg_total;
 	if (total > kSegMaxSegments) total = kSegMaxSegments;
 	if (v >= total) return;
-	const SegEntry e = mseg_entries(args.seg_table)[v];
-	SegBigGroup *b = mseg_big(args.seg_table) + e.slot;
-	const double *ff = mseg_first(args.seg_table) + (size_t)e.slot * (P16 + 2);
-	double *recs = mseg_records(args.seg_table, T);
+	const SegEntry e = wseg_entries(args.seg_table, kSegMaxBig)[v];
+	SegBigGroup *b = wseg_big(args.seg_table) + e.slot;
+	const double *ff = wseg_first(args.seg_table, kSegMaxBig, kSegMaxSegments) + (size_t)e.slot * (P16 + 2);
+	double *recs = wseg_records(args.seg_table, T, kSegMaxBig, kSegMaxSegments);
 	mid_accumulate_rows<T, WEIGHTED, CENTER>(args, e.lo, e.hi, recs + (int64_t)v * reclen, ff, lane);
 	__threadfence(); // this segment's record before the counter
 	int old = 0;

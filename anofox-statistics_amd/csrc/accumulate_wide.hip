@@ -117,17 +117,17 @@ __device__ __forceinline__ void compute_chunk(const double *img, int ycol, int l
 	}
 }
 
+// The rows [lo, hi) of one group — or of one segment of a very large group, then with the group's first valid
+// row handed in (`forced_first`: x per column, y at index 16 T) — into one moment record at `rec`, by a workgroup.
 template <int T, bool WEIGHTED, bool CENTER>
-__global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) {
+__device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
+                                                     const double *forced_first) {
 	using Cfg = WideCfg<T>;
 	constexpr int P16 = 16 * T;
 	const int p = args.p;
 	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	const int64_t g = blockIdx.x;
-	const int64_t lo = args.row_offsets[args.group_base + g];
-	const int64_t hi = args.row_offsets[args.group_base + g + 1];
 	const int64_t nrows = hi - lo;
 
 	extern __shared__ double lds[];
@@ -174,6 +174,12 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 	double first_y = 0.0;
 	bool have_first = false;
 	int cnt = 0;
+	if (forced_first) {
+#pragma unroll
+		for (int I = 0; I < T; ++I) first[I] = forced_first[16 * I + (lane & 15)]; // padding columns: 0
+		first_y = forced_first[P16];
+		have_first = true;
+	}
 
 	const int64_t n_chunks = (nrows + kChunkRows - 1) / kChunkRows;
 	double v0[kMaxLoads], v1[kMaxLoads]; // staging registers: rows 2*rp, 2*rp+1 of this lane's columns
@@ -274,7 +280,6 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 	}
 
 	// ---- write the moment record ----
-	double *rec = args.moments + g * (int64_t)wide_record_len(T);
 	// tiles: tile-major, 256 doubles each, element (row, col) at row*16 + col
 	{
 		int tile = 0;
@@ -327,6 +332,57 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 	}
 }
 
+template <int T, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) {
+	const int64_t g = blockIdx.x;
+	const int64_t lo = args.row_offsets[args.group_base + g];
+	const int64_t hi = args.row_offsets[args.group_base + g + 1];
+	if (args.seg_table && hi - lo > args.seg_rows) {
+		// four waves stream a group at ~25 GB/s: hand it to accumulate_wide_segments_kernel in pieces
+		if (threadIdx.x < 64) wide_register_big_group(args, g, lo, hi, T, (int)threadIdx.x, kWideSegMaxBig, kWideSegMaxSegments);
+		return;
+	}
+	wide_accumulate_rows<T, WEIGHTED, CENTER>(args, lo, hi, args.moments + g * (int64_t)wide_record_len(T), nullptr);
+}
+
+// One workgroup per registered segment; every segment of a group uses the group's first valid row as its shift,
+// so the workgroup that completes the last one merges by plain (ordered) sums.
+template <int T, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256, 2) void accumulate_wide_segments_kernel(WideArgs args) {
+	constexpr int P16 = 16 * T;
+	constexpr int NT = T * (T + 1) / 2;
+	const int reclen = wide_record_len(T);
+	const int v = blockIdx.x;
+	SegHeader *h = wseg_header(args.seg_table);
+	int total = h->seg_total;
+	if (total > kWideSegMaxSegments) total = kWideSegMaxSegments;
+	if (v >= total) return;
+	const SegEntry e = wseg_entries(args.seg_table, kWideSegMaxBig)[v];
+	SegBigGroup *b = wseg_big(args.seg_table) + e.slot;
+	const double *ff = wseg_first(args.seg_table, kWideSegMaxBig, kWideSegMaxSegments) + (size_t)e.slot * (P16 + 2);
+	double *recs = wseg_records(args.seg_table, T, kWideSegMaxBig, kWideSegMaxSegments);
+	wide_accumulate_rows<T, WEIGHTED, CENTER>(args, e.lo, e.hi, recs + (int64_t)v * reclen, ff);
+	__shared__ int last;
+	__threadfence(); // this segment's record before the counter
+	__syncthreads();
+	if (threadIdx.x == 0) last = (atomicAdd(&b->done, 1) == b->nseg - 1) ? 1 : 0;
+	__syncthreads();
+	if (!last) return;
+	__threadfence(); // every other segment's record after the counter
+	const double *src = recs + (int64_t)b->base * reclen;
+	double *dst = args.moments + b->g * (int64_t)reclen;
+	const int vec0 = NT * 256;
+	for (int k = threadIdx.x; k < reclen; k += 256) {
+		const bool is_first = (k >= vec0 + 2 * P16 && k < vec0 + 3 * P16) || k == vec0 + 4 * P16 + 4; // first x / first y: shared
+		const bool is_flag = k >= vec0 + 3 * P16 && k < vec0 + 4 * P16;                                   // non-constant flags: OR
+		double acc = 0.0;
+		for (int t = 0; t < b->nseg; ++t) acc += src[(int64_t)t * reclen + k];
+		if (is_first) acc = src[k];
+		if (is_flag) acc = acc > 0.0 ? 1.0 : 0.0;
+		dst[k] = acc;
+	}
+}
+
 template <int T>
 hipError_t launch_T(const WideArgs &a, hipStream_t stream) {
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
@@ -334,13 +390,20 @@ hipError_t launch_T(const WideArgs &a, hipStream_t stream) {
 	const int ncol_pad = wide_ncol_pad(a.p, weighted);
 	const size_t lds = (size_t)2 * ncol_pad * kLdsStride * sizeof(double) + (size_t)ncol_pad * sizeof(double *) + 64;
 	const dim3 grid((unsigned)a.n_groups), block(256);
+	const dim3 seg_grid((unsigned)kWideSegMaxSegments); // idle unless some group exceeded seg_rows
+#define ANOFOX_WIDE_LAUNCH(W, C)                                                                                  \
+	do {                                                                                                          \
+		hipLaunchKernelGGL((accumulate_wide_kernel<T, W, C>), grid, block, lds, stream, a);                       \
+		if (a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, W, C>), seg_grid, block, lds, stream, a); \
+	} while (0)
 	if (weighted) {
-		if (center) hipLaunchKernelGGL((accumulate_wide_kernel<T, true, true>), grid, block, lds, stream, a);
-		else hipLaunchKernelGGL((accumulate_wide_kernel<T, true, false>), grid, block, lds, stream, a);
+		if (center) ANOFOX_WIDE_LAUNCH(true, true);
+		else ANOFOX_WIDE_LAUNCH(true, false);
 	} else {
-		if (center) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true>), grid, block, lds, stream, a);
-		else hipLaunchKernelGGL((accumulate_wide_kernel<T, false, false>), grid, block, lds, stream, a);
+		if (center) ANOFOX_WIDE_LAUNCH(false, true);
+		else ANOFOX_WIDE_LAUNCH(false, false);
 	}
+#undef ANOFOX_WIDE_LAUNCH
 	return hipGetLastError();
 }
 

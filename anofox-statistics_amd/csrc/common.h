@@ -156,10 +156,84 @@ struct WideArgs {
 
 // wide-record segment table: SegHeader | SegBigGroup[kSegMaxBig] | SegEntry[kSegMaxSegments] |
 //   first[kSegMaxBig][16 T + 2] (x at the group's first valid row, then y) | records[kSegMaxSegments][record_len]
-inline __host__ __device__ size_t wide_seg_table_bytes(int T) {
-	return sizeof(SegHeader) + sizeof(SegBigGroup) * kSegMaxBig + sizeof(SegEntry) * kSegMaxSegments +
-	       sizeof(double) * ((size_t)kSegMaxBig * (size_t)(16 * T + 2) + (size_t)kSegMaxSegments * (size_t)wide_record_len(T));
+inline __host__ __device__ size_t wide_seg_table_bytes(int T, int max_big, int max_seg) {
+	return sizeof(SegHeader) + sizeof(SegBigGroup) * (size_t)max_big + sizeof(SegEntry) * (size_t)max_seg +
+	       sizeof(double) * ((size_t)max_big * (size_t)(16 * T + 2) + (size_t)max_seg * (size_t)wide_record_len(T));
 }
+// workgroup-per-segment path (accumulate_wide.hip): a quarter of the segments fill the chip (4 waves each), and the
+// segment records are up to 74 KB
+constexpr int kWideSegTarget = 512;
+constexpr int kWideSegMaxBig = kWideSegTarget + 8;
+constexpr int kWideSegMaxSegments = 2 * kWideSegTarget + 16;
+inline __host__ __device__ int64_t wide_seg_rows_for(int64_t n_rows) {
+	int64_t s = (n_rows + kWideSegTarget - 1) / kWideSegTarget;
+	s = (s + 127) / 128 * 128;
+	return s < kSegMinRows ? kSegMinRows : s;
+}
+
+
+// ---- segment tables of the wide-record paths (accumulate_mid.hip, accumulate_wide.hip): device-side accessors and
+// the registration of a very large group.  max_big / max_seg are the capacities the table was laid out with.
+#ifdef __HIPCC__
+__device__ __forceinline__ SegHeader *wseg_header(void *t) { return static_cast<SegHeader *>(t); }
+__device__ __forceinline__ SegBigGroup *wseg_big(void *t) { return reinterpret_cast<SegBigGroup *>(wseg_header(t) + 1); }
+__device__ __forceinline__ SegEntry *wseg_entries(void *t, int max_big) { return reinterpret_cast<SegEntry *>(wseg_big(t) + max_big); }
+__device__ __forceinline__ double *wseg_first(void *t, int max_big, int max_seg) {
+	return reinterpret_cast<double *>(wseg_entries(t, max_big) + max_seg);
+}
+__device__ __forceinline__ double *wseg_records(void *t, int T, int max_big, int max_seg) {
+	return wseg_first(t, max_big, max_seg) + (size_t)max_big * (16 * T + 2);
+}
+
+// Called by ONE wavefront for a group it will not stream itself: find the group's first valid row (the shift and
+// the reference point of the constant-column test: ols.rs:59-87), store it, cut the rows into segments.
+__device__ inline void wide_register_big_group(const WideArgs &args, int64_t gl, int64_t lo, int64_t hi, int T, int lane,
+                                               int max_big, int max_seg) {
+	const int p = args.p;
+	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
+	int64_t rfirst = -1;
+	for (int64_t base = lo; base < hi && rfirst < 0; base += 64) {
+		const int64_t r = base + lane < hi ? base + lane : hi - 1;
+		bool ok = (base + lane < hi) && isfinite(args.y[r]);
+		for (int j = 0; j < p; ++j) ok = ok && isfinite(args.x_table[j][r]);
+		if (weighted) {
+			const double w = args.w[r];
+			ok = ok && isfinite(w) && (w > 0.0);
+		}
+		const unsigned long long b = __ballot(ok);
+		if (b != 0ull) rfirst = base + (__ffsll((long long)b) - 1);
+	}
+	SegHeader *h = wseg_header(args.seg_table);
+	const int64_t S = args.seg_rows;
+	const int nseg = (int)((hi - lo + S - 1) / S);
+	int slot = 0, base = 0;
+	if (lane == 0) {
+		slot = atomicAdd(&h->big_total, 1);
+		base = atomicAdd(&h->seg_total, nseg);
+	}
+	slot = __builtin_amdgcn_readfirstlane(slot);
+	base = __builtin_amdgcn_readfirstlane(base);
+	if (slot >= max_big) return;
+	double *ff = wseg_first(args.seg_table, max_big, max_seg) + (size_t)slot * (16 * T + 2);
+	for (int j = lane; j <= 16 * T; j += 64) {
+		double v = 0.0;
+		if (rfirst >= 0) v = j < p ? args.x_table[j][rfirst] : (j == 16 * T ? args.y[rfirst] : 0.0);
+		ff[j] = v;
+	}
+	if (lane == 0) {
+		SegBigGroup b;
+		b.g = gl; b.base = base; b.nseg = nseg; b.done = 0; b.pad = 0;
+		wseg_big(args.seg_table)[slot] = b;
+	}
+	for (int k = lane; k < nseg && base + k < max_seg; k += 64) {
+		SegEntry e;
+		e.lo = lo + k * S;
+		e.hi = (e.lo + S < hi) ? e.lo + S : hi;
+		e.slot = slot; e.pad = 0;
+		wseg_entries(args.seg_table, max_big)[base + k] = e;
+	}
+}
+#endif
 
 // per-row predictions (predict.hip), any p <= kWideMaxP
 struct PredictArgs {

@@ -145,7 +145,9 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	const bool mid = solve_mid_supports((int)p);
 	static const bool mid_acc_on = !(getenv("ANOFOX_MID_ACC") && atoi(getenv("ANOFOX_MID_ACC")) == 0); // A/B switch for measurements
 	const bool mid_acc = mid_acc_on && accumulate_mid_supports((int)p);
-	const size_t b_seg = mid_acc ? align_up(wide_seg_table_bytes(T), 256) : 0; // very large groups are split (accumulate_mid.hip)
+	// very large groups are split into row segments (accumulate_mid.hip: a wave each; accumulate_wide.hip: a workgroup each)
+	const size_t b_seg = align_up(mid_acc ? wide_seg_table_bytes(T, kSegMaxBig, kSegMaxSegments)
+	                                      : wide_seg_table_bytes(T, kWideSegMaxBig, kWideSegMaxSegments), 256);
 	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256 + kTcritTableBytes + b_seg, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 
@@ -174,10 +176,8 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.rule_counts = d_rule_counts;
 
 	hipStream_t st = ctx->stream;
-	if (mid_acc) {
-		a.seg_table = base + b_mom + b_rss + b_lst + 256 + kTcritTableBytes;
-		a.seg_rows = seg_rows_for(n_rows);
-	}
+	a.seg_table = base + b_mom + b_rss + b_lst + 256 + kTcritTableBytes;
+	a.seg_rows = mid_acc ? seg_rows_for(n_rows) : wide_seg_rows_for(n_rows);
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
 	for (int64_t g0 = 0; g0 < G; g0 += slab) {
 		a.group_base = g0;

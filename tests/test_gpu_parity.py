@@ -423,9 +423,10 @@ def test_very_large_groups_are_split_and_merged(pkg, ctx, model, icpt):
     _assert_vif_match(v, rv, 4, "split vif")
 
 
-@pytest.mark.parametrize("model,p", [("ols", 12), ("wls", 20), ("ridge", 32)])
+@pytest.mark.parametrize("model,p", [("ols", 12), ("wls", 20), ("ridge", 32), ("ols", 40), ("wls", 100)])
 def test_very_large_groups_are_split_and_merged_mid(pkg, ctx, model, p):
-    """The same for the wave-per-group MFMA path (8 < p <= 32): segments share the group's first valid row."""
+    """The same for the MFMA paths (8 < p <= 32: a wave per segment; beyond: a workgroup per segment): segments
+    share the group's first valid row, the last finisher sums the segment records."""
     rng = np.random.default_rng(17 + p)
     ns = [30_000, 5, 9_000, 0, 8193, 200]
     offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
