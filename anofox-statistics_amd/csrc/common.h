@@ -246,6 +246,18 @@ struct PredictArgs {
 	int p;
 	double confidence_level;
 	void *tcrit_table;
+	// rows beyond the first seg_rows of a group are handed to extra wavefronts (PredictSegTable, filled by the group's
+	// own wave); nullptr disables it
+	void *seg_table;
+	int64_t seg_rows;
+};
+struct PredictSegEntry {
+	int64_t g, lo, hi;
+};
+struct PredictSegTable {
+	int32_t count;
+	int32_t pad[15];
+	PredictSegEntry entries[kSegTargetWaves + 16]; // sum over groups of (ceil(n_g / seg_rows) - 1) <= n_rows / seg_rows <= 2048
 };
 hipError_t launch_predict(const PredictArgs &a, hipStream_t stream);
 

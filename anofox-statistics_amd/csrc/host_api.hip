@@ -462,10 +462,12 @@ bool anofox_hip_fit_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t
 namespace {
 
 // per-row predictions from fit records; uses (and zeroes) the t table at the end of the workspace
-bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *const *x_cols,
+bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const int64_t *d_off, const double *const *x_cols,
                  const double *d_core, double confidence, double *d_pred, AnofoxError *e) {
 	if (G == 0) return true;
-	if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, kTcritTableBytes + (size_t)G * sizeof(double), "predict scratch", e)) return false;
+	// scratch: t memo | overflow-segment table (its count sits right behind the memo: one memset) | margin[G]
+	const size_t b_tab = align_up(sizeof(PredictSegTable), 256);
+	if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, kTcritTableBytes + b_tab + (size_t)G * sizeof(double), "predict scratch", e)) return false;
 	PredictArgs a;
 	memset(&a, 0, sizeof a);
 	a.row_offsets = d_off;
@@ -476,8 +478,10 @@ bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_of
 	a.p = (int)p;
 	a.confidence_level = confidence;
 	a.tcrit_table = ctx->aux;
-	a.margin = (double *)((char *)ctx->aux + kTcritTableBytes);
-	if (hip_fail(hipMemsetAsync(ctx->aux, 0, kTcritTableBytes, ctx->stream), "hipMemsetAsync", e)) return false;
+	a.seg_table = (char *)ctx->aux + kTcritTableBytes;
+	a.seg_rows = seg_rows_for(n_rows);
+	a.margin = (double *)((char *)ctx->aux + kTcritTableBytes + b_tab);
+	if (hip_fail(hipMemsetAsync(ctx->aux, 0, kTcritTableBytes + 64, ctx->stream), "hipMemsetAsync", e)) return false;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->timing) {
 		e0 = get_event(ctx);
@@ -498,7 +502,6 @@ bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, si
                                      const int64_t *d_row_offsets, const double *const *x_cols, const double *d_core,
                                      double confidence_level, double *d_pred, AnofoxError *out_error) {
 	reset_error(out_error);
-	(void)n_rows;
 	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
 	if (n_groups < 0 || n_features == 0 || n_features > (size_t)kWideMaxP || !x_cols) {
 		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "invalid n_groups / n_features / x");
@@ -510,7 +513,7 @@ bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, si
 	}
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
-	return run_predict(ctx, n_groups, n_features, d_row_offsets, x_cols, d_core, confidence_level, d_pred, out_error);
+	return run_predict(ctx, n_groups, n_features, n_rows, d_row_offsets, x_cols, d_core, confidence_level, d_pred, out_error);
 }
 
 bool anofox_hip_fit_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
@@ -528,7 +531,7 @@ bool anofox_hip_fit_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups
 	if (!run_device_batch(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, options, d_core, nullptr,
 	                      out_error, d_train_counts))
 		return false;
-	return run_predict(ctx, n_groups, n_features, d_row_offsets, x_cols, d_core, options.confidence_level, d_pred,
+	return run_predict(ctx, n_groups, n_features, n_rows, d_row_offsets, x_cols, d_core, options.confidence_level, d_pred,
 	                   out_error);
 }
 
@@ -599,7 +602,7 @@ bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int64_t n_groups, 
 	cur += b_core;
 	double *d_pred = (double *)cur;
 	if (!run_device_batch(ctx, n_groups, p, n_rows, d_off, d_y, d_x, d_w, options, d_core, nullptr, out_error, d_cnt)) return false;
-	if (!run_predict(ctx, n_groups, p, d_off, d_x, d_core, options.confidence_level, d_pred, out_error)) return false;
+	if (!run_predict(ctx, n_groups, p, n_rows, d_off, d_x, d_core, options.confidence_level, d_pred, out_error)) return false;
 	if (hip_fail(hipMemcpyAsync(core, d_core, G * core_len * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;
 	if (R > 0 && hip_fail(hipMemcpyAsync(pred, d_pred, R * 3 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H pred", out_error)) return false;
 	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
@@ -1146,7 +1149,7 @@ bool anofox_predict(const AnofoxDataArray *x, size_t x_count, const double *coef
 			cur += align_up(core.size() * sizeof(double), 256);
 			double *d_pred = (double *)cur;
 			ok = ok && !hip_fail(hipMemcpyAsync(d_core, core.data(), core.size() * sizeof(double), hipMemcpyHostToDevice, st), "H2D", out_error);
-			ok = ok && run_predict(ctx, 1, p, d_off, d_x, d_core, 0.95, d_pred, out_error);
+			ok = ok && run_predict(ctx, 1, p, (int64_t)n, d_off, d_x, d_core, 0.95, d_pred, out_error);
 			ok = ok && !hip_fail(hipMemcpyAsync(pred.data(), d_pred, 3 * n * sizeof(double), hipMemcpyDeviceToHost, st), "D2H", out_error);
 			ok = ok && !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
 		}

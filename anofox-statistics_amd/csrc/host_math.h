@@ -10,7 +10,8 @@ namespace hostmath {
 inline double betacf(double a, double b, double x) {
 	const double qab = a + b, qap = a + 1.0, qam = a - 1.0;
 	double am = 1.0, bm = 1.0, az = 1.0, bz = 1.0 - qab * x / qap;
-	for (int m = 1; m <= 10000; ++m) {
+	const int cap = 10000 + (int)(4.0 * sqrt(a > b ? a : b)); // O(sqrt(max(a, b))) terms near the mode
+	for (int m = 1; m <= cap; ++m) {
 		const double em = m, tem = em + em;
 		double d = em * (b - em) * x / ((qam + tem) * (a + tem));
 		const double ap = az + d * am, bp = bz + d * bm;
@@ -39,6 +40,21 @@ inline double t_upper(double t, double df) { return 0.5 * betainc(0.5 * df, 0.5,
 // quantile at prob in (0.5, 1)
 inline double t_quantile_upper(double prob, double df) {
 	const double tail = 1.0 - prob;
+	if (df > 1e5) {
+		// Cornish-Fisher series around the normal quantile (Abramowitz & Stegun 26.7.5), exact to < 1e-16 here;
+		// z by bisection on the normal tail
+		double zl = 0.0, zh = 40.0;
+		for (int i = 0; i < 200; ++i) {
+			const double zm = 0.5 * (zl + zh);
+			if (0.5 * erfc(zm * M_SQRT1_2) > tail) zl = zm; else zh = zm;
+		}
+		const double z = 0.5 * (zl + zh), z2 = z * z, r = 1.0 / df;
+		const double g1 = z * (z2 + 1.0) * 0.25;
+		const double g2 = z * ((5.0 * z2 + 16.0) * z2 + 3.0) * (1.0 / 96.0);
+		const double g3 = z * (((3.0 * z2 + 19.0) * z2 + 17.0) * z2 - 15.0) * (1.0 / 384.0);
+		const double g4 = z * ((((79.0 * z2 + 776.0) * z2 + 1482.0) * z2 - 1920.0) * z2 - 945.0) * (1.0 / 92160.0);
+		return z + r * (g1 + r * (g2 + r * (g3 + r * g4)));
+	}
 	double lo = 0.0, hi = 1.0;
 	for (int i = 0; i < 1100 && t_upper(hi, df) > tail; ++i) { lo = hi; hi *= 2.0; }
 	const double lnc = lgamma(0.5 * (df + 1.0)) - lgamma(0.5 * df) - 0.5 * log(df * M_PI);

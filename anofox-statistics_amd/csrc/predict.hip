@@ -43,13 +43,28 @@ __global__ __launch_bounds__(256) void predict_margin_kernel(PredictArgs args) {
 	args.margin[g] = margin;
 }
 
-__global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
-	__shared__ double coef_s[4][kWideMaxP];
-	__shared__ int dead_s[4][kWideMaxP];
-	const int lane = threadIdx.x & 63;
-	const int wv = threadIdx.x >> 6;
-	const int64_t g = (int64_t)blockIdx.x * 4 + wv;
-	if (g >= args.n_groups) return;
+// A wavefront streams its group at a few GB/s only: rows beyond the first seg_rows are handed to extra wavefronts
+// (the SEGMENTS launch).  Called by the group's own wave; returns the end of the rows it keeps.
+__device__ __forceinline__ int64_t predict_register_overflow(const PredictArgs &args, int64_t g, int64_t lo, int64_t hi, int lane) {
+	const int64_t S = args.seg_rows;
+	if (!args.seg_table || hi - lo <= S) return hi;
+	PredictSegTable *t = static_cast<PredictSegTable *>(args.seg_table);
+	const int extra = (int)((hi - lo - 1) / S);
+	int base = 0;
+	if (lane == 0) base = atomicAdd(&t->count, extra);
+	base = __builtin_amdgcn_readfirstlane(base);
+	for (int k = lane; k < extra && base + k < kSegTargetWaves + 16; k += 64) {
+		PredictSegEntry e;
+		e.g = g;
+		e.lo = lo + (k + 1) * S;
+		e.hi = e.lo + S < hi ? e.lo + S : hi;
+		t->entries[base + k] = e;
+	}
+	return lo + S;
+}
+
+__device__ __forceinline__ void predict_rows_generic(const PredictArgs &args, int64_t g, int64_t lo, int64_t hi, double (*coef_s)[kWideMaxP],
+                                                     int (*dead_s)[kWideMaxP], int lane, int wv) {
 	const int p = args.p;
 	const double *core = args.core + g * (int64_t)(p + 6);
 	for (int j = lane; j < p; j += 64) {
@@ -64,7 +79,6 @@ __global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
 	const double margin = args.margin[g]; // 0 => bounds equal yhat
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the wave's own LDS writes above
 	__builtin_amdgcn_wave_barrier();
-	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
 	const double nanv = __builtin_nan("");
 	for (int64_t r = lo + lane; r < hi; r += 64) {
 		double yhat = b0;
@@ -79,15 +93,49 @@ __global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
 	}
 }
 
+// SEGMENTS = false: wave per group (its first seg_rows rows); true: wave per registered overflow segment
+template <bool SEGMENTS>
+__global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
+	__shared__ double coef_s[4][kWideMaxP];
+	__shared__ int dead_s[4][kWideMaxP];
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	const int64_t v = (int64_t)blockIdx.x * 4 + wv;
+	int64_t g, lo, hi;
+	if (SEGMENTS) {
+		const PredictSegTable *t = static_cast<const PredictSegTable *>(args.seg_table);
+		int n = t->count;
+		if (n > kSegTargetWaves + 16) n = kSegTargetWaves + 16;
+		if (v >= n) return;
+		g = t->entries[v].g; lo = t->entries[v].lo; hi = t->entries[v].hi;
+	} else {
+		if (v >= args.n_groups) return;
+		g = v; lo = args.row_offsets[g];
+		hi = predict_register_overflow(args, g, lo, args.row_offsets[g + 1], lane);
+	}
+	predict_rows_generic(args, g, lo, hi, coef_s, dead_s, lane, wv);
+}
+
 // p <= 8: coefficients in registers, 128-row tiles with one 16-byte load per column and lane (rows 2l, 2l+1),
 // all loads of a tile in flight together; 48 contiguous output bytes per lane.
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
 
-template <int P>
+template <int P, bool SEGMENTS>
 __global__ __launch_bounds__(256) void predict_narrow_kernel(PredictArgs args) {
 	const int lane = threadIdx.x & 63;
-	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
-	if (g >= args.n_groups) return;
+	const int64_t v = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+	int64_t g, lo, hi;
+	if (SEGMENTS) {
+		const PredictSegTable *t = static_cast<const PredictSegTable *>(args.seg_table);
+		int n = t->count;
+		if (n > kSegTargetWaves + 16) n = kSegTargetWaves + 16;
+		if (v >= n) return;
+		g = t->entries[v].g; lo = t->entries[v].lo; hi = t->entries[v].hi;
+	} else {
+		if (v >= args.n_groups) return;
+		g = v; lo = args.row_offsets[g];
+		hi = predict_register_overflow(args, g, lo, args.row_offsets[g + 1], lane);
+	}
 	const double *core = args.core + g * (int64_t)(P + 6);
 	double coef[P];
 	bool dead[P];
@@ -101,7 +149,6 @@ __global__ __launch_bounds__(256) void predict_narrow_kernel(PredictArgs args) {
 	const bool is_null = core[P + 5] != 0.0;
 	const double b0 = isnan(icpt) ? 0.0 : icpt;
 	const double margin = args.margin[g];
-	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
 	const double nanv = __builtin_nan("");
 	for (int64_t base = lo; base < hi; base += 128) {
 		const int64_t r0 = base + 2 * lane;
@@ -152,7 +199,9 @@ __global__ __launch_bounds__(256) void predict_narrow_kernel(PredictArgs args) {
 
 template <int P>
 hipError_t launch_predict_p(const PredictArgs &a, hipStream_t stream) {
-	hipLaunchKernelGGL((predict_narrow_kernel<P>), dim3((unsigned)((a.n_groups + 3) / 4)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL((predict_narrow_kernel<P, false>), dim3((unsigned)((a.n_groups + 3) / 4)), dim3(256), 0, stream, a);
+	if (a.seg_table) // idle unless some group exceeded seg_rows
+		hipLaunchKernelGGL((predict_narrow_kernel<P, true>), dim3((unsigned)((kSegTargetWaves + 16 + 3) / 4)), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 
@@ -172,7 +221,8 @@ hipError_t launch_predict(const PredictArgs &a, hipStream_t stream) {
 	case 8: return launch_predict_p<8>(a, stream);
 	default: break;
 	}
-	hipLaunchKernelGGL(predict_kernel, dim3((unsigned)((a.n_groups + 3) / 4)), dim3(256), 0, stream, a);
+	hipLaunchKernelGGL(predict_kernel<false>, dim3((unsigned)((a.n_groups + 3) / 4)), dim3(256), 0, stream, a);
+	if (a.seg_table) hipLaunchKernelGGL(predict_kernel<true>, dim3((unsigned)((kSegTargetWaves + 16 + 3) / 4)), dim3(256), 0, stream, a);
 	return hipGetLastError();
 }
 

@@ -454,6 +454,52 @@ def test_very_large_groups_are_split_and_merged_mid(pkg, ctx, model, p):
         assert np.isnan(core[2, 3]) and not np.isnan(core[2, 5])
 
 
+@pytest.mark.parametrize("p", [3, 8, 12])
+def test_fit_predict_on_very_large_groups(pkg, ctx, p):
+    """Rows beyond the first seg_rows of a group are predicted by extra wavefronts (predict.hip)."""
+    rng = np.random.default_rng(5 + p)
+    ns = [40_000, 7, 8193, 0, 20_000]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    X = rng.uniform(-5, 5, (N, p))
+    y = 1.0 + X @ rng.uniform(-1, 1, p) + 0.1 * rng.standard_normal(N)
+    y[::5] = np.nan                                               # prediction rows
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    core, pred = pkg.fit_predict_batch_host(offs, y, x_cols, None, _opts(pkg, "ols", confidence_level=0.9), ctx=ctx)
+    rcore, rpred = oracle.fit_predict_groups(y, x_cols, offs, model="ols", confidence_level=0.9)
+    assert_records_match(core, rcore, p, what=f"big fit_predict p={p}")
+    assert np.array_equal(np.isnan(pred), np.isnan(rpred))
+    m = ~np.isnan(rpred)
+    assert np.max(np.abs(pred[m] - rpred[m]) / np.maximum(np.abs(rpred[m]), 1.0)) < 1e-9
+
+
+def test_inference_with_millions_of_rows(pkg, ctx):
+    """df ~ 3e6: the incomplete-beta continued fraction needs thousands of terms there and ln Gamma(a + 1/2) -
+    ln Gamma(a) cancels; p-values and critical values are checked against scipy's Student-t."""
+    from scipy import stats as sps
+    rng = np.random.default_rng(77)
+    n = 3_000_000
+    X = rng.standard_normal((n, 3))
+    y = 0.5 + X @ np.array([0.0008, 0.3, 0.0]) + rng.standard_normal(n)     # weak, strong and null effects
+    offs = np.array([0, n], dtype=np.int64)
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(3)]
+    for hc in ("none", "hc1"):
+        core, inf = _host_fit(pkg, ctx, "ols", offs, y, x_cols, compute_inference=True, confidence_level=0.99, hc_type=hc)
+        assert core[0, 8] == 0
+        df = n - 4
+        coef, se, tv, pv, lo, hi = core[0, :3], inf[0, 0:3], inf[0, 3:6], inf[0, 6:9], inf[0, 9:12], inf[0, 12:15]
+        assert np.allclose(tv, coef / se, rtol=1e-12)
+        want_p = 2.0 * sps.t.sf(np.abs(tv), df)
+        assert np.allclose(pv, want_p, rtol=1e-6, atol=0.0), (pv, want_p)
+        tcrit = sps.t.ppf(0.995, df)
+        assert np.allclose(hi - coef, tcrit * se, rtol=1e-9) and np.allclose(coef - lo, tcrit * se, rtol=1e-9)
+    rcore, rinf = oracle.fit_groups(y, x_cols, offs, model="ols", compute_inference=True, confidence_level=0.99)
+    core, inf = _host_fit(pkg, ctx, "ols", offs, y, x_cols, compute_inference=True, confidence_level=0.99)
+    assert_records_match(core, rcore, 3, inf, rinf, what="3M rows")
+    assert abs(pkg.t_critical(0.99, 10_000_000) / sps.t.ppf(0.995, 10_000_000) - 1.0) < 1e-12
+    assert abs(pkg.t_critical(0.9, 250_000) / sps.t.ppf(0.95, 250_000) - 1.0) < 1e-12
+
+
 def test_alpha_negative_and_bad_arguments(pkg, ctx):
     a = import_pkg("_abi")
     rng = np.random.default_rng(2)
