@@ -259,6 +259,26 @@ struct PredictSegTable {
 	int32_t pad[15];
 	PredictSegEntry entries[kSegTargetWaves + 16]; // sum over groups of (ceil(n_g / seg_rows) - 1) <= n_rows / seg_rows <= 2048
 };
+#ifdef __HIPCC__
+// Called by a group's own wavefront in the per-row kernels (predict, HC): keeps the first seg_rows rows, hands the
+// rest to extra wavefronts through the table.  Returns the end of the rows the caller keeps.
+__device__ __forceinline__ int64_t register_overflow_rows(void *table, int64_t seg_rows, int64_t g, int64_t lo, int64_t hi, int lane) {
+	if (!table || hi - lo <= seg_rows) return hi;
+	PredictSegTable *t = static_cast<PredictSegTable *>(table);
+	const int extra = (int)((hi - lo - 1) / seg_rows);
+	int base = 0;
+	if (lane == 0) base = atomicAdd(&t->count, extra);
+	base = __builtin_amdgcn_readfirstlane(base);
+	for (int k = lane; k < extra && base + k < kSegTargetWaves + 16; k += 64) {
+		PredictSegEntry e;
+		e.g = g;
+		e.lo = lo + (k + 1) * seg_rows;
+		e.hi = e.lo + seg_rows < hi ? e.lo + seg_rows : hi;
+		t->entries[base + k] = e;
+	}
+	return lo + seg_rows;
+}
+#endif
 hipError_t launch_predict(const PredictArgs &a, hipStream_t stream);
 
 // expanding-window fit + predict (window_narrow.hip), p <= kNarrowMaxP
@@ -309,6 +329,6 @@ hipError_t launch_vif_from_core(const double *core, const int64_t *row_offsets, 
                                 int64_t min_rows, double *out, hipStream_t stream);
 // hc_narrow.hip: HC0..HC3 standard errors over the finished fit (rewrites se/t/p/ci of the inference records)
 size_t hc_prep_bytes(int64_t n_groups, int p); // scratch the pass needs (prep records)
-hipError_t launch_hc_narrow(const BatchArgs &a, double *prep, hipStream_t stream);
+hipError_t launch_hc_narrow(const BatchArgs &a, double *prep, void *overflow_table, hipStream_t stream); // table: PredictSegTable, count zeroed
 
 } // namespace anofox

@@ -21,6 +21,8 @@
 //   hc_narrow_kernel   one wavefront per group: the prep record is wave-uniform (scalar loads), the rows
 //                      stream through lane-strided loads; writes the HC standard errors;
 //   hc_finish_kernel   one lane per group: t, p-value and interval from those errors.
+// Rows beyond a group's first seg_rows go to extra wavefronts (second launch of hc_narrow_kernel, idle otherwise);
+// the partial V_jj of such a group are summed with atomics in its prep record.
 #include "common.h"
 #include "device_math.h"
 
@@ -40,7 +42,8 @@ struct HcPrep {
 	static constexpr int OFF_DF = OFF_B0 + 3;
 	static constexpr int OFF_VALID = OFF_B0 + 4;
 	static constexpr int OFF_MASK = OFF_B0 + 5;
-	static constexpr int REC = OFF_B0 + 6;
+	static constexpr int OFF_VSUM = OFF_B0 + 6; // [P] V_jj of groups whose rows were split over several wavefronts (atomic sums)
+	static constexpr int REC = OFF_B0 + 6 + P;
 	__host__ __device__ static constexpr int li(int i, int j) { return i * (i + 1) / 2 + j; } // i >= j
 };
 
@@ -67,6 +70,8 @@ __global__ __launch_bounds__(64) void hc_prepare_kernel(BatchArgs args, double *
 	}
 	prep[H::OFF_VALID] = rank > 0 ? 1.0 : 0.0; // rank 0: intercept-only fit, inference is None (ols.rs:101-130)
 	prep[H::OFF_MASK] = (double)mask;
+#pragma unroll
+	for (int j = 0; j < P; ++j) prep[H::OFF_VSUM + j] = 0.0;
 	if (rank == 0) return;
 
 	const double sw = rec[L::OFF_SW];
@@ -130,14 +135,33 @@ __global__ __launch_bounds__(64) void hc_prepare_kernel(BatchArgs args, double *
 	prep[H::OFF_DF] = df;
 }
 
-template <int P, bool WEIGHTED>
-__global__ __launch_bounds__(256) void hc_narrow_kernel(BatchArgs args, const double *__restrict__ prep_all) {
+// SEGMENTS = false: wave per group (its first seg_rows rows); true: wave per registered overflow segment
+template <int P, bool WEIGHTED, bool SEGMENTS>
+__global__ __launch_bounds__(256) void hc_narrow_kernel(BatchArgs args, const double *__restrict__ prep_all, double *prep_sums,
+                                                        void *overflow) {
+	// prep_all and prep_sums are the same buffer: the kernel only READS the record fields through prep_all (uniform,
+	// scalar loads) and only ADDS to the OFF_VSUM slots through prep_sums, which it never reads
 	using H = HcPrep<P>;
 	const int lane = threadIdx.x & 63;
-	const int g = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-	if (g >= args.n_groups) return;
+	const int v = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+	int g;
+	int64_t lo, hi;
+	bool split;
+	if (SEGMENTS) {
+		const PredictSegTable *t = static_cast<const PredictSegTable *>(overflow);
+		int n = t->count;
+		if (n > kSegTargetWaves + 16) n = kSegTargetWaves + 16;
+		if (v >= n) return;
+		g = (int)t->entries[v].g; lo = t->entries[v].lo; hi = t->entries[v].hi;
+		split = true;
+	} else {
+		if (v >= args.n_groups) return;
+		g = v; lo = args.row_offsets[g]; hi = args.row_offsets[g + 1];
+		split = overflow && hi - lo > args.seg_rows;
+	}
 	const double *__restrict__ prep = prep_all + (int64_t)g * H::REC;
 	if (prep[H::OFF_VALID] == 0.0) return;
+	if (!SEGMENTS) hi = register_overflow_rows(overflow, args.seg_rows, g, lo, hi, lane);
 	const int hc = args.hc_type;
 
 	double Li[H::LT], xbar[P], b[P];
@@ -155,7 +179,6 @@ __global__ __launch_bounds__(256) void hc_narrow_kernel(BatchArgs args, const do
 #pragma unroll
 	for (int j = 0; j < P; ++j) acc[j] = 0.0;
 
-	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
 	for (int64_t base = lo; base < hi; base += 64) {
 		const bool in = base + lane < hi;
 		const int64_t r = in ? base + lane : hi - 1; // clamped: loads stay unconditional
@@ -208,7 +231,10 @@ __global__ __launch_bounds__(256) void hc_narrow_kernel(BatchArgs args, const do
 	double vmine = 0.0;
 #pragma unroll
 	for (int j = 0; j < P; ++j) vmine = (lane == j) ? acc[j] : vmine;
-	if (lane < P && ((mask >> lane) & 1u)) args.inference[(int64_t)g * (5 * P + 2) + lane] = sqrt(vmine);
+	if (lane < P && ((mask >> lane) & 1u)) {
+		if (split) atomicAdd(prep_sums + (int64_t)g * H::REC + H::OFF_VSUM + lane, vmine); // finished in hc_finish_kernel
+		else args.inference[(int64_t)g * (5 * P + 2) + lane] = sqrt(vmine);
+	}
 }
 
 // t, p and the interval from the HC errors, one lane per group (the special functions are out-of-line calls:
@@ -224,8 +250,10 @@ __global__ __launch_bounds__(64) void hc_finish_kernel(BatchArgs args, const dou
 	const unsigned mask = (unsigned)prep[H::OFF_MASK];
 	const double tcrit = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
 	double *inf = args.inference + g * (int64_t)(5 * P + 2);
+	const bool split = args.seg_table && args.row_offsets[g + 1] - args.row_offsets[g] > args.seg_rows;
 	for (int j = 0; j < P; ++j) {
 		if (!((mask >> j) & 1u)) continue;
+		if (split) inf[j] = sqrt(prep[H::OFF_VSUM + j]);
 		const double se = inf[j];
 		const double bj = prep[H::OFF_B + j];
 		const double tv = bj / se;
@@ -237,11 +265,16 @@ __global__ __launch_bounds__(64) void hc_finish_kernel(BatchArgs args, const dou
 }
 
 template <int P>
-hipError_t launch_hc_p(const BatchArgs &a, double *prep, hipStream_t stream) {
+hipError_t launch_hc_p(const BatchArgs &a, double *prep, void *overflow, hipStream_t stream) {
 	hipLaunchKernelGGL((hc_prepare_kernel<P>), dim3((unsigned)((a.n_groups + 63) / 64)), dim3(64), 0, stream, a, prep);
-	const unsigned grid = (unsigned)((a.n_groups + 3) / 4);
-	if (a.model == ANOFOX_HIP_MODEL_WLS) hipLaunchKernelGGL((hc_narrow_kernel<P, true>), dim3(grid), dim3(256), 0, stream, a, prep);
-	else hipLaunchKernelGGL((hc_narrow_kernel<P, false>), dim3(grid), dim3(256), 0, stream, a, prep);
+	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), seg_grid((unsigned)((kSegTargetWaves + 16 + 3) / 4)), block(256);
+	if (a.model == ANOFOX_HIP_MODEL_WLS) {
+		hipLaunchKernelGGL((hc_narrow_kernel<P, true, false>), grid, block, 0, stream, a, prep, prep, overflow);
+		if (overflow) hipLaunchKernelGGL((hc_narrow_kernel<P, true, true>), seg_grid, block, 0, stream, a, prep, prep, overflow);
+	} else {
+		hipLaunchKernelGGL((hc_narrow_kernel<P, false, false>), grid, block, 0, stream, a, prep, prep, overflow);
+		if (overflow) hipLaunchKernelGGL((hc_narrow_kernel<P, false, true>), seg_grid, block, 0, stream, a, prep, prep, overflow);
+	}
 	hipLaunchKernelGGL((hc_finish_kernel<P>), dim3((unsigned)((a.n_groups + 63) / 64)), dim3(64), 0, stream, a, prep);
 	return hipGetLastError();
 }
@@ -249,21 +282,21 @@ hipError_t launch_hc_p(const BatchArgs &a, double *prep, hipStream_t stream) {
 } // namespace
 
 size_t hc_prep_bytes(int64_t n_groups, int p) {
-	return (size_t)n_groups * (size_t)(p * (p + 1) / 2 + 2 * p + 6) * sizeof(double);
+	return (size_t)n_groups * (size_t)(p * (p + 1) / 2 + 3 * p + 6) * sizeof(double);
 }
 
-hipError_t launch_hc_narrow(const BatchArgs &a, double *prep, hipStream_t stream) {
+hipError_t launch_hc_narrow(const BatchArgs &a, double *prep, void *overflow, hipStream_t stream) {
 	if (a.n_groups <= 0 || !a.inference) return hipSuccess;
 	if (a.n_groups > (int64_t)0x7fffffff / 4) return hipErrorInvalidValue;
 	switch (a.p) {
-	case 1: return launch_hc_p<1>(a, prep, stream);
-	case 2: return launch_hc_p<2>(a, prep, stream);
-	case 3: return launch_hc_p<3>(a, prep, stream);
-	case 4: return launch_hc_p<4>(a, prep, stream);
-	case 5: return launch_hc_p<5>(a, prep, stream);
-	case 6: return launch_hc_p<6>(a, prep, stream);
-	case 7: return launch_hc_p<7>(a, prep, stream);
-	case 8: return launch_hc_p<8>(a, prep, stream);
+	case 1: return launch_hc_p<1>(a, prep, overflow, stream);
+	case 2: return launch_hc_p<2>(a, prep, overflow, stream);
+	case 3: return launch_hc_p<3>(a, prep, overflow, stream);
+	case 4: return launch_hc_p<4>(a, prep, overflow, stream);
+	case 5: return launch_hc_p<5>(a, prep, overflow, stream);
+	case 6: return launch_hc_p<6>(a, prep, overflow, stream);
+	case 7: return launch_hc_p<7>(a, prep, overflow, stream);
+	case 8: return launch_hc_p<8>(a, prep, overflow, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -274,8 +274,10 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	if (hip_fail(launch_refine_fused_narrow(a, kRefineSteps, st), "refine kernel launch", e)) return false;
 	// ols.rs:209-231, wls.rs:230-252: HC errors replace the classical ones; ridge has no such branch
 	if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE) {
-		if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, hc_prep_bytes(G, (int)p), "hc scratch", e)) return false;
-		if (hip_fail(launch_hc_narrow(a, (double *)ctx->aux, st), "hc kernel launch", e)) return false;
+		const size_t b_tab = align_up(sizeof(PredictSegTable), 256); // overflow segments of very large groups, then the prep records
+		if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, b_tab + hc_prep_bytes(G, (int)p), "hc scratch", e)) return false;
+		if (hip_fail(hipMemsetAsync(ctx->aux, 0, 64, st), "hipMemsetAsync", e)) return false;
+		if (hip_fail(launch_hc_narrow(a, (double *)((char *)ctx->aux + b_tab), ctx->aux, st), "hc kernel launch", e)) return false;
 	}
 	if (ctx->timing) {
 		(void)hipEventRecord(e2, st);

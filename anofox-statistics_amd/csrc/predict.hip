@@ -43,26 +43,6 @@ __global__ __launch_bounds__(256) void predict_margin_kernel(PredictArgs args) {
 	args.margin[g] = margin;
 }
 
-// A wavefront streams its group at a few GB/s only: rows beyond the first seg_rows are handed to extra wavefronts
-// (the SEGMENTS launch).  Called by the group's own wave; returns the end of the rows it keeps.
-__device__ __forceinline__ int64_t predict_register_overflow(const PredictArgs &args, int64_t g, int64_t lo, int64_t hi, int lane) {
-	const int64_t S = args.seg_rows;
-	if (!args.seg_table || hi - lo <= S) return hi;
-	PredictSegTable *t = static_cast<PredictSegTable *>(args.seg_table);
-	const int extra = (int)((hi - lo - 1) / S);
-	int base = 0;
-	if (lane == 0) base = atomicAdd(&t->count, extra);
-	base = __builtin_amdgcn_readfirstlane(base);
-	for (int k = lane; k < extra && base + k < kSegTargetWaves + 16; k += 64) {
-		PredictSegEntry e;
-		e.g = g;
-		e.lo = lo + (k + 1) * S;
-		e.hi = e.lo + S < hi ? e.lo + S : hi;
-		t->entries[base + k] = e;
-	}
-	return lo + S;
-}
-
 __device__ __forceinline__ void predict_rows_generic(const PredictArgs &args, int64_t g, int64_t lo, int64_t hi, double (*coef_s)[kWideMaxP],
                                                      int (*dead_s)[kWideMaxP], int lane, int wv) {
 	const int p = args.p;
@@ -111,7 +91,7 @@ __global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
 	} else {
 		if (v >= args.n_groups) return;
 		g = v; lo = args.row_offsets[g];
-		hi = predict_register_overflow(args, g, lo, args.row_offsets[g + 1], lane);
+		hi = register_overflow_rows(args.seg_table, args.seg_rows, g, lo, args.row_offsets[g + 1], lane);
 	}
 	predict_rows_generic(args, g, lo, hi, coef_s, dead_s, lane, wv);
 }
@@ -134,7 +114,7 @@ __global__ __launch_bounds__(256) void predict_narrow_kernel(PredictArgs args) {
 	} else {
 		if (v >= args.n_groups) return;
 		g = v; lo = args.row_offsets[g];
-		hi = predict_register_overflow(args, g, lo, args.row_offsets[g + 1], lane);
+		hi = register_overflow_rows(args.seg_table, args.seg_rows, g, lo, args.row_offsets[g + 1], lane);
 	}
 	const double *core = args.core + g * (int64_t)(P + 6);
 	double coef[P];

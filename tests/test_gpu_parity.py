@@ -418,6 +418,11 @@ def test_very_large_groups_are_split_and_merged(pkg, ctx, model, icpt):
     rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
     assert_records_match(core, rcore, p, inf, rinf, what=f"split {model} icpt={icpt}")
     assert np.isnan(core[2, 2]) and core[7, 5 + 5] == 0 and not np.isnan(core[7, 3])
+    if model != "ridge":                                         # HC pass: overflow rows go to extra wavefronts, V by atomics
+        kw["hc_type"] = "hc3"
+        core, inf = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+        rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
+        assert_records_match(core, rcore, p, inf, rinf, what=f"split hc3 {model} icpt={icpt}")
     v = pkg.vif_batch_host(offs, x_cols[:4], ctx=ctx)            # the same accumulate kernel under vif_agg
     rv = oracle.vif_groups(x_cols[:4], offs)
     _assert_vif_match(v, rv, 4, "split vif")
