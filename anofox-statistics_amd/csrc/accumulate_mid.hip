@@ -270,8 +270,7 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const int64_t lo = args.row_offsets[args.group_base + gl];
 	const int64_t hi = args.row_offsets[args.group_base + gl + 1];
 	if (args.seg_table && hi - lo > args.seg_rows) {
-		wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments);
-		return;
+		if (wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments)) return;
 	}
 	mid_accumulate_rows<T, WEIGHTED, CENTER>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), nullptr, lane);
 }
@@ -286,10 +285,10 @@ __global__ __launch_bounds__(256) void accumulate_mid_segments_kernel(WideArgs a
 	const int lane = threadIdx.x & 63;
 	const int v = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int)blockIdx.x * 4;
 	SegHeader *h = wseg_header(args.seg_table);
-	int total = h->seg_total;
-	if (total > kSegMaxSegments) total = kSegMaxSegments;
+	const int total = h->seg_total; // reservations never exceed the capacity
 	if (v >= total) return;
 	const SegEntry e = wseg_entries(args.seg_table, kSegMaxBig)[v];
+	if (e.slot < 0) return; // reserved but unclaimed
 	SegBigGroup *b = wseg_big(args.seg_table) + e.slot;
 	const double *ff = wseg_first(args.seg_table, kSegMaxBig, kSegMaxSegments) + (size_t)e.slot * (P16 + 2);
 	double *recs = wseg_records(args.seg_table, T, kSegMaxBig, kSegMaxSegments);

@@ -234,27 +234,34 @@ __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) 
 	const int64_t lo = args.row_offsets[g];
 	const int64_t hi = args.row_offsets[g + 1];
 	if (args.seg_table && hi - lo > args.seg_rows) {
-		// a single wavefront streams at ~5 GB/s: hand the group to accumulate_segments_kernel in pieces
+		// a single wavefront streams at ~5 GB/s: hand the group to accumulate_segments_kernel in pieces (unless the
+		// tables are full, which only happens when the caller understated n_rows: then it stays with this wave)
+		SegHeader *h = seg_header(args.seg_table);
+		const int64_t S = args.seg_rows;
+		const int nseg = (int)((hi - lo + S - 1) / S);
+		int slot = -1, base = -1;
 		if (lane == 0) {
-			SegHeader *h = seg_header(args.seg_table);
-			const int64_t S = args.seg_rows;
-			const int nseg = (int)((hi - lo + S - 1) / S);
-			const int slot = atomicAdd(&h->big_total, 1);
-			const int base = atomicAdd(&h->seg_total, nseg);
-			if (slot < kSegMaxBig) {
+			base = reserve_table_entries(&h->seg_total, nseg, kSegMaxSegments);
+			if (base >= 0) slot = reserve_table_entries(&h->big_total, 1, kSegMaxBig);
+		}
+		slot = __builtin_amdgcn_readfirstlane(slot);
+		base = __builtin_amdgcn_readfirstlane(base);
+		if (base >= 0) {
+			if (slot >= 0 && lane == 0) {
 				SegBigGroup b;
 				b.g = g; b.base = base; b.nseg = nseg; b.done = 0; b.pad = 0;
 				seg_big(args.seg_table)[slot] = b;
-				for (int k = 0; k < nseg && base + k < kSegMaxSegments; ++k) {
-					SegEntry e;
-					e.lo = lo + k * S;
-					e.hi = (e.lo + S < hi) ? e.lo + S : hi;
-					e.slot = slot; e.pad = 0;
-					seg_entries(args.seg_table)[base + k] = e;
-				}
 			}
+			for (int k = lane; k < nseg; k += 64) {
+				SegEntry e;
+				e.lo = lo + k * S;
+				e.hi = (e.lo + S < hi) ? e.lo + S : hi;
+				e.slot = slot; e.pad = 0;
+				if (slot < 0) e.hi = e.lo; // reserved without a group slot: empty, unclaimed
+				seg_entries(args.seg_table)[base + k] = e;
+			}
+			if (slot >= 0) return;
 		}
-		return;
 	}
 	accumulate_rows<P, WEIGHTED, CENTER, NT>(args, lo, hi, args.moments + g * (int64_t)L::REC, lane);
 }
@@ -320,10 +327,10 @@ __global__ __launch_bounds__(256) void accumulate_segments_kernel(BatchArgs args
 	const int lane = threadIdx.x & 63;
 	const int v = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int)blockIdx.x * 4;
 	SegHeader *h = seg_header(args.seg_table);
-	int total = h->seg_total;
-	if (total > kSegMaxSegments) total = kSegMaxSegments;
+	const int total = h->seg_total; // reservations never exceed the capacity
 	if (v >= total) return;
 	const SegEntry e = seg_entries(args.seg_table)[v];
+	if (e.slot < 0) return; // reserved but unclaimed
 	double *recs = seg_records(args.seg_table);
 	accumulate_rows<P, WEIGHTED, CENTER, NT>(args, e.lo, e.hi, recs + (int64_t)v * L::REC, lane);
 	__threadfence(); // this segment's record before the counter

@@ -339,8 +339,13 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) 
 	const int64_t hi = args.row_offsets[args.group_base + g + 1];
 	if (args.seg_table && hi - lo > args.seg_rows) {
 		// four waves stream a group at ~25 GB/s: hand it to accumulate_wide_segments_kernel in pieces
-		if (threadIdx.x < 64) wide_register_big_group(args, g, lo, hi, T, (int)threadIdx.x, kWideSegMaxBig, kWideSegMaxSegments);
-		return;
+		__shared__ int registered;
+		if (threadIdx.x < 64) {
+			const bool ok = wide_register_big_group(args, g, lo, hi, T, (int)threadIdx.x, kWideSegMaxBig, kWideSegMaxSegments);
+			if (threadIdx.x == 0) registered = ok ? 1 : 0;
+		}
+		__syncthreads();
+		if (registered) return; // (tables full: the workgroup accumulates the group itself)
 	}
 	wide_accumulate_rows<T, WEIGHTED, CENTER>(args, lo, hi, args.moments + g * (int64_t)wide_record_len(T), nullptr);
 }
@@ -354,10 +359,10 @@ __global__ __launch_bounds__(256, 2) void accumulate_wide_segments_kernel(WideAr
 	const int reclen = wide_record_len(T);
 	const int v = blockIdx.x;
 	SegHeader *h = wseg_header(args.seg_table);
-	int total = h->seg_total;
-	if (total > kWideSegMaxSegments) total = kWideSegMaxSegments;
+	const int total = h->seg_total; // reservations never exceed the capacity
 	if (v >= total) return;
 	const SegEntry e = wseg_entries(args.seg_table, kWideSegMaxBig)[v];
+	if (e.slot < 0) return; // reserved but unclaimed
 	SegBigGroup *b = wseg_big(args.seg_table) + e.slot;
 	const double *ff = wseg_first(args.seg_table, kWideSegMaxBig, kWideSegMaxSegments) + (size_t)e.slot * (P16 + 2);
 	double *recs = wseg_records(args.seg_table, T, kWideSegMaxBig, kWideSegMaxSegments);

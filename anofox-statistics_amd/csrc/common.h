@@ -172,6 +172,19 @@ inline __host__ __device__ int64_t wide_seg_rows_for(int64_t n_rows) {
 }
 
 
+#ifdef __HIPCC__
+// Reserve `n` consecutive entries of a fixed-capacity device table whose fill count is *counter; -1 when they do not
+// fit (the caller then keeps the work for itself).  Never over-commits, so readers may trust every index < *counter.
+__device__ __forceinline__ int reserve_table_entries(int32_t *counter, int n, int capacity) {
+	int old = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	while (true) {
+		if (old + n > capacity) return -1;
+		if (__hip_atomic_compare_exchange_strong(counter, &old, old + n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+			return old;
+	}
+}
+#endif
+
 // ---- segment tables of the wide-record paths (accumulate_mid.hip, accumulate_wide.hip): device-side accessors and
 // the registration of a very large group.  max_big / max_seg are the capacities the table was laid out with.
 #ifdef __HIPCC__
@@ -187,33 +200,43 @@ __device__ __forceinline__ double *wseg_records(void *t, int T, int max_big, int
 
 // Called by ONE wavefront for a group it will not stream itself: find the group's first valid row (the shift and
 // the reference point of the constant-column test: ols.rs:59-87), store it, cut the rows into segments.
-__device__ inline void wide_register_big_group(const WideArgs &args, int64_t gl, int64_t lo, int64_t hi, int T, int lane,
+// Returns false when the tables are full (the caller then accumulates the group itself).
+__device__ inline bool wide_register_big_group(const WideArgs &args, int64_t gl, int64_t lo, int64_t hi, int T, int lane,
                                                int max_big, int max_seg) {
 	const int p = args.p;
 	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
+	SegHeader *h = wseg_header(args.seg_table);
+	const int64_t S = args.seg_rows;
+	const int nseg = (int)((hi - lo + S - 1) / S);
+	int slot = -1, base = -1;
+	if (lane == 0) {
+		base = reserve_table_entries(&h->seg_total, nseg, max_seg);
+		if (base >= 0) slot = reserve_table_entries(&h->big_total, 1, max_big);
+	}
+	slot = __builtin_amdgcn_readfirstlane(slot);
+	base = __builtin_amdgcn_readfirstlane(base);
+	if (slot < 0 || base < 0) {
+		// (segments reserved without a group slot stay unclaimed: mark them empty)
+		if (base >= 0)
+			for (int k = lane; k < nseg; k += 64) {
+				SegEntry e;
+				e.lo = e.hi = lo; e.slot = -1; e.pad = 0;
+				wseg_entries(args.seg_table, max_big)[base + k] = e;
+			}
+		return false;
+	}
 	int64_t rfirst = -1;
-	for (int64_t base = lo; base < hi && rfirst < 0; base += 64) {
-		const int64_t r = base + lane < hi ? base + lane : hi - 1;
-		bool ok = (base + lane < hi) && isfinite(args.y[r]);
+	for (int64_t b0 = lo; b0 < hi && rfirst < 0; b0 += 64) {
+		const int64_t r = b0 + lane < hi ? b0 + lane : hi - 1;
+		bool ok = (b0 + lane < hi) && isfinite(args.y[r]);
 		for (int j = 0; j < p; ++j) ok = ok && isfinite(args.x_table[j][r]);
 		if (weighted) {
 			const double w = args.w[r];
 			ok = ok && isfinite(w) && (w > 0.0);
 		}
 		const unsigned long long b = __ballot(ok);
-		if (b != 0ull) rfirst = base + (__ffsll((long long)b) - 1);
+		if (b != 0ull) rfirst = b0 + (__ffsll((long long)b) - 1);
 	}
-	SegHeader *h = wseg_header(args.seg_table);
-	const int64_t S = args.seg_rows;
-	const int nseg = (int)((hi - lo + S - 1) / S);
-	int slot = 0, base = 0;
-	if (lane == 0) {
-		slot = atomicAdd(&h->big_total, 1);
-		base = atomicAdd(&h->seg_total, nseg);
-	}
-	slot = __builtin_amdgcn_readfirstlane(slot);
-	base = __builtin_amdgcn_readfirstlane(base);
-	if (slot >= max_big) return;
 	double *ff = wseg_first(args.seg_table, max_big, max_seg) + (size_t)slot * (16 * T + 2);
 	for (int j = lane; j <= 16 * T; j += 64) {
 		double v = 0.0;
@@ -225,13 +248,14 @@ __device__ inline void wide_register_big_group(const WideArgs &args, int64_t gl,
 		b.g = gl; b.base = base; b.nseg = nseg; b.done = 0; b.pad = 0;
 		wseg_big(args.seg_table)[slot] = b;
 	}
-	for (int k = lane; k < nseg && base + k < max_seg; k += 64) {
+	for (int k = lane; k < nseg; k += 64) {
 		SegEntry e;
 		e.lo = lo + k * S;
 		e.hi = (e.lo + S < hi) ? e.lo + S : hi;
 		e.slot = slot; e.pad = 0;
 		wseg_entries(args.seg_table, max_big)[base + k] = e;
 	}
+	return true;
 }
 #endif
 
@@ -266,10 +290,11 @@ __device__ __forceinline__ int64_t register_overflow_rows(void *table, int64_t s
 	if (!table || hi - lo <= seg_rows) return hi;
 	PredictSegTable *t = static_cast<PredictSegTable *>(table);
 	const int extra = (int)((hi - lo - 1) / seg_rows);
-	int base = 0;
-	if (lane == 0) base = atomicAdd(&t->count, extra);
+	int base = -1;
+	if (lane == 0) base = reserve_table_entries(&t->count, extra, kSegTargetWaves + 16);
 	base = __builtin_amdgcn_readfirstlane(base);
-	for (int k = lane; k < extra && base + k < kSegTargetWaves + 16; k += 64) {
+	if (base < 0) return hi; // table full (n_rows understated by the caller): this wave keeps every row
+	for (int k = lane; k < extra; k += 64) {
 		PredictSegEntry e;
 		e.g = g;
 		e.lo = lo + (k + 1) * seg_rows;

@@ -149,9 +149,7 @@ __global__ __launch_bounds__(256) void hc_narrow_kernel(BatchArgs args, const do
 	bool split;
 	if (SEGMENTS) {
 		const PredictSegTable *t = static_cast<const PredictSegTable *>(overflow);
-		int n = t->count;
-		if (n > kSegTargetWaves + 16) n = kSegTargetWaves + 16;
-		if (v >= n) return;
+		if (v >= t->count) return; // reservations never exceed the capacity
 		g = (int)t->entries[v].g; lo = t->entries[v].lo; hi = t->entries[v].hi;
 		split = true;
 	} else {

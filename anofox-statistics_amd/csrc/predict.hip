@@ -84,9 +84,7 @@ __global__ __launch_bounds__(256) void predict_kernel(PredictArgs args) {
 	int64_t g, lo, hi;
 	if (SEGMENTS) {
 		const PredictSegTable *t = static_cast<const PredictSegTable *>(args.seg_table);
-		int n = t->count;
-		if (n > kSegTargetWaves + 16) n = kSegTargetWaves + 16;
-		if (v >= n) return;
+		if (v >= t->count) return; // reservations never exceed the capacity
 		g = t->entries[v].g; lo = t->entries[v].lo; hi = t->entries[v].hi;
 	} else {
 		if (v >= args.n_groups) return;
@@ -107,9 +105,7 @@ __global__ __launch_bounds__(256) void predict_narrow_kernel(PredictArgs args) {
 	int64_t g, lo, hi;
 	if (SEGMENTS) {
 		const PredictSegTable *t = static_cast<const PredictSegTable *>(args.seg_table);
-		int n = t->count;
-		if (n > kSegTargetWaves + 16) n = kSegTargetWaves + 16;
-		if (v >= n) return;
+		if (v >= t->count) return; // reservations never exceed the capacity
 		g = t->entries[v].g; lo = t->entries[v].lo; hi = t->entries[v].hi;
 	} else {
 		if (v >= args.n_groups) return;

@@ -505,6 +505,39 @@ def test_inference_with_millions_of_rows(pkg, ctx):
     assert abs(pkg.t_critical(0.9, 250_000) / sps.t.ppf(0.95, 250_000) - 1.0) < 1e-12
 
 
+def test_segment_tables_never_overflow(pkg, ctx):
+    """The row-segment tables are sized from n_rows.  A caller of the device entry point that understates n_rows
+    makes more segments than fit: the reservations are compare-and-swap bounded and a group that does not fit
+    is accumulated by its own wavefront instead (slow, but the same result)."""
+    import ctypes as C
+    import torch
+    a = import_pkg("_abi")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(3)
+    ns = [8192 * 3000, 8192 * 1500 + 7, 500]                     # 4501 segments at seg_rows = 8192: more than the 4112 slots
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    x = rng.standard_normal(N)
+    y = 1.0 + 2.0 * x + rng.standard_normal(N)
+    t_off, t_y, t_x = (torch.from_numpy(v).to(dev) for v in (offs, y, x))
+    opts = _opts(pkg, "ols", compute_inference=True)
+    core = torch.empty((3, 7), dtype=torch.float64, device=dev)
+    inf = torch.empty((3, 7), dtype=torch.float64, device=dev)
+    cols = (C.c_void_p * 1)(t_x.data_ptr())
+    err = a.AnofoxError()
+    ok = ctx._lib.anofox_hip_fit_batch_device(ctx._h, 3, 1, 1, C.c_void_p(t_off.data_ptr()), C.c_void_p(t_y.data_ptr()), cols,
+                                              C.c_void_p(0), opts, C.c_void_p(core.data_ptr()), C.c_void_p(inf.data_ptr()),
+                                              C.byref(err))                       # n_rows = 1: a lie
+    assert ok, err.text()
+    torch.cuda.synchronize()
+    good, good_inf = ctx.fit_batch_device(t_off, t_y, [t_x], None, opts)           # n_rows = N: everything is split
+    torch.cuda.synchronize()
+    assert torch.allclose(core, good, rtol=1e-10, atol=0.0, equal_nan=True)
+    assert torch.allclose(inf, good_inf, rtol=1e-8, atol=0.0, equal_nan=True)
+    rcore, _ = oracle.fit_groups(y[-500:], [x[-500:]], [0, 500], model="ols")
+    assert np.allclose(good[2, :2].cpu().numpy(), rcore[0, :2], rtol=1e-9)
+
+
 def test_alpha_negative_and_bad_arguments(pkg, ctx):
     a = import_pkg("_abi")
     rng = np.random.default_rng(2)
