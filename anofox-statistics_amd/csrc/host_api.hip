@@ -383,7 +383,15 @@ bool anofox_hip_context_set_stream(AnofoxHipContext *ctx, void *hip_stream, Anof
 	reset_error(out_error);
 	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
 	std::lock_guard<std::mutex> lk(ctx->mu);
-	ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+	ctx->stream = (hipStream_t)hip_stream; // NULL = HIP's default stream (torch's default stream), used as given
+	return true;
+}
+
+bool anofox_hip_context_use_own_stream(AnofoxHipContext *ctx, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	ctx->stream = ctx->own_stream;
 	return true;
 }
 

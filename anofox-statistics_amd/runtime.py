@@ -38,8 +38,13 @@ class Context:
             raise AnofoxStatsError(err.code, err.text())
 
     def set_stream(self, hip_stream: Optional[int]):
+        """Launch on the given hipStream_t handle.  0 is HIP's default stream (= torch's default stream) and is used
+        as given; None goes back to the context's own non-blocking stream."""
         err = _abi.AnofoxError()
-        self._check(self._lib.anofox_hip_context_set_stream(self._h, C.c_void_p(hip_stream or 0), C.byref(err)), err)
+        if hip_stream is None:
+            self._check(self._lib.anofox_hip_context_use_own_stream(self._h, C.byref(err)), err)
+        else:
+            self._check(self._lib.anofox_hip_context_set_stream(self._h, C.c_void_p(int(hip_stream)), C.byref(err)), err)
 
     def synchronize(self):
         err = _abi.AnofoxError()

@@ -99,8 +99,8 @@ def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--groups", type=int, default=1_000_000, help="total groups over all ranks")
     ap.add_argument("--rows", type=int, default=1000, help="rows per group")
     ap.add_argument("--features", type=int, default=8)

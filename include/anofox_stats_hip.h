@@ -266,9 +266,11 @@ ANOFOX_HIP_API size_t anofox_hip_max_features(void);
 ANOFOX_HIP_API bool anofox_hip_context_create(int device_id, AnofoxHipContext **out_ctx, AnofoxError *out_error);
 ANOFOX_HIP_API void anofox_hip_context_destroy(AnofoxHipContext *ctx);
 
-/* Launch on a caller-owned hipStream_t (passed as void*) instead of the context's own stream;
- * NULL restores the context's stream. */
+/* Launch on a caller-owned hipStream_t (passed as void*) instead of the context's own (non-blocking) stream.
+ * NULL is a stream too — HIP's default stream, which is what PyTorch's default stream is — and is used as given;
+ * anofox_hip_context_use_own_stream goes back to the context's stream. */
 ANOFOX_HIP_API bool anofox_hip_context_set_stream(AnofoxHipContext *ctx, void *hip_stream, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_context_use_own_stream(AnofoxHipContext *ctx, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_context_synchronize(AnofoxHipContext *ctx, AnofoxError *out_error);
 
 /*
