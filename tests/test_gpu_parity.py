@@ -538,6 +538,32 @@ def test_segment_tables_never_overflow(pkg, ctx):
     assert np.allclose(good[2, :2].cpu().numpy(), rcore[0, :2], rtol=1e-9)
 
 
+def test_device_calls_are_ordered_with_torch_streams(pkg, ctx):
+    """The device entry points launch on torch's current stream — including the default stream, whose handle is 0 —
+    so inputs produced by torch kernels just before the call are complete when the fit reads them, on the default
+    stream and on a side stream alike."""
+    import torch
+    dev = torch.device("cuda:0")
+    G, n = 20_000, 1000
+    offs = torch.arange(0, G + 1, dtype=torch.int64, device=dev) * n
+    opts = _opts(pkg, "ols")
+    gen = torch.Generator(device=dev).manual_seed(5)
+    for stream in (None, torch.cuda.Stream(device=dev)):
+        with torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.default_stream(dev)):
+            x = torch.randn(G * n, dtype=torch.float64, device=dev, generator=gen)
+            y = torch.zeros_like(x)
+            torch.cuda.synchronize()
+            # a chain of element-wise kernels that is still running when the fit is enqueued
+            t = x.clone()
+            for _ in range(20):
+                t = torch.sin(t) + x
+            y.copy_(1.0 + 2.0 * x + 0.0 * t)
+            core, _ = ctx.fit_batch_device(offs, y, [x], None, opts)       # no synchronisation in between
+            torch.cuda.synchronize()
+            assert float((core[:, 0] - 2.0).abs().max()) < 1e-9 and float((core[:, 1] - 1.0).abs().max()) < 1e-9
+            assert bool((core[:, 6] == 0).all())
+
+
 def test_alpha_negative_and_bad_arguments(pkg, ctx):
     a = import_pkg("_abi")
     rng = np.random.default_rng(2)
