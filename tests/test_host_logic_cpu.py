@@ -82,3 +82,30 @@ def test_shard_ranges_cover_all_groups():
                 got.extend(range(lo, hi)) if G <= 1000 else None
             if G <= 1000:
                 assert got == list(range(G))
+
+
+def test_window_frame_parsing():
+    agg = import_pkg("aggregate")
+    assert agg._parse_frame(None, "current row") == (None, 0)
+    assert agg._parse_frame(None, "1 preceding") == (None, 1)
+    assert agg._parse_frame(("9 preceding", "current row"), "current row") == (9, 0)
+    assert agg._parse_frame((7, 3), "current row") == (7, 3)
+    assert agg._parse_frame(("unbounded", "2 preceding"), "current row") == (None, 2)
+    pkg = import_pkg()
+    for bad in (("current row", "3 preceding"), (2, 5), ("unbounded", "unbounded"), ("x", 0)):
+        with pytest.raises(pkg.InvalidInputException):
+            agg._parse_frame(bad, "current row")
+
+
+def test_vif_agg_null_rules_need_no_gpu():
+    """vif_aggregate.cpp:154: NULL unless >= 2 features and >= 3 buffered values; a NaN shortens only its own column
+    (:88-93), unequal columns make compute_vif fail -> NULL.  None of these groups reaches the GPU."""
+    pkg = import_pkg()
+    keys, res = pkg.vif_agg(["a"] * 4 + ["b"] * 2 + ["c"] * 4 + ["d"] * 3,
+                            [[1.0], [2.0], [3.0], [4.0],                      # a: one feature
+                             [1.0, 2.0], [2.0, 1.0],                          # b: two rows
+                             [1.0, 2.0], [2.0, float("nan")], [3.0, 1.0], [4.0, 5.0],   # c: NaN shortens column 2
+                             None, None, None])                               # d: only NULL lists
+    assert keys.tolist() == ["a", "b", "c", "d"] and res == [None, None, None, None]
+    with pytest.raises(pkg.InvalidInputException, match="Inconsistent feature count"):
+        pkg.vif_agg([0, 0, 0], [[1.0, 2.0], [1.0], [2.0, 3.0]])
