@@ -30,7 +30,7 @@ namespace anofox {
 
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
 
-// 16-byte streaming load; NT = non-temporal (the rows are read exactly once, keep them out of the caches' LRU)
+// 16-byte streaming load; NT = non-temporal (measured: no gain over the default policy, kept for experiments)
 template <bool NT>
 __device__ __forceinline__ dbl2u load2(const double *p) {
 	if (NT) return __builtin_nontemporal_load(reinterpret_cast<const dbl2u *>(p));
@@ -68,7 +68,7 @@ __device__ __forceinline__ double fold_shfl(double a, double b, int lane) {
 }
 
 // The rows [lo, hi) of one group (or of one segment of a very large group) -> one moment record at `rec`.
-template <int P, bool WEIGHTED, bool CENTER, bool NT>
+template <int P, bool WEIGHTED, bool CENTER, bool PREFETCH>
 __device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t lo, int64_t hi, double *rec, int lane) {
 	using L = MomentLayout<P>;
 	constexpr int Z = L::Z;
@@ -89,46 +89,61 @@ __device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t l
 	int cnt = 0;
 	unsigned mask = 0;
 
-	for (int64_t base = lo; base < hi; base += 128) {
+	// the loads of tile t + 1 are issued before the arithmetic of tile t (PREFETCH), so that a wave always has
+	// one tile of loads in flight; all loads of a tile sit in one arm of the (wave-uniform) full / ragged branch
+	double n0[Z], n1[Z], nw0 = 1.0, nw1 = 1.0;
+	auto load_tile = [&](int64_t base) {
 		const int64_t r0 = base + 2 * lane;
-		double z0[Z], z1[Z];
-		double w0 = 1.0, w1 = 1.0;
-		bool in0, in1;
-		if (base + 128 <= hi) { // full tile (wave-uniform): one 16-byte load per column
-			in0 = in1 = true;
+		if (base + 128 <= hi) { // full tile: one 16-byte load per column
 #pragma unroll
 			for (int j = 0; j < P; ++j) {
-				const dbl2u v = load2<NT>(args.x[j] + r0);
-				z0[j] = v.x;
-				z1[j] = v.y;
+				const dbl2u v = load2<false>(args.x[j] + r0);
+				n0[j] = v.x;
+				n1[j] = v.y;
 			}
 			{
-				const dbl2u v = load2<NT>(args.y + r0);
-				z0[P] = v.x;
-				z1[P] = v.y;
+				const dbl2u v = load2<false>(args.y + r0);
+				n0[P] = v.x;
+				n1[P] = v.y;
 			}
 			if (WEIGHTED) {
-				const dbl2u v = load2<NT>(args.w + r0);
-				w0 = v.x;
-				w1 = v.y;
+				const dbl2u v = load2<false>(args.w + r0);
+				nw0 = v.x;
+				nw1 = v.y;
 			}
 		} else { // ragged tail: unconditional 8-byte loads from clamped (valid) rows; a guarded load per element
 			// would sit behind its own branch and wait.  Rows past the end are masked by in0 / in1 below.
-			in0 = r0 < hi;
-			in1 = r0 + 1 < hi;
-			const int64_t c0 = in0 ? r0 : hi - 1, c1 = in1 ? r0 + 1 : hi - 1;
+			const int64_t c0 = r0 < hi ? r0 : hi - 1, c1 = r0 + 1 < hi ? r0 + 1 : hi - 1;
 #pragma unroll
 			for (int j = 0; j < P; ++j) {
-				z0[j] = args.x[j][c0];
-				z1[j] = args.x[j][c1];
+				n0[j] = args.x[j][c0];
+				n1[j] = args.x[j][c1];
 			}
-			z0[P] = args.y[c0];
-			z1[P] = args.y[c1];
+			n0[P] = args.y[c0];
+			n1[P] = args.y[c1];
 			if (WEIGHTED) {
-				w0 = args.w[c0];
-				w1 = args.w[c1];
+				nw0 = args.w[c0];
+				nw1 = args.w[c1];
 			}
 		}
+	};
+	if (PREFETCH && lo < hi) load_tile(lo);
+	for (int64_t base = lo; base < hi; base += 128) {
+		const int64_t r0 = base + 2 * lane;
+		if (!PREFETCH) load_tile(base);
+		double z0[Z], z1[Z];
+		double w0 = 1.0, w1 = 1.0;
+#pragma unroll
+		for (int a = 0; a < Z; ++a) {
+			z0[a] = n0[a];
+			z1[a] = n1[a];
+		}
+		if (WEIGHTED) {
+			w0 = nw0;
+			w1 = nw1;
+		}
+		const bool in0 = r0 < hi, in1 = r0 + 1 < hi;
+		if (PREFETCH && base + 128 < hi) load_tile(base + 128);
 
 		// row filter: everything finite (and w > 0), ols.rs:59-66 / wls.rs:76-86
 		bool v0 = in0, v1 = in1;
@@ -225,7 +240,7 @@ __device__ __forceinline__ SegBigGroup *seg_big(void *t) { return reinterpret_ca
 __device__ __forceinline__ SegEntry *seg_entries(void *t) { return reinterpret_cast<SegEntry *>(seg_big(t) + kSegMaxBig); }
 __device__ __forceinline__ double *seg_records(void *t) { return reinterpret_cast<double *>(seg_entries(t) + kSegMaxSegments); }
 
-template <int P, bool WEIGHTED, bool CENTER, bool NT>
+template <int P, bool WEIGHTED, bool CENTER, bool PF>
 __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) {
 	using L = MomentLayout<P>;
 	const int lane = threadIdx.x & 63;
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) 
 			if (slot >= 0) return;
 		}
 	}
-	accumulate_rows<P, WEIGHTED, CENTER, NT>(args, lo, hi, args.moments + g * (int64_t)L::REC, lane);
+	accumulate_rows<P, WEIGHTED, CENTER, PF>(args, lo, hi, args.moments + g * (int64_t)L::REC, lane);
 }
 
 // Merge the segment records of one group into its moment record: lane k owns moment k.  Segment b was shifted by
@@ -321,7 +336,7 @@ __device__ void merge_segments(const double *seg_rec, int nseg, double *rec, int
 }
 
 // One wavefront per registered segment; the wave that completes a group's last segment merges them.
-template <int P, bool WEIGHTED, bool CENTER, bool NT>
+template <int P, bool WEIGHTED, bool CENTER, bool PF>
 __global__ __launch_bounds__(256) void accumulate_segments_kernel(BatchArgs args) {
 	using L = MomentLayout<P>;
 	const int lane = threadIdx.x & 63;
@@ -332,7 +347,7 @@ __global__ __launch_bounds__(256) void accumulate_segments_kernel(BatchArgs args
 	const SegEntry e = seg_entries(args.seg_table)[v];
 	if (e.slot < 0) return; // reserved but unclaimed
 	double *recs = seg_records(args.seg_table);
-	accumulate_rows<P, WEIGHTED, CENTER, NT>(args, e.lo, e.hi, recs + (int64_t)v * L::REC, lane);
+	accumulate_rows<P, WEIGHTED, CENTER, PF>(args, e.lo, e.hi, recs + (int64_t)v * L::REC, lane);
 	__threadfence(); // this segment's record before the counter
 	SegBigGroup *b = seg_big(args.seg_table) + e.slot;
 	int old = 0;
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(256) void accumulate_segments_kernel(BatchArgs args
 	merge_segments<P, CENTER>(recs + (int64_t)b->base * L::REC, b->nseg, args.moments + b->g * (int64_t)L::REC, lane);
 }
 
-template <int P, bool NT>
+template <int P, bool PF>
 static hipError_t launch_pn(const BatchArgs &a, hipStream_t stream) {
 	const dim3 block(256);
 	const dim3 grid((unsigned)((a.n_groups + 3) / 4));
@@ -352,8 +367,8 @@ static hipError_t launch_pn(const BatchArgs &a, hipStream_t stream) {
 	const bool center = a.fit_intercept != 0;
 #define ANOFOX_ACC_LAUNCH(W, C)                                                                               \
 	do {                                                                                                      \
-		hipLaunchKernelGGL((accumulate_narrow_kernel<P, W, C, NT>), grid, block, 0, stream, a);               \
-		if (a.seg_table) hipLaunchKernelGGL((accumulate_segments_kernel<P, W, C, NT>), seg_grid, block, 0, stream, a); \
+		hipLaunchKernelGGL((accumulate_narrow_kernel<P, W, C, PF>), grid, block, 0, stream, a);               \
+		if (a.seg_table) hipLaunchKernelGGL((accumulate_segments_kernel<P, W, C, PF>), seg_grid, block, 0, stream, a); \
 	} while (0)
 	if (weighted) {
 		if (center) ANOFOX_ACC_LAUNCH(true, true);
@@ -368,9 +383,9 @@ static hipError_t launch_pn(const BatchArgs &a, hipStream_t stream) {
 
 template <int P>
 static hipError_t launch_p(const BatchArgs &a, hipStream_t stream) {
-	// ANOFOX_ACC_NT=0/1 overrides the load policy (A/B measurements)
-	static const int nt = [] { const char *e = getenv("ANOFOX_ACC_NT"); return e ? atoi(e) : 0; }();
-	return nt ? launch_pn<P, true>(a, stream) : launch_pn<P, false>(a, stream);
+	// ANOFOX_ACC_PF=0 issues a tile's loads at the top of its own iteration instead of one tile ahead (A/B measurements)
+	static const int pf = [] { const char *e = getenv("ANOFOX_ACC_PF"); return e ? atoi(e) : 1; }();
+	return pf ? launch_pn<P, true>(a, stream) : launch_pn<P, false>(a, stream);
 }
 
 hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream) {
