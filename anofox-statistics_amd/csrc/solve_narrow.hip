@@ -45,7 +45,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 
 	double *core = args.core + g * (int64_t)(p + 6);
 	double *inf = (args.inference && args.compute_inference) ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
-	const double *rv = args.refine_vec + g * (int64_t)(p + 2); // [rss, sum w r, X'Wr] from residual_grad_kernel
+	const double *rv = args.refine_vec + g * (int64_t)(p + 2); // [rss, sum w r, X'Wr] from residual_grad_wave
 
 	int status = ANOFOX_ERROR_SUCCESS;
 	double coef[P];
@@ -175,7 +175,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 			rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
 			refine = !(rss > kRefineTol * tss) || (min_ratio < kPivotWarn);
 		} else {
-			// current coefficients come from the record; residual_grad_kernel used exactly these
+			// current coefficients come from the record; residual_grad_wave used exactly these
 #pragma unroll
 			for (int i = 0; i < P; ++i) {
 				const double b = core[i];
