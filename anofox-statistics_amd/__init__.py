@@ -20,6 +20,18 @@ from .options import InvalidInputException, RegressionOptions, parse_options  # 
 from .runtime import Context, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host, fit_predict_window_host, vif_batch_host  # noqa: E402
 from .scalar import aic, bic, ols_fit, predict, predict_with_interval, ridge_fit, t_critical, vif, wls_fit  # noqa: E402
 
+# the scalar functions under their SQL names (src/table_functions/{ols,ridge,wls}_fit.cpp, predict.cpp,
+# src/scalar_functions/{aic_bic,vif}.cpp) and the deprecated aggregate aliases
+SQL_FUNCTIONS.update({
+    "anofox_stats_ols_fit": ols_fit, "ols_fit": ols_fit,
+    "anofox_stats_ridge_fit": ridge_fit, "ridge_fit": ridge_fit,
+    "anofox_stats_wls_fit": wls_fit, "wls_fit": wls_fit,
+    "anofox_stats_predict": predict,
+    "anofox_stats_aic": aic, "aic": aic, "anofox_stats_bic": bic, "bic": bic,
+    "anofox_stats_vif": vif, "vif": vif,
+    "ridge_predict_agg": ridge_fit_predict_agg, "wls_predict_agg": wls_fit_predict_agg,
+})
+
 __all__ = [
     "AnofoxStatsError", "Context", "FitAggResult", "InvalidInputException", "OlsFitAgg", "RegressionOptions",
     "RidgeFitAgg", "SQL_FUNCTIONS", "WlsFitAgg", "aic", "bic", "fit_batch_host", "ols_fit", "ols_fit_agg",

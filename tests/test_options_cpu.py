@@ -49,3 +49,18 @@ def test_sql_function_names_registered():
     for name in ("anofox_stats_ols_fit_agg", "ols_fit_agg", "anofox_stats_ridge_fit_agg", "ridge_fit_agg",
                  "anofox_stats_wls_fit_agg", "wls_fit_agg"):
         assert name in pkg.SQL_FUNCTIONS
+
+
+def test_sql_function_table_covers_the_reference_registrations():
+    """Every name the reference registers for this path (ScalarFunctionSet / AggregateFunctionSet names in
+    src/{aggregate,window,table,scalar}_functions for ols / ridge / wls / vif / aic / bic / predict)."""
+    pkg = import_pkg()
+    names = """aic anofox_stats_aic anofox_stats_bic anofox_stats_ols_fit anofox_stats_ols_fit_agg
+        anofox_stats_ols_fit_predict anofox_stats_ols_fit_predict_agg anofox_stats_predict anofox_stats_ridge_fit
+        anofox_stats_ridge_fit_agg anofox_stats_ridge_fit_predict anofox_stats_ridge_fit_predict_agg anofox_stats_vif
+        anofox_stats_vif_agg anofox_stats_wls_fit anofox_stats_wls_fit_agg anofox_stats_wls_fit_predict
+        anofox_stats_wls_fit_predict_agg bic ols_fit ols_fit_agg ols_fit_predict ols_fit_predict_agg ols_predict_agg
+        ridge_fit ridge_fit_agg ridge_fit_predict ridge_fit_predict_agg ridge_predict_agg vif vif_agg wls_fit wls_fit_agg
+        wls_fit_predict wls_fit_predict_agg wls_predict_agg""".split()
+    missing = [n for n in names if n not in pkg.SQL_FUNCTIONS]
+    assert not missing, missing
