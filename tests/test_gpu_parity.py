@@ -961,6 +961,39 @@ def test_window_frames_match_oracle(pkg, ctx, model, frame):
                 assert np.quantile(np.abs(wid[ok] / wid_ref[ok] - 1.0), 0.95) < 1e-5, what
 
 
+def test_window_reference_sql_structural_tests(pkg, ctx):
+    """test/sql/fit_predict/test_ridge_fit_predict_rolling.test (non-NULL counts 13 / 13 / 8 / 13 and the partitioned
+    case) and test_wls_fit_predict_edge.test (8): which rows get a prediction depends only on the frame, not on the
+    random values of the reference's tables."""
+    rng = np.random.default_rng(0)
+    t = np.arange(1, 16)
+    x = t.astype(float)
+    y = 2.0 * t + 0.5 * rng.random(15)
+    keys = np.zeros(15, dtype=np.int64)
+    opts = {"intercept": 1.0, "alpha": 1.0}
+    X = x[:, None].tolist()
+
+    def count(frame, sel=slice(None)):
+        yh, _, _ = pkg.ridge_fit_predict(keys, t, y, X, opts, context=ctx, frame=frame)
+        return int(np.sum(~np.isnan(yh[sel])))
+
+    assert count(("unbounded", "current row")) == 13
+    assert count(("4 preceding", "current row")) == 13
+    assert count(("7 preceding", "3 preceding"), t >= 8) == 8
+    assert count(("3 preceding", "current row")) == 13
+    tt = np.tile(np.arange(1, 11), 2)
+    kk = np.array(["A"] * 10 + ["B"] * 10)
+    yy = tt * np.where(kk == "A", 2.0, 3.0) + 0.3 * rng.random(20)
+    yh, _, _ = pkg.ridge_fit_predict(kk, tt, yy, tt.astype(float)[:, None].tolist(), {"intercept": 1.0, "alpha": 0.5},
+                                     context=ctx, frame=("3 preceding", "current row"))
+    assert np.all(~np.isnan(yh[(tt >= 3) & (tt <= 5)])) and np.all(np.isnan(yh[tt <= 2]))
+    i = np.arange(1, 11)
+    ye = [float(2.0 * v + 1.0) if v <= 6 else None for v in i]
+    yh, lo, hi = pkg.wls_fit_predict(np.zeros(10, dtype=np.int64), i, ye, i.astype(float)[:, None].tolist(), np.ones(10), context=ctx)
+    assert int(np.sum(~np.isnan(yh))) == 8 and np.all(np.isnan(yh[:2]))
+    assert np.allclose(yh[2:], 2.0 * i[2:] + 1.0, rtol=1e-9)        # exact line: the later rows are extrapolated
+
+
 def test_window_frame_validation(pkg, ctx):
     rng = np.random.default_rng(5)
     offs, y, x_cols, w = _random_groups(rng, 3, 2, 5, 30)
