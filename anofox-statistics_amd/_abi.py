@@ -155,6 +155,7 @@ SYMBOLS = {
     "anofox_hip_context_enable_timing": (C.c_bool, [_CTX, C.c_bool, _ERRP]),
     "anofox_hip_context_collect_timing": (C.c_bool, [_CTX, C.POINTER(AnofoxHipKernelTimes), _ERRP]),
     "anofox_hip_context_use_own_stream": (C.c_bool, [_CTX, _ERRP]),
+    "anofox_hip_context_set_accumulate_gate": (C.c_bool, [_CTX, C.c_void_p, C.c_void_p, _ERRP]),
     "anofox_hip_context_last_refine_count": (C.c_bool, [_CTX, C.POINTER(C.c_int64), _ERRP]),
     "anofox_hip_version": (C.c_char_p, []),
 }

@@ -36,6 +36,7 @@ struct AnofoxHipContext {
 	void *aux = nullptr;
 	size_t aux_bytes = 0;
 	const int32_t *last_refine_count = nullptr; // device address of the most recent launch's queue counter
+	hipEvent_t gate_wait = nullptr, gate_record = nullptr; // anofox_hip_context_set_accumulate_gate
 	// Student-t critical values for df = 1..kWindowTcritCap at the confidence level of the last window call
 	void *wtab = nullptr;
 	size_t wtab_bytes = 0;
@@ -191,8 +192,15 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 			e2 = get_event(ctx);
 			(void)hipEventRecord(e0, st);
 		}
+		// pipelining gate (anofox_hip_context_set_accumulate_gate): wait before the first accumulate kernel of the
+		// call, record after the last one
+		if (g0 == 0 && ctx->gate_wait) {
+			if (hip_fail(hipStreamWaitEvent(st, ctx->gate_wait, 0), "hipStreamWaitEvent", e)) return false;
+			if (ctx->timing) (void)hipEventRecord(e0, st);
+		}
 		if (hip_fail(mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st), "wide accumulate kernel launch", e)) return false;
 		if (ctx->timing) (void)hipEventRecord(e1, st);
+		if (g0 + slab >= G && ctx->gate_record && hip_fail(hipEventRecord(ctx->gate_record, st), "hipEventRecord", e)) return false;
 		// moderately wide designs: one lane per group (solve_mid.hip); beyond that one workgroup per group
 		auto solve = [&](int mode) { return mid ? launch_solve_mid(a, mode, st) : launch_solve_wide(a, mode, st); };
 		if (hip_fail(solve(0), "wide solve kernel launch", e)) return false;
@@ -267,8 +275,11 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 		e2 = get_event(ctx);
 		(void)hipEventRecord(e0, st);
 	}
+	if (ctx->gate_wait && hip_fail(hipStreamWaitEvent(st, ctx->gate_wait, 0), "hipStreamWaitEvent", e)) return false;
+	if (ctx->timing) (void)hipEventRecord(e0, st); // (again: the accumulate kernel starts after the gate)
 	if (hip_fail(launch_accumulate_narrow(a, st), "accumulate kernel launch", e)) return false;
 	if (ctx->timing) (void)hipEventRecord(e1, st);
+	if (ctx->gate_record && hip_fail(hipEventRecord(ctx->gate_record, st), "hipEventRecord", e)) return false;
 	if (hip_fail(launch_solve_narrow(a, st), "solve kernel launch", e)) return false;
 	// queued groups only: kRefineSteps x (b += (X'WX)^-1 X'Wr), then the statistics from the directly summed RSS
 	if (hip_fail(launch_refine_fused_narrow(a, kRefineSteps, st), "refine kernel launch", e)) return false;
@@ -384,6 +395,15 @@ bool anofox_hip_context_set_stream(AnofoxHipContext *ctx, void *hip_stream, Anof
 	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	ctx->stream = (hipStream_t)hip_stream; // NULL = HIP's default stream (torch's default stream), used as given
+	return true;
+}
+
+bool anofox_hip_context_set_accumulate_gate(AnofoxHipContext *ctx, void *wait_event, void *record_event, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	ctx->gate_wait = (hipEvent_t)wait_event;
+	ctx->gate_record = (hipEvent_t)record_event;
 	return true;
 }
 

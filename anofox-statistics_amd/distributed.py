@@ -61,9 +61,13 @@ def gather_records(local: torch.Tensor, n_groups: int, group: Optional[dist.Proc
 class ShardedBatchFit:
     """One rank's part of a sharded GROUP BY fit on device-resident grouped columns.
 
-    The record buffers are double buffered and the all-gather of step k is only waited for when its buffers are
-    reused (step k+2) or in `finish()`, so the gather (RCCL's own stream, xGMI) overlaps the next step's
-    accumulate kernel (HBM-bound) instead of serialising behind it."""
+    Two things overlap with the HBM-bound accumulate kernel of the NEXT step instead of serialising behind it:
+      * the all-gather of a step's records (RCCL's own stream, xGMI): the record buffers are multi-buffered and a
+        gather is only waited for when its buffers are reused or in `finish()`;
+      * the small latency-bound kernels of a step (solve, refinement): consecutive steps alternate between `depth`
+        contexts, each with its own workspace and its own torch stream, so step k+1's accumulate kernel starts
+        while step k's solve is still running.
+    Every step's work is enqueued when `fit()` returns; `finish()` makes the calling stream wait for all of it."""
 
     def __init__(self, ctx, n_groups_total: int, group: Optional[dist.ProcessGroup] = None, depth: int = 2):
         self.ctx = ctx
@@ -74,7 +78,9 @@ class ShardedBatchFit:
         self.lo, self.hi = shard_range(n_groups_total, self.rank, self.world)
         self.depth = depth
         self._slot = 0
-        self._bufs = [dict(core=None, inf=None, out=None, out_inf=None, work=[]) for _ in range(depth)]
+        self._bufs = [dict(core=None, inf=None, out=None, out_inf=None, work=[], ctx=None, stream=None, acc_done=None)
+                      for _ in range(depth)]
+        self._last_acc = None  # event recorded after the most recent accumulate kernel
 
     def _wait(self, b):
         for w in b["work"]:
@@ -82,34 +88,65 @@ class ShardedBatchFit:
                 w.wait()
         b["work"] = []
 
+    def contexts(self):
+        """The contexts in use (for timing collection)."""
+        return [b["ctx"] for b in self._bufs if b["ctx"] is not None]
+
     def fit(self, row_offsets, y, x_cols, w, options):
-        """Inputs hold this rank's groups only.  Returns (core_all[G, p+6], inf_all or None); with several
-        ranks the returned tensors are complete after `finish()` (or once their slot is reused)."""
-        if self.world == 1:
-            return self.ctx.fit_batch_device(row_offsets, y, x_cols, w, options)
+        """Inputs hold this rank's groups only.  Returns (core_all[G, p+6], inf_all or None); the returned tensors
+        are complete after `finish()` (or once their slot is reused)."""
         b = self._bufs[self._slot]
         self._slot = (self._slot + 1) % self.depth
-        self._wait(b)  # the gather that last read these buffers
         p = len(x_cols)
         G_local = int(row_offsets.numel()) - 1
         per = padded_shard_len(self.n_groups_total, self.world)
         dev = y.device
-        if b["core"] is None:
+        caller = torch.cuda.current_stream(dev)
+        if b["ctx"] is None:
+            first = all(o["ctx"] is None for o in self._bufs)
+            b["ctx"] = self.ctx if first else type(self.ctx)(dev.index)
+            b["stream"] = torch.cuda.Stream(device=dev)
+            b["acc_done"] = torch.cuda.Event()
             b["core"] = torch.empty((G_local, p + 6), dtype=torch.float64, device=dev)
-            b["out"] = torch.empty((per * self.world, p + 6), dtype=torch.float64, device=dev)
             if options.compute_inference:
                 b["inf"] = torch.empty((G_local, 5 * p + 2), dtype=torch.float64, device=dev)
-                b["out_inf"] = torch.empty((per * self.world, 5 * p + 2), dtype=torch.float64, device=dev)
-        core, inf = self.ctx.fit_batch_device(row_offsets, y, x_cols, w, options, core=b["core"], inference=b["inf"])
-        all_core, wk = gather_records(core, self.n_groups_total, self.group, out=b["out"], async_op=True)
-        b["work"].append(wk)
-        all_inf = None
-        if inf is not None:
-            all_inf, wk2 = gather_records(inf, self.n_groups_total, self.group, out=b["out_inf"], async_op=True)
-            b["work"].append(wk2)
+            if self.world > 1:
+                b["out"] = torch.empty((per * self.world, p + 6), dtype=torch.float64, device=dev)
+                if options.compute_inference:
+                    b["out_inf"] = torch.empty((per * self.world, 5 * p + 2), dtype=torch.float64, device=dev)
+        s = b["stream"]
+        s.wait_stream(caller)  # the inputs were produced on the caller's stream
+        with torch.cuda.stream(s):
+            self._wait(b)      # the gather that last read these buffers
+            # the accumulate kernels of consecutive steps run one after the other (both are HBM-bound); only the
+            # solve / refinement tail of step k overlaps the accumulate kernel of step k + 1
+            b["acc_done"].record(s)  # materialise the event handle before the library records into it
+            b["ctx"].set_accumulate_gate(self._last_acc, b["acc_done"])
+            self._last_acc = b["acc_done"]
+            core, inf = b["ctx"].fit_batch_device(row_offsets, y, x_cols, w, options, core=b["core"], inference=b["inf"])
+            if self.world == 1:
+                return core, inf
+            all_core, wk = gather_records(core, self.n_groups_total, self.group, out=b["out"], async_op=True)
+            b["work"].append(wk)
+            all_inf = None
+            if inf is not None:
+                all_inf, wk2 = gather_records(inf, self.n_groups_total, self.group, out=b["out_inf"], async_op=True)
+                b["work"].append(wk2)
         return all_core, all_inf
 
+    def prepare(self, row_offsets, y, x_cols, w, options):
+        """Create every slot's context, stream, buffers and workspace now (one fit per slot), so that no allocation
+        happens inside a timed or latency-sensitive region later."""
+        for _ in range(self.depth):
+            self.fit(row_offsets, y, x_cols, w, options)
+        self.finish()
+        torch.cuda.synchronize(y.device)
+
     def finish(self):
-        """Wait for every outstanding gather (makes the current stream wait; call before reading results)."""
+        """Make the calling stream wait for every outstanding step and gather (call before reading results)."""
         for b in self._bufs:
-            self._wait(b)
+            if b["stream"] is None:
+                continue
+            with torch.cuda.stream(b["stream"]):
+                self._wait(b)
+            torch.cuda.current_stream(b["stream"].device).wait_stream(b["stream"])

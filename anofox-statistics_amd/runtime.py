@@ -46,6 +46,13 @@ class Context:
         else:
             self._check(self._lib.anofox_hip_context_set_stream(self._h, C.c_void_p(int(hip_stream)), C.byref(err)), err)
 
+    def set_accumulate_gate(self, wait_event=None, record_event=None):
+        """torch.cuda.Event objects (or None): wait for `wait_event` before the accumulate kernel of the next fit
+        calls, record `record_event` right after it (see anofox_hip_context_set_accumulate_gate)."""
+        err = _abi.AnofoxError()
+        h = lambda ev: C.c_void_p(0 if ev is None else int(ev.cuda_event))
+        self._check(self._lib.anofox_hip_context_set_accumulate_gate(self._h, h(wait_event), h(record_event), C.byref(err)), err)
+
     def synchronize(self):
         err = _abi.AnofoxError()
         self._check(self._lib.anofox_hip_context_synchronize(self._h, C.byref(err)), err)

@@ -272,6 +272,13 @@ ANOFOX_HIP_API void anofox_hip_context_destroy(AnofoxHipContext *ctx);
 ANOFOX_HIP_API bool anofox_hip_context_set_stream(AnofoxHipContext *ctx, void *hip_stream, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_context_use_own_stream(AnofoxHipContext *ctx, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_context_synchronize(AnofoxHipContext *ctx, AnofoxError *out_error);
+/* Pipelining hook for callers that alternate consecutive batches between two contexts on two streams, so that the
+ * small solve / refinement kernels of batch k overlap the HBM-bound accumulate kernel of batch k + 1: the fit entry
+ * points make the stream wait for `wait_event` (hipEvent_t as void*, may be NULL) before the accumulate kernel and
+ * record `record_event` (may be NULL) right after it.  Chaining the events keeps the accumulate kernels of the two
+ * contexts from running against each other. */
+ANOFOX_HIP_API bool anofox_hip_context_set_accumulate_gate(AnofoxHipContext *ctx, void *wait_event, void *record_event,
+                                            AnofoxError *out_error);
 
 /*
  * Device-resident batch fit.  d_* are device pointers on the context's device; x_cols is a HOST array of
