@@ -6,11 +6,12 @@
 // of crates/anofox-stats-core/src/models/ols.rs:59-87).  The workgroup-per-group kernel stages 16-row chunks
 // through LDS behind a barrier per chunk; with one or two column blocks that overhead, not HBM or the matrix
 // pipe, set the pace (1.7-2.8 TB/s at p = 9..32).  Here a wave owns its group and nothing is shared:
-//   * a step is 16 rows; lane (kk, lj) loads rows 4 kk .. 4 kk + 3 of column 16 I + lj straight into MFMA
-//     fragment layout (two 16-byte loads per column block, the 16 lanes of a column cover one 128-byte line);
+//   * a step is 16 rows; lane (kk, lj) loads rows 2 kk, 2 kk + 1 and 8 + 2 kk, 9 + 2 kk of column 16 I + lj straight
+//     into MFMA fragment layout (two 16-byte loads per column block; each instruction covers a contiguous 64-byte
+//     half line per column);
 //     a loop trip is 2 or 4 steps and the next trip's loads are in flight while this one computes;
-//   * K-step m of the MFMA takes the lanes' m-th row: A[i = lj][k = kk] = w d[4 kk + m][16 I + lj],
-//     B[k = kk][j = lj] = d[4 kk + m][16 J + lj]  (which rows share a K-step is irrelevant to the sum);
+//   * K-step m of the MFMA takes the lanes' m-th row r = mid_row(kk, m): A[i = lj][k = kk] = w d[r][16 I + lj],
+//     B[k = kk][j = lj] = d[r][16 J + lj]  (which rows share a K-step is irrelevant to the sum);
 //   * row validity: one ballot says whether all 16 rows of a step pass (then the step runs without masks);
 //     otherwise 4 ballots give the row mask (the 16 lanes of a kk group hold the 16 columns of a block) and
 //     invalid rows are removed with bit masks;
@@ -33,16 +34,23 @@ __device__ __forceinline__ double mid_mask(double v, long long m) {
 	return __longlong_as_double(__double_as_longlong(v) & m);
 }
 
-// four consecutive rows r .. r + 3 of one column, all inside the group: two 16-byte loads
-__device__ __forceinline__ void load4_full(mid_gptr_t col, int64_t r, double (&v)[4]) {
-	const mid_dbl2u a = *reinterpret_cast<mid_gptr2_t>(col + r);
-	const mid_dbl2u b = *reinterpret_cast<mid_gptr2_t>(col + r + 2);
+// Which row of a 16-row step lane group kk holds in its m-th value: rows 2 kk, 2 kk + 1 of the first half, then the
+// same of the second half — so that one load instruction covers a contiguous 64-byte half line per column.
+__device__ __forceinline__ int mid_row(int kk, int m) { return 8 * (m >> 1) + 2 * kk + (m & 1); }
+
+// the lane's four rows of one column, all inside the group: two 16-byte loads (r0 = first row of the step)
+__device__ __forceinline__ void load4_full(mid_gptr_t col, int64_t r0, int kk, double (&v)[4]) {
+	const mid_dbl2u a = *reinterpret_cast<mid_gptr2_t>(col + r0 + 2 * kk);
+	const mid_dbl2u b = *reinterpret_cast<mid_gptr2_t>(col + r0 + 8 + 2 * kk);
 	v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
 }
 // the same at the end of a group: rows at or past `hi` are clamped (their values are masked later)
-__device__ __forceinline__ void load4_tail(mid_gptr_t col, int64_t r, int64_t hi, double (&v)[4]) {
+__device__ __forceinline__ void load4_tail(mid_gptr_t col, int64_t r0, int kk, int64_t hi, double (&v)[4]) {
 #pragma unroll
-	for (int m = 0; m < 4; ++m) v[m] = col[r + m < hi ? r + m : hi - 1];
+	for (int m = 0; m < 4; ++m) {
+		const int64_t r = r0 + mid_row(kk, m);
+		v[m] = col[r < hi ? r : hi - 1];
+	}
 }
 
 template <int T>
@@ -60,8 +68,8 @@ template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID>
 __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4], const double (&y)[4], const double (&w)[4],
                                          unsigned rowmask, int kk, int lj) {
 	if (!st.have_first) {
-		const int r = __ffs((int)rowmask) - 1; // first valid row of the group: held by the lanes of kk = r / 4
-		const int src = 16 * (r >> 2) + lj, m = r & 3;
+		const int r = __ffs((int)rowmask) - 1; // first valid row of the group; mid_row(kk, m) == r
+		const int src = 16 * ((r >> 1) & 3) + lj, m = ((r >> 3) << 1) | (r & 1);
 #pragma unroll
 		for (int I = 0; I < T; ++I) {
 			const double mine = m == 0 ? x[I][0] : (m == 1 ? x[I][1] : (m == 2 ? x[I][2] : x[I][3]));
@@ -74,7 +82,7 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 	st.cnt += ALLVALID ? 16 : __popc(rowmask);
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
-		const long long rm = ALLVALID ? -1ll : -(long long)((rowmask >> (4 * kk + m)) & 1u); // all ones when the row is valid
+		const long long rm = ALLVALID ? -1ll : -(long long)((rowmask >> mid_row(kk, m)) & 1u); // all ones when the row is valid
 		double d[T], a[T];
 #pragma unroll
 		for (int I = 0; I < T; ++I) {
@@ -156,20 +164,20 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 		if (r0 + 16 * S <= hi) {
 #pragma unroll
 			for (int q = 0; q < S; ++q) {
-				const int64_t r = r0 + 16 * q + 4 * kk;
+				const int64_t r = r0 + 16 * q;
 #pragma unroll
-				for (int I = 0; I < T; ++I) load4_full(col[I], r, xn[q][I]);
-				load4_full(ycol, r, yn[q]);
-				if (WEIGHTED) load4_full(wcol, r, wn[q]);
+				for (int I = 0; I < T; ++I) load4_full(col[I], r, kk, xn[q][I]);
+				load4_full(ycol, r, kk, yn[q]);
+				if (WEIGHTED) load4_full(wcol, r, kk, wn[q]);
 			}
 		} else {
 #pragma unroll
 			for (int q = 0; q < S; ++q) {
-				const int64_t r = r0 + 16 * q + 4 * kk;
+				const int64_t r = r0 + 16 * q;
 #pragma unroll
-				for (int I = 0; I < T; ++I) load4_tail(col[I], r, hi, xn[q][I]);
-				load4_tail(ycol, r, hi, yn[q]);
-				if (WEIGHTED) load4_tail(wcol, r, hi, wn[q]);
+				for (int I = 0; I < T; ++I) load4_tail(col[I], r, kk, hi, xn[q][I]);
+				load4_tail(ycol, r, kk, hi, yn[q]);
+				if (WEIGHTED) load4_tail(wcol, r, kk, hi, wn[q]);
 			}
 		}
 	};
@@ -207,16 +215,16 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 				mid_step<T, WEIGHTED, CENTER, true>(st, x, y, w, 0xFFFFu, kk, lj);
 				continue;
 			}
-			unsigned rowmask = 0; // bit 4 kk + m
+			unsigned rowmask = 0; // bit = row of the step
 #pragma unroll
 			for (int m = 0; m < 4; ++m) {
-				bool ok = isfinite(y[m]) && (r0 + 4 * kk + m < hi);
+				bool ok = isfinite(y[m]) && (r0 + mid_row(kk, m) < hi);
 				if (WEIGHTED) ok = ok && isfinite(w[m]) && (w[m] > 0.0);
 #pragma unroll
 				for (int I = 0; I < T; ++I) ok = ok && isfinite(x[I][m]);
 				const unsigned long long b = __ballot(ok);
 #pragma unroll
-				for (int k = 0; k < 4; ++k) rowmask |= (((b >> (16 * k)) & 0xFFFFull) == 0xFFFFull) ? (1u << (4 * k + m)) : 0u;
+				for (int k = 0; k < 4; ++k) rowmask |= (((b >> (16 * k)) & 0xFFFFull) == 0xFFFFull) ? (1u << mid_row(k, m)) : 0u;
 			}
 			rowmask = __builtin_amdgcn_readfirstlane(rowmask);
 			if (rowmask == 0u) continue;
