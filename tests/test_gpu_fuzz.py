@@ -104,3 +104,78 @@ def test_fuzz_narrow(pkg, ctx, seed):
 @pytest.mark.parametrize("seed", range(80))
 def test_fuzz_wide(pkg, ctx, seed):
     _run(pkg, ctx, 20_000 + seed, wide=True)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_fuzz_fit_predict(pkg, ctx, seed):
+    """*_fit_predict_agg: per-row predictions and intervals against the oracle on random shapes / NULL patterns."""
+    rng = np.random.default_rng(30_000 + seed)
+    p = int(rng.integers(1, 13))
+    G = int(rng.integers(1, 30))
+    ns = rng.choice([0, 1, 2, 3, 5, p + 1, p + 2, 2 * p + 3, 40, 127, 128, 129, 300], size=G)
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    X = rng.uniform(-5, 5, (N, p)) + rng.uniform(-3, 3, p)
+    gid = np.repeat(np.arange(G), ns)
+    beta = rng.uniform(-2, 2, (G, p))
+    y = rng.uniform(-5, 5, G)[gid] + np.einsum("ij,ij->i", X, beta[gid]) + 0.3 * rng.standard_normal(N)
+    y[rng.random(N) < 0.2] = np.nan                                   # prediction rows
+    X[rng.random(N) < 0.01, int(rng.integers(0, p))] = np.nan         # NULL features
+    w = rng.uniform(0.3, 2.0, N)
+    model = ["ols", "ridge", "wls"][int(rng.integers(0, 3))]
+    kw = dict(fit_intercept=bool(rng.integers(0, 2)), confidence_level=float(rng.choice([0.8, 0.95])))
+    if model == "ridge":
+        kw["alpha"] = float(10.0 ** rng.uniform(-2, 0.5))
+    wv = w if model == "wls" else None
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    opts = pkg.RegressionOptions(**kw).batch_options(model)
+    core, pred = pkg.fit_predict_batch_host(offs, y, x_cols, wv, opts, ctx=ctx)
+    rcore, rpred = oracle.fit_predict_groups(y, x_cols, offs, w=wv, model=model, **kw)
+    n_obs = rcore[:, p + 4]
+    n_par = np.sum(~np.isnan(rcore[:, :p]), axis=1) + (1 if kw["fit_intercept"] else 0)
+    tight = [g for g in range(G) if rcore[g, p + 5] == 0 and n_obs[g] - n_par[g] <= 0]
+    assert_records_match(core, rcore, p, what=f"fit_predict seed {seed} {model} p={p} {kw}", skip_diag_groups=tight)
+    keep = np.ones(N, dtype=bool)
+    for g in tight:                                                   # zero residual df: sigma is 0/0
+        keep[offs[g]:offs[g + 1]] = False
+    assert np.array_equal(np.isnan(pred[keep]), np.isnan(rpred[keep])), f"seed {seed}: NULL pattern"
+    m = keep[:, None] & ~np.isnan(rpred)
+    if m.any():
+        err = np.abs(pred[m] - rpred[m]) / np.maximum(np.abs(rpred[m]), 1.0)
+        assert err.max() < 1e-8, (seed, model, p, kw, err.max())
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_fuzz_window_frames(pkg, ctx, seed):
+    """*_fit_predict OVER (... ROWS BETWEEN a PRECEDING AND b PRECEDING): random frames, partitions and NULL patterns."""
+    rng = np.random.default_rng(40_000 + seed)
+    p = int(rng.integers(1, 9))
+    G = int(rng.integers(1, 8))
+    ns = rng.choice([0, 1, 2, 5, 17, 64, 65, 130], size=G)
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    if N == 0:
+        return
+    X = rng.uniform(-5, 5, (N, p))
+    y = 1.0 + X @ rng.uniform(-2, 2, p) + 0.3 * rng.standard_normal(N)
+    y[rng.random(N) < 0.15] = np.nan
+    X[rng.random(N) < 0.02, int(rng.integers(0, p))] = np.nan
+    w = rng.uniform(0.3, 2.0, N)
+    b = int(rng.choice([0, 0, 1, 3]))
+    a = None if rng.random() < 0.35 else b + int(rng.integers(0, 40))
+    model = ["ols", "ridge", "wls"][int(rng.integers(0, 3))]
+    kw = dict(fit_intercept=bool(rng.integers(0, 2)), confidence_level=0.9)
+    if model == "ridge":
+        kw["alpha"] = float(10.0 ** rng.uniform(-2, 0.5))
+    wv = w if model == "wls" else None
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    pred = pkg.fit_predict_window_host(offs, y, x_cols, wv, pkg.RegressionOptions(**kw).batch_options(model), (a, b), ctx=ctx)
+    ref = oracle.fit_predict_window(y, x_cols, offs, w=wv, start_preceding=-1 if a is None else a, end_preceding=b,
+                                    model=model, **kw)
+    what = f"window seed {seed} {model} p={p} frame=({a},{b}) {kw}"
+    assert np.array_equal(np.isnan(pred[:, 0]), np.isnan(ref[:, 0])), f"NULL pattern {what}"
+    m = ~np.isnan(ref[:, 0])
+    if m.any():
+        err = np.abs(pred[m, 0] - ref[m, 0]) / np.maximum(np.abs(ref[m, 0]), 1.0)
+        # frames with barely more rows than parameters are ill-conditioned; the window kernels have no refinement pass
+        assert np.quantile(err, 0.9) < 1e-8 and err.max() < 1e-3, (what, np.quantile(err, 0.9), err.max())
