@@ -7,7 +7,7 @@
 // constant-column / finite-row predicates stay on the VALU (they are O(p) per row).
 //
 // Mapping: one 256-thread workgroup (4 wavefronts) per group.
-//   * A chunk is 16 consecutive rows of every column (x_1..x_p, y, [w]).  The four waves load it coalesced
+//   * A chunk is 32 (16 for p > 96) consecutive rows of every column (x_1..x_p, y, [w]).  The four waves load it coalesced
 //     (each load instruction: 8 columns x 128 contiguous bytes) one chunk ahead into registers and write it to
 //     a double-buffered LDS image laid out [column][18 doubles] (conflict-free for the fragment reads below).
 //   * A slab is 4 rows.  For the 16-column block I, lane l of a wave reads the fragment element
@@ -35,8 +35,6 @@ typedef const dbl2u __attribute__((address_space(1))) *gptr2_t;
 
 namespace {
 
-constexpr int kChunkRows = 16;
-constexpr int kLdsStride = 18;   // doubles per column in the LDS image (16 rows + 2 pad: conflict-free b64 reads)
 constexpr int kWaves = 4;
 
 __device__ __forceinline__ double readlane_d(double v, int src) {
@@ -51,6 +49,10 @@ struct WideCfg {
 	static constexpr int NT = T * (T + 1) / 2;             // upper-triangular tiles
 	static constexpr int TPW = (NT + kWaves - 1) / kWaves; // tiles per wave
 	static constexpr int OWN = (T + kWaves - 1) / kWaves;  // column blocks owned per wave
+	// rows staged per barrier: 32 where the registers allow it (6.5 TB/s at p = 96 against 6.1 with 16), 16 for the
+	// widest designs (72 accumulator registers per wave at T = 8: the extra staging registers would spill)
+	static constexpr int CH = (T <= 6) ? 32 : 16;
+	static constexpr int STRIDE = CH + 2; // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
 };
 
 __device__ __forceinline__ double mask_f64(double v, long long m) {
@@ -67,6 +69,7 @@ __device__ __forceinline__ void compute_chunk(const double *img, int ycol, int l
                                               dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
                                               double (&sxy)[WideCfg<T>::OWN], unsigned &ncmask, double &sy,
                                               double &syy, double &sw) {
+	constexpr int kChunkRows = WideCfg<T>::CH, kLdsStride = WideCfg<T>::STRIDE;
 	const int k = lane >> 4;
 	const int i = lane & 15;
 #pragma unroll 1
@@ -123,6 +126,8 @@ template <int T, bool WEIGHTED, bool CENTER>
 __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
                                                      const double *forced_first) {
 	using Cfg = WideCfg<T>;
+	constexpr int kChunkRows = Cfg::CH, kLdsStride = Cfg::STRIDE;
+	constexpr bool kWideChunk = kChunkRows == 32;
 	constexpr int P16 = 16 * T;
 	const int p = args.p;
 	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
@@ -182,7 +187,8 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 	}
 
 	const int64_t n_chunks = (nrows + kChunkRows - 1) / kChunkRows;
-	double v0[kMaxLoads], v1[kMaxLoads]; // staging registers: rows 2*rp, 2*rp+1 of this lane's columns
+	// staging registers: rows 2 rp, 2 rp + 1 (v0, v1) and 16 + 2 rp, 17 + 2 rp (v2, v3) of this lane's columns
+	double v0[kMaxLoads], v1[kMaxLoads], v2[kMaxLoads], v3[kMaxLoads];
 
 	// issue the loads of one chunk (global -> registers); consumed by stage_store
 	auto stage_load = [&](int64_t chunk) {
@@ -191,23 +197,30 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
 			const int li = wave + kWaves * q;
-			v0[q] = v1[q] = 0.0;
+			v0[q] = v1[q] = v2[q] = v3[q] = 0.0;
 			if (li < n_loads_total) { // wave-uniform
 				const gptr_t b = reinterpret_cast<gptr_t>(colbase[8 * li + colsub]);
 				if (full) {
-					const dbl2u v = *reinterpret_cast<gptr2_t>(b + r0);
-					v0[q] = v.x;
-					v1[q] = v.y;
+					const dbl2u va = *reinterpret_cast<gptr2_t>(b + r0);
+					v0[q] = va.x;
+					v1[q] = va.y;
+					if (kWideChunk) {
+						const dbl2u vb = *reinterpret_cast<gptr2_t>(b + r0 + 16);
+						v2[q] = vb.x;
+						v3[q] = vb.y;
+					}
 				} else {
 					if (r0 < nrows) v0[q] = b[r0];
 					if (r0 + 1 < nrows) v1[q] = b[r0 + 1];
+					if (kWideChunk && r0 + 16 < nrows) v2[q] = b[r0 + 16];
+					if (kWideChunk && r0 + 17 < nrows) v3[q] = b[r0 + 17];
 				}
 			}
 		}
 	};
 	// registers -> LDS image `buf`, plus this wave's partial row-validity mask (ols.rs:59-66, wls.rs:76-86)
 	auto stage_store = [&](int64_t chunk, int buf) {
-		bool ok0 = true, ok1 = true;
+		bool ok0 = true, ok1 = true, ok2 = true, ok3 = true;
 		double *img = image + buf * ncol_pad * kLdsStride;
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
@@ -215,29 +228,43 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 			if (li < n_loads_total) {
 				const int src = 8 * li + colsub;
 				if (src < ncol) {
-					bool f0 = isfinite(v0[q]), f1 = isfinite(v1[q]);
+					bool f0 = isfinite(v0[q]), f1 = isfinite(v1[q]), f2 = isfinite(v2[q]), f3 = isfinite(v3[q]);
 					if (WEIGHTED && src == p + 1) {
 						f0 = f0 && v0[q] > 0.0;
 						f1 = f1 && v1[q] > 0.0;
+						f2 = f2 && v2[q] > 0.0;
+						f3 = f3 && v3[q] > 0.0;
 					}
 					ok0 = ok0 && f0;
 					ok1 = ok1 && f1;
+					ok2 = ok2 && f2;
+					ok3 = ok3 && f3;
 					const int col = src < p ? src : ycol + (src - p);
 					double *dst = img + col * kLdsStride + 2 * rp;
 					dst[0] = v0[q];
 					dst[1] = v1[q];
+					if (kWideChunk) {
+						dst[16] = v2[q];
+						dst[17] = v3[q];
+					}
 				}
 			}
 		}
-		// fold the 8 column sub-groups: bit m = rows 2m / 2m+1 valid in every column this wave staged
-		unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
+		// fold the 8 column sub-groups: bit = row of the chunk, set when the row is valid in every column this wave staged
+		unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1), b2 = __ballot(ok2), b3 = __ballot(ok3);
 		b0 &= b0 >> 32; b0 &= b0 >> 16; b0 &= b0 >> 8;
 		b1 &= b1 >> 32; b1 &= b1 >> 16; b1 &= b1 >> 8;
+		b2 &= b2 >> 32; b2 &= b2 >> 16; b2 &= b2 >> 8;
+		b3 &= b3 >> 32; b3 &= b3 >> 16; b3 &= b3 >> 8;
 		unsigned m = 0;
 #pragma unroll
 		for (int r = 0; r < 8; ++r) {
 			m |= ((unsigned)(b0 >> r) & 1u) << (2 * r);
 			m |= ((unsigned)(b1 >> r) & 1u) << (2 * r + 1);
+			if (kWideChunk) {
+				m |= ((unsigned)(b2 >> r) & 1u) << (16 + 2 * r);
+				m |= ((unsigned)(b3 >> r) & 1u) << (17 + 2 * r);
+			}
 		}
 		const int64_t left = nrows - chunk * kChunkRows; // rows past the end of the group are invalid
 		if (left < kChunkRows) m &= (left <= 0) ? 0u : ((1u << left) - 1u);
@@ -393,7 +420,7 @@ hipError_t launch_T(const WideArgs &a, hipStream_t stream) {
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
 	const int ncol_pad = wide_ncol_pad(a.p, weighted);
-	const size_t lds = (size_t)2 * ncol_pad * kLdsStride * sizeof(double) + (size_t)ncol_pad * sizeof(double *) + 64;
+	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::STRIDE * sizeof(double) + (size_t)ncol_pad * sizeof(double *) + 64;
 	const dim3 grid((unsigned)a.n_groups), block(256);
 	const dim3 seg_grid((unsigned)kWideSegMaxSegments); // idle unless some group exceeded seg_rows
 #define ANOFOX_WIDE_LAUNCH(W, C)                                                                                  \
