@@ -240,12 +240,10 @@ __device__ __forceinline__ SegBigGroup *seg_big(void *t) { return reinterpret_ca
 __device__ __forceinline__ SegEntry *seg_entries(void *t) { return reinterpret_cast<SegEntry *>(seg_big(t) + kSegMaxBig); }
 __device__ __forceinline__ double *seg_records(void *t) { return reinterpret_cast<double *>(seg_entries(t) + kSegMaxSegments); }
 
+// One group per wavefront: accumulate it, or register it for row splitting when it is very large.
 template <int P, bool WEIGHTED, bool CENTER, bool PF>
-__global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) {
+__device__ __forceinline__ void accumulate_group(const BatchArgs &args, int64_t g, int lane) {
 	using L = MomentLayout<P>;
-	const int lane = threadIdx.x & 63;
-	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
-	if (g >= args.n_groups) return;
 	const int64_t lo = args.row_offsets[g];
 	const int64_t hi = args.row_offsets[g + 1];
 	if (args.seg_table && hi - lo > args.seg_rows) {
@@ -279,6 +277,24 @@ __global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) 
 		}
 	}
 	accumulate_rows<P, WEIGHTED, CENTER, PF>(args, lo, hi, args.moments + g * (int64_t)L::REC, lane);
+}
+
+template <int P, bool WEIGHTED, bool CENTER, bool PF>
+__global__ __launch_bounds__(256) void accumulate_narrow_kernel(BatchArgs args) {
+	const int lane = threadIdx.x & 63;
+	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+	if (g >= args.n_groups) return;
+	accumulate_group<P, WEIGHTED, CENTER, PF>(args, g, lane);
+}
+
+// The same for an explicit list of groups (the ones accumulate_small.hip leaves out): persistent grid.
+template <int P, bool WEIGHTED, bool CENTER, bool PF>
+__global__ __launch_bounds__(256) void accumulate_narrow_list_kernel(BatchArgs args, const int32_t *list, const int32_t *count) {
+	const int lane = threadIdx.x & 63;
+	const int n = *count;
+	const int n_waves = (int)gridDim.x * 4;
+	for (int v = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); v < n; v += n_waves)
+		accumulate_group<P, WEIGHTED, CENTER, PF>(args, list[v], lane);
 }
 
 // Merge the segment records of one group into its moment record: lane k owns moment k.  Segment b was shifted by
@@ -381,26 +397,56 @@ static hipError_t launch_pn(const BatchArgs &a, hipStream_t stream) {
 	return hipGetLastError();
 }
 
+template <int P, bool PF>
+static hipError_t launch_list_pn(const BatchArgs &a, const int32_t *list, const int32_t *count, hipStream_t stream) {
+	const dim3 block(256), grid(2048);
+	const dim3 seg_grid((unsigned)((kSegMaxSegments + 3) / 4));
+	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
+	const bool center = a.fit_intercept != 0;
+#define ANOFOX_ACC_LIST_LAUNCH(W, C)                                                                          \
+	do {                                                                                                      \
+		hipLaunchKernelGGL((accumulate_narrow_list_kernel<P, W, C, PF>), grid, block, 0, stream, a, list, count); \
+		if (a.seg_table) hipLaunchKernelGGL((accumulate_segments_kernel<P, W, C, PF>), seg_grid, block, 0, stream, a); \
+	} while (0)
+	if (weighted) {
+		if (center) ANOFOX_ACC_LIST_LAUNCH(true, true);
+		else ANOFOX_ACC_LIST_LAUNCH(true, false);
+	} else {
+		if (center) ANOFOX_ACC_LIST_LAUNCH(false, true);
+		else ANOFOX_ACC_LIST_LAUNCH(false, false);
+	}
+#undef ANOFOX_ACC_LIST_LAUNCH
+	return hipGetLastError();
+}
+
 template <int P>
-static hipError_t launch_p(const BatchArgs &a, hipStream_t stream) {
+static hipError_t launch_p(const BatchArgs &a, const int32_t *list, const int32_t *count, hipStream_t stream) {
 	// ANOFOX_ACC_PF=0 issues a tile's loads at the top of its own iteration instead of one tile ahead (A/B measurements)
 	static const int pf = [] { const char *e = getenv("ANOFOX_ACC_PF"); return e ? atoi(e) : 1; }();
+	if (list) return pf ? launch_list_pn<P, true>(a, list, count, stream) : launch_list_pn<P, false>(a, list, count, stream);
 	return pf ? launch_pn<P, true>(a, stream) : launch_pn<P, false>(a, stream);
 }
 
-hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream) {
+static hipError_t launch_any(const BatchArgs &a, const int32_t *list, const int32_t *count, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
 	switch (a.p) {
-	case 1: return launch_p<1>(a, stream);
-	case 2: return launch_p<2>(a, stream);
-	case 3: return launch_p<3>(a, stream);
-	case 4: return launch_p<4>(a, stream);
-	case 5: return launch_p<5>(a, stream);
-	case 6: return launch_p<6>(a, stream);
-	case 7: return launch_p<7>(a, stream);
-	case 8: return launch_p<8>(a, stream);
+	case 1: return launch_p<1>(a, list, count, stream);
+	case 2: return launch_p<2>(a, list, count, stream);
+	case 3: return launch_p<3>(a, list, count, stream);
+	case 4: return launch_p<4>(a, list, count, stream);
+	case 5: return launch_p<5>(a, list, count, stream);
+	case 6: return launch_p<6>(a, list, count, stream);
+	case 7: return launch_p<7>(a, list, count, stream);
+	case 8: return launch_p<8>(a, list, count, stream);
 	default: return hipErrorInvalidValue;
 	}
+}
+
+hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream) { return launch_any(a, nullptr, nullptr, stream); }
+
+// only the groups in list[0 .. *count) (device memory), e.g. the ones accumulate_small.hip left out
+hipError_t launch_accumulate_narrow_list(const BatchArgs &a, const int32_t *list, const int32_t *count, hipStream_t stream) {
+	return launch_any(a, list, count, stream);
 }
 
 } // namespace anofox

@@ -343,6 +343,10 @@ hipError_t launch_hc_wide(const WideArgs &a, hipStream_t stream);
 
 // launchers implemented in the .hip translation units
 hipError_t launch_accumulate_narrow(const BatchArgs &a, hipStream_t stream);
+hipError_t launch_accumulate_narrow_list(const BatchArgs &a, const int32_t *list, const int32_t *count, hipStream_t stream);
+// accumulate_small.hip: several small groups per wavefront; groups too long for it are appended to big_list / big_count
+int accumulate_small_segment_width(double avg_rows); // 0 = not worth it
+hipError_t launch_accumulate_small(const BatchArgs &a, int segw, int32_t *big_list, int32_t *big_count, hipStream_t stream);
 // primary solve of every group (queues the groups that need refinement), then ONE launch that takes every queued
 // group through `steps` iterative-refinement updates and the final statistics from the directly summed RSS
 hipError_t launch_solve_narrow(const BatchArgs &a, hipStream_t stream);

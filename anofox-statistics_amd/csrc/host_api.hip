@@ -277,7 +277,16 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	}
 	if (ctx->gate_wait && hip_fail(hipStreamWaitEvent(st, ctx->gate_wait, 0), "hipStreamWaitEvent", e)) return false;
 	if (ctx->timing) (void)hipEventRecord(e0, st); // (again: the accumulate kernel starts after the gate)
-	if (hip_fail(launch_accumulate_narrow(a, st), "accumulate kernel launch", e)) return false;
+	// batches of small groups (<= 128 rows on average): several groups per wavefront, the long ones through a list
+	static const bool small_on = !(getenv("ANOFOX_ACC_SMALL") && atoi(getenv("ANOFOX_ACC_SMALL")) == 0); // A/B switch
+	const int segw = (small_on && n_rows > 0 && G < (int64_t)0x7fffffff) ? accumulate_small_segment_width((double)n_rows / (double)G) : 0;
+	if (segw) {
+		int32_t *big_count = ws.refine_count + 4; // zeroed with the other counters; the list borrows the (still unused) refine queue
+		if (hip_fail(launch_accumulate_small(a, segw, ws.refine_list, big_count, st), "accumulate kernel launch", e)) return false;
+		if (hip_fail(launch_accumulate_narrow_list(a, ws.refine_list, big_count, st), "accumulate kernel launch", e)) return false;
+	} else if (hip_fail(launch_accumulate_narrow(a, st), "accumulate kernel launch", e)) {
+		return false;
+	}
 	if (ctx->timing) (void)hipEventRecord(e1, st);
 	if (ctx->gate_record && hip_fail(hipEventRecord(ctx->gate_record, st), "hipEventRecord", e)) return false;
 	if (hip_fail(launch_solve_narrow(a, st), "solve kernel launch", e)) return false;

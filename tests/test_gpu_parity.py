@@ -564,6 +564,49 @@ def test_device_calls_are_ordered_with_torch_streams(pkg, ctx):
             assert bool((core[:, 6] == 0).all())
 
 
+@pytest.mark.parametrize("model", ["ols", "ridge", "wls"])
+@pytest.mark.parametrize("avg", [6, 12, 28, 50])
+def test_small_groups_share_a_wavefront(pkg, ctx, model, avg):
+    """Batches that average at most 64 rows per group run several groups per wavefront (accumulate_small.hip:
+    16- or 32-lane segments); groups too long for that kernel go through a list to the one-wave-per-group kernel,
+    very large ones are split on top of that."""
+    for p in (1, 3, 8):
+        rng = np.random.default_rng(1000 * avg + 10 * p + len(model))
+        G = 700
+        ns = rng.integers(0, 2 * avg + 1, size=G)
+        ns[5] = 300                                              # too long for the packed kernel -> list
+        ns[77] = 1000
+        if avg == 28:
+            ns[200] = 9000                                       # > seg_rows: split into segments as well
+        offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+        N = int(offs[-1])
+        X = rng.uniform(-10, 10, (N, p)) + rng.uniform(-20, 20, p)
+        gid = np.repeat(np.arange(G), ns)
+        y = rng.uniform(-5, 5, G)[gid] + np.einsum("ij,ij->i", X, rng.uniform(-3, 3, (G, p))[gid]) + rng.standard_normal(N)
+        w = rng.uniform(0.5, 1.5, N)
+        y[rng.random(N) < 0.03] = np.nan                         # invalid rows, also first rows of groups
+        X[rng.random(N) < 0.01, 0] = np.inf
+        for g in range(10, G, 37):                               # constant columns
+            X[offs[g]:offs[g + 1], p - 1] = 2.5
+        if p >= 3:
+            for g in range(20, G, 53):                           # aliased columns
+                X[offs[g]:offs[g + 1], 2] = 3.0 * X[offs[g]:offs[g + 1], 0] - 1.0
+        w[rng.random(N) < 0.02] = 0.0
+        x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+        for icpt in (True, False):
+            kw = dict(fit_intercept=icpt, compute_inference=True)
+            if model == "ridge":
+                kw["alpha"] = 0.8
+            wv = w if model == "wls" else None
+            core, inf = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+            rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
+            n_obs = rcore[:, p + 4]
+            n_par = np.sum(~np.isnan(rcore[:, :p]), axis=1) + (1 if icpt else 0)
+            tight = [g for g in range(G) if rcore[g, p + 5] == 0 and n_obs[g] - n_par[g] <= 0]
+            assert_records_match(core, rcore, p, inf, rinf, what=f"small {model} avg={avg} p={p} icpt={icpt}",
+                                 skip_diag_groups=tight)
+
+
 def test_alpha_negative_and_bad_arguments(pkg, ctx):
     a = import_pkg("_abi")
     rng = np.random.default_rng(2)
