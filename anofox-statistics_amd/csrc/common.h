@@ -274,6 +274,7 @@ struct PredictArgs {
 	// own wave); nullptr disables it
 	void *seg_table;
 	int64_t seg_rows;
+	double avg_rows; // rows per group on average (0 = unknown): small groups share a wavefront
 };
 struct PredictSegEntry {
 	int64_t g, lo, hi;

@@ -519,6 +519,7 @@ bool run_predict(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, con
 	a.tcrit_table = ctx->aux;
 	a.seg_table = (char *)ctx->aux + kTcritTableBytes;
 	a.seg_rows = seg_rows_for(n_rows);
+	a.avg_rows = (n_rows > 0 && G > 0) ? (double)n_rows / (double)G : 0.0;
 	a.margin = (double *)((char *)ctx->aux + kTcritTableBytes + b_tab);
 	if (hip_fail(hipMemsetAsync(ctx->aux, 0, kTcritTableBytes + 64, ctx->stream), "hipMemsetAsync", e)) return false;
 	hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -12,6 +12,7 @@
 // Mapping: one wavefront per group, lanes stride the rows; the group's coefficients sit in LDS.
 // HBM-bound: 8p B/row read, 24 B/row written.
 #include "common.h"
+#include <cstdlib>
 #include "device_math.h"
 
 namespace anofox {
@@ -173,9 +174,99 @@ __global__ __launch_bounds__(256) void predict_narrow_kernel(PredictArgs args) {
 	}
 }
 
+// Small groups: several groups per wavefront (segments of SEGW lanes, one group each, lanes stride the rows) — with
+// 20 rows per group the 128-row tiles above leave 84 % of the lanes idle.
+template <int P, int SEGW>
+__global__ __launch_bounds__(256) void predict_small_kernel(PredictArgs args) {
+	constexpr int GPW = 64 / SEGW;
+	const int lane = threadIdx.x & 63;
+	const int seg = lane / SEGW, sl = lane % SEGW;
+	const int64_t wave_id = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+	const int64_t g = wave_id * GPW + seg;
+	const bool live = g < args.n_groups;
+	const int64_t gc = live ? g : 0;
+	int64_t lo = 0, hi = 0;
+	if (live) {
+		lo = args.row_offsets[g];
+		hi = args.row_offsets[g + 1];
+	}
+	if (args.seg_table && hi - lo > args.seg_rows) { // very large group: its first lane hands the tail to extra wavefronts
+		PredictSegTable *t = static_cast<PredictSegTable *>(args.seg_table);
+		const int64_t S = args.seg_rows;
+		const int extra = (int)((hi - lo - 1) / S);
+		int base = -1;
+		if (sl == 0) {
+			base = reserve_table_entries(&t->count, extra, kSegTargetWaves + 16);
+			for (int k = 0; base >= 0 && k < extra; ++k) {
+				PredictSegEntry e;
+				e.g = g;
+				e.lo = lo + (k + 1) * S;
+				e.hi = e.lo + S < hi ? e.lo + S : hi;
+				t->entries[base + k] = e;
+			}
+		}
+		base = __shfl(base, seg * SEGW, 64);
+		if (base >= 0) hi = lo + S;
+	}
+	const double *core = args.core + gc * (int64_t)(P + 6);
+	double coef[P];
+	bool dead[P];
+#pragma unroll
+	for (int j = 0; j < P; ++j) {
+		const double c = core[j];
+		dead[j] = isnan(c);
+		coef[j] = dead[j] ? 0.0 : c;
+	}
+	const double icpt = core[P];
+	const bool is_null = core[P + 5] != 0.0;
+	const double b0 = isnan(icpt) ? 0.0 : icpt;
+	const double margin = args.margin[gc];
+	const double nanv = __builtin_nan("");
+	int64_t nmax = hi - lo;
+#pragma unroll
+	for (int m = 32; m >= SEGW; m >>= 1) {
+		const int64_t o = __shfl_xor(nmax, m, 64);
+		nmax = o > nmax ? o : nmax;
+	}
+	for (int64_t off = sl; off < nmax; off += SEGW) {
+		const int64_t r = lo + off;
+		const bool in = r < hi;
+		const int64_t rc = in ? r : (hi > lo ? hi - 1 : 0); // clamped: loads stay unconditional
+		double yhat = b0;
+#pragma unroll
+		for (int j = 0; j < P; ++j) { // NaN coefficients are skipped whatever x holds (lib.rs:2300-2304)
+			const double xv = args.x_table[j][rc];
+			yhat = fma(coef[j], dead[j] ? 0.0 : xv, yhat);
+		}
+		const bool ok = !is_null && isfinite(yhat);
+		if (in) {
+			double *out = args.pred + r * 3;
+			out[0] = ok ? yhat : nanv;
+			out[1] = ok ? yhat - margin : nanv;
+			out[2] = ok ? yhat + margin : nanv;
+		}
+	}
+}
+
+template <int P, int SEGW>
+void launch_predict_small(const PredictArgs &a, hipStream_t stream) {
+	constexpr int GPW = 64 / SEGW;
+	const int64_t waves = (a.n_groups + GPW - 1) / GPW;
+	hipLaunchKernelGGL((predict_small_kernel<P, SEGW>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, a);
+}
+
 template <int P>
 hipError_t launch_predict_p(const PredictArgs &a, hipStream_t stream) {
-	hipLaunchKernelGGL((predict_narrow_kernel<P, false>), dim3((unsigned)((a.n_groups + 3) / 4)), dim3(256), 0, stream, a);
+	int segw = 0;
+	if (a.avg_rows > 0.0 && a.avg_rows <= 12.0) segw = 8;
+	else if (a.avg_rows > 0.0 && a.avg_rows <= 24.0) segw = 16;
+	else if (a.avg_rows > 0.0 && a.avg_rows <= 64.0) segw = 32;
+	if (const char *e = getenv("ANOFOX_PRED_SEGW")) segw = atoi(e);
+	if (segw == 4) launch_predict_small<P, 4>(a, stream);
+	else if (segw == 8) launch_predict_small<P, 8>(a, stream);
+	else if (segw == 16) launch_predict_small<P, 16>(a, stream);
+	else if (segw == 32) launch_predict_small<P, 32>(a, stream);
+	else hipLaunchKernelGGL((predict_narrow_kernel<P, false>), dim3((unsigned)((a.n_groups + 3) / 4)), dim3(256), 0, stream, a);
 	if (a.seg_table) // idle unless some group exceeded seg_rows
 		hipLaunchKernelGGL((predict_narrow_kernel<P, true>), dim3((unsigned)((kSegTargetWaves + 16 + 3) / 4)), dim3(256), 0, stream, a);
 	return hipGetLastError();

@@ -478,6 +478,35 @@ def test_fit_predict_on_very_large_groups(pkg, ctx, p):
     assert np.max(np.abs(pred[m] - rpred[m]) / np.maximum(np.abs(rpred[m]), 1.0)) < 1e-9
 
 
+@pytest.mark.parametrize("avg", [6, 18, 40])
+def test_fit_predict_small_groups_with_a_very_large_one(pkg, ctx, avg):
+    """Batches averaging <= 64 rows per group predict several groups per wavefront (predict.hip, segments of 8 / 16 /
+    32 lanes); a group beyond seg_rows inside such a batch still hands its tail to the extra wavefronts."""
+    p = 4
+    rng = np.random.default_rng(900 + avg)
+    ns = rng.integers(0, 2 * avg + 1, size=3000)
+    ns[1234] = 9000
+    ns[17] = 700
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    assert N / len(ns) <= {6: 12, 18: 24, 40: 64}[avg]
+    X = rng.uniform(-5, 5, (N, p))
+    gid = np.repeat(np.arange(len(ns)), ns)
+    y = rng.uniform(-2, 2, len(ns))[gid] + X @ rng.uniform(-1, 1, p) + 0.1 * rng.standard_normal(N)
+    y[rng.random(N) < 0.2] = np.nan                               # prediction rows
+    X[rng.random(N) < 0.01, 1] = np.nan                           # NULL feature: NULL prediction
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    core, pred = pkg.fit_predict_batch_host(offs, y, x_cols, None, _opts(pkg, "ols"), ctx=ctx)
+    rcore, rpred = oracle.fit_predict_groups(y, x_cols, offs, model="ols")
+    n_par = np.sum(~np.isnan(rcore[:, :p]), axis=1) + 1
+    tight = np.flatnonzero((rcore[:, p + 5] == 0) & (rcore[:, p + 4] - n_par <= 1))
+    assert_records_match(core, rcore, p, what=f"small fit_predict avg={avg}", skip_diag_groups=list(tight))
+    assert np.array_equal(np.isnan(pred[:, 0]), np.isnan(rpred[:, 0]))
+    m = ~np.isnan(rpred) & ~np.isin(gid, tight)[:, None]
+    assert np.array_equal(np.isnan(pred[m]), np.isnan(rpred[m]))
+    assert np.max(np.abs(pred[m] - rpred[m]) / np.maximum(np.abs(rpred[m]), 1.0)) < 1e-8
+
+
 def test_inference_with_millions_of_rows(pkg, ctx):
     """df ~ 3e6: the incomplete-beta continued fraction needs thousands of terms there and ln Gamma(a + 1/2) -
     ln Gamma(a) cancels; p-values and critical values are checked against scipy's Student-t."""
