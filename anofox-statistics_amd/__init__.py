@@ -15,10 +15,11 @@ from ._abi import AnofoxStatsError  # noqa: E402
 from .aggregate import (FitAggResult, FitPredictAggResult, OlsFitAgg, OlsFitPredictAgg, RidgeFitAgg,  # noqa: E402
                         RidgeFitPredictAgg, WlsFitAgg, WlsFitPredictAgg, SQL_FUNCTIONS, ols_fit_agg,
                         ols_fit_predict_agg, ridge_fit_agg, ridge_fit_predict_agg, wls_fit_agg, wls_fit_predict_agg,
-                        result_from_records, ols_fit_predict, ridge_fit_predict, wls_fit_predict, vif_agg)
+                        result_from_records, ols_fit_predict, ridge_fit_predict, wls_fit_predict, vif_agg,
+                        residuals_diagnostics_agg)
 from .options import InvalidInputException, RegressionOptions, parse_options  # noqa: E402
-from .runtime import Context, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host, fit_predict_window_host, vif_batch_host  # noqa: E402
-from .scalar import aic, bic, ols_fit, predict, predict_with_interval, ridge_fit, t_critical, vif, wls_fit  # noqa: E402
+from .runtime import Context, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host, fit_predict_window_host, vif_batch_host, residuals_batch_host  # noqa: E402
+from .scalar import aic, bic, ols_fit, predict, predict_with_interval, ridge_fit, t_critical, vif, wls_fit, residuals_diagnostics  # noqa: E402
 
 # the scalar functions under their SQL names (src/table_functions/{ols,ridge,wls}_fit.cpp, predict.cpp,
 # src/scalar_functions/{aic_bic,vif}.cpp) and the deprecated aggregate aliases
@@ -29,6 +30,7 @@ SQL_FUNCTIONS.update({
     "anofox_stats_predict": predict,
     "anofox_stats_aic": aic, "aic": aic, "anofox_stats_bic": bic, "bic": bic,
     "anofox_stats_vif": vif, "vif": vif,
+    "anofox_stats_residuals_diagnostics": residuals_diagnostics, "residuals_diagnostics": residuals_diagnostics,
     "ridge_predict_agg": ridge_fit_predict_agg, "wls_predict_agg": wls_fit_predict_agg,
 })
 
@@ -39,7 +41,7 @@ __all__ = [
     "FitPredictAggResult", "OlsFitPredictAgg", "RidgeFitPredictAgg", "WlsFitPredictAgg", "fit_predict_batch_host",
     "ols_fit_predict_agg", "ridge_fit_predict_agg", "wls_fit_predict_agg", "predict", "predict_with_interval",
     "t_critical", "fit_predict_expanding_host", "fit_predict_window_host", "ols_fit_predict", "ridge_fit_predict", "wls_fit_predict",
-    "vif", "vif_agg", "vif_batch_host",
+    "vif", "vif_agg", "vif_batch_host", "residuals_diagnostics", "residuals_diagnostics_agg", "residuals_batch_host",
 ]
 
 

@@ -92,6 +92,15 @@ class AnofoxPredictionResult(C.Structure):
     _fields_ = [("yhat", C.c_double), ("yhat_lower", C.c_double), ("yhat_upper", C.c_double)]
 
 
+RESIDUALS_HAS_STANDARDIZED, RESIDUALS_HAS_STUDENTIZED, RESIDUALS_HAS_LEVERAGE = 1, 2, 4
+
+
+class AnofoxResidualsResult(C.Structure):  # anofox_stats_ffi.h:527-536
+    _fields_ = [("raw", C.POINTER(C.c_double)), ("standardized", C.POINTER(C.c_double)),
+                ("studentized", C.POINTER(C.c_double)), ("leverage", C.POINTER(C.c_double)), ("len", C.c_size_t),
+                ("has_standardized", C.c_bool), ("has_studentized", C.c_bool), ("has_leverage", C.c_bool)]
+
+
 # every symbol include/anofox_stats_hip.h declares: name -> (restype, argtypes)
 _ERRP = C.POINTER(AnofoxError)
 _CTX = C.c_void_p
@@ -127,6 +136,15 @@ SYMBOLS = {
     "anofox_free_predictions": (None, [_DP]),
     "anofox_compute_vif": (C.c_bool, [C.POINTER(AnofoxDataArray), C.c_size_t, C.POINTER(_DP), C.POINTER(C.c_size_t), _ERRP]),
     "anofox_free_vif": (None, [_DP]),
+    "anofox_compute_residuals": (C.c_bool, [AnofoxDataArray, AnofoxDataArray, C.POINTER(AnofoxDataArray), C.c_size_t, C.c_double,
+                                            C.c_bool, C.POINTER(AnofoxResidualsResult), _ERRP]),
+    "anofox_free_residuals": (None, [C.POINTER(AnofoxResidualsResult)]),
+    "anofox_hip_residuals_max_features": (C.c_size_t, []),
+    "anofox_hip_residuals_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.POINTER(C.c_void_p), C.c_void_p, C.c_bool, C.c_bool, C.c_void_p,
+                                                     C.c_void_p, _ERRP]),
+    "anofox_hip_residuals_batch_host": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.POINTER(C.c_int64), _DP, _DP,
+                                                   C.POINTER(_DP), _DP, C.c_bool, C.c_bool, _DP, _DP, _ERRP]),
     "anofox_hip_vif_record_len": (C.c_size_t, [C.c_size_t]),
     "anofox_hip_vif_max_features": (C.c_size_t, []),
     "anofox_hip_vif_batch_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p),

@@ -547,3 +547,58 @@ SQL_FUNCTIONS.update({
     "anofox_stats_ridge_fit_predict": ridge_fit_predict, "ridge_fit_predict": ridge_fit_predict,
     "anofox_stats_wls_fit_predict": wls_fit_predict, "wls_fit_predict": wls_fit_predict,
 })
+
+
+# ------------------------------------------------------------------------------------------------------
+# residuals_diagnostics_agg(y, y_hat[, x LIST(DOUBLE)]) -> STRUCT(raw, standardized, studentized, leverage)
+# (src/aggregate_functions/residuals_diagnostics_aggregate.cpp)
+# ------------------------------------------------------------------------------------------------------
+def residuals_diagnostics_agg(group_keys, y, y_hat, x=None, context=None):
+    """GROUP BY mirror of residuals_diagnostics_agg.  Returns (keys, [dict(raw=, standardized=, studentized=,
+    leverage=) or None per group]).
+
+    Update (residuals_diagnostics_aggregate.cpp:71-163): rows with a NULL / NaN y or y_hat (or a NULL x list) are
+    skipped.  Finalize (:213-286): NULL for fewer than 3 buffered rows; the residual standard error is passed as NaN
+    (:232), so `standardized` and `studentized` are always NULL and the 3-argument form adds `leverage` (NULL when
+    the design is rank deficient)."""
+    from .runtime import residuals_batch_host
+    from . import _abi
+    keys = np.asarray(group_keys)
+    yv = np.array([np.nan if v is None else float(v) for v in y], dtype=np.float64)
+    yh = np.array([np.nan if v is None else float(v) for v in y_hat], dtype=np.float64)
+    keep = ~np.isnan(yv) & ~np.isnan(yh)
+    p = 0
+    xm = None
+    if x is not None:
+        keep &= np.array([r is not None for r in x], dtype=bool)
+        first = next((r for r, k in zip(x, keep) if k and len(r) > 0), None)   # :141-145: first non-empty valid row
+        p = 0 if first is None else len(first)
+        for r, k in zip(x, keep):
+            if k and len(r) != p:
+                raise InvalidInputException(f"Inconsistent feature count: expected {p}, got {len(r)}")
+        xm = np.array([[np.nan if v is None else float(v) for v in r] if k else [np.nan] * p
+                       for r, k in zip(x, keep)], dtype=np.float64).reshape(len(keys), p)
+    ukeys, gid = np.unique(keys, return_inverse=True)
+    order = np.argsort(gid[keep], kind="stable")
+    rows = np.flatnonzero(keep)[order]
+    counts = np.bincount(gid[keep], minlength=len(ukeys))
+    offsets = np.zeros(len(ukeys) + 1, dtype=np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    x_cols = [np.ascontiguousarray(xm[rows, j]) for j in range(p)] if p else []
+    result = [None] * len(ukeys)
+    if len(ukeys) == 0:
+        return ukeys, result
+    out, group = residuals_batch_host(offsets, yv[rows], yh[rows], x_cols, None, include_studentized=x is not None,
+                                      drop_nan_rows=True, ctx=context)
+    for g in range(len(ukeys)):
+        lo, hi = offsets[g], offsets[g + 1]
+        if hi - lo < 3:
+            continue                                             # SQL NULL (:223)
+        flags = int(group[g, 1])
+        result[g] = dict(raw=[float(v) for v in out[lo:hi, 0]], standardized=None, studentized=None,
+                         leverage=[float(v) for v in out[lo:hi, 3]] if flags & _abi.RESIDUALS_HAS_LEVERAGE else None)
+    return ukeys, result
+
+
+SQL_FUNCTIONS.update({"anofox_stats_residuals_diagnostics_agg": residuals_diagnostics_agg,
+                      "residuals_diagnostics_agg": residuals_diagnostics_agg})

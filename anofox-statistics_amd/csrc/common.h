@@ -330,6 +330,22 @@ constexpr int kWindowTcritCap = 65536;
 hipError_t launch_tcrit_table(double *table, int cap, double prob, hipStream_t stream);
 hipError_t launch_window_predict(const WindowArgs &a, hipStream_t stream);
 
+// residual diagnostics (residuals_narrow.hip), p <= kNarrowMaxP
+struct ResidualArgs {
+	const int64_t *row_offsets;
+	const double *y;
+	const double *y_hat;
+	const double *x[kNarrowMaxP];
+	const double *rse; // one per group, NaN = none; may be null
+	double *out;       // [N * 4]
+	double *group_out; // [G * 2]
+	int64_t n_groups;
+	int p;
+	int include_studentized;
+	int drop_nan_rows;
+};
+hipError_t launch_residuals_narrow(const ResidualArgs &a, hipStream_t stream);
+
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);

@@ -1394,3 +1394,209 @@ void anofox_free_vif(double *vif) {
 }
 
 } // extern "C"
+
+/* ===================================================================================================== */
+/* Residual diagnostics (residuals_diagnostics_agg / residuals_diagnostics / anofox_compute_residuals)   */
+/* ===================================================================================================== */
+namespace {
+
+bool validate_residuals(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const void *off, const void *y,
+                        const void *y_hat, const double *const *x_cols, const void *out, const void *group, AnofoxError *e) {
+	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (G < 0 || n_rows < 0) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "negative n_groups or n_rows"); return false; }
+	if (p > (size_t)kNarrowMaxP) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT,
+		          "n_features = " + std::to_string(p) + " exceeds the supported maximum of " + std::to_string(kNarrowMaxP) +
+		              " for residual diagnostics");
+		return false;
+	}
+	if (p > 0 && !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x is NULL"); return false; }
+	if (G > 0 && (!off || !group)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "row_offsets or group output is NULL"); return false; }
+	if (n_rows > 0 && (!y || !y_hat || !out)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "y, y_hat or output is NULL"); return false; }
+	for (size_t j = 0; j < p; ++j)
+		if (n_rows > 0 && !x_cols[j]) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x column pointer is NULL"); return false; }
+	return true;
+}
+
+bool run_residuals(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *d_y, const double *d_y_hat,
+                   const double *const *x_cols, const double *d_rse, bool include_studentized, bool drop_nan_rows,
+                   double *d_out, double *d_group, AnofoxError *e) {
+	if (G == 0) return true;
+	ResidualArgs a{};
+	a.row_offsets = d_off;
+	a.y = d_y;
+	a.y_hat = d_y_hat;
+	for (size_t j = 0; j < p; ++j) a.x[j] = x_cols[j];
+	a.rse = d_rse;
+	a.out = d_out;
+	a.group_out = d_group;
+	a.n_groups = G;
+	a.p = (int)p;
+	a.include_studentized = include_studentized ? 1 : 0;
+	a.drop_nan_rows = drop_nan_rows ? 1 : 0;
+	return !hip_fail(launch_residuals_narrow(a, ctx->stream), "residuals kernel launch", e);
+}
+
+bool residuals_host(AnofoxHipContext *ctx, int64_t n_groups, size_t p, int64_t n_rows, const int64_t *row_offsets,
+                    const double *y, const double *y_hat, const double *const *x_cols, const double *rse,
+                    bool include_studentized, bool drop_nan_rows, double *out, double *group, AnofoxError *out_error) {
+	if (!ctx) {
+		ctx = default_context(out_error);
+		if (!ctx) return false;
+	}
+	if (!validate_residuals(ctx, n_groups, p, n_rows, row_offsets, y, y_hat, x_cols, out, group, out_error)) return false;
+	if (n_groups == 0) return true;
+	if (row_offsets[0] != 0 || row_offsets[n_groups] != n_rows) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must start at 0 and end at n_rows");
+		return false;
+	}
+	for (int64_t g = 0; g < n_groups; ++g)
+		if (row_offsets[g + 1] < row_offsets[g]) {
+			set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "row_offsets must be non-decreasing");
+			return false;
+		}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	const size_t R = (size_t)n_rows, G = (size_t)n_groups;
+	const size_t b_off = align_up((G + 1) * sizeof(int64_t), 256);
+	const size_t b_col = align_up((R + 2) * sizeof(double), 256);
+	const size_t b_grp = align_up(G * 2 * sizeof(double), 256);
+	const size_t b_out = align_up(R * 4 * sizeof(double) + 8, 256);
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_off + (p + 2) * b_col + 2 * b_grp + b_out, "staging", out_error)) return false;
+	char *cur = (char *)ctx->stage;
+	hipStream_t st = ctx->stream;
+	int64_t *d_off = (int64_t *)cur;
+	cur += b_off;
+	if (hip_fail(hipMemcpyAsync(d_off, row_offsets, (G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D offsets", out_error)) return false;
+	const double *src[2] = {y, y_hat};
+	const double *d_yy[2];
+	for (int k = 0; k < 2; ++k) {
+		if (R > 0 && hip_fail(hipMemcpyAsync(cur, src[k], R * sizeof(double), hipMemcpyHostToDevice, st), "H2D y", out_error)) return false;
+		d_yy[k] = (const double *)cur;
+		cur += b_col;
+	}
+	std::vector<const double *> d_x(p);
+	for (size_t j = 0; j < p; ++j) {
+		if (R > 0 && hip_fail(hipMemcpyAsync(cur, x_cols[j], R * sizeof(double), hipMemcpyHostToDevice, st), "H2D x", out_error)) return false;
+		d_x[j] = (const double *)cur;
+		cur += b_col;
+	}
+	double *d_rse = nullptr;
+	if (rse) {
+		d_rse = (double *)cur;
+		if (hip_fail(hipMemcpyAsync(d_rse, rse, G * sizeof(double), hipMemcpyHostToDevice, st), "H2D rse", out_error)) return false;
+	}
+	cur += b_grp;
+	double *d_group = (double *)cur;
+	cur += b_grp;
+	double *d_out = (double *)cur;
+	if (!run_residuals(ctx, n_groups, p, d_off, d_yy[0], d_yy[1], d_x.data(), d_rse, include_studentized, drop_nan_rows, d_out,
+	                   d_group, out_error))
+		return false;
+	if (R > 0 && hip_fail(hipMemcpyAsync(out, d_out, R * 4 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H residuals", out_error)) return false;
+	if (hip_fail(hipMemcpyAsync(group, d_group, G * 2 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H residual groups", out_error)) return false;
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
+}
+
+} // namespace
+
+extern "C" {
+
+size_t anofox_hip_residuals_max_features(void) { return (size_t)kNarrowMaxP; }
+
+bool anofox_hip_residuals_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                       const int64_t *d_row_offsets, const double *d_y, const double *d_y_hat,
+                                       const double *const *x_cols, const double *d_rse, bool include_studentized,
+                                       bool drop_nan_rows, double *d_out, double *d_group, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!validate_residuals(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, d_y_hat, x_cols, d_out, d_group, out_error))
+		return false;
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	return run_residuals(ctx, n_groups, n_features, d_row_offsets, d_y, d_y_hat, x_cols, d_rse, include_studentized,
+	                     drop_nan_rows, d_out, d_group, out_error);
+}
+
+bool anofox_hip_residuals_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                     const int64_t *row_offsets, const double *y, const double *y_hat,
+                                     const double *const *x_cols, const double *rse, bool include_studentized,
+                                     bool drop_nan_rows, double *out, double *group, AnofoxError *out_error) {
+	reset_error(out_error);
+	return residuals_host(ctx, n_groups, n_features, n_rows, row_offsets, y, y_hat, x_cols, rse, include_studentized,
+	                      drop_nan_rows, out, group, out_error);
+}
+
+// lib.rs:1787-1894 over residuals.rs:30-145
+bool anofox_compute_residuals(AnofoxDataArray y, AnofoxDataArray y_hat, const AnofoxDataArray *x, size_t x_count,
+                              double residual_std_error, bool include_studentized, AnofoxResidualsResult *out_result,
+                              AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!out_result) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "out_result is NULL"); return false; }
+	*out_result = AnofoxResidualsResult{};
+	const size_t n = y.len;
+	if (n == 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "Invalid input: Empty y array"); return false; } // residuals.rs:39-41
+	if (y_hat.len != n) { // residuals.rs:43-49
+		set_error(out_error, ANOFOX_ERROR_DIMENSION_MISMATCH,
+		          "Dimension mismatch: y has " + std::to_string(n) + " elements, y_hat has " + std::to_string(y_hat.len));
+		return false;
+	}
+	const size_t p = (x && x_count > 0) ? x_count : 0;
+	std::vector<double> yv, yh;
+	expand(y, yv);
+	expand(y_hat, yh);
+	std::vector<std::vector<double>> cols(p);
+	std::vector<const double *> ptrs(p);
+	for (size_t j = 0; j < p; ++j) {
+		if (include_studentized && x[j].len != n) { // the reference indexes x[j][i] for i < n and panics on a short column
+			set_error(out_error, ANOFOX_ERROR_DIMENSION_MISMATCH, "Dimension mismatch: Feature " + std::to_string(j) + " has " +
+			          std::to_string(x[j].len) + " observations, expected " + std::to_string(n));
+			return false;
+		}
+		expand(x[j], cols[j]);
+		cols[j].resize(n, NAN);
+		ptrs[j] = cols[j].data();
+	}
+	const int64_t off[2] = {0, (int64_t)n};
+	std::vector<double> rec(n * 4);
+	double grp[2] = {0.0, 0.0};
+	const double rse = residual_std_error;
+	if (!residuals_host(nullptr, 1, p, (int64_t)n, off, yv.data(), yh.data(), ptrs.data(), &rse, include_studentized, false,
+	                    rec.data(), grp, out_error))
+		return false;
+	const int flags = (int)grp[1];
+	const bool has[4] = {true, (flags & ANOFOX_HIP_RESIDUALS_HAS_STANDARDIZED) != 0, (flags & ANOFOX_HIP_RESIDUALS_HAS_STUDENTIZED) != 0,
+	                     (flags & ANOFOX_HIP_RESIDUALS_HAS_LEVERAGE) != 0};
+	double *arr[4] = {nullptr, nullptr, nullptr, nullptr};
+	for (int k = 0; k < 4; ++k) {
+		if (!has[k]) continue;
+		arr[k] = (double *)malloc(n * sizeof(double));
+		if (!arr[k]) {
+			for (int m = 0; m < k; ++m) free(arr[m]);
+			set_error(out_error, ANOFOX_ERROR_ALLOCATION_FAILURE, "Failed to allocate residuals");
+			return false;
+		}
+		for (size_t i = 0; i < n; ++i) arr[k][i] = rec[i * 4 + k];
+	}
+	out_result->raw = arr[0];
+	out_result->standardized = arr[1];
+	out_result->studentized = arr[2];
+	out_result->leverage = arr[3];
+	out_result->len = n;
+	out_result->has_standardized = has[1];
+	out_result->has_studentized = has[2];
+	out_result->has_leverage = has[3];
+	return true;
+}
+
+void anofox_free_residuals(AnofoxResidualsResult *result) {
+	if (!result) return;
+	free(result->raw);
+	free(result->standardized);
+	free(result->studentized);
+	free(result->leverage);
+	result->raw = result->standardized = result->studentized = result->leverage = nullptr;
+	result->len = 0;
+	result->has_standardized = result->has_studentized = result->has_leverage = false;
+}
+
+} // extern "C"

@@ -177,6 +177,30 @@ class Context:
         self._check(ok, err)
         return out
 
+    def residuals_batch_device(self, row_offsets, y, y_hat, x_cols: Sequence = (), rse=None, include_studentized: bool = True,
+                               drop_nan_rows: bool = True, out=None, group=None, use_current_torch_stream: bool = True):
+        """Grouped residual diagnostics, device resident.  Returns (out[N, 4] = raw / standardized / studentized /
+        leverage per row, group[G, 2] = rows used / ANOFOX_HIP_RESIDUALS_HAS_* flags)."""
+        import torch
+
+        p = len(x_cols)
+        G = int(row_offsets.numel()) - 1
+        N = int(y.numel())
+        if out is None:
+            out = torch.empty((N, 4), dtype=torch.float64, device=y.device)
+        if group is None:
+            group = torch.empty((G, 2), dtype=torch.float64, device=y.device)
+        if use_current_torch_stream:
+            self.set_stream(torch.cuda.current_stream(y.device).cuda_stream)
+        cols = (C.c_void_p * max(p, 1))(*[c.data_ptr() for c in x_cols])
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_residuals_batch_device(
+            self._h, G, p, N, C.c_void_p(row_offsets.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(y_hat.data_ptr()),
+            cols if p else None, C.c_void_p(rse.data_ptr()) if rse is not None else None, bool(include_studentized),
+            bool(drop_nan_rows), C.c_void_p(out.data_ptr()), C.c_void_p(group.data_ptr()), C.byref(err))
+        self._check(ok, err)
+        return out, group
+
     # ---- host-resident batch (numpy) ----------------------------------------------------------
     def fit_batch_host(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions):
         return fit_batch_host(row_offsets, y, x_cols, w, options, ctx=self)
@@ -283,3 +307,26 @@ def vif_batch_host(row_offsets, x_cols: Sequence, ctx: Optional[Context] = None)
     if not ok:
         raise AnofoxStatsError(err.code, err.text())
     return out
+
+
+def residuals_batch_host(row_offsets, y, y_hat, x_cols: Sequence = (), rse=None, include_studentized: bool = True,
+                         drop_nan_rows: bool = True, ctx: Optional[Context] = None):
+    """numpy in, numpy out: (out[N, 4] = raw / standardized / studentized / leverage, group[G, 2] = rows used / flags)."""
+    lib = _abi.load()
+    off = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    yh = np.ascontiguousarray(y_hat, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    p, G, N = len(cols), len(off) - 1, len(yv)
+    out = np.empty((N, 4), dtype=np.float64)
+    group = np.empty((G, 2), dtype=np.float64)
+    colp = (_DP * max(p, 1))(*[c.ctypes.data_as(_DP) for c in cols])
+    rse_arr = None if rse is None else np.ascontiguousarray(rse, dtype=np.float64)
+    err = _abi.AnofoxError()
+    ok = lib.anofox_hip_residuals_batch_host(
+        ctx._h if ctx is not None else None, G, p, N, off.ctypes.data_as(C.POINTER(C.c_int64)), yv.ctypes.data_as(_DP),
+        yh.ctypes.data_as(_DP), colp if p else None, None if rse_arr is None else rse_arr.ctypes.data_as(_DP),
+        bool(include_studentized), bool(drop_nan_rows), out.ctypes.data_as(_DP), group.ctypes.data_as(_DP), C.byref(err))
+    if not ok:
+        raise AnofoxStatsError(err.code, err.text())
+    return out, group

@@ -183,3 +183,37 @@ def vif(x):
         return [outp[i] for i in range(outn.value)]
     finally:
         lib.anofox_free_vif(outp)
+
+
+def residuals_diagnostics(y, y_hat, x=None, residual_std_error=None, include_studentized=True):
+    """anofox_stats_residuals_diagnostics(y LIST, y_hat LIST[, x LIST(LIST), rse DOUBLE, include_studentized BOOL])
+    -> STRUCT(raw, standardized, studentized, leverage) (src/scalar_functions/residuals_diagnostics.cpp:75-192): x is a
+    list of feature COLUMNS; NULL for fewer than 3 values or lists of unequal length (:85-88) and when the C call
+    fails (:158-161).  Runs on the GPU."""
+    if len(y) < 3 or len(y) != len(y_hat):
+        return None
+    lib = _abi.load()
+    ya, k1 = _data_array(y)
+    ha, k2 = _data_array(y_hat)
+    cols = list(x) if x is not None else []
+    xs = (_abi.AnofoxDataArray * max(len(cols), 1))()
+    keep = [k1, k2]
+    for j, col in enumerate(cols):
+        a, k = _data_array(col)
+        xs[j] = a
+        keep.append(k)
+    res = _abi.AnofoxResidualsResult()
+    err = _abi.AnofoxError()
+    rse = float("nan") if residual_std_error is None else float(residual_std_error)
+    if not lib.anofox_compute_residuals(ya, ha, xs if cols else None, len(cols), rse, bool(include_studentized),
+                                        C.byref(res), C.byref(err)):
+        return None
+    try:
+        n = res.len
+
+        def take(ptr, has):
+            return [ptr[i] for i in range(n)] if has and ptr else None
+        return dict(raw=take(res.raw, True), standardized=take(res.standardized, res.has_standardized),
+                    studentized=take(res.studentized, res.has_studentized), leverage=take(res.leverage, res.has_leverage))
+    finally:
+        lib.anofox_free_residuals(C.byref(res))

@@ -210,6 +210,26 @@ ANOFOX_HIP_API bool anofox_compute_vif(const AnofoxDataArray *x, size_t x_count,
                         AnofoxError *out_error);
 ANOFOX_HIP_API void anofox_free_vif(double *vif);
 
+/* replaces AnofoxResidualsResult / anofox_compute_residuals / anofox_free_residuals, anofox_stats_ffi.h:527-558
+ * (lib.rs:1752-1920 over crates/anofox-stats-core/src/diagnostics/residuals.rs:30-145): raw = y - y_hat;
+ * standardized = raw / s when residual_std_error s is not NaN; with x and include_studentized the leverage
+ * h_i = x~_i' (X~'X~)^-1 x~_i of the intercept-augmented design and studentized = raw / (s sqrt(max(1 - h, 1e-10))).
+ * A rank-deficient design yields no leverage (has_leverage = false).  Runs on the GPU; x_count <= 8. */
+typedef struct {
+	double *raw;
+	double *standardized;
+	double *studentized;
+	double *leverage;
+	size_t len;
+	bool has_standardized;
+	bool has_studentized;
+	bool has_leverage;
+} AnofoxResidualsResult;
+ANOFOX_HIP_API bool anofox_compute_residuals(AnofoxDataArray y, AnofoxDataArray y_hat, const AnofoxDataArray *x, size_t x_count,
+                              double residual_std_error, bool include_studentized, AnofoxResidualsResult *out_result,
+                              AnofoxError *out_error);
+ANOFOX_HIP_API void anofox_free_residuals(AnofoxResidualsResult *result);
+
 #endif /* ANOFOX_STATS_FFI_H */
 
 /* ------------------------------------------------------------------------ */
@@ -371,6 +391,29 @@ ANOFOX_HIP_API bool anofox_hip_vif_batch_device(AnofoxHipContext *ctx, int64_t n
 ANOFOX_HIP_API bool anofox_hip_vif_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                const int64_t *row_offsets, const double *const *x_cols, double *vif,
                                AnofoxError *out_error);
+
+/*
+ * Grouped residual diagnostics: the Finalize loop of residuals_diagnostics_agg
+ * (src/aggregate_functions/residuals_diagnostics_aggregate.cpp:213-286) in one call.  Per row r the record
+ * d_out[4 r ..] = { raw, standardized, studentized, leverage } (NaN where the part is absent); per group
+ * d_group[2 g ..] = { rows used, ANOFOX_HIP_RESIDUALS_HAS_* flags }.  With drop_nan_rows the rows whose y or
+ * y_hat is NaN are left out, as the aggregate's Update does (:154-163; their records are all NaN); the aggregate
+ * itself returns NULL for groups with fewer than 3 used rows (:223) and passes no residual standard error (:232),
+ * so d_rse (one value per group, NaN = none) may be NULL.  x_cols / n_features may be NULL / 0 (no leverage);
+ * n_features <= anofox_hip_residuals_max_features() = 8.
+ */
+#define ANOFOX_HIP_RESIDUALS_HAS_STANDARDIZED 1
+#define ANOFOX_HIP_RESIDUALS_HAS_STUDENTIZED 2
+#define ANOFOX_HIP_RESIDUALS_HAS_LEVERAGE 4
+ANOFOX_HIP_API size_t anofox_hip_residuals_max_features(void);
+ANOFOX_HIP_API bool anofox_hip_residuals_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                       const int64_t *d_row_offsets, const double *d_y, const double *d_y_hat,
+                                       const double *const *x_cols, const double *d_rse, bool include_studentized,
+                                       bool drop_nan_rows, double *d_out, double *d_group, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_residuals_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
+                                     const int64_t *row_offsets, const double *y, const double *y_hat,
+                                     const double *const *x_cols, const double *rse, bool include_studentized,
+                                     bool drop_nan_rows, double *out, double *group, AnofoxError *out_error);
 
 /* Predictions only, from existing fit records (d_core as produced by the fit entry points). */
 ANOFOX_HIP_API bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,

@@ -103,6 +103,9 @@ def lib():
                                                 C.POINTER(OracleOptions), C.c_int64, C.c_int64, _DP]
         L.oracle_vif_groups.restype = C.c_int
         L.oracle_vif_groups.argtypes = [C.POINTER(_DP), C.POINTER(C.c_int64), C.c_int64, C.c_size_t, C.c_int64, _DP]
+        L.oracle_residuals_groups.restype = C.c_int
+        L.oracle_residuals_groups.argtypes = [_DP, _DP, C.POINTER(_DP), C.POINTER(C.c_int64), C.c_int64, C.c_size_t, _DP,
+                                              C.c_int, C.c_int, _DP, _DP]
         for name in ("oracle_aic", "oracle_bic"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [C.c_double, C.c_int64, C.c_int64, _DP]
@@ -259,3 +262,24 @@ def vif_groups(x_cols, offsets, min_rows=3):
     if rc != 0:
         raise RuntimeError(f"oracle_vif_groups failed: {rc}")
     return out
+
+
+def residuals_groups(y, y_hat, x_cols, offsets, rse=None, include_studentized=True, drop_nan_rows=True):
+    """(out[N, 4] = raw / standardized / studentized / leverage, group[G, 2] = rows used / flags); restates
+    crates/anofox-stats-core/src/diagnostics/residuals.rs:30-145 per group."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    y_hat = np.ascontiguousarray(y_hat, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in (x_cols or [])]
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    p, G, N = len(cols), len(offsets) - 1, len(y)
+    out = np.empty((N, 4))
+    group = np.empty((G, 2))
+    rse_arr = None if rse is None else np.ascontiguousarray(rse, dtype=np.float64)
+    rc = lib().oracle_residuals_groups(y.ctypes.data_as(_DP), y_hat.ctypes.data_as(_DP), _col_ptrs(cols) if p else None,
+                                       offsets.ctypes.data_as(C.POINTER(C.c_int64)), G, p,
+                                       None if rse_arr is None else rse_arr.ctypes.data_as(_DP),
+                                       int(bool(include_studentized)), int(bool(drop_nan_rows)),
+                                       out.ctypes.data_as(_DP), group.ctypes.data_as(_DP))
+    if rc != 0:
+        raise RuntimeError(f"oracle_residuals_groups failed: {rc}")
+    return out, group

@@ -849,3 +849,91 @@ ORACLE_EXPORT int oracle_vif_groups(const double *const *x, const int64_t *offse
 	free(coef); free((void *)xs);
 	return ORC_SUCCESS;
 }
+
+/* Residual diagnostics, crates/anofox-stats-core/src/diagnostics/residuals.rs:30-145 (PARITY UNPINNED: upstream's
+ * tests only check lengths and 0 <= h <= 1, residuals.rs:204-263).  raw = y - yhat (:52); standardized = raw / s
+ * for s > 0, raw itself for s <= 0, absent without s (:55-61); with x and include_studentized (:64-68) the
+ * (k+1)x(k+1) cross-product matrix of [1, X] (:96-108) is inverted by Gauss-Jordan elimination with partial
+ * pivoting, "singular" when the pivot's magnitude is below 1e-14 (:148-204) -> no leverage, no studentized;
+ * otherwise h_i = x~_i' inv x~_i (:117-128) and studentized = raw / (s sqrt(max(1 - h, 1e-10))) when s is given
+ * (:131-141).  Grouped driver: with drop_nan_rows the rows whose y or yhat is NaN are skipped, as the Update of
+ * residuals_diagnostics_agg does (src/aggregate_functions/residuals_diagnostics_aggregate.cpp:154-163).
+ * out[r] = { raw, standardized, studentized, leverage } (NaN = absent / skipped), group[g] = { rows used, flags }
+ * with flags 1 = standardized, 2 = studentized, 4 = leverage present. */
+static int orc_gauss_jordan_inverse(double *aug, size_t n) { /* aug: n x 2n, row-major */
+	for (size_t col = 0; col < n; col++) {
+		size_t max_row = col;
+		double max_val = fabs(aug[col * 2 * n + col]);
+		for (size_t row = col + 1; row < n; row++)
+			if (fabs(aug[row * 2 * n + col]) > max_val) { max_val = fabs(aug[row * 2 * n + col]); max_row = row; }
+		if (max_val < 1e-14) return 0;
+		if (max_row != col)
+			for (size_t j = 0; j < 2 * n; j++) {
+				double t = aug[col * 2 * n + j]; aug[col * 2 * n + j] = aug[max_row * 2 * n + j]; aug[max_row * 2 * n + j] = t;
+			}
+		double pivot = aug[col * 2 * n + col];
+		for (size_t j = 0; j < 2 * n; j++) aug[col * 2 * n + j] /= pivot;
+		for (size_t row = 0; row < n; row++)
+			if (row != col) {
+				double f = aug[row * 2 * n + col];
+				for (size_t j = 0; j < 2 * n; j++) aug[row * 2 * n + j] -= f * aug[col * 2 * n + j];
+			}
+	}
+	return 1;
+}
+
+ORACLE_EXPORT int oracle_residuals_groups(const double *y, const double *y_hat, const double *const *x, const int64_t *offsets,
+                                          int64_t n_groups, size_t p, const double *rse, int include_studentized,
+                                          int drop_nan_rows, double *out, double *group) {
+	size_t nc = p + 1;
+	double *aug = (double *)malloc(nc * 2 * nc * sizeof(double));
+	double *xi = (double *)malloc(nc * sizeof(double));
+	for (int64_t g = 0; g < n_groups; g++) {
+		int64_t lo = offsets[g], hi = offsets[g + 1];
+		double s = rse ? rse[g] : NAN;
+		int has_s = !isnan(s), has_lev = 0;
+		int64_t n_used = 0;
+		for (int64_t r = lo; r < hi; r++) {
+			int used = !drop_nan_rows || (!isnan(y[r]) && !isnan(y_hat[r]));
+			double *o = out + (size_t)r * 4;
+			o[0] = o[1] = o[2] = o[3] = NAN;
+			if (!used) continue;
+			n_used++;
+			o[0] = y[r] - y_hat[r];
+			if (has_s) o[1] = s > 0.0 ? o[0] / s : o[0];
+		}
+		if (include_studentized && p > 0 && n_used > 0) {
+			memset(aug, 0, nc * 2 * nc * sizeof(double));
+			for (int64_t r = lo; r < hi; r++) {
+				if (drop_nan_rows && (isnan(y[r]) || isnan(y_hat[r]))) continue;
+				xi[0] = 1.0;
+				for (size_t j = 0; j < p; j++) xi[j + 1] = x[j][r];
+				for (size_t j = 0; j < nc; j++)
+					for (size_t l = 0; l < nc; l++) aug[j * 2 * nc + l] += xi[j] * xi[l];
+			}
+			for (size_t j = 0; j < nc; j++) aug[j * 2 * nc + nc + j] = 1.0;
+			if (orc_gauss_jordan_inverse(aug, nc)) {
+				has_lev = 1;
+				for (int64_t r = lo; r < hi; r++) {
+					if (drop_nan_rows && (isnan(y[r]) || isnan(y_hat[r]))) continue;
+					xi[0] = 1.0;
+					for (size_t j = 0; j < p; j++) xi[j + 1] = x[j][r];
+					double h = 0.0;
+					for (size_t j = 0; j < nc; j++)
+						for (size_t l = 0; l < nc; l++) h += xi[j] * aug[j * 2 * nc + nc + l] * xi[l];
+					double *o = out + (size_t)r * 4;
+					o[3] = h;
+					if (has_s) {
+						double om = 1.0 - h;
+						if (!(om > 1e-10)) om = 1e-10; /* f64::max(1 - h, 1e-10): a NaN operand yields the other one */
+						o[2] = o[0] / (s * sqrt(om));
+					}
+				}
+			}
+		}
+		group[(size_t)g * 2] = (double)n_used;
+		group[(size_t)g * 2 + 1] = (double)((has_s ? 1 : 0) | ((has_lev && has_s) ? 2 : 0) | (has_lev ? 4 : 0));
+	}
+	free(aug); free(xi);
+	return ORC_SUCCESS;
+}

@@ -1250,3 +1250,168 @@ def test_entry_points_are_reentrant_across_threads(pkg):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+# --------------------------------------------------------------------------------------------------
+# residual diagnostics: residuals_diagnostics_agg / residuals_diagnostics / anofox_compute_residuals
+# --------------------------------------------------------------------------------------------------
+def _assert_residuals_match(out, grp, rout, rgrp, what):
+    assert np.array_equal(grp, rgrp), what
+    assert np.array_equal(np.isnan(out), np.isnan(rout)), what
+    m = ~np.isnan(rout)
+    assert np.array_equal(out[:, 0][m[:, 0]], rout[:, 0][m[:, 0]]), what          # raw = y - yhat: same subtraction
+    inf = np.isinf(rout)                                                          # s = 0: studentized = raw / 0
+    assert np.array_equal(out[inf], rout[inf]), what
+    m &= ~inf
+    scale = np.maximum(np.abs(rout[m]), 1.0)
+    assert np.max(np.abs(out[m] - rout[m]) / scale, initial=0.0) < 1e-9, what
+
+
+@pytest.mark.parametrize("p", [0, 1, 3, 8])
+def test_residuals_batch_matches_oracle(pkg, ctx, p):
+    """Tolerance 1e-9 relative on every part (the stated bar is 1e-6 for diagnostics)."""
+    rng = np.random.default_rng(4100 + p)
+    G = 120
+    offs, y, x_cols, _ = _random_groups(rng, G, p, 2 * p + 4, 300, offset=25.0)
+    ns = np.diff(offs)
+    N = len(y)
+    y_hat = y + 0.5 * rng.standard_normal(N)
+    y = y.copy()
+    y[rng.random(N) < 0.05] = np.nan                                  # skipped rows, also first rows of groups
+    y_hat[rng.random(N) < 0.03] = np.nan
+    rse = rng.uniform(0.2, 2.0, G)
+    rse[::7] = np.nan                                                 # no residual standard error for these groups
+    rse[3] = 0.0                                                      # s <= 0: standardized = raw (residuals.rs:56-60)
+    rse[5] = -1.0
+    for drop in (True, False):
+        for stud in (True, False):
+            for r in (rse, None):
+                out, grp = pkg.residuals_batch_host(offs, y, y_hat, x_cols, r, include_studentized=stud, drop_nan_rows=drop, ctx=ctx)
+                rout, rgrp = oracle.residuals_groups(y, y_hat, x_cols, offs, rse=r, include_studentized=stud, drop_nan_rows=drop)
+                _assert_residuals_match(out, grp, rout, rgrp, f"residuals p={p} drop={drop} stud={stud} rse={r is not None}")
+    if p:
+        flags = grp[:, 1].astype(int)
+        assert np.all(flags & 4 == (4 if stud else 0)) or stud         # every group of this data has full rank
+        out, grp = pkg.residuals_batch_host(offs, y, y_hat, x_cols, rse, ctx=ctx)
+        gid = np.repeat(np.arange(G), ns)
+        used = ~np.isnan(out[:, 0])
+        hsum = np.bincount(gid[used], weights=out[used, 3], minlength=G)
+        assert np.allclose(hsum, p + 1, rtol=0, atol=1e-8)              # trace of the hat matrix = p + 1
+        assert np.all(out[used, 3] > 0) and np.all(out[used, 3] < 1 + 1e-12)
+
+
+def test_residuals_rank_deficient_empty_and_poisoned_groups(pkg, ctx):
+    x1 = np.arange(1.0, 11.0)
+    rng = np.random.default_rng(8)
+    blocks = [
+        (x1, 2.0 * x1),                                   # exactly collinear: no leverage here and upstream
+        (x1, np.full(10, 4.0)),                           # constant column: collinear with the intercept
+        (x1, rng.standard_normal(10)),                    # full rank
+        (np.array([1.0, 2.0]), np.array([0.5, -1.0])),    # fewer rows than parameters
+        (np.empty(0), np.empty(0)),                       # empty group
+        (x1, np.where(np.arange(10) == 4, np.nan, rng.standard_normal(10))),   # NaN feature value in a used row
+    ]
+    ns = [len(b[0]) for b in blocks]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    x_cols = [np.concatenate([b[j] for b in blocks]) for j in range(2)]
+    N = int(offs[-1])
+    y = rng.standard_normal(N)
+    y_hat = y + 0.1 * rng.standard_normal(N)
+    rse = np.full(len(blocks), 0.1)
+    out, grp = pkg.residuals_batch_host(offs, y, y_hat, x_cols, rse, ctx=ctx)
+    rout, rgrp = oracle.residuals_groups(y, y_hat, x_cols, offs, rse=rse)
+    assert list(grp[:, 0]) == ns
+    assert list(grp[:, 1].astype(int)) == [1, 1, 7, 1, 1, 7]
+    # upstream agrees wherever its elimination meets an exact zero (integer data); the 2-row group is one of the
+    # cases where it would divide by rounding noise instead (residuals_narrow.hip header)
+    assert list(rgrp[[0, 1, 2, 4, 5], 1].astype(int)) == [1, 1, 7, 1, 7]
+    lo, hi = offs[2], offs[3]
+    assert np.allclose(out[lo:hi], rout[lo:hi], rtol=1e-10, atol=0)
+    lo, hi = offs[5], offs[6]
+    assert np.all(np.isnan(out[lo:hi, 3])) and np.all(np.isnan(rout[lo:hi, 3]))     # poisoned leverage, flag still set
+    assert np.allclose(out[lo:hi, 2], rout[lo:hi, 2], rtol=1e-12)                   # max(1 - NaN, 1e-10) = 1e-10
+    assert np.array_equal(out[:, :2], rout[:, :2])
+
+
+def test_residuals_reference_structural_tests(pkg, ctx):
+    """test/sql/diagnostics/test_residuals_diagnostics_agg.test (reg_data, reg_data_with_x), the scalar form of
+    test/sql/scalar/test_diagnostics_scalar.test:126-140 and the unit tests of residuals.rs:204-263."""
+    ya = [5.2, 9.8, 15.1, 20.0, 24.9, 30.2, 35.0, 39.8, 45.1, 50.0]
+    yp = [5.0, 10.0, 15.0, 20.0, 25.0, 30.0, 35.0, 40.0, 45.0, 50.0]
+    keys = np.zeros(10, dtype=np.int64)
+    _, res = pkg.residuals_diagnostics_agg(keys, ya, yp, context=ctx)
+    assert res[0]["raw"] == [a - b for a, b in zip(ya, yp)]
+    assert res[0]["standardized"] is None and res[0]["studentized"] is None and res[0]["leverage"] is None
+    x = [[float(i), 2.0 * i] for i in range(1, 11)]                  # x2 = 2 x1: singular design -> leverage NULL
+    _, res = pkg.SQL_FUNCTIONS["anofox_stats_residuals_diagnostics_agg"](keys, ya, yp, x, context=ctx)
+    assert res[0]["raw"] == [a - b for a, b in zip(ya, yp)] and res[0]["leverage"] is None
+    x = [[float(i), float((i * 7) % 5)] for i in range(1, 11)]
+    ya2 = list(ya)
+    ya2[3] = None                                                    # NULL y: the row is skipped
+    _, res = pkg.residuals_diagnostics_agg(keys, ya2, yp, x, context=ctx)
+    assert len(res[0]["raw"]) == 9 and abs(sum(res[0]["leverage"]) - 3.0) < 1e-10
+    _, res = pkg.residuals_diagnostics_agg([0, 0, 1, 1, 1], ya[:5], yp[:5], context=ctx)
+    assert res[0] is None and len(res[1]["raw"]) == 3                # fewer than 3 rows -> NULL (:223)
+    # scalar: residuals.rs unit tests
+    y = [1.0, 2.0, 3.0, 4.0, 5.0]
+    yh = [1.1, 1.9, 3.0, 4.1, 4.9]
+    r = pkg.residuals_diagnostics(y, yh)
+    assert max(abs(a - b) for a, b in zip(r["raw"], [-0.1, 0.1, 0.0, -0.1, 0.1])) < 1e-10
+    assert r["standardized"] is None and r["studentized"] is None and r["leverage"] is None
+    r = pkg.residuals_diagnostics(y, y, None, 0.1, False)
+    assert r["standardized"] == [0.0] * 5
+    r = pkg.SQL_FUNCTIONS["residuals_diagnostics"](y, yh, [[1.0, 2.0, 3.0, 4.0, 5.0]], 0.1, True)
+    assert np.allclose(r["leverage"], [0.6, 0.3, 0.2, 0.3, 0.6], rtol=1e-13)          # textbook hat values of x = 1..5
+    assert np.allclose(r["studentized"], np.array(r["raw"]) / (0.1 * np.sqrt(1 - np.array(r["leverage"]))), rtol=1e-13)
+    assert pkg.residuals_diagnostics([1.0, 2.0], [1.0, 2.0]) is None                 # fewer than 3 values (:85-88)
+    assert pkg.residuals_diagnostics(y, yh[:4]) is None
+    r = pkg.residuals_diagnostics([1.0, float("nan"), 3.0], [1.0, 2.0, 2.5])          # the scalar form keeps NaN rows
+    assert np.isnan(r["raw"][1]) and r["raw"][2] == 0.5
+
+
+def test_compute_residuals_c_symbol_errors(pkg):
+    import ctypes as C
+    abi = import_pkg("_abi")
+    lib = abi.load()
+    arr = (C.c_double * 3)(1.0, 2.0, 3.0)
+    a3 = abi.AnofoxDataArray(arr, None, 3)
+    a2 = abi.AnofoxDataArray(arr, None, 2)
+    a0 = abi.AnofoxDataArray(arr, None, 0)
+    res = abi.AnofoxResidualsResult()
+    err = abi.AnofoxError()
+    assert not lib.anofox_compute_residuals(a0, a0, None, 0, float("nan"), False, C.byref(res), C.byref(err))
+    assert err.code == 1 and "Empty y array" in err.text()                           # InvalidInput (residuals.rs:39-41)
+    assert not lib.anofox_compute_residuals(a3, a2, None, 0, float("nan"), False, C.byref(res), C.byref(err))
+    assert err.code == 9 and "y has 3 elements, y_hat has 2" in err.text()           # DimensionMismatch (:43-49)
+    assert not lib.anofox_compute_residuals(a3, a3, None, 0, float("nan"), False, None, C.byref(err))
+    assert lib.anofox_compute_residuals(a3, a3, None, 0, 2.0, True, C.byref(res), C.byref(err))
+    assert res.len == 3 and res.has_standardized and not res.has_studentized and not res.has_leverage
+    assert [res.raw[i] for i in range(3)] == [0.0, 0.0, 0.0]
+    lib.anofox_free_residuals(C.byref(res))
+    assert not res.raw and res.len == 0
+    xs = (abi.AnofoxDataArray * 9)(*[a3] * 9)
+    assert not lib.anofox_compute_residuals(a3, a3, xs, 9, 1.0, True, C.byref(res), C.byref(err))
+    assert err.code == 1 and "maximum of 8" in err.text()
+
+
+def test_residuals_device_full_size_properties(pkg, ctx):
+    """1M-row device-resident batch: per-group trace of the hat matrix = p + 1, raw = y - yhat exactly, and a sample of
+    groups against the oracle."""
+    import torch
+    G, n, p = 10_000, 100, 8
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    y = torch.randn(G * n, dtype=torch.float64, device="cuda", generator=gen)
+    y_hat = y + 0.1 * torch.randn(G * n, dtype=torch.float64, device="cuda", generator=gen)
+    x_cols = [torch.randn(G * n, dtype=torch.float64, device="cuda", generator=gen) * (j + 1) + 10.0 * j for j in range(p)]
+    offs = torch.arange(0, G * n + 1, n, dtype=torch.int64, device="cuda")
+    rse = torch.full((G,), 0.1, dtype=torch.float64, device="cuda")
+    out, grp = ctx.residuals_batch_device(offs, y, y_hat, x_cols, rse)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, 0], y - y_hat)
+    assert torch.all(grp[:, 0] == n) and torch.all(grp[:, 1] == 7)
+    assert torch.allclose(out[:, 3].view(G, n).sum(1), torch.full((G,), p + 1.0, dtype=torch.float64, device="cuda"), rtol=0, atol=1e-9)
+    S = 50
+    rout, rgrp = oracle.residuals_groups(y[:S * n].cpu().numpy(), y_hat[:S * n].cpu().numpy(),
+                                         [c[:S * n].cpu().numpy() for c in x_cols], offs[:S + 1].cpu().numpy(),
+                                         rse=rse[:S].cpu().numpy())
+    _assert_residuals_match(out[:S * n].cpu().numpy(), grp[:S].cpu().numpy(), rout, rgrp, "device sample")

@@ -358,3 +358,26 @@ def test_vif_oracle_matches_closed_form_and_reference_unit_tests():
     c = oracle.vif_groups([[1.0, 2, 3, 4, 5], [2.0, 4, 6, 8, 10]], [0, 5])[0]
     assert np.isinf(c[0]) and np.isinf(c[1])                                    # perfectly correlated
     assert oracle.vif_groups([[1.0, 2], [2.0, 1]], [0, 2])[0, 2] == 100         # aggregate rule: < 3 rows -> NULL
+
+
+def test_residuals_oracle_textbook_values_and_reference_unit_tests():
+    """crates/anofox-stats-core/src/diagnostics/residuals.rs:204-263 (upstream's tests pin lengths and 0 <= h <= 1 only;
+    the hat values of x = 1..5 with an intercept are the textbook 1/n + (x - 3)^2 / 10)."""
+    y = [1.0, 2.0, 3.0, 4.0, 5.0]
+    yh = [1.1, 1.9, 3.0, 4.1, 4.9]
+    out, grp = oracle.residuals_groups(y, yh, [[1.0, 2.0, 3.0, 4.0, 5.0]], [0, 5], rse=[0.1], drop_nan_rows=False)
+    assert np.allclose(out[:, 0], [-0.1, 0.1, 0.0, -0.1, 0.1], atol=1e-10)
+    assert np.allclose(out[:, 1], out[:, 0] / 0.1)
+    assert np.allclose(out[:, 3], [0.6, 0.3, 0.2, 0.3, 0.6], rtol=1e-12)
+    assert np.allclose(out[:, 2], out[:, 0] / (0.1 * np.sqrt(1 - out[:, 3])), rtol=1e-12)
+    assert list(grp[0]) == [5.0, 7.0]
+    out, grp = oracle.residuals_groups(y, y, None, [0, 5], rse=[0.1])
+    assert np.all(out[:, 1] == 0.0) and list(grp[0]) == [5.0, 1.0]
+    out, grp = oracle.residuals_groups(y, yh, None, [0, 5])
+    assert np.all(np.isnan(out[:, 1:])) and list(grp[0]) == [5.0, 0.0]
+    x1 = np.arange(1.0, 11.0)                                          # test_residuals_diagnostics_agg.test: x2 = 2 x1
+    out, grp = oracle.residuals_groups(np.arange(10.0), np.arange(10.0) + 0.1, [x1, 2 * x1], [0, 10])
+    assert list(grp[0]) == [10.0, 0.0] and np.all(np.isnan(out[:, 3]))
+    yn = np.array([1.0, np.nan, 3.0, 4.0])                              # aggregate Update: NaN rows are skipped
+    out, grp = oracle.residuals_groups(yn, [1.0, 2.0, np.nan, 3.5], None, [0, 4])
+    assert grp[0, 0] == 2 and np.isnan(out[1, 0]) and np.isnan(out[2, 0]) and out[3, 0] == 0.5
