@@ -22,6 +22,7 @@
 // Two passes over the group's rows: moments (shifted by the group's first used row, summed per lane, butterfly
 // reduction so that every lane holds the totals), then the per-row outputs — 32 contiguous bytes per row.
 #include "common.h"
+#include "wave_reduce.h"
 
 namespace anofox {
 
@@ -38,7 +39,7 @@ __device__ inline double wave_uniform(double v) {
 }
 
 template <int P>
-__global__ __launch_bounds__(256, 2) void residuals_narrow_kernel(ResidualArgs args) {
+__global__ __launch_bounds__(256, 3) void residuals_narrow_kernel(ResidualArgs args) {
 	constexpr int NQ = P * (P + 1) / 2;
 	const int lane = threadIdx.x & 63;
 	const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -89,13 +90,21 @@ __global__ __launch_bounds__(256, 2) void residuals_narrow_kernel(ResidualArgs a
 				}
 			}
 		}
+		{ // transposing butterfly: total k lands on lane k, then one broadcast per total
+			double v[64];
 #pragma unroll
-		for (int m = 32; m >= 1; m >>= 1) {
-			cnt += __shfl_xor(cnt, m, 64);
+			for (int k = 0; k < 64; ++k) v[k] = 0.0;
 #pragma unroll
-			for (int j = 0; j < P; ++j) sum[j] += __shfl_xor(sum[j], m, 64);
+			for (int k = 0; k < NQ; ++k) v[k] = q[k];
 #pragma unroll
-			for (int k = 0; k < NQ; ++k) q[k] += __shfl_xor(q[k], m, 64);
+			for (int j = 0; j < P; ++j) v[NQ + j] = sum[j];
+			v[NQ + P] = cnt;
+			transpose_reduce64(v, lane);
+#pragma unroll
+			for (int k = 0; k < NQ; ++k) q[k] = readlane_f64(v[0], k);
+#pragma unroll
+			for (int j = 0; j < P; ++j) sum[j] = readlane_f64(v[0], NQ + j);
+			cnt = readlane_f64(v[0], NQ + P);
 		}
 		if (cnt > 0.0) {
 			inv_n = 1.0 / cnt;
@@ -130,15 +139,19 @@ __global__ __launch_bounds__(256, 2) void residuals_narrow_kernel(ResidualArgs a
 				}
 			}
 #pragma unroll
-			for (int j = 0; j < P; ++j) { // column j of L^-1
-				Linv[j * (j + 1) / 2 + j] = rdiag[j];
+			for (int j = P - 1; j >= 0; --j) { // L^-1 in place (off-diagonal part; its diagonal is rdiag), last column first
 #pragma unroll
-				for (int i = j + 1; i < P; ++i) {
-					double v = 0.0;
+				for (int i = P - 1; i > j; --i) { // descending i: q[k][j], k < i, still hold L
+					double v = rdiag[i] * q[i * (i + 1) / 2 + j];
 #pragma unroll
-					for (int k = j; k < i; ++k) v -= q[i * (i + 1) / 2 + k] * Linv[k * (k + 1) / 2 + j];
-					Linv[i * (i + 1) / 2 + j] = v * rdiag[i];
+					for (int k = j + 1; k < i; ++k) v = fma(q[i * (i + 1) / 2 + k], q[k * (k + 1) / 2 + j], v);
+					q[i * (i + 1) / 2 + j] = -v * rdiag[j];
 				}
+			}
+#pragma unroll
+			for (int i = 0; i < P; ++i) {
+#pragma unroll
+				for (int k = 0; k <= i; ++k) Linv[i * (i + 1) / 2 + k] = k == i ? rdiag[i] : q[i * (i + 1) / 2 + k];
 			}
 			// a NaN / inf feature value in a used row poisons every leverage of the group in the reference (its
 			// elimination carries the NaN through); the NaN moments end in !ok here, restore that outcome
