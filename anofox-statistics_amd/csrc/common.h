@@ -325,6 +325,7 @@ struct WindowArgs {
 	// ROWS BETWEEN frame_start PRECEDING AND frame_end PRECEDING; frame_start < 0 = UNBOUNDED PRECEDING
 	int64_t frame_start;
 	int64_t frame_end;
+	double avg_rows; // rows per partition on average (0 = unknown)
 };
 constexpr int kWindowTcritCap = 65536;
 hipError_t launch_tcrit_table(double *table, int cap, double prob, hipStream_t stream);

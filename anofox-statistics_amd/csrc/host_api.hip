@@ -651,7 +651,7 @@ bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int64_t n_groups, 
 
 namespace {
 
-bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off, const double *d_y,
+bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const int64_t *d_off, const double *d_y,
                 const double *const *x_cols, const double *d_w, const AnofoxHipWindowFrame &frame,
                 const AnofoxHipBatchOptions &opt, double *d_pred, AnofoxError *e) {
 	if (G == 0) return true;
@@ -678,6 +678,7 @@ bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_off
 	a.tcrit_cap = kWindowTcritCap;
 	a.frame_start = frame.start_preceding < 0 ? -1 : frame.start_preceding;
 	a.frame_end = frame.end_preceding;
+	a.avg_rows = (n_rows > 0 && G > 0) ? (double)n_rows / (double)G : 0.0;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->timing) {
 		e0 = get_event(ctx);
@@ -723,7 +724,7 @@ bool anofox_hip_fit_predict_window_device(AnofoxHipContext *ctx, int64_t n_group
 	if (!validate_window(ctx, n_groups, n_features, d_row_offsets, d_y, x_cols, d_w, frame, options, d_pred, out_error)) return false;
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
-	return run_window(ctx, n_groups, n_features, d_row_offsets, d_y, x_cols, d_w, frame, options, d_pred, out_error);
+	return run_window(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, frame, options, d_pred, out_error);
 }
 
 bool anofox_hip_fit_predict_expanding_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
@@ -794,7 +795,7 @@ bool anofox_hip_fit_predict_window_host(AnofoxHipContext *ctx, int64_t n_groups,
 		cur += b_col;
 	}
 	double *d_pred = (double *)cur;
-	if (!run_window(ctx, n_groups, p, d_off, d_y, d_x, d_w, frame, options, d_pred, out_error)) return false;
+	if (!run_window(ctx, n_groups, p, n_rows, d_off, d_y, d_x, d_w, frame, options, d_pred, out_error)) return false;
 	if (R > 0 && hip_fail(hipMemcpyAsync(pred, d_pred, R * 3 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H pred", out_error)) return false;
 	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
 }

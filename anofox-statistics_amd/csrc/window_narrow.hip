@@ -24,6 +24,7 @@
 // consecutive rows and hit L1/L2 after the first touch, so the direct sum costs O(frame) cached loads per row.
 #include "common.h"
 #include "device_math.h"
+#include <cstdlib>
 
 namespace anofox {
 
@@ -171,20 +172,23 @@ __device__ __forceinline__ void fit_from_moments(const double (&rec)[MomentLayou
 	out.nobs = cnt;
 }
 
-__device__ __forceinline__ double scan_incl(double v, int lane) {
+// inclusive prefix within segments of SEGW consecutive lanes (sl = lane % SEGW)
+template <int SEGW>
+__device__ __forceinline__ double scan_incl(double v, int sl) {
 #pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
+	for (int d = 1; d < SEGW; d <<= 1) {
 		const double u = __shfl_up(v, d, 64);
-		v += (lane >= d) ? u : 0.0;
+		v += (sl >= d) ? u : 0.0;
 	}
 	return v;
 }
 
-__device__ __forceinline__ unsigned scan_or(unsigned v, int lane) {
+template <int SEGW>
+__device__ __forceinline__ unsigned scan_or(unsigned v, int sl) {
 #pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
+	for (int d = 1; d < SEGW; d <<= 1) {
 		const unsigned u = (unsigned)__shfl_up((int)v, d, 64);
-		v |= (lane >= d) ? u : 0u;
+		v |= (sl >= d) ? u : 0u;
 	}
 	return v;
 }
@@ -194,19 +198,43 @@ __device__ __forceinline__ double rl64(double v, int src) {
 	                        __builtin_amdgcn_readlane(__double2loint(v), src));
 }
 
-template <int P, bool WEIGHTED, bool CENTER>
+// the value held by lane `src` (wave-uniform for whole-wave segments, else per segment)
+template <int SEGW>
+__device__ __forceinline__ double seg_pick(double v, int src) {
+	if (SEGW == 64) return rl64(v, __builtin_amdgcn_readfirstlane(src));
+	return __shfl(v, src, 64);
+}
+
+// Partitions are mapped to segments of SEGW lanes (64 = one partition per wavefront; 8 / 16 for batches of short
+// partitions, which would leave most of a wavefront idle): g = the lane's partition, sl = its lane within the segment.
+template <int SEGW>
+struct SegMap {
+	int lane, sl, seg_base;
+	int64_t g;
+	unsigned long long segmask;
+	__device__ __forceinline__ SegMap() {
+		lane = threadIdx.x & 63;
+		sl = lane & (SEGW - 1);
+		seg_base = lane - sl;
+		const int64_t wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
+		g = wave * (64 / SEGW) + lane / SEGW;
+		segmask = SEGW == 64 ? ~0ull : (((1ull << (SEGW & 63)) - 1ull) << seg_base);
+	}
+};
+
+template <int P, bool WEIGHTED, bool CENTER, int SEGW>
 __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args) {
 	using L = MomentLayout<P>;
 	constexpr int Z = L::Z;
 	constexpr int ZZ = L::ZZ;
-	const int lane = threadIdx.x & 63;
-	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
-	if (g >= args.n_groups) return;
-	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+	const SegMap<SEGW> sm;
+	const int lane = sm.lane, sl = sm.sl;
+	const bool glive = sm.g < args.n_groups;
+	const int64_t lo = glive ? args.row_offsets[sm.g] : 0, hi = glive ? args.row_offsets[sm.g + 1] : 0;
 	const bool icpt = CENTER;
 	const double nanv = __builtin_nan("");
 
-	// running totals of the rows of all previous tiles (wave-uniform)
+	// running totals of the rows of all previous tiles (uniform within the segment)
 	double car_s[Z], car_q[ZZ], car_w = 0.0, car_n = 0.0, car_ny = 0.0;
 	unsigned car_mask = 0;
 #pragma unroll
@@ -218,10 +246,10 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 	for (int a = 0; a < Z; ++a) first[a] = 0.0;
 	bool have_first = false;
 
-	for (int64_t base = lo; base < hi; base += 64) {
-		const int64_t r = base + lane;
+	for (int64_t base = lo; __ballot(base < hi) != 0ull; base += SEGW) { // until every segment of the wave is done
+		const int64_t r = base + sl;
 		const bool in = r < hi;
-		const int64_t rc = in ? r : hi - 1; // clamped: unconditional loads
+		const int64_t rc = in ? r : (hi > 0 ? hi - 1 : 0); // clamped: unconditional loads
 		double z[Z];
 #pragma unroll
 		for (int j = 0; j < P; ++j) z[j] = args.x[j][rc];
@@ -233,16 +261,20 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 		for (int j = 0; j < P; ++j) xfinite = xfinite && isfinite(z[j]);
 		bool valid = in && xfinite && isfinite(z[P]);
 		if (WEIGHTED) valid = valid && (w > 0.0) && isfinite(w);
-		const unsigned long long bv = __ballot(valid);
+		const unsigned long long bv = __ballot(valid) & sm.segmask;
 		// the window aggregate counts every row whose y is not NULL (NaN here) as a training row for its
 		// "enough rows" rule, before the fit drops the non-finite ones (ols_fit_predict.cpp:164-190,257-262)
-		const unsigned long long by = __ballot(in && !isnan(z[P]));
+		const unsigned long long by = __ballot(in && !isnan(z[P])) & sm.segmask;
 		const double n_y = car_ny + (double)__popcll(by & ((2ull << lane) - 1ull));
-		if (!have_first && bv != 0ull) {
-			const int fl = __ffsll((long long)bv) - 1;
+		{
+			const bool take = !have_first && bv != 0ull;
+			const int fl = bv != 0ull ? __ffsll((long long)bv) - 1 : lane;
 #pragma unroll
-			for (int a = 0; a < Z; ++a) first[a] = rl64(z[a], fl);
-			have_first = true;
+			for (int a = 0; a < Z; ++a) {
+				const double zf = seg_pick<SEGW>(z[a], fl);
+				first[a] = take ? zf : first[a];
+			}
+			have_first = have_first || take;
 		}
 		// this row's contribution (zero when it does not train), then inclusive prefix over the tile + carry
 		double rec[L::REC];
@@ -258,30 +290,31 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 #pragma unroll
 		for (int a = 0; a < Z; ++a) {
 			const double wd = WEIGHTED ? ww * d[a] : d[a];
-			rec[L::OFF_S + a] = car_s[a] + scan_incl(wd, lane);
+			rec[L::OFF_S + a] = car_s[a] + scan_incl<SEGW>(wd, sl);
 #pragma unroll
 			for (int b = a; b < Z; ++b) {
 				const int k = a * Z - a * (a - 1) / 2 + (b - a);
-				rec[L::OFF_Q + k] = car_q[k] + scan_incl(wd * d[b], lane);
+				rec[L::OFF_Q + k] = car_q[k] + scan_incl<SEGW>(wd * d[b], sl);
 			}
 		}
-		rec[L::OFF_SW] = car_w + scan_incl(ww, lane);
+		rec[L::OFF_SW] = car_w + scan_incl<SEGW>(ww, sl);
 		const double cnt = car_n + (double)__popcll(bv & ((2ull << lane) - 1ull));
 		rec[L::OFF_CNT] = cnt;
-		const unsigned mask = car_mask | scan_or(m, lane);
+		const unsigned mask = car_mask | scan_or<SEGW>(m, sl);
 		rec[L::OFF_MASK] = (double)mask;
 #pragma unroll
 		for (int a = 0; a < Z; ++a) rec[L::OFF_FIRST + a] = first[a];
 
-		// carry for the next tile = lane 63's inclusive prefix
+		// carry for the next tile = the inclusive prefix of the segment's last lane
+		const int last = sm.seg_base + SEGW - 1;
 #pragma unroll
-		for (int a = 0; a < Z; ++a) car_s[a] = rl64(rec[L::OFF_S + a], 63);
+		for (int a = 0; a < Z; ++a) car_s[a] = seg_pick<SEGW>(rec[L::OFF_S + a], last);
 #pragma unroll
-		for (int k = 0; k < ZZ; ++k) car_q[k] = rl64(rec[L::OFF_Q + k], 63);
-		car_w = rl64(rec[L::OFF_SW], 63);
+		for (int k = 0; k < ZZ; ++k) car_q[k] = seg_pick<SEGW>(rec[L::OFF_Q + k], last);
+		car_w = seg_pick<SEGW>(rec[L::OFF_SW], last);
 		car_n += (double)__popcll(bv);
 		car_ny += (double)__popcll(by);
-		car_mask = (unsigned)__builtin_amdgcn_readlane((int)mask, 63);
+		car_mask = SEGW == 64 ? (unsigned)__builtin_amdgcn_readlane((int)mask, 63) : (unsigned)__shfl((int)mask, last, 64);
 
 		// Finalize of the window aggregate for the frame ending at this row
 		double yhat = nanv, ylo = nanv, yhi = nanv;
@@ -348,21 +381,21 @@ __device__ __forceinline__ void predict_from_moments(const WindowArgs &args, con
 	yhi = v + margin;
 }
 
-template <int P, bool WEIGHTED, bool CENTER>
+template <int P, bool WEIGHTED, bool CENTER, int SEGW>
 __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 	using L = MomentLayout<P>;
 	constexpr int Z = L::Z;
 	constexpr int ZZ = L::ZZ;
-	const int lane = threadIdx.x & 63;
-	const int64_t g = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
-	if (g >= args.n_groups) return;
-	const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+	const SegMap<SEGW> sm;
+	const int sl = sm.sl;
+	const bool glive = sm.g < args.n_groups;
+	const int64_t lo = glive ? args.row_offsets[sm.g] : 0, hi = glive ? args.row_offsets[sm.g + 1] : 0;
 	const int64_t fa = args.frame_start, fb = args.frame_end; // fa >= fb >= 0
 	const bool icpt = CENTER;
 	const double nanv = __builtin_nan("");
 
-	for (int64_t base = lo; base < hi; base += 64) {
-		const int64_t e = base + lane;
+	for (int64_t base = lo; __ballot(base < hi) != 0ull; base += SEGW) { // until every segment of the wave is done
+		const int64_t e = base + sl;
 		const bool in = e < hi;
 		double s[Z], q[ZZ], first[Z], z[Z];
 #pragma unroll
@@ -373,13 +406,20 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 		unsigned mask = 0;
 		bool have_first = false, live = false, xfinite = false;
 
-		// offsets beyond the start of the partition hold no row for any lane of this tile
-		int64_t k_hi = base + 63 - lo;
+		// offsets beyond the start of the partition hold no row for any lane of this tile (wave-uniform bound)
+		int64_t k_hi = base < hi ? base + (SEGW - 1) - lo : -1;
 		if (k_hi > fa) k_hi = fa;
+		if (SEGW != 64) {
+#pragma unroll
+			for (int m = 32; m >= SEGW; m >>= 1) {
+				const int64_t o = __shfl_xor(k_hi, m, 64);
+				k_hi = o > k_hi ? o : k_hi;
+			}
+		}
 		for (int64_t k = k_hi; k >= fb; --k) {
 			const int64_t r = e - k;
 			live = in && r >= lo;
-			const int64_t rc = r < lo ? lo : (r >= hi ? hi - 1 : r); // clamped: unconditional loads
+			const int64_t rc = r < lo ? lo : (r >= hi ? (hi > 0 ? hi - 1 : 0) : r); // clamped: unconditional loads
 #pragma unroll
 			for (int j = 0; j < P; ++j) z[j] = args.x[j][rc];
 			z[P] = args.y[rc];
@@ -438,26 +478,49 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 	}
 }
 
-template <int P>
-hipError_t launch_window_p(const WindowArgs &a, hipStream_t stream) {
-	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
+template <int P, int SEGW>
+hipError_t launch_window_ps(const WindowArgs &a, hipStream_t stream) {
+	const int64_t waves = (a.n_groups + (64 / SEGW) - 1) / (64 / SEGW);
+	const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
 	const bool rolling = a.frame_start >= 0;
 #define ANOFOX_WINDOW_LAUNCH(KERNEL)                                                                             \
 	do {                                                                                                         \
 		if (weighted) {                                                                                          \
-			if (center) hipLaunchKernelGGL((KERNEL<P, true, true>), grid, block, 0, stream, a);                  \
-			else hipLaunchKernelGGL((KERNEL<P, true, false>), grid, block, 0, stream, a);                        \
+			if (center) hipLaunchKernelGGL((KERNEL<P, true, true, SEGW>), grid, block, 0, stream, a);            \
+			else hipLaunchKernelGGL((KERNEL<P, true, false, SEGW>), grid, block, 0, stream, a);                  \
 		} else {                                                                                                 \
-			if (center) hipLaunchKernelGGL((KERNEL<P, false, true>), grid, block, 0, stream, a);                 \
-			else hipLaunchKernelGGL((KERNEL<P, false, false>), grid, block, 0, stream, a);                       \
+			if (center) hipLaunchKernelGGL((KERNEL<P, false, true, SEGW>), grid, block, 0, stream, a);           \
+			else hipLaunchKernelGGL((KERNEL<P, false, false, SEGW>), grid, block, 0, stream, a);                 \
 		}                                                                                                        \
 	} while (0)
 	if (rolling) ANOFOX_WINDOW_LAUNCH(rolling_predict_kernel);
 	else ANOFOX_WINDOW_LAUNCH(expanding_predict_kernel);
 #undef ANOFOX_WINDOW_LAUNCH
 	return hipGetLastError();
+}
+
+template <int P>
+hipError_t launch_window_p(const WindowArgs &a, hipStream_t stream) {
+	// Narrow segments waste fewer lanes on a partition's last tile and scan in fewer steps (3 instead of 6), so the
+	// expanding kernel prefers 8 lanes per partition whenever there are enough partitions to fill the machine that way
+	// (1M x 100 x 3: 3.5 ms vs 4.7 ms with a wavefront each; 4M x 20 x 3: 3.3 ms vs 9.1 ms); few long partitions keep
+	// whole wavefronts.  The rolling kernel has no scans: narrow segments only for short partitions.
+	int segw = 64;
+	if (a.avg_rows > 0.0) {
+		if (a.frame_start < 0) {
+			if (a.avg_rows <= 8.0 || a.n_groups >= 32768) segw = 8;
+			else if (a.avg_rows <= 16.0 || a.n_groups >= 16384) segw = 16;
+		} else {
+			if (a.avg_rows <= 24.0) segw = 8;
+			else if (a.avg_rows <= 48.0) segw = 16;
+		}
+	}
+	if (const char *e = getenv("ANOFOX_WIN_SEGW")) segw = atoi(e);
+	if (segw == 8) return launch_window_ps<P, 8>(a, stream);
+	if (segw == 16) return launch_window_ps<P, 16>(a, stream);
+	return launch_window_ps<P, 64>(a, stream);
 }
 
 } // namespace
