@@ -472,24 +472,33 @@ SQL_FUNCTIONS.update({"anofox_stats_vif_agg": vif_agg, "vif_agg": vif_agg})
 # CURRENT ROW | k PRECEDING, or any ROWS BETWEEN a PRECEDING AND b PRECEDING): the window functions (src/window_functions/{ols,ridge,wls}_fit_predict.cpp)
 # ------------------------------------------------------------------------------------------------------
 def _parse_frame(frame, frame_end):
-    """(start_preceding or None, end_preceding) from `frame` = (start, end) with start in {None, "unbounded", k}
-    and end in {"current row", k}; `frame_end` is the older spelling for UNBOUNDED frames."""
-    def bound(v, what):
+    """(start, end) in rows PRECEDING the current row (negative = FOLLOWING; start None = UNBOUNDED PRECEDING, end
+    None = UNBOUNDED FOLLOWING) from `frame` = (start, end), each "unbounded preceding" / "unbounded following" /
+    "<k> preceding" / "current row" / "<k> following" or an integer; `frame_end` is the older spelling for frames
+    that start UNBOUNDED PRECEDING."""
+    def bound(v, what, is_start):
         if isinstance(v, str):
             t = v.strip().lower()
             if t in ("current row", "current"):
                 return 0
-            if t in ("unbounded", "unbounded preceding"):
+            if t == "unbounded":
+                return None
+            if t == "unbounded preceding" and is_start:
+                return None
+            if t == "unbounded following" and not is_start:
                 return None
             if t.endswith(" preceding") and t[:-10].strip().isdigit():
                 return int(t[:-10])
-            raise InvalidInputException(f"{what} must be 'unbounded', 'current row' or '<k> preceding'")
+            if t.endswith(" following") and t[:-10].strip().isdigit():
+                return -int(t[:-10])
+            raise InvalidInputException(f"{what} must be 'unbounded preceding|following', 'current row', '<k> preceding' "
+                                        "or '<k> following'")
         return v if v is None else int(v)
     if frame is None:
         frame = (None, frame_end)
-    start, end = bound(frame[0], "frame start"), bound(frame[1], "frame end")
-    if end is None or end < 0 or (start is not None and start < end):
-        raise InvalidInputException("the frame must end at or before the current row and start at or before its end")
+    start, end = bound(frame[0], "frame start", True), bound(frame[1], "frame end", False)
+    if start is not None and end is not None and start < end:
+        raise InvalidInputException("the frame must start at or before its end")
     return start, end
 
 

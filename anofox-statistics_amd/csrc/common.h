@@ -322,12 +322,14 @@ struct WindowArgs {
 	double alpha;
 	const double *tcrit; // [tcrit_cap + 1], see tcrit_table_kernel
 	int tcrit_cap;
-	// ROWS BETWEEN frame_start PRECEDING AND frame_end PRECEDING; frame_start < 0 = UNBOUNDED PRECEDING
+	// ROWS BETWEEN frame_start PRECEDING AND frame_end PRECEDING; negative = FOLLOWING; frame_start = kFrameUnbounded =
+	// UNBOUNDED PRECEDING, frame_end = -kFrameUnbounded = UNBOUNDED FOLLOWING
 	int64_t frame_start;
 	int64_t frame_end;
 	double avg_rows; // rows per partition on average (0 = unknown)
 };
 constexpr int kWindowTcritCap = 65536;
+constexpr int64_t kFrameUnbounded = ANOFOX_HIP_FRAME_UNBOUNDED;
 hipError_t launch_tcrit_table(double *table, int cap, double prob, hipStream_t stream);
 hipError_t launch_window_predict(const WindowArgs &a, hipStream_t stream);
 

@@ -676,7 +676,7 @@ bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, cons
 	a.alpha = opt.alpha;
 	a.tcrit = (const double *)ctx->wtab;
 	a.tcrit_cap = kWindowTcritCap;
-	a.frame_start = frame.start_preceding < 0 ? -1 : frame.start_preceding;
+	a.frame_start = frame.start_preceding;
 	a.frame_end = frame.end_preceding;
 	a.avg_rows = (n_rows > 0 && G > 0) ? (double)n_rows / (double)G : 0.0;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -697,8 +697,9 @@ bool validate_window(AnofoxHipContext *ctx, int64_t G, size_t p, const void *off
                      const void *w, const AnofoxHipWindowFrame &frame, const AnofoxHipBatchOptions &opt, const void *pred,
                      AnofoxError *e) {
 	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
-	if (frame.end_preceding < 0 || (frame.start_preceding >= 0 && frame.start_preceding < frame.end_preceding)) {
-		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "window frame must end at or before the current row and start at or before its end");
+	if (frame.start_preceding < frame.end_preceding || frame.start_preceding == -ANOFOX_HIP_FRAME_UNBOUNDED ||
+	    frame.end_preceding == ANOFOX_HIP_FRAME_UNBOUNDED) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "window frame must start at or before its end");
 		return false;
 	}
 	if (G < 0 || p == 0 || !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "invalid n_groups / n_features / x"); return false; }
@@ -731,7 +732,7 @@ bool anofox_hip_fit_predict_expanding_device(AnofoxHipContext *ctx, int64_t n_gr
                                              const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
                                              const double *d_w, AnofoxHipBatchOptions options, double *d_pred,
                                              AnofoxError *out_error) {
-	const AnofoxHipWindowFrame frame = {-1, 0}; // UNBOUNDED PRECEDING .. CURRENT ROW
+	const AnofoxHipWindowFrame frame = {ANOFOX_HIP_FRAME_UNBOUNDED, 0}; // UNBOUNDED PRECEDING .. CURRENT ROW
 	return anofox_hip_fit_predict_window_device(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, frame,
 	                                            options, d_pred, out_error);
 }
@@ -740,7 +741,7 @@ bool anofox_hip_fit_predict_expanding_host(AnofoxHipContext *ctx, int64_t n_grou
                                            const int64_t *row_offsets, const double *y, const double *const *x_cols,
                                            const double *w, AnofoxHipBatchOptions options, double *pred,
                                            AnofoxError *out_error) {
-	const AnofoxHipWindowFrame frame = {-1, 0}; // UNBOUNDED PRECEDING .. CURRENT ROW
+	const AnofoxHipWindowFrame frame = {ANOFOX_HIP_FRAME_UNBOUNDED, 0}; // UNBOUNDED PRECEDING .. CURRENT ROW
 	return anofox_hip_fit_predict_window_host(ctx, n_groups, n_features, n_rows, row_offsets, y, x_cols, w, frame, options, pred,
 	                                          out_error);
 }

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 #pragma unroll
 	for (int a = 0; a < Z; ++a) first[a] = 0.0;
 	bool have_first = false;
+	double fin[3] = {nanv, nanv, nanv};
 
 	for (int64_t base = lo; __ballot(base < hi) != 0ull; base += SEGW) { // until every segment of the wave is done
 		const int64_t r = base + sl;
@@ -342,9 +343,9 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 				}
 			}
 		}
+		const int64_t b = args.frame_end; // frame ends b rows before the current row: row r + b gets this result
 		if (in) {
-			const int64_t b = args.frame_end; // frame ends b rows before the current row: row r + b gets this result
-			if (r + b < hi) {
+			if (r + b < hi && r + b >= lo) { // b < 0 (FOLLOWING): the frame of row r + b ends here
 				double *out = args.pred + (r + b) * 3;
 				out[0] = yhat;
 				out[1] = ylo;
@@ -354,6 +355,24 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 				double *out = args.pred + r * 3;
 				out[0] = out[1] = out[2] = nanv;
 			}
+		}
+		if (b < 0) { // wave-uniform: remember the result of the partition's last row (segment-wide)
+			const bool has_last = base < hi && hi - 1 < base + SEGW;
+			const int src = sm.seg_base + (has_last ? (int)(hi - 1 - base) : 0);
+			const double f0 = seg_pick<SEGW>(yhat, src), f1 = seg_pick<SEGW>(ylo, src), f2 = seg_pick<SEGW>(yhi, src);
+			fin[0] = has_last ? f0 : fin[0];
+			fin[1] = has_last ? f1 : fin[1];
+			fin[2] = has_last ? f2 : fin[2];
+		}
+	}
+	if (args.frame_end < 0 && hi > lo) { // frames reaching past the partition's end stop at its last row: same result
+		int64_t t0 = hi + args.frame_end;
+		if (t0 < lo) t0 = lo;
+		for (int64_t t = t0 + sl; t < hi; t += SEGW) {
+			double *out = args.pred + t * 3;
+			out[0] = fin[0];
+			out[1] = fin[1];
+			out[2] = fin[2];
 		}
 	}
 }
@@ -390,7 +409,7 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 	const int sl = sm.sl;
 	const bool glive = sm.g < args.n_groups;
 	const int64_t lo = glive ? args.row_offsets[sm.g] : 0, hi = glive ? args.row_offsets[sm.g + 1] : 0;
-	const int64_t fa = args.frame_start, fb = args.frame_end; // fa >= fb >= 0
+	const int64_t fa = args.frame_start, fb = args.frame_end; // fa >= fb; negative = FOLLOWING, +-kFrameUnbounded
 	const bool icpt = CENTER;
 	const double nanv = __builtin_nan("");
 
@@ -406,19 +425,25 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 		unsigned mask = 0;
 		bool have_first = false, live = false, xfinite = false;
 
-		// offsets beyond the start of the partition hold no row for any lane of this tile (wave-uniform bound)
-		int64_t k_hi = base < hi ? base + (SEGW - 1) - lo : -1;
-		if (k_hi > fa) k_hi = fa;
-		if (SEGW != 64) {
-#pragma unroll
-			for (int m = 32; m >= SEGW; m >>= 1) {
-				const int64_t o = __shfl_xor(k_hi, m, 64);
-				k_hi = o > k_hi ? o : k_hi;
-			}
+		// this lane's frame = offsets kl..kh (row e - k), clipped to the partition; the loop walks the union over the wave
+		const int64_t kh = in ? (fa < e - lo ? fa : e - lo) : INT64_MIN + 1;
+		const int64_t kl = in ? (fb > e - (hi - 1) ? fb : e - (hi - 1)) : INT64_MAX;
+		// union over the segment's rows in closed form, then over the segments of the wave
+		int64_t k_hi = INT64_MIN + 1, k_lo = INT64_MAX;
+		if (base < hi) {
+			const int64_t e_last = base + (SEGW - 1) < hi - 1 ? base + (SEGW - 1) : hi - 1;
+			k_hi = fa < e_last - lo ? fa : e_last - lo;
+			k_lo = fb > base - (hi - 1) ? fb : base - (hi - 1);
 		}
-		for (int64_t k = k_hi; k >= fb; --k) {
+#pragma unroll
+		for (int m = 32; m >= SEGW; m >>= 1) {
+			const int64_t oh = __shfl_xor(k_hi, m, 64), ol = __shfl_xor(k_lo, m, 64);
+			k_hi = oh > k_hi ? oh : k_hi;
+			k_lo = ol < k_lo ? ol : k_lo;
+		}
+		for (int64_t k = k_hi; k >= k_lo; --k) {
 			const int64_t r = e - k;
-			live = in && r >= lo;
+			live = k <= kh && k >= kl;
 			const int64_t rc = r < lo ? lo : (r >= hi ? (hi > 0 ? hi - 1 : 0) : r); // clamped: unconditional loads
 #pragma unroll
 			for (int j = 0; j < P; ++j) z[j] = args.x[j][rc];
@@ -456,9 +481,19 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 			sw += ww;
 			cnt += valid ? 1.0 : 0.0;
 		}
-		// after the loop z / live / xfinite describe the LAST row of the frame (offset fb): the x to predict
+		// the x to predict is the LAST row of the frame (offset kl): read it again (an L1 hit) instead of tracking it
+		const bool any_live = in && kh >= kl;
+		bool xfl = true;
+		{
+			const int64_t rl = any_live ? e - kl : (hi > 0 ? hi - 1 : 0);
+#pragma unroll
+			for (int j = 0; j < P; ++j) {
+				z[j] = args.x[j][rl];
+				xfl = xfl && isfinite(z[j]);
+			}
+		}
 		double yhat = nanv, ylo = nanv, yhi = nanv;
-		if (k_hi >= fb && live && xfinite && n_y > (double)(P + (icpt ? 1 : 0))) { // ols_fit_predict.cpp:253-262
+		if (any_live && xfl && n_y > (double)(P + (icpt ? 1 : 0))) { // ols_fit_predict.cpp:253-262
 			double rec[L::REC];
 #pragma unroll
 			for (int a = 0; a < Z; ++a) { rec[L::OFF_S + a] = s[a]; rec[L::OFF_FIRST + a] = first[a]; }
@@ -484,7 +519,7 @@ hipError_t launch_window_ps(const WindowArgs &a, hipStream_t stream) {
 	const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
-	const bool rolling = a.frame_start >= 0;
+	const bool rolling = a.frame_start != kFrameUnbounded;
 #define ANOFOX_WINDOW_LAUNCH(KERNEL)                                                                             \
 	do {                                                                                                         \
 		if (weighted) {                                                                                          \
@@ -509,7 +544,7 @@ hipError_t launch_window_p(const WindowArgs &a, hipStream_t stream) {
 	// whole wavefronts.  The rolling kernel has no scans: narrow segments only for short partitions.
 	int segw = 64;
 	if (a.avg_rows > 0.0) {
-		if (a.frame_start < 0) {
+		if (a.frame_start == kFrameUnbounded) {
 			if (a.avg_rows <= 8.0 || a.n_groups >= 32768) segw = 8;
 			else if (a.avg_rows <= 16.0 || a.n_groups >= 16384) segw = 16;
 		} else {
@@ -532,7 +567,7 @@ hipError_t launch_tcrit_table(double *table, int cap, double prob, hipStream_t s
 
 hipError_t launch_window_predict(const WindowArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
-	if (a.frame_end < 0 || (a.frame_start >= 0 && a.frame_start < a.frame_end)) return hipErrorInvalidValue;
+	if (a.frame_start < a.frame_end || a.frame_start == -kFrameUnbounded || a.frame_end == kFrameUnbounded) return hipErrorInvalidValue;
 	switch (a.p) {
 	case 1: return launch_window_p<1>(a, stream);
 	case 2: return launch_window_p<2>(a, stream);

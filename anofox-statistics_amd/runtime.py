@@ -259,9 +259,15 @@ def fit_predict_batch_host(row_offsets, y, x_cols: Sequence, w, options: _abi.An
     return core, pred
 
 
+FRAME_UNBOUNDED = 2 ** 63 - 1        # ANOFOX_HIP_FRAME_UNBOUNDED
+
+
 def _frame(frame) -> _abi.AnofoxHipWindowFrame:
+    """(start, end) in rows PRECEDING the current row (negative = FOLLOWING); start None = UNBOUNDED PRECEDING,
+    end None = UNBOUNDED FOLLOWING."""
     start, end = frame
-    return _abi.AnofoxHipWindowFrame(-1 if start is None else int(start), int(end))
+    return _abi.AnofoxHipWindowFrame(FRAME_UNBOUNDED if start is None else int(start),
+                                     -FRAME_UNBOUNDED if end is None else int(end))
 
 
 def fit_predict_expanding_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
@@ -273,7 +279,8 @@ def fit_predict_expanding_host(row_offsets, y, x_cols: Sequence, w, options: _ab
 def fit_predict_window_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
                             frame=(None, 0), ctx: Optional[Context] = None):
     """numpy in, numpy out: pred[N, 3] of the window functions over ROWS BETWEEN frame[0] PRECEDING AND frame[1]
-    PRECEDING (frame[0] None = UNBOUNDED PRECEDING, frame[1] 0 = CURRENT ROW)."""
+    PRECEDING (negative = FOLLOWING; frame[0] None = UNBOUNDED PRECEDING, frame[1] 0 = CURRENT ROW, None = UNBOUNDED
+    FOLLOWING)."""
     lib = _abi.load()
     off = np.ascontiguousarray(row_offsets, dtype=np.int64)
     yv = np.ascontiguousarray(y, dtype=np.float64)

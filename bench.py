@@ -244,7 +244,7 @@ def main():
         nr = int(offs[S].item())
         ref = oracle.fit_predict_window(y[:nr].cpu().numpy(), [c[:nr].cpu().numpy() for c in x_cols],
                                         offs[:S + 1].cpu().numpy(), w=w[:nr].cpu().numpy() if w is not None else None,
-                                        start_preceding=-1 if frame[0] is None else frame[0], end_preceding=frame[1],
+                                        start_preceding=frame[0], end_preceding=frame[1],
                                         model=args.model, **{k: v for k, v in kw.items() if k != "compute_inference"})
         got = pred_buf[:nr].cpu().numpy()
         m = ~np.isnan(ref[:, 0])

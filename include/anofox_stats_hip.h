@@ -356,13 +356,17 @@ ANOFOX_HIP_API bool anofox_hip_fit_predict_expanding_host(AnofoxHipContext *ctx,
                                            AnofoxError *out_error);
 
 /*
- * The same window functions over any ROWS frame that ends at or before the current row:
+ * The same window functions over any ROWS frame:
  *   ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING
- * (start_preceding < 0 = UNBOUNDED PRECEDING; end_preceding = 0 = CURRENT ROW; start_preceding >= end_preceding).
+ * Offsets count rows before the current row; 0 = CURRENT ROW, negative = FOLLOWING (-3 = 3 FOLLOWING);
+ * start_preceding = ANOFOX_HIP_FRAME_UNBOUNDED = UNBOUNDED PRECEDING, end_preceding = -ANOFOX_HIP_FRAME_UNBOUNDED =
+ * UNBOUNDED FOLLOWING; start_preceding >= end_preceding.  Frames are clipped to the partition, as DuckDB does.
  * The aggregate trains on the frame's rows with non-NULL y and predicts the x of the LAST row of the frame
- * (ols_fit_predict.cpp:157-162), so with end_preceding = b the output of row e uses x of row e - b; rows whose
- * frame is empty are NULL.  UNBOUNDED frames run the one-pass prefix kernel, finite ones sum each frame directly.
+ * (ols_fit_predict.cpp:157-162), so with end_preceding = b the output of row e uses x of row e - b (or of the
+ * partition's last row when the frame reaches past it); rows whose frame is empty are NULL.  Frames that start
+ * UNBOUNDED PRECEDING run the one-pass prefix kernel, the others sum each frame directly (O(frame) per row).
  */
+#define ANOFOX_HIP_FRAME_UNBOUNDED INT64_MAX
 typedef struct {
 	int64_t start_preceding;
 	int64_t end_preceding;

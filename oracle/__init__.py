@@ -233,9 +233,11 @@ def fit_predict_expanding(y, x_cols, offsets, w=None, **kw):
     return pred
 
 
-def fit_predict_window(y, x_cols, offsets, w=None, start_preceding=-1, end_preceding=0, **kw):
+def fit_predict_window(y, x_cols, offsets, w=None, start_preceding=None, end_preceding=0, **kw):
     """pred[N, 3] of the window functions over ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING
-    (start_preceding < 0 = UNBOUNDED PRECEDING)."""
+    (negative = FOLLOWING; None = UNBOUNDED PRECEDING / FOLLOWING)."""
+    start_preceding = 2 ** 63 - 1 if start_preceding is None else start_preceding
+    end_preceding = -(2 ** 63 - 1) if end_preceding is None else end_preceding
     y = np.ascontiguousarray(y, dtype=np.float64)
     cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)

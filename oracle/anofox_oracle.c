@@ -750,7 +750,7 @@ ORACLE_EXPORT int oracle_fit_predict_expanding(const double *y, const double *co
 }
 
 /* The window functions over ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING
- * (start_preceding < 0 = UNBOUNDED PRECEDING): the aggregate's Update/Finalize applied to every frame from
+ * (negative = FOLLOWING, +-INT64_MAX = UNBOUNDED): the aggregate's Update/Finalize applied to every frame from
  * scratch (src/window_functions/ols_fit_predict.cpp:110-324).  Training rows = frame rows with y not NULL
  * (:164-190); the x that is predicted is the one of the LAST frame row (:157-162); NULL for an empty frame
  * (:253-256) and unless MORE than p + [intercept] training rows exist (:257-262).  O(n * frame) fits. */
@@ -758,7 +758,7 @@ ORACLE_EXPORT int oracle_fit_predict_window(const double *y, const double *const
                                             const int64_t *offsets, int64_t n_groups, size_t p,
                                             const OracleOptions *opt, int64_t start_preceding, int64_t end_preceding,
                                             double *pred) {
-	if (end_preceding < 0 || (start_preceding >= 0 && start_preceding < end_preceding)) return ORC_INVALID_INPUT;
+	if (start_preceding < end_preceding) return ORC_INVALID_INPUT;
 	OracleOptions o = *opt;
 	o.compute_inference = 0;
 	double *coef = (double *)malloc(p * sizeof(double));
@@ -774,9 +774,12 @@ ORACLE_EXPORT int oracle_fit_predict_window(const double *y, const double *const
 		for (int64_t e = lo; e < hi; e++) {
 			double *out = pred + (size_t)e * 3;
 			out[0] = out[1] = out[2] = NAN;
-			int64_t last = e - end_preceding;
-			int64_t first = start_preceding < 0 ? lo : e - start_preceding;
+			/* offsets count rows before the current one, negative = FOLLOWING, +-INT64_MAX = UNBOUNDED; the frame is
+			 * clipped to the partition */
+			int64_t last = end_preceding == -INT64_MAX ? hi - 1 : e - end_preceding;
+			int64_t first = start_preceding == INT64_MAX ? lo : e - start_preceding;
 			if (first < lo) first = lo;
+			if (last > hi - 1) last = hi - 1;
 			if (last < first) continue; /* empty frame */
 			size_t nt = 0;
 			for (int64_t r = first; r <= last; r++) {

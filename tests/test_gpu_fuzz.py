@@ -161,8 +161,8 @@ def test_fuzz_window_frames(pkg, ctx, seed):
     y[rng.random(N) < 0.15] = np.nan
     X[rng.random(N) < 0.02, int(rng.integers(0, p))] = np.nan
     w = rng.uniform(0.3, 2.0, N)
-    b = int(rng.choice([0, 0, 1, 3]))
-    a = None if rng.random() < 0.35 else b + int(rng.integers(0, 40))
+    b = int(rng.choice([0, 0, 1, 3, -1, -4])) if rng.random() < 0.9 else None      # negative = FOLLOWING, None = UNBOUNDED
+    a = None if rng.random() < 0.35 else (b if b is not None else -5) + int(rng.integers(0, 40))
     model = ["ols", "ridge", "wls"][int(rng.integers(0, 3))]
     kw = dict(fit_intercept=bool(rng.integers(0, 2)), confidence_level=0.9)
     if model == "ridge":
@@ -170,7 +170,7 @@ def test_fuzz_window_frames(pkg, ctx, seed):
     wv = w if model == "wls" else None
     x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
     pred = pkg.fit_predict_window_host(offs, y, x_cols, wv, pkg.RegressionOptions(**kw).batch_options(model), (a, b), ctx=ctx)
-    ref = oracle.fit_predict_window(y, x_cols, offs, w=wv, start_preceding=-1 if a is None else a, end_preceding=b,
+    ref = oracle.fit_predict_window(y, x_cols, offs, w=wv, start_preceding=a, end_preceding=b,
                                     model=model, **kw)
     what = f"window seed {seed} {model} p={p} frame=({a},{b}) {kw}"
     assert np.array_equal(np.isnan(pred[:, 0]), np.isnan(ref[:, 0])), f"NULL pattern {what}"

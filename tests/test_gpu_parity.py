@@ -991,13 +991,14 @@ def test_expanding_window_matches_oracle(pkg, ctx, model, p):
 
 
 @pytest.mark.parametrize("model", ["ols", "ridge", "wls"])
-@pytest.mark.parametrize("frame", [(9, 0), (20, 0), (9, 1), (7, 3), (2, 0), (89, 0), (150, 150), (None, 2), (None, 0)])
+@pytest.mark.parametrize("frame", [(9, 0), (20, 0), (9, 1), (7, 3), (2, 0), (89, 0), (150, 150), (None, 2), (None, 0),
+                                   (5, -5), (0, -12), (-2, -9), (10, None), (None, -3), (None, None), (-250, -250)])
 def test_window_frames_match_oracle(pkg, ctx, model, frame):
     """ROWS BETWEEN a PRECEDING AND b PRECEDING — the rolling and lagged frames of the reference's docs and tests
     (e.g. test/sql: '9 PRECEDING AND CURRENT ROW', '7 PRECEDING AND 3 PRECEDING', '89 PRECEDING AND CURRENT ROW',
     'UNBOUNDED PRECEDING AND 1 PRECEDING'): every frame refitted by the oracle."""
     for p in (1, 3, 8):
-        rng = np.random.default_rng(1000 + 7 * p + len(model) + (frame[0] or 0) + 13 * frame[1])
+        rng = np.random.default_rng(1000 + 7 * p + len(model) + abs(frame[0] or 0) + 13 * abs(frame[1] or 0))
         offs, y, x_cols, w = _random_groups(rng, 10, p, 1, 200)
         x_cols = [c.copy() for c in x_cols]
         gid = np.repeat(np.arange(len(offs) - 1), np.diff(offs))
@@ -1012,7 +1013,7 @@ def test_window_frames_match_oracle(pkg, ctx, model, frame):
                 kw["alpha"] = 0.5
             wv = w if model == "wls" else None
             pred = pkg.fit_predict_window_host(offs, y, x_cols, wv, _opts(pkg, model, **kw), frame, ctx=ctx)
-            ref = oracle.fit_predict_window(y, x_cols, offs, w=wv, start_preceding=-1 if frame[0] is None else frame[0],
+            ref = oracle.fit_predict_window(y, x_cols, offs, w=wv, start_preceding=frame[0],
                                             end_preceding=frame[1], **_oracle_kw(model, kw))
             what = f"{model} p={p} icpt={icpt} frame={frame}"
             assert np.array_equal(np.isnan(pred[:, 0]), np.isnan(ref[:, 0])), f"NULL pattern {what}"
@@ -1069,9 +1070,19 @@ def test_window_reference_sql_structural_tests(pkg, ctx):
 def test_window_frame_validation(pkg, ctx):
     rng = np.random.default_rng(5)
     offs, y, x_cols, w = _random_groups(rng, 3, 2, 5, 30)
-    for bad in ((3, 5), (0, -1), (None, -2)):
+    for bad in ((3, 5), (-2, -1), (0, 1)):                           # the frame must start at or before its end
         with pytest.raises(pkg.AnofoxStatsError):
             pkg.fit_predict_window_host(offs, y, x_cols, None, _opts(pkg, "ols"), bad, ctx=ctx)
+    a = pkg.ols_fit_predict(np.zeros(len(y), dtype=np.int64), np.arange(len(y)), y, np.stack(x_cols, 1).tolist(), context=ctx,
+                            frame=("2 preceding", "3 following"))
+    b = pkg.fit_predict_window_host(np.array([0, len(y)]), y, x_cols, None, _opts(pkg, "ols"), (2, -3), ctx=ctx)
+    assert np.array_equal(a[0], b[:, 0], equal_nan=True) and not np.all(np.isnan(b[:, 0]))
+    # UNBOUNDED PRECEDING AND UNBOUNDED FOLLOWING: every row of a partition gets the fit on the whole partition,
+    # predicting the partition's last row (ols_fit_predict.cpp:157-162)
+    full = pkg.fit_predict_window_host(offs, y, x_cols, None, _opts(pkg, "ols"), (None, None), ctx=ctx)
+    for g in range(3):
+        blk = full[offs[g]:offs[g + 1]]
+        assert np.all(blk == blk[0]) and np.isfinite(blk[0, 0])
     keys = np.zeros(len(y), dtype=np.int64)
     a = pkg.ols_fit_predict(keys, np.arange(len(y)), y, np.stack(x_cols, 1).tolist(), context=ctx, frame=("9 preceding", "current row"))
     b = pkg.fit_predict_window_host(np.array([0, len(y)]), y, x_cols, None, _opts(pkg, "ols"), (9, 0), ctx=ctx)

@@ -91,8 +91,13 @@ def test_window_frame_parsing():
     assert agg._parse_frame(("9 preceding", "current row"), "current row") == (9, 0)
     assert agg._parse_frame((7, 3), "current row") == (7, 3)
     assert agg._parse_frame(("unbounded", "2 preceding"), "current row") == (None, 2)
+    assert agg._parse_frame(("3 preceding", "2 following"), "current row") == (3, -2)
+    assert agg._parse_frame(("1 following", "unbounded following"), "current row") == (-1, None)
+    assert agg._parse_frame(("unbounded preceding", "unbounded following"), "current row") == (None, None)
+    assert agg._parse_frame(("current row", "current row"), "current row") == (0, 0)
     pkg = import_pkg()
-    for bad in (("current row", "3 preceding"), (2, 5), ("unbounded", "unbounded"), ("x", 0)):
+    for bad in (("current row", "3 preceding"), (2, 5), ("2 following", "1 following"), ("x", 0),
+                ("unbounded following", 0), (0, "unbounded preceding")):
         with pytest.raises(pkg.InvalidInputException):
             agg._parse_frame(bad, "current row")
 
