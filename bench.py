@@ -33,6 +33,11 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # FP64 matrix (v_mfma_f64_16x16x4_f64) dense peak.  The guide lists the FP32 matrix peak (157.3 TFLOP/s = the
 # vector rate); FP64 MFMA runs at half of it on MI355X (AMD datasheet: 78.6 TFLOP/s FP64 matrix = FP64 vector).
 FP64_MFMA_PEAK_TFLOPS = 78.6
+# Measured on the MI355X boxes of this pool (not datasheet): a plain 16-B/lane streaming read reaches 6.05-6.39 TB/s
+# (csrc/tools/hbm_read_rate, profiles/r01_hbm_read_rate.txt) and a pure v_mfma_f64_16x16x4_f64 loop 47 TFLOP/s
+# (csrc/tools/mfma_f64_rate).  Reported next to `peak`; `frac` stays achieved / peak.
+MEASURED_STREAM_READ_GBS = 6390.0
+MEASURED_MFMA_F64_TFLOPS = 47.0
 
 
 def algorithmic_bytes_per_fit(n: int, p: int, weighted: bool, inference: bool) -> int:
@@ -316,6 +321,10 @@ def main():
                          # span from the end of a step's accumulate kernel to the end of its solve / refinement; in the
                          # fit path consecutive steps alternate between two streams, so this span runs concurrently with
                          # the NEXT step's accumulate kernel and is not an addend of ms_per_step
+                         # what a plain streaming-read kernel / a pure MFMA loop reach on this device (csrc/tools/
+                         # hbm_read_rate, mfma_f64_rate; profiles/r01_hbm_read_rate.txt): the practical ceiling under `peak`
+                         "measured_ceiling": MEASURED_STREAM_READ_GBS if bound == "hbm" else MEASURED_MFMA_F64_TFLOPS,
+                         "frac_of_measured_ceiling": achieved / (MEASURED_STREAM_READ_GBS if bound == "hbm" else MEASURED_MFMA_F64_TFLOPS),
                          "solve_span_ms_per_step": kt["solve_ms"] / args.steps,
                          "solve_overlaps_next_accumulate": not (args.predict or args.window or args.vif)},
         }
