@@ -9,11 +9,13 @@
 // Mapping: one 256-thread workgroup (4 wavefronts) per group.
 //   * A chunk is 32 (16 for p > 96) consecutive rows of every column (x_1..x_p, y, [w]).  The four waves load it coalesced
 //     (each load instruction: 8 columns x 128 contiguous bytes) one chunk ahead into registers and write it to
-//     a double-buffered LDS image laid out [column][18 doubles] (conflict-free for the fragment reads below).
+//     a double-buffered LDS image laid out [column][18 doubles] (conflict-free for the fragment reads below); the
+//     image holds the values already shifted by the group's first valid row, with the rows that do not take part
+//     zeroed (the staging lanes do both; the chunk that contains the first valid row, and chunks with an invalid
+//     row, are repaired in place once the row masks of all four waves are known).
 //   * A slab is 4 rows.  For the 16-column block I, lane l of a wave reads the fragment element
-//     (row 4t + (l>>4), column 16I + (l&15)) with one ds_read_b64; after shifting by the group's first valid
-//     row (and zeroing invalid rows) the same register is the MFMA's A operand for tile row I and the B
-//     operand for tile column I:  M[16I+i][16J+j] += sum_k w_k d[k][16I+i] d[k][16J+j].
+//     (row 4t + (l>>4), column 16I + (l&15)) with one ds_read_b64; the same register is the MFMA's A operand
+//     for tile row I and the B operand for tile column I:  M[16I+i][16J+j] += sum_k w_k d[k][16I+i] d[k][16J+j].
 //   * The T(T+1)/2 upper-triangular 16x16 tiles are dealt round-robin to the four waves (9 tiles = 72
 //     accumulator registers each at p = 128), so every wave issues the same number of MFMAs per slab.
 //   * Column block I is "owned" by wave I % 4, which also accumulates sum w d, sum w d dy and the
@@ -55,41 +57,34 @@ struct WideCfg {
 	static constexpr int STRIDE = CH + 2; // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
 };
 
-__device__ __forceinline__ double mask_f64(double v, long long m) {
-	return __longlong_as_double(__double_as_longlong(v) & m);
-}
-
-// One wave's share of a chunk: 4 slabs of MFMAs + the VALU side sums.  WAVE is a compile-time constant so
-// that the tile list unrolls into straight-line MFMAs.  `img` is the chunk's LDS image; every LDS read is
-// unconditional (padding columns hold zeros) and invalid rows are removed with a bit mask, so the slab is
-// branch-free.
+// One wave's share of a chunk: the slabs of MFMAs + the VALU side sums.  WAVE is a compile-time constant so
+// that the tile list unrolls into straight-line MFMAs.  `img` is the chunk's LDS image, already in the form the
+// matrix cores consume: shifted by the group's first valid row (CENTER) and with every row that does not take part
+// (non-finite value, w <= 0, past the end of the group) zeroed in ALL columns by the staging side — so a fragment
+// goes from ds_read_b64 straight into the MFMA and the only VALU work left per slab is the side sums of the column
+// blocks this wave owns.  (Shifting and masking inside the slab loop cost ~5 VALU instructions per block in each of
+// the four waves.)
 template <int T, int WAVE, bool WEIGHTED, bool CENTER>
-__device__ __forceinline__ void compute_chunk(const double *img, int ycol, int lane, unsigned rowmask,
-                                              const double (&first)[T], double first_y,
+__device__ __forceinline__ void compute_chunk(const double *img, const double *firstcol, int ycol, int lane, unsigned rowmask,
                                               dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
                                               double (&sxy)[WideCfg<T>::OWN], unsigned &ncmask, double &sy,
                                               double &syy, double &sw) {
-	constexpr int kChunkRows = WideCfg<T>::CH, kLdsStride = WideCfg<T>::STRIDE;
+	constexpr int kChunkRows = WideCfg<T>::CH, kLdsStride = WideCfg<T>::STRIDE, OWN = WideCfg<T>::OWN;
 	const int k = lane >> 4;
 	const int i = lane & 15;
+	// without an intercept the image holds raw values; the constant-column test still compares with the first valid row
+	double fown[OWN];
+#pragma unroll
+	for (int o = 0; o < OWN; ++o) fown[o] = (!CENTER && WAVE + kWaves * o < T) ? firstcol[16 * (WAVE + kWaves * o) + i] : 0.0;
 #pragma unroll 1
 	for (int t = 0; t < kChunkRows / 4; ++t) {
 		const int row = 4 * t + k;
-		const long long rm = -(long long)((rowmask >> row) & 1u); // all ones when the row is valid
 		double d[T];
 #pragma unroll
-		for (int I = 0; I < T; ++I) {
-			const double raw = img[(16 * I + i) * kLdsStride + row];
-			const double dev = mask_f64(raw - first[I], rm); // deviation from the first valid row
-			d[I] = CENTER ? dev : mask_f64(raw, rm);
-			if (I % kWaves == WAVE) {
-				// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row
-				ncmask |= !(fabs(dev) < 1e-10) ? (1u << I) : 0u;
-			}
-		}
-		const double yraw = img[ycol * kLdsStride + row];
-		const double dy = mask_f64(CENTER ? yraw - first_y : yraw, rm);
-		const double w = mask_f64(WEIGHTED ? img[(ycol + 1) * kLdsStride + row] : 1.0, rm);
+		for (int I = 0; I < T; ++I) d[I] = img[(16 * I + i) * kLdsStride + row];
+		const double dy = img[ycol * kLdsStride + row];
+		double w = 1.0;
+		if (WEIGHTED) w = img[(ycol + 1) * kLdsStride + row];
 		double a[T];
 #pragma unroll
 		for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? w * d[I] : d[I];
@@ -107,6 +102,11 @@ __device__ __forceinline__ void compute_chunk(const double *img, int ycol, int l
 #pragma unroll
 		for (int I = 0; I < T; ++I) {
 			if (I % kWaves == WAVE) {
+				// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row (a zeroed row of a
+				// shifted image gives 0; a raw image needs the row's validity)
+				const double dev = CENTER ? d[I] : d[I] - fown[I / kWaves];
+				const bool moved = !(fabs(dev) < 1e-10) && (CENTER || ((rowmask >> row) & 1u));
+				ncmask |= moved ? (1u << I) : 0u;
 				sx[I / kWaves] += a[I];
 				sxy[I / kWaves] = fma(a[I], dy, sxy[I / kWaves]);
 			}
@@ -115,7 +115,7 @@ __device__ __forceinline__ void compute_chunk(const double *img, int ycol, int l
 			const double wdy = WEIGHTED ? w * dy : dy;
 			sy += wdy;
 			syy = fma(wdy, dy, syy);
-			sw += w;
+			if (WEIGHTED) sw += w; // unweighted: the row count, taken from the masks
 		}
 	}
 }
@@ -128,6 +128,7 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 	using Cfg = WideCfg<T>;
 	constexpr int kChunkRows = Cfg::CH, kLdsStride = Cfg::STRIDE;
 	constexpr bool kWideChunk = kChunkRows == 32;
+	constexpr unsigned kFullMask = kWideChunk ? 0xffffffffu : 0xffffu;
 	constexpr int P16 = 16 * T;
 	const int p = args.p;
 	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
@@ -136,13 +137,14 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 	const int64_t nrows = hi - lo;
 
 	extern __shared__ double lds[];
-	// layout: image[2][ncol_pad][18] | colbase[ncol_pad] (as pointers) | rowmask partials [2][4]
+	// layout: image[2][ncol_pad][STRIDE] | colbase[ncol_pad] (as pointers) | firstcol[ncol_pad] | rowmask partials [2][4]
 	// image columns: x_0..x_{p-1} | zeros up to 16T | y | w | padding to a multiple of 8
 	const int ncol_pad = wide_ncol_pad(p, WEIGHTED);
 	const int ycol = P16;
 	double *image = lds;
 	unsigned long long *colbase = reinterpret_cast<unsigned long long *>(lds + 2 * ncol_pad * kLdsStride);
-	unsigned *maskslot = reinterpret_cast<unsigned *>(colbase + ncol_pad);
+	double *firstcol = reinterpret_cast<double *>(colbase + ncol_pad); // value at the group's first valid row, by image column
+	unsigned *maskslot = reinterpret_cast<unsigned *>(firstcol + ncol_pad);
 
 	// source column c (x_0.., y, w) is staged by load slot c; slot -> image column: x in place, y/w after 16T
 	for (int c = threadIdx.x; c < ncol_pad; c += 256) {
@@ -150,6 +152,9 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 		if (c < p) b = args.x_table[c];
 		else if (WEIGHTED && c == p + 1) b = args.w;
 		colbase[c] = reinterpret_cast<unsigned long long>(b + lo);
+		double f = 0.0;
+		if (forced_first) f = c < P16 ? forced_first[c] : (c == ycol ? forced_first[P16] : 0.0);
+		firstcol[c] = f;
 	}
 	// zero the padding columns p .. 16T-1 of both buffers once; nothing writes them afterwards
 	for (int idx = threadIdx.x; idx < 2 * (P16 - p) * kLdsStride; idx += 256) {
@@ -173,67 +178,75 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 	for (int o = 0; o < Cfg::OWN; ++o) sx[o] = sxy[o] = 0.0;
 	unsigned ncmask = 0;
 	double sy = 0.0, syy = 0.0, sw = 0.0;
-	double first[T]; // x at the first valid row (the shift when CENTER, and the reference point of the constant test)
-#pragma unroll
-	for (int I = 0; I < T; ++I) first[I] = 0.0;
-	double first_y = 0.0;
-	bool have_first = false;
+	bool have_first = forced_first != nullptr; // wave-uniform
 	int cnt = 0;
-	if (forced_first) {
+	// the shift the staging side applies to the columns THIS lane stages (0 until the first valid row is known, 0 for
+	// the weight column and when there is no intercept)
+	double fq[kMaxLoads];
 #pragma unroll
-		for (int I = 0; I < T; ++I) first[I] = forced_first[16 * I + (lane & 15)]; // padding columns: 0
-		first_y = forced_first[P16];
-		have_first = true;
+	for (int q = 0; q < kMaxLoads; ++q) {
+		fq[q] = 0.0;
+		const int src = 8 * (wave + kWaves * q) + colsub;
+		if (CENTER && forced_first && src <= p) fq[q] = src < p ? forced_first[src] : forced_first[P16];
 	}
 
 	const int64_t n_chunks = (nrows + kChunkRows - 1) / kChunkRows;
-	// staging registers: rows 2 rp, 2 rp + 1 (v0, v1) and 16 + 2 rp, 17 + 2 rp (v2, v3) of this lane's columns
-	double v0[kMaxLoads], v1[kMaxLoads], v2[kMaxLoads], v3[kMaxLoads];
+	// staging registers of one chunk: rows 2 rp, 2 rp + 1 (v0, v1) and 16 + 2 rp, 17 + 2 rp (v2, v3) of this lane's columns
+	struct Stage {
+		double v0[kMaxLoads], v1[kMaxLoads], v2[kMaxLoads], v3[kMaxLoads];
+	};
+	// A workgroup is latency-bound with one chunk of loads in flight (2-3 workgroups x 16 KB per CU against ~3.5 us of
+	// loaded HBM latency = ~3 TB/s over the chip): where the registers allow it the loads run TWO chunks ahead, in two
+	// register sets that alternate.  At T = 8 the 72 accumulator registers leave room for one set only.
+	constexpr bool kDeep = T <= 7;
 
 	// issue the loads of one chunk (global -> registers); consumed by stage_store
-	auto stage_load = [&](int64_t chunk) {
+	auto stage_load = [&](int64_t chunk, Stage &sg) {
 		const int64_t r0 = chunk * kChunkRows + 2 * rp; // row within the group
 		const bool full = (chunk + 1) * kChunkRows <= nrows; // wave-uniform: every row of the chunk exists
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
 			const int li = wave + kWaves * q;
-			v0[q] = v1[q] = v2[q] = v3[q] = 0.0;
+			sg.v0[q] = sg.v1[q] = sg.v2[q] = sg.v3[q] = 0.0;
 			if (li < n_loads_total) { // wave-uniform
 				const gptr_t b = reinterpret_cast<gptr_t>(colbase[8 * li + colsub]);
 				if (full) {
 					const dbl2u va = *reinterpret_cast<gptr2_t>(b + r0);
-					v0[q] = va.x;
-					v1[q] = va.y;
+					sg.v0[q] = va.x;
+					sg.v1[q] = va.y;
 					if (kWideChunk) {
 						const dbl2u vb = *reinterpret_cast<gptr2_t>(b + r0 + 16);
-						v2[q] = vb.x;
-						v3[q] = vb.y;
+						sg.v2[q] = vb.x;
+						sg.v3[q] = vb.y;
 					}
 				} else {
-					if (r0 < nrows) v0[q] = b[r0];
-					if (r0 + 1 < nrows) v1[q] = b[r0 + 1];
-					if (kWideChunk && r0 + 16 < nrows) v2[q] = b[r0 + 16];
-					if (kWideChunk && r0 + 17 < nrows) v3[q] = b[r0 + 17];
+					if (r0 < nrows) sg.v0[q] = b[r0];
+					if (r0 + 1 < nrows) sg.v1[q] = b[r0 + 1];
+					if (kWideChunk && r0 + 16 < nrows) sg.v2[q] = b[r0 + 16];
+					if (kWideChunk && r0 + 17 < nrows) sg.v3[q] = b[r0 + 17];
 				}
 			}
 		}
 	};
-	// registers -> LDS image `buf`, plus this wave's partial row-validity mask (ols.rs:59-66, wls.rs:76-86)
-	auto stage_store = [&](int64_t chunk, int buf) {
+	// registers -> LDS image `buf` (shifted by fq; rows past the end of the group as zeros), plus this wave's partial
+	// row-validity mask (ols.rs:59-66, wls.rs:76-86)
+	auto stage_store = [&](int64_t chunk, int buf, const Stage &sg) {
 		bool ok0 = true, ok1 = true, ok2 = true, ok3 = true;
 		double *img = image + buf * ncol_pad * kLdsStride;
+		const int64_t left = nrows - chunk * kChunkRows; // rows of the group in this chunk (wave-uniform)
+		const bool in0 = 2 * rp < left, in1 = 2 * rp + 1 < left, in2 = 2 * rp + 16 < left, in3 = 2 * rp + 17 < left;
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
 			const int li = wave + kWaves * q;
 			if (li < n_loads_total) {
 				const int src = 8 * li + colsub;
 				if (src < ncol) {
-					bool f0 = isfinite(v0[q]), f1 = isfinite(v1[q]), f2 = isfinite(v2[q]), f3 = isfinite(v3[q]);
+					bool f0 = isfinite(sg.v0[q]), f1 = isfinite(sg.v1[q]), f2 = isfinite(sg.v2[q]), f3 = isfinite(sg.v3[q]);
 					if (WEIGHTED && src == p + 1) {
-						f0 = f0 && v0[q] > 0.0;
-						f1 = f1 && v1[q] > 0.0;
-						f2 = f2 && v2[q] > 0.0;
-						f3 = f3 && v3[q] > 0.0;
+						f0 = f0 && sg.v0[q] > 0.0;
+						f1 = f1 && sg.v1[q] > 0.0;
+						f2 = f2 && sg.v2[q] > 0.0;
+						f3 = f3 && sg.v3[q] > 0.0;
 					}
 					ok0 = ok0 && f0;
 					ok1 = ok1 && f1;
@@ -241,11 +254,11 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 					ok3 = ok3 && f3;
 					const int col = src < p ? src : ycol + (src - p);
 					double *dst = img + col * kLdsStride + 2 * rp;
-					dst[0] = v0[q];
-					dst[1] = v1[q];
+					dst[0] = in0 ? sg.v0[q] - fq[q] : 0.0;
+					dst[1] = in1 ? sg.v1[q] - fq[q] : 0.0;
 					if (kWideChunk) {
-						dst[16] = v2[q];
-						dst[17] = v3[q];
+						dst[16] = in2 ? sg.v2[q] - fq[q] : 0.0;
+						dst[17] = in3 ? sg.v3[q] - fq[q] : 0.0;
 					}
 				}
 			}
@@ -266,44 +279,98 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 				m |= ((unsigned)(b3 >> r) & 1u) << (17 + 2 * r);
 			}
 		}
-		const int64_t left = nrows - chunk * kChunkRows; // rows past the end of the group are invalid
-		if (left < kChunkRows) m &= (left <= 0) ? 0u : ((1u << left) - 1u);
+		if (left < kChunkRows) m &= (left <= 0) ? 0u : ((1u << left) - 1u); // rows past the end of the group are invalid
 		if (lane == 0) maskslot[buf * kWaves + wave] = m;
 	};
+	// Rare repairs of a staged image, each lane on the elements it staged itself (so reads precede writes in program
+	// order): `shift` — the chunk was staged before the group's first valid row was known, subtract it now; and every
+	// row that is in range but invalid (NaN / inf somewhere, w <= 0) becomes zero in all columns.
+	auto repair_image = [&](int buf, unsigned rowmask, bool shift) {
+		double *img = image + buf * ncol_pad * kLdsStride;
+#pragma unroll
+		for (int q = 0; q < kMaxLoads; ++q) {
+			const int li = wave + kWaves * q;
+			if (li < n_loads_total) {
+				const int src = 8 * li + colsub;
+				if (src < ncol) {
+					const int col = src < p ? src : ycol + (src - p);
+					double *dst = img + col * kLdsStride + 2 * rp;
+					const double f = shift ? fq[q] : 0.0;
+#pragma unroll
+					for (int e = 0; e < (kWideChunk ? 4 : 2); ++e) {
+						const int row = 2 * rp + (e & 1) + 16 * (e >> 1);
+						const double cur = dst[(e & 1) + 16 * (e >> 1)];
+						dst[(e & 1) + 16 * (e >> 1)] = ((rowmask >> row) & 1u) ? cur - f : 0.0;
+					}
+				}
+			}
+		}
+	};
 
-	if (n_chunks > 0) {
-		stage_load(0);
-		stage_store(0, 0);
-	}
-	__syncthreads();
-
-	for (int64_t c = 0; c < n_chunks; ++c) {
+	// one chunk: `ahead` holds the loads of chunk c + 1 (to be stored at the end), `spare` takes the next loads
+	auto iteration = [&](int64_t c, Stage &ahead, Stage &spare) {
 		const int buf = (int)(c & 1);
 		const double *img = image + buf * ncol_pad * kLdsStride;
 		unsigned rowmask = maskslot[buf * kWaves + 0] & maskslot[buf * kWaves + 1] & maskslot[buf * kWaves + 2] &
 		                   maskslot[buf * kWaves + 3];
 		rowmask = __builtin_amdgcn_readfirstlane(rowmask);
-		const bool more = c + 1 < n_chunks;
-		if (more) stage_load(c + 1); // in flight while this chunk's MFMAs run
+		const int64_t left = nrows - c * kChunkRows;
+		const unsigned rangemask = left >= kChunkRows ? kFullMask : ((1u << left) - 1u);
+		const int64_t next_load = c + (kDeep ? 2 : 1);
+		if (next_load < n_chunks) stage_load(next_load, spare); // in flight while this chunk's (and the next one's) MFMAs run
 
-		if (rowmask != 0u) {
-			if (!have_first) {
+		const bool found_first = !have_first && rowmask != 0u; // wave-uniform
+		if (found_first || (rowmask != rangemask && rowmask != 0u)) {
+			if (found_first) {
+				// the group's first valid row: remember its values (the shift when CENTER, the reference point of the
+				// constant-column test, part of the record) and shift this chunk, which was staged unshifted
 				const int r = __ffs((int)rowmask) - 1;
 #pragma unroll
-				for (int I = 0; I < T; ++I) first[I] = img[(16 * I + (lane & 15)) * kLdsStride + r]; // padding: 0
-				first_y = img[ycol * kLdsStride + r];
-				have_first = true;
+				for (int q = 0; q < kMaxLoads; ++q) {
+					const int li = wave + kWaves * q;
+					if (li < n_loads_total) {
+						const int src = 8 * li + colsub;
+						if (src <= p) { // x columns and y; the weight column is never shifted
+							const int col = src < p ? src : ycol;
+							const double f = img[col * kLdsStride + r];
+							if (rp == 0) firstcol[col] = f;
+							if (CENTER) fq[q] = f;
+						}
+					}
+				}
 			}
+			repair_image(buf, rowmask, CENTER && found_first);
+			__syncthreads();
+		}
+		have_first = have_first || found_first;
+
+		if (rowmask != 0u) {
 			cnt += __popc(rowmask);
 			switch (wave) {
-			case 0: compute_chunk<T, 0, WEIGHTED, CENTER>(img, ycol, lane, rowmask, first, first_y, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			case 1: compute_chunk<T, 1, WEIGHTED, CENTER>(img, ycol, lane, rowmask, first, first_y, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			case 2: compute_chunk<T, 2, WEIGHTED, CENTER>(img, ycol, lane, rowmask, first, first_y, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			default: compute_chunk<T, 3, WEIGHTED, CENTER>(img, ycol, lane, rowmask, first, first_y, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			case 0: compute_chunk<T, 0, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			case 1: compute_chunk<T, 1, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			case 2: compute_chunk<T, 2, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
+			default: compute_chunk<T, 3, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
 			}
 		}
-		if (more) stage_store(c + 1, buf ^ 1);
+		if (c + 1 < n_chunks) stage_store(c + 1, buf ^ 1, ahead);
 		__syncthreads();
+	};
+
+	Stage s0, s1;
+	if (n_chunks > 0) {
+		stage_load(0, s0);
+		stage_store(0, 0, s0);
+		if (kDeep && n_chunks > 1) stage_load(1, s1);
+	}
+	__syncthreads();
+	if (kDeep) {
+		for (int64_t c = 0; c < n_chunks; c += 2) {
+			iteration(c, s1, s0); // chunk c + 1 is in s1; s0 is free for chunk c + 2
+			if (c + 1 < n_chunks) iteration(c + 1, s0, s1);
+		}
+	} else {
+		for (int64_t c = 0; c < n_chunks; ++c) iteration(c, s0, s0);
 	}
 
 	// ---- write the moment record ----
@@ -337,7 +404,7 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 			if (lane < 16) {
 				vec[0 * P16 + 16 * I + lane] = a;
 				vec[1 * P16 + 16 * I + lane] = b;
-				vec[2 * P16 + 16 * I + lane] = first[I];
+				vec[2 * P16 + 16 * I + lane] = firstcol[16 * I + lane]; // padding columns: 0
 				vec[3 * P16 + 16 * I + lane] = (double)nc;
 			}
 		}
@@ -348,13 +415,14 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 		a += shfl_xor_d(a, 16); a += shfl_xor_d(a, 32);
 		b += shfl_xor_d(b, 16); b += shfl_xor_d(b, 32);
 		c2 += shfl_xor_d(c2, 16); c2 += shfl_xor_d(c2, 32);
+		if (!WEIGHTED) c2 = (double)cnt;
 		if (lane == 0) {
 			double *sc = vec + 4 * P16;
 			sc[0] = a;
 			sc[1] = b;
 			sc[2] = c2;
 			sc[3] = (double)cnt;
-			sc[4] = first_y;
+			sc[4] = firstcol[ycol];
 		}
 	}
 }
@@ -420,7 +488,7 @@ hipError_t launch_T(const WideArgs &a, hipStream_t stream) {
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
 	const int ncol_pad = wide_ncol_pad(a.p, weighted);
-	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::STRIDE * sizeof(double) + (size_t)ncol_pad * sizeof(double *) + 64;
+	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::STRIDE * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
 	const dim3 grid((unsigned)a.n_groups), block(256);
 	const dim3 seg_grid((unsigned)kWideSegMaxSegments); // idle unless some group exceeded seg_rows
 #define ANOFOX_WIDE_LAUNCH(W, C)                                                                                  \
