@@ -195,11 +195,6 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 	struct Stage {
 		double v0[kMaxLoads], v1[kMaxLoads], v2[kMaxLoads], v3[kMaxLoads];
 	};
-	// A workgroup is latency-bound with one chunk of loads in flight (2-3 workgroups x 16 KB per CU against ~3.5 us of
-	// loaded HBM latency = ~3 TB/s over the chip): where the registers allow it the loads run TWO chunks ahead, in two
-	// register sets that alternate.  At T = 8 the 72 accumulator registers leave room for one set only.
-	constexpr bool kDeep = T <= 7;
-
 	// issue the loads of one chunk (global -> registers); consumed by stage_store
 	auto stage_load = [&](int64_t chunk, Stage &sg) {
 		const int64_t r0 = chunk * kChunkRows + 2 * rp; // row within the group
@@ -307,8 +302,9 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 		}
 	};
 
-	// one chunk: `ahead` holds the loads of chunk c + 1 (to be stored at the end), `spare` takes the next loads
-	auto iteration = [&](int64_t c, Stage &ahead, Stage &spare) {
+	// One chunk.  The loads run one chunk ahead (two ahead, in a second register set, measured the same at p = 48..112:
+	// the kernel is not waiting for HBM) and are stored to the other image once this chunk's MFMAs are issued.
+	auto iteration = [&](int64_t c, Stage &ahead) {
 		const int buf = (int)(c & 1);
 		const double *img = image + buf * ncol_pad * kLdsStride;
 		unsigned rowmask = maskslot[buf * kWaves + 0] & maskslot[buf * kWaves + 1] & maskslot[buf * kWaves + 2] &
@@ -316,8 +312,7 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 		rowmask = __builtin_amdgcn_readfirstlane(rowmask);
 		const int64_t left = nrows - c * kChunkRows;
 		const unsigned rangemask = left >= kChunkRows ? kFullMask : ((1u << left) - 1u);
-		const int64_t next_load = c + (kDeep ? 2 : 1);
-		if (next_load < n_chunks) stage_load(next_load, spare); // in flight while this chunk's (and the next one's) MFMAs run
+		if (c + 1 < n_chunks) stage_load(c + 1, ahead); // in flight while this chunk's MFMAs run
 
 		const bool found_first = !have_first && rowmask != 0u; // wave-uniform
 		if (found_first || (rowmask != rangemask && rowmask != 0u)) {
@@ -357,21 +352,13 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 		__syncthreads();
 	};
 
-	Stage s0, s1;
+	Stage sg;
 	if (n_chunks > 0) {
-		stage_load(0, s0);
-		stage_store(0, 0, s0);
-		if (kDeep && n_chunks > 1) stage_load(1, s1);
+		stage_load(0, sg);
+		stage_store(0, 0, sg);
 	}
 	__syncthreads();
-	if (kDeep) {
-		for (int64_t c = 0; c < n_chunks; c += 2) {
-			iteration(c, s1, s0); // chunk c + 1 is in s1; s0 is free for chunk c + 2
-			if (c + 1 < n_chunks) iteration(c + 1, s0, s1);
-		}
-	} else {
-		for (int64_t c = 0; c < n_chunks; ++c) iteration(c, s0, s0);
-	}
+	for (int64_t c = 0; c < n_chunks; ++c) iteration(c, sg);
 
 	// ---- write the moment record ----
 	// tiles: tile-major, 256 doubles each, element (row, col) at row*16 + col

@@ -109,12 +109,13 @@ int main(int argc, char **argv) {
 	std::vector<double> h((size_t)(p + 6));
 	CHECK(hipMemcpy(h.data(), core, h.size() * sizeof(double), hipMemcpyDeviceToHost));
 	const double bytes = (double)G * (8.0 * n * (p + 1 + (weighted ? 1 : 0)) + 8.0 * (p + 6) + (inference ? 8.0 * (5 * p + 2) : 0.0));
-	const double acc_ms = kt.accumulate_count ? kt.accumulate_ms / kt.accumulate_count : 0.0;
+	// per step: a wide batch runs in several launches (slabs of groups), all of them counted
+	const double acc_ms = steps > 0 ? kt.accumulate_ms / steps : 0.0;
 	printf("{\"groups\": %lld, \"rows\": %lld, \"features\": %d, \"model\": \"%s\", \"steps\": %d, \"ms_per_step\": %.4f, "
 	       "\"fits_per_s\": %.1f, \"accumulate_ms\": %.4f, \"solve_ms\": %.4f, \"accumulate_GBps\": %.1f, "
 	       "\"group0_intercept\": %.12g, \"group0_r2\": %.12g, \"group0_status\": %g}\n",
 	       G, n, p, model, steps, sec / steps * 1e3, G * steps / sec, acc_ms,
-	       kt.solve_count ? kt.solve_ms / kt.solve_count : 0.0, acc_ms > 0 ? bytes / (acc_ms * 1e-3) / 1e9 : 0.0, h[p],
+	       steps > 0 ? kt.solve_ms / steps : 0.0, acc_ms > 0 ? bytes / (acc_ms * 1e-3) / 1e9 : 0.0, h[p],
 	       h[p + 1], h[p + 5]);
 	anofox_hip_context_destroy(ctx);
 	return 0;
