@@ -351,6 +351,7 @@ hipError_t launch_residuals_narrow(const ResidualArgs &a, hipStream_t stream);
 
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);
+hipError_t launch_inference_wide_finish(const WideArgs &a, hipStream_t stream); // after the last solve_wide mode
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);
 // accumulate_mid.hip: wave-per-group accumulation into the same records for 8 < p <= 32
 bool accumulate_mid_supports(int p);

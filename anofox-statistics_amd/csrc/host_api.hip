@@ -210,6 +210,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		}
 		if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
 		if (hip_fail(solve(2), "wide final kernel launch", e)) return false;
+		if (!mid && hip_fail(launch_inference_wide_finish(a, st), "wide inference finish kernel launch", e)) return false;
 		if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE) {
 			if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, (size_t)slab * sizeof(double), "hc scratch", e)) return false;
 			a.hc_df = (double *)ctx->aux;

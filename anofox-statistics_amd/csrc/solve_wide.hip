@@ -393,8 +393,11 @@ __device__ void load_moment_matrix(const WideLds &l, const double *rec, int p, b
 	}
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
+// OCC = workgroups per CU the register budget is cut for: 2 where the LDS matrix leaves room for two (p <= 88; the
+// spills that costs are cheaper than an idle half of the CU: solve -26 % at p = 64), 1 for the widest designs, whose
+// 134 KB matrix fills the CU's LDS anyway (there the tighter budget only adds spills: +22..47 %).
+template <int MODE, int OCC>
+__global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 	extern __shared__ double sm[];
 	const int p = args.p;
 	const int tid = threadIdx.x;
@@ -589,33 +592,56 @@ __global__ __launch_bounds__(256) void solve_wide_kernel(WideArgs args) {
 		SOLVE_STAMP(5);
 
 		if (inf) {
-			if (tid == 0) l.red[8] = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
-			__syncthreads();
-			const double tcrit = l.red[8];
+			// standard errors and the F statistic; t, p, the interval and the F p-value are filled in by
+			// inference_wide_finish_kernel (the special functions' ~240-VGPR call tree stays out of this kernel, which
+			// then fits 2-4 workgroups per CU instead of one).  df travels in the F p-value's slot.
 			const double sigma2 = rss / df;
-			for (int j = tid; j < p; j += 256) {
-				double se = nan64w(), tval = nan64w(), pval = nan64w(), lo = nan64w(), hi = nan64w();
-				if (l.live[j]) {
-					const double b = l.bv[j];
-					se = sqrt(sigma2 * l.diag0[j]);
-					tval = b / se;
-					pval = dm_t_two_sided_p(tval, df);
-					lo = b - tcrit * se;
-					hi = b + tcrit * se;
-				}
-				inf[j] = se;
-				inf[p + j] = tval;
-				inf[2 * p + j] = pval;
-				inf[3 * p + j] = lo;
-				inf[4 * p + j] = hi;
-			}
+			for (int j = tid; j < p; j += 256) inf[j] = l.live[j] ? sqrt(sigma2 * l.diag0[j]) : nan64w();
 			if (tid == 0) {
 				inf[5 * p] = fstat;
-				inf[5 * p + 1] = dm_f_sf(fstat, dfm, df);
+				inf[5 * p + 1] = df;
 			}
 		}
 		SOLVE_STAMP(6);
 	}
+}
+
+// t, p, interval and F p-value of the classical inference from the standard errors solve_wide_kernel left behind:
+// one 128-thread workgroup per group (lib.rs:188-254 fills the same five arrays from anofox-regression's result).
+__global__ __launch_bounds__(128) void inference_wide_finish_kernel(WideArgs args) {
+	__shared__ double sh[4];
+	__shared__ int cnt_sh[2];
+	const int p = args.p;
+	const int tid = threadIdx.x;
+	const int64_t g = args.group_base + blockIdx.x;
+	double *inf = args.inference + g * (int64_t)(5 * p + 2);
+	const double *core = args.core + g * (int64_t)(p + 6);
+	const double df = inf[5 * p + 1]; // left there by the solve; NaN = no inference for this group
+	if (isnan(df)) return;            // (uniform over the workgroup)
+	int mine = 0;
+	for (int j = tid; j < p; j += 128) mine += isnan(core[j]) ? 0 : 1;
+	for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m, 64);
+	if ((tid & 63) == 0) cnt_sh[tid >> 6] = mine;
+	if (tid == 0) sh[0] = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
+	__syncthreads();
+	const double tcrit = sh[0];
+	const double dfm = (double)(cnt_sh[0] + cnt_sh[1]);
+	const double fstat = inf[5 * p];
+	for (int j = tid; j < p; j += 128) {
+		const double b = core[j], se = inf[j];
+		double tval = nan64w(), pval = nan64w(), lo = nan64w(), hi = nan64w();
+		if (!isnan(b) && !isnan(se)) {
+			tval = b / se;
+			pval = dm_t_two_sided_p(tval, df);
+			lo = b - tcrit * se;
+			hi = b + tcrit * se;
+		}
+		inf[p + j] = tval;
+		inf[2 * p + j] = pval;
+		inf[3 * p + j] = lo;
+		inf[4 * p + j] = hi;
+	}
+	if (tid == 0) inf[5 * p + 1] = dm_f_sf(fstat, dfm, df); // every thread read df before the barrier above
 }
 
 // One workgroup per queued group, straight from the data with the record's current coefficients:
@@ -952,28 +978,39 @@ size_t hc_wide_lds_bytes(int p) {
 
 } // namespace
 
-hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream) {
-	if (a.n_groups <= 0) return hipSuccess;
-	const size_t lds = solve_wide_lds_bytes(a.p);
+hipError_t launch_inference_wide_finish(const WideArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0 || !a.inference || !a.compute_inference) return hipSuccess;
+	hipLaunchKernelGGL(inference_wide_finish_kernel, dim3((unsigned)a.n_groups), dim3(128), 0, stream, a);
+	return hipGetLastError();
+}
+
+template <int OCC>
+hipError_t launch_solve_wide_occ(const WideArgs &a, int mode, size_t lds, hipStream_t stream) {
 	static bool attr_set = false;
 	if (!attr_set) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_PRIMARY>),
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_PRIMARY, OCC>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_UPDATE>),
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_UPDATE, OCC>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_FINAL>),
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_FINAL, OCC>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		attr_set = true;
 	}
 	if (mode == MODE_PRIMARY) {
 		const unsigned grid = (unsigned)(a.n_groups < 65535 * 16 ? a.n_groups : 65535 * 16);
-		hipLaunchKernelGGL((solve_wide_kernel<MODE_PRIMARY>), dim3(grid), dim3(256), lds, stream, a);
+		hipLaunchKernelGGL((solve_wide_kernel<MODE_PRIMARY, OCC>), dim3(grid), dim3(256), lds, stream, a);
 	} else if (mode == MODE_UPDATE) {
-		hipLaunchKernelGGL((solve_wide_kernel<MODE_UPDATE>), dim3(256), dim3(256), lds, stream, a);
+		hipLaunchKernelGGL((solve_wide_kernel<MODE_UPDATE, OCC>), dim3(256), dim3(256), lds, stream, a);
 	} else {
-		hipLaunchKernelGGL((solve_wide_kernel<MODE_FINAL>), dim3(256), dim3(256), lds, stream, a);
+		hipLaunchKernelGGL((solve_wide_kernel<MODE_FINAL, OCC>), dim3(256), dim3(256), lds, stream, a);
 	}
 	return hipGetLastError();
+}
+
+hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	const size_t lds = solve_wide_lds_bytes(a.p);
+	return 2 * lds <= (size_t)160 * 1024 ? launch_solve_wide_occ<2>(a, mode, lds, stream) : launch_solve_wide_occ<1>(a, mode, lds, stream);
 }
 
 #ifdef ANOFOX_SOLVE_STAMPS
