@@ -10,6 +10,7 @@
 // Queued groups (small pivot ratio or RSS/TSS < 1e-7) get the same iterative-refinement passes as in
 // solve_narrow.hip: MODE 1 = b += (X'WX)^-1 X'Wr from residual_grad_wide_kernel, MODE 2 = final statistics.
 #include "common.h"
+#include <mutex>
 #include "device_math.h"
 
 namespace anofox {
@@ -986,16 +987,15 @@ hipError_t launch_inference_wide_finish(const WideArgs &a, hipStream_t stream) {
 
 template <int OCC>
 hipError_t launch_solve_wide_occ(const WideArgs &a, int mode, size_t lds, hipStream_t stream) {
-	static bool attr_set = false;
-	if (!attr_set) {
+	static std::once_flag attr_once; // contexts of several host threads launch concurrently
+	std::call_once(attr_once, [] {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_PRIMARY, OCC>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_UPDATE, OCC>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_FINAL, OCC>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		attr_set = true;
-	}
+	});
 	if (mode == MODE_PRIMARY) {
 		const unsigned grid = (unsigned)(a.n_groups < 65535 * 16 ? a.n_groups : 65535 * 16);
 		hipLaunchKernelGGL((solve_wide_kernel<MODE_PRIMARY, OCC>), dim3(grid), dim3(256), lds, stream, a);
@@ -1024,11 +1024,10 @@ hipError_t launch_hc_wide(const WideArgs &a, hipStream_t stream) {
 	if (!a.hc_df) return hipErrorInvalidValue;
 	const size_t lds = hc_wide_lds_bytes(a.p);
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
-	static bool attr_set = false;
-	if (!attr_set) {
+	static std::once_flag attr_once;
+	std::call_once(attr_once, [] {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		attr_set = true;
-	}
+	});
 	const unsigned grid = (unsigned)(a.n_groups < 65535 * 16 ? a.n_groups : 65535 * 16);
 	hipLaunchKernelGGL(hc_wide_kernel, dim3(grid), dim3(256), lds, stream, a);
 	const int64_t elems = a.n_groups * (int64_t)a.p;
