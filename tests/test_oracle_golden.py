@@ -381,3 +381,68 @@ def test_residuals_oracle_textbook_values_and_reference_unit_tests():
     yn = np.array([1.0, np.nan, 3.0, 4.0])                              # aggregate Update: NaN rows are skipped
     out, grp = oracle.residuals_groups(yn, [1.0, 2.0, np.nan, 3.5], None, [0, 4])
     assert grp[0, 0] == 2 and np.isnan(out[1, 0]) and np.isnan(out[2, 0]) and out[3, 0] == 0.5
+
+
+def test_oracle_matches_independent_numpy_scipy_solution():
+    """The oracle against a solution that shares no code with it: numpy's SVD least squares on the sqrt(w)-scaled
+    design, closed-form ridge on centred data, scipy's Student-t and F distributions.  Conventions as pinned by the
+    reference's fixtures: no-intercept fits use the uncentred total sum of squares and
+    adj = 1 - (1 - r2) n / (n - p); WLS statistics are weighted."""
+    from scipy import stats as sps
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        p = int(rng.integers(1, 13))
+        n = int(rng.integers(p + 5, 200))
+        icpt = bool(rng.integers(0, 2))
+        model = ["ols", "wls", "ridge"][trial % 3]
+        X = rng.uniform(-5, 5, (n, p)) + rng.uniform(-20, 20, p)
+        y = rng.uniform(-3, 3) + X @ rng.uniform(-2, 2, p) + rng.standard_normal(n)
+        w = rng.uniform(0.2, 3.0, n) if model == "wls" else np.ones(n)
+        alpha = float(10.0 ** rng.uniform(-2, 1)) if model == "ridge" else 0.0
+        kw = dict(model=model, fit_intercept=icpt, compute_inference=(model != "ridge"), confidence_level=0.9)
+        if model == "ridge":
+            kw["alpha"] = alpha
+        core, inf = oracle.fit_groups(y, [np.ascontiguousarray(X[:, j]) for j in range(p)], [0, n],
+                                      w=w if model == "wls" else None, **kw)
+        assert core[0, p + 5] == 0
+        sw = w.sum()
+        if model == "ridge":
+            xm, ym = (X.mean(0), y.mean()) if icpt else (np.zeros(p), 0.0)
+            Xc, yc = X - xm, y - ym
+            beta = np.linalg.solve(Xc.T @ Xc + alpha * np.eye(p), Xc.T @ yc)
+            b0 = ym - xm @ beta if icpt else np.nan
+        else:
+            D = np.column_stack([np.ones(n), X]) if icpt else X
+            sol = np.linalg.lstsq(D * np.sqrt(w)[:, None], y * np.sqrt(w), rcond=None)[0]
+            b0, beta = (sol[0], sol[1:]) if icpt else (np.nan, sol)
+        assert np.allclose(core[0, :p], beta, rtol=1e-9, atol=1e-11 * np.abs(beta).max()), (trial, model)
+        if icpt:
+            assert abs(core[0, p] - b0) <= 1e-9 * max(abs(b0), np.abs(beta * X.mean(0)).sum(), 1.0)
+        else:
+            assert np.isnan(core[0, p])
+        fitted = X @ beta + (b0 if icpt else 0.0)
+        rss = float(np.sum(w * (y - fitted) ** 2))
+        ybar = float(np.sum(w * y) / sw)
+        tss = float(np.sum(w * (y - ybar) ** 2)) if icpt else float(np.sum(w * y * y))
+        k = p + (1 if icpt else 0)
+        r2 = 1.0 - rss / tss
+        assert abs(core[0, p + 1] - r2) < 1e-10
+        assert abs(core[0, p + 2] - (1.0 - (1.0 - r2) * (n - (1 if icpt else 0)) / (n - k))) < 1e-9
+        assert abs(core[0, p + 3] - np.sqrt(rss / (n - k))) < 1e-9 * np.sqrt(rss / (n - k))
+        assert core[0, p + 4] == n
+        if model == "ridge":
+            continue
+        D = np.column_stack([np.ones(n), X]) if icpt else X
+        cov = rss / (n - k) * np.linalg.inv(D.T @ (D * w[:, None]))
+        se = np.sqrt(np.diag(cov))[(1 if icpt else 0):]
+        tval = beta / se
+        assert np.allclose(inf[0, :p], se, rtol=1e-7)
+        assert np.allclose(inf[0, p:2 * p], tval, rtol=1e-7)
+        pv = 2.0 * sps.t.sf(np.abs(tval), n - k)
+        assert np.allclose(inf[0, 2 * p:3 * p], pv, rtol=1e-6, atol=1e-300)
+        tc = sps.t.ppf(0.95, n - k)
+        assert np.allclose(inf[0, 3 * p:4 * p], beta - tc * se, rtol=1e-7, atol=1e-9)
+        assert np.allclose(inf[0, 4 * p:5 * p], beta + tc * se, rtol=1e-7, atol=1e-9)
+        fstat = ((tss - rss) / p) / (rss / (n - k))
+        assert abs(inf[0, 5 * p] - fstat) < 1e-8 * fstat
+        assert np.isclose(inf[0, 5 * p + 1], sps.f.sf(fstat, p, n - k), rtol=1e-6, atol=1e-300)
