@@ -99,7 +99,7 @@ def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=CO
         extra = np.nansum(np.abs(np.asarray(xbar)[ok]) * np.where(np.isnan(rc), 0.0, ctol), axis=1, keepdims=True)
     chk_coef(gi, ri, "intercept", extra)
 
-    def chk_diag(g, r, name, rtol=diag_rtol, stat=None):
+    def chk_diag(g, r, name, rtol=diag_rtol, stat=None, atol=0.0):
         """`stat` = (got, ref) of the statistic a tail probability was computed from: an extreme p-value amplifies the
         statistic's relative error by |d ln p / d ln t| <= 2 |ln p| + 2 (p = 1e-246 at t = 85.7, df = 371 turns a
         2.9e-9 difference in t — itself held to `rtol` — into 1e-6), so the p-value may differ by that much more."""
@@ -117,20 +117,29 @@ def assert_records_match(core, ref_core, p, inf=None, ref_inf=None, coef_rtol=CO
                 rel_stat = np.where(np.isfinite(sr) & (sr != 0), np.abs(sg - sr) / np.abs(sr), 0.0)
                 amp = 2.0 * np.abs(np.log(np.maximum(np.abs(r[fin]), 1e-320))) + 2.0
             rel = np.maximum(rel, amp * rel_stat)
-        tol = rel * np.abs(r[fin]) + 1e-300
+        tol = rel * np.abs(r[fin]) + (np.asarray(atol)[fin] if np.ndim(atol) else atol) + 1e-300
         worst = np.max(err / tol) if err.size else 0.0
         assert worst <= 1.0, f"{what}: {name} off by {worst:.3g} x tolerance"
 
     okd = ok.copy()
     okd[list(skip_diag_groups)] = False
     for k, name in ((1, "r_squared"), (2, "adj_r_squared"), (3, "residual_std_error"), (4, "n_observations")):
-        chk_diag(core[okd, p + k], ref_core[okd, p + k], name, rtol=(0.0 if k == 4 else diag_rtol))
+        # r^2 and adjusted r^2 are 1 - (a ratio): their rounding error is absolute (~1e-15 x conditioning), so a value
+        # that is itself ~1e-10 (no signal) cannot be held to a relative 1e-6
+        chk_diag(core[okd, p + k], ref_core[okd, p + k], name, rtol=(0.0 if k == 4 else diag_rtol),
+                 atol=(1e-12 if k in (1, 2) else 0.0))
     if ref_inf is not None:
         inf = np.asarray(inf)
         ref_inf = np.asarray(ref_inf)
         names = ["std_errors", "t_values", "p_values", "ci_lower", "ci_upper"]
+        # an interval bound b -+ t se that happens to fall near zero is a difference of two larger numbers: its error
+        # is measured against the larger of the two bounds' magnitudes
+        ci_scale = np.maximum(np.abs(ref_inf[okd, 3 * p:4 * p]), np.abs(ref_inf[okd, 4 * p:5 * p]))
+        ci_scale = np.where(np.isfinite(ci_scale), ci_scale, 0.0)
         for k, name in enumerate(names):
             stat = (inf[okd, p:2 * p], ref_inf[okd, p:2 * p]) if name == "p_values" else None
-            chk_diag(inf[okd, k * p:(k + 1) * p], ref_inf[okd, k * p:(k + 1) * p], name, stat=stat)
-        chk_diag(inf[okd, 5 * p], ref_inf[okd, 5 * p], "f_statistic")
+            atol = diag_rtol * ci_scale if name in ("ci_lower", "ci_upper") else 0.0
+            chk_diag(inf[okd, k * p:(k + 1) * p], ref_inf[okd, k * p:(k + 1) * p], name, stat=stat, atol=atol)
+        # F = (TSS - RSS) / dfm / (RSS / df): with no signal at all TSS - RSS cancels (same absolute floor as r^2, x df/dfm)
+        chk_diag(inf[okd, 5 * p], ref_inf[okd, 5 * p], "f_statistic", atol=1e-9)
         chk_diag(inf[okd, 5 * p + 1], ref_inf[okd, 5 * p + 1], "f_pvalue", stat=(inf[okd, 5 * p], ref_inf[okd, 5 * p]))
