@@ -88,6 +88,7 @@ def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=12.0):
     xs = [c[:n_rows].cpu().numpy() for c in x_cols]
     ws = w[:n_rows].cpu().numpy() if w is not None else None
     so = offs[:S + 1].cpu().numpy()
+    kw = dict(kw, plain_qr=True)   # the reference's algorithm class as it is: no refinement pass in the timed baseline
     oracle.fit_groups(ys, xs, so, w=ws, model=model, n_threads=cores, **kw)       # warm the pages
     passes, t0 = 0, time.perf_counter()
     while True:

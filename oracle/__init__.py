@@ -27,7 +27,7 @@ class OracleOptions(C.Structure):
         ("confidence_level", C.c_double),
         ("alpha", C.c_double),
         ("hc_type", C.c_int32),
-        ("reserved", C.c_int32),
+        ("plain_qr", C.c_int32),
     ]
 
 
@@ -114,10 +114,12 @@ def lib():
 
 
 def _opts(model="ols", fit_intercept=True, compute_inference=False, confidence_level=0.95, alpha=1.0,
-          lambda_scaling="raw", hc_type="none") -> OracleOptions:
+          lambda_scaling="raw", hc_type="none", plain_qr=False) -> OracleOptions:
+    """plain_qr=True stops after the QR solve (the reference's algorithm class as it is — the CPU baseline that
+    bench.py times); the default adds the extended-precision refinement that makes the oracle the checker."""
     return OracleOptions(MODEL[model], int(bool(fit_intercept)), int(bool(compute_inference)),
                          {"raw": 0, "glmnet": 1}[lambda_scaling], float(confidence_level), float(alpha),
-                         {"none": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}[hc_type], 0)
+                         {"none": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}[hc_type], int(bool(plain_qr)))
 
 
 def _col_ptrs(cols):

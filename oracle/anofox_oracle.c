@@ -70,7 +70,7 @@ typedef struct {
 	double confidence_level;
 	double alpha; /* ridge penalty */
 	int32_t hc_type; /* AnofoxHcType: 0 none, 1..4 = HC0..HC3 (anofox_stats_ffi.h:119-125); OLS and WLS only */
-	int32_t reserved;
+	int32_t plain_qr; /* 1 = stop after the QR solve (the reference's algorithm class as it is: what bench.py times as the CPU baseline); 0 = refine (the checker) */
 } OracleOptions;
 
 typedef struct {
@@ -416,7 +416,7 @@ ORACLE_EXPORT int oracle_fit(const double *y, const double *const *x, const doub
 		long double *res_l = (long double *)malloc(m * sizeof(long double));
 		double *gvec = (double *)malloc((qd ? qd : 1) * sizeof(double));
 		if (res_l && gvec) {
-			for (int it = 0; it < 2 && rank > 0; it++) {
+			for (int it = 0; it < 2 && rank > 0 && !opt->plain_qr; it++) {
 				for (size_t i = 0; i < m; i++) {
 					long double acc = (long double)b0v[i];
 					for (int l = 0; l < rank; l++) acc -= (long double)A0[(size_t)piv[l] * m + i] * (long double)beta[piv[l]];
