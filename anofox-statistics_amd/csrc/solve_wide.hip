@@ -15,6 +15,8 @@
 
 namespace anofox {
 
+typedef double sw_dbl4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 // Diagnostic build only (-DANOFOX_SOLVE_STAMPS, csrc/Makefile target `diag`): workgroup 0 records s_memtime at
@@ -183,42 +185,30 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 #ifdef ANOFOX_SOLVE_STAMPS
 		if (blockIdx.x == 0 && tid == 0 && kb == 0) g_solve_stamps[10] = __builtin_amdgcn_s_memtime();
 #endif
-		// (c) trailing update with the 16 new columns, 4x4 register tiles over the lower triangle
+		// (c) trailing update with the 16 new columns on the matrix cores: one 16x16 tile of the lower triangle per
+		// wave and trip, C -= L_i L_c' as four v_mfma_f64_16x16x4 (the 4x4 register tiles this replaces read eight
+		// LDS operands per 16 FMAs and were LDS-bound).  Diagonal tiles are updated in full: their upper halves land
+		// in the upper triangle, which nothing reads before blocked_tri_inverse clears it.
 		const int mrem = P16 - k0 - 16; // remaining x rows (multiple of 16)
 		const int nt = mrem >> 2;
-		const int ntri = nt * (nt + 1) / 2;
-		for (int t = tid; t < ntri; t += 256) {
-			int a4, b4;
-			tri_decode(t, a4, b4);
-			const int i0 = k0 + 16 + 4 * a4, c0 = k0 + 16 + 4 * b4;
-			double acc[4][4];
+		{
+			const int nb = mrem >> 4;
+			const int ntri = nb * (nb + 1) / 2;
+			const int fr = lane & 15, fk = lane >> 4;
+			for (int t = wave; t < ntri; t += 4) {
+				int a16, b16;
+				tri_decode(t, a16, b16);
+				const int i0 = k0 + 16 + 16 * a16, c0 = k0 + 16 + 16 * b16;
+				sw_dbl4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-			for (int rr = 0; rr < 4; ++rr)
+				for (int q = 0; q < 4; ++q) {
+					const double aop = A[(size_t)(i0 + fr) * LD + k0 + 4 * q + fk];
+					const double bop = A[(size_t)(c0 + fr) * LD + k0 + 4 * q + fk];
+					acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+				}
 #pragma unroll
-				for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = 0.0;
-#pragma unroll 4
-			for (int m = 0; m < 16; ++m) {
-				double xa[4], xb[4];
-#pragma unroll
-				for (int rr = 0; rr < 4; ++rr) xa[rr] = A[(size_t)(i0 + rr) * LD + k0 + m];
-#pragma unroll
-				for (int cc = 0; cc < 4; ++cc) xb[cc] = A[(size_t)(c0 + cc) * LD + k0 + m];
-#pragma unroll
-				for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-					for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = fma(xa[rr], xb[cc], acc[rr][cc]);
+				for (int r = 0; r < 4; ++r) A[(size_t)(i0 + fk + 4 * r) * LD + c0 + fr] -= acc[r];
 			}
-			// unconditional read-modify-write: the above-diagonal entries of diagonal tiles land in the (still
-			// unused) upper triangle
-			double old[4][4];
-#pragma unroll
-			for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-				for (int cc = 0; cc < 4; ++cc) old[rr][cc] = A[(size_t)(i0 + rr) * LD + c0 + cc];
-#pragma unroll
-			for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-				for (int cc = 0; cc < 4; ++cc) A[(size_t)(i0 + rr) * LD + c0 + cc] = old[rr][cc] - acc[rr][cc];
 		}
 		// y row: 1 x 4 tiles
 		for (int b4 = tid; b4 < nt; b4 += 256) {
@@ -276,40 +266,26 @@ __device__ void blocked_tri_inverse(const WideLds &l, int tid) {
 				if (k0 + r > j) A[(size_t)j * LD + k0 + r] = x[r];
 		}
 		__syncthreads();
-		// (ii) rows below: 4x4 tiles over (P16 - k0 - 16) x (k0 + 16)
-		const int nr = (P16 - k0 - 16) >> 2, nc = (k0 + 16) >> 2;
-		for (int t = tid; t < nr * nc; t += 256) {
-			const int a4 = t / nc, b4 = t - a4 * nc;
-			const int i0 = k0 + 16 + 4 * a4, j0 = 4 * b4;
-			const bool inblock = j0 >= k0; // columns of the current block: W's block is lower triangular
-			double acc[4][4];
+		// (ii) rows below: 16x16 tiles over (P16 - k0 - 16) x (k0 + 16) on the matrix cores, RHS -= L_i W_kb
+		{
+			const int nrb = (P16 - k0 - 16) >> 4, ncb = (k0 + 16) >> 4;
+			const int lane = tid & 63, wave = tid >> 6;
+			const int fr = lane & 15, fk = lane >> 4;
+			for (int t = wave; t < nrb * ncb; t += 4) {
+				const int a16 = t / ncb, b16 = t - a16 * ncb;
+				const int i0 = k0 + 16 + 16 * a16, j0 = 16 * b16;
+				const bool inblock = j0 >= k0; // columns of the current block: W's block is lower triangular
+				sw_dbl4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-			for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-				for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = 0.0;
-#pragma unroll 4
-			for (int m = 0; m < 16; ++m) {
-				double xa[4], xb[4];
-#pragma unroll
-				for (int rr = 0; rr < 4; ++rr) xa[rr] = A[(size_t)(i0 + rr) * LD + k0 + m];
-#pragma unroll
-				for (int cc = 0; cc < 4; ++cc) {
-					const double raw = A[(size_t)(j0 + cc) * LD + k0 + m];
-					const int kk = k0 + m, jj = j0 + cc;
-					xb[cc] = (!inblock || kk > jj) ? raw : ((kk == jj) ? l.linv[jj] : 0.0);
+				for (int q = 0; q < 4; ++q) {
+					const int kk = k0 + 4 * q + fk, jj = j0 + fr;
+					const double aop = A[(size_t)(i0 + fr) * LD + kk];
+					const double raw = A[(size_t)jj * LD + kk];
+					const double bop = (!inblock || kk > jj) ? raw : ((kk == jj) ? l.linv[jj] : 0.0);
+					acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
 				}
 #pragma unroll
-				for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-					for (int cc = 0; cc < 4; ++cc) acc[rr][cc] = fma(xa[rr], xb[cc], acc[rr][cc]);
-			}
-#pragma unroll
-			for (int cc = 0; cc < 4; ++cc) {
-				double old[4];
-#pragma unroll
-				for (int rr = 0; rr < 4; ++rr) old[rr] = A[(size_t)(j0 + cc) * LD + i0 + rr];
-#pragma unroll
-				for (int rr = 0; rr < 4; ++rr) A[(size_t)(j0 + cc) * LD + i0 + rr] = old[rr] - acc[rr][cc];
+				for (int r = 0; r < 4; ++r) A[(size_t)(j0 + fr) * LD + i0 + fk + 4 * r] -= acc[r];
 			}
 		}
 		__syncthreads();
