@@ -195,12 +195,18 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		// pipelining gate (anofox_hip_context_set_accumulate_gate): wait before the first accumulate kernel of the
 		// call, record after the last one
 		if (g0 == 0 && ctx->gate_wait) {
-			if (hip_fail(hipStreamWaitEvent(st, ctx->gate_wait, 0), "hipStreamWaitEvent", e)) return false;
+			hipEvent_t gw = ctx->gate_wait;
+			ctx->gate_wait = nullptr; // one-shot: the handle belongs to the caller and may be gone after this call
+			if (hip_fail(hipStreamWaitEvent(st, gw, 0), "hipStreamWaitEvent", e)) return false;
 			if (ctx->timing) (void)hipEventRecord(e0, st);
 		}
 		if (hip_fail(mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st), "wide accumulate kernel launch", e)) return false;
 		if (ctx->timing) (void)hipEventRecord(e1, st);
-		if (g0 + slab >= G && ctx->gate_record && hip_fail(hipEventRecord(ctx->gate_record, st), "hipEventRecord", e)) return false;
+		if (g0 + slab >= G && ctx->gate_record) {
+			hipEvent_t gr = ctx->gate_record;
+			ctx->gate_record = nullptr;
+			if (hip_fail(hipEventRecord(gr, st), "hipEventRecord", e)) return false;
+		}
 		// moderately wide designs: one lane per group (solve_mid.hip); beyond that one workgroup per group
 		auto solve = [&](int mode) { return mid ? launch_solve_mid(a, mode, st) : launch_solve_wide(a, mode, st); };
 		if (hip_fail(solve(0), "wide solve kernel launch", e)) return false;
@@ -276,7 +282,11 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 		e2 = get_event(ctx);
 		(void)hipEventRecord(e0, st);
 	}
-	if (ctx->gate_wait && hip_fail(hipStreamWaitEvent(st, ctx->gate_wait, 0), "hipStreamWaitEvent", e)) return false;
+	if (ctx->gate_wait) { // one-shot: the handles belong to the caller and may be gone after this call
+		hipEvent_t gw = ctx->gate_wait;
+		ctx->gate_wait = nullptr;
+		if (hip_fail(hipStreamWaitEvent(st, gw, 0), "hipStreamWaitEvent", e)) return false;
+	}
 	if (ctx->timing) (void)hipEventRecord(e0, st); // (again: the accumulate kernel starts after the gate)
 	// batches of small groups (<= 128 rows on average): several groups per wavefront, the long ones through a list
 	static const bool small_on = !(getenv("ANOFOX_ACC_SMALL") && atoi(getenv("ANOFOX_ACC_SMALL")) == 0); // A/B switch
@@ -289,7 +299,11 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 		return false;
 	}
 	if (ctx->timing) (void)hipEventRecord(e1, st);
-	if (ctx->gate_record && hip_fail(hipEventRecord(ctx->gate_record, st), "hipEventRecord", e)) return false;
+	if (ctx->gate_record) {
+		hipEvent_t gr = ctx->gate_record;
+		ctx->gate_record = nullptr;
+		if (hip_fail(hipEventRecord(gr, st), "hipEventRecord", e)) return false;
+	}
 	if (hip_fail(launch_solve_narrow(a, st), "solve kernel launch", e)) return false;
 	// queued groups only: kRefineSteps x (b += (X'WX)^-1 X'Wr), then the statistics from the directly summed RSS
 	if (hip_fail(launch_refine_fused_narrow(a, kRefineSteps, st), "refine kernel launch", e)) return false;
@@ -494,8 +508,10 @@ bool anofox_hip_fit_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t
 		return false;
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
-	return run_device_batch(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, options, d_core,
-	                        d_inference, out_error);
+	const bool ok = run_device_batch(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, options, d_core,
+	                                 d_inference, out_error);
+	ctx->gate_wait = ctx->gate_record = nullptr; // the gate never outlives the call it was set for
+	return ok;
 }
 
 

@@ -29,10 +29,12 @@ def padded_shard_len(n_groups: int, world: int) -> int:
 
 
 def gather_records(local: torch.Tensor, n_groups: int, group: Optional[dist.ProcessGroup] = None,
-                   out: Optional[torch.Tensor] = None, async_op: bool = False):
+                   out: Optional[torch.Tensor] = None, async_op: bool = False, padded: Optional[torch.Tensor] = None):
     """All-gather the per-rank record blocks [G_local, L] into [n_groups, L] on every rank.
 
-    Shards are padded to ceil(G/W) rows so that one `all_gather_into_tensor` moves everything."""
+    Shards are padded to ceil(G/W) rows so that one `all_gather_into_tensor` moves everything.  `padded`
+    (optional): a [ceil(G/W), L] buffer whose first G_local rows ARE `local` (same storage) and whose other rows
+    are already NaN — then nothing is allocated or copied here (ShardedBatchFit keeps such buffers per slot)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     L = local.shape[1]
@@ -40,7 +42,11 @@ def gather_records(local: torch.Tensor, n_groups: int, group: Optional[dist.Proc
     lo, hi = shard_range(n_groups, rank, world)
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank} holds {local.shape[0]} records, expected {hi - lo}")
-    if local.shape[0] != per:
+    if padded is not None:
+        if padded.shape != (per, L) or padded.data_ptr() != local.data_ptr():
+            raise ValueError("`padded` must be the [ceil(G/W), L] buffer that `local` is the head of")
+        local = padded
+    elif local.shape[0] != per:
         pad = torch.full((per, L), float("nan"), dtype=local.dtype, device=local.device)
         pad[: local.shape[0]] = local
         local = pad
@@ -78,7 +84,8 @@ class ShardedBatchFit:
         self.lo, self.hi = shard_range(n_groups_total, self.rank, self.world)
         self.depth = depth
         self._slot = 0
-        self._bufs = [dict(core=None, inf=None, out=None, out_inf=None, work=[], ctx=None, stream=None, acc_done=None)
+        self._bufs = [dict(core=None, inf=None, core_pad=None, inf_pad=None, out=None, out_inf=None, work=[], ctx=None,
+                           stream=None, acc_done=None)
                       for _ in range(depth)]
         self._last_acc = None  # event recorded after the most recent accumulate kernel
 
@@ -107,9 +114,19 @@ class ShardedBatchFit:
             b["ctx"] = self.ctx if first else type(self.ctx)(dev.index)
             b["stream"] = torch.cuda.Stream(device=dev)
             b["acc_done"] = torch.cuda.Event()
-            b["core"] = torch.empty((G_local, p + 6), dtype=torch.float64, device=dev)
+        shape = (G_local, p, bool(options.compute_inference))
+        if b.get("shape") != shape:
+            self._wait(b)
+            b["shape"] = shape
+            # record buffers padded to the all-gather's shard length once, here: the fit writes the first G_local
+            # rows, the padding rows stay NaN, and no per-step allocation or copy sits between fit and gather
+            rows = per if self.world > 1 else G_local
+            b["core_pad"] = torch.full((rows, p + 6), float("nan"), dtype=torch.float64, device=dev)
+            b["core"] = b["core_pad"][:G_local]
+            b["inf_pad"] = b["inf"] = b["out"] = b["out_inf"] = None
             if options.compute_inference:
-                b["inf"] = torch.empty((G_local, 5 * p + 2), dtype=torch.float64, device=dev)
+                b["inf_pad"] = torch.full((rows, 5 * p + 2), float("nan"), dtype=torch.float64, device=dev)
+                b["inf"] = b["inf_pad"][:G_local]
             if self.world > 1:
                 b["out"] = torch.empty((per * self.world, p + 6), dtype=torch.float64, device=dev)
                 if options.compute_inference:
@@ -121,16 +138,20 @@ class ShardedBatchFit:
             # the accumulate kernels of consecutive steps run one after the other (both are HBM-bound); only the
             # solve / refinement tail of step k overlaps the accumulate kernel of step k + 1
             b["acc_done"].record(s)  # materialise the event handle before the library records into it
+            # (the gate is one-shot: the library drops both handles inside the fit call below, so neither a destroyed
+            # event nor a stale one is ever waited for or recorded by a later direct use of the context)
             b["ctx"].set_accumulate_gate(self._last_acc, b["acc_done"])
             self._last_acc = b["acc_done"]
             core, inf = b["ctx"].fit_batch_device(row_offsets, y, x_cols, w, options, core=b["core"], inference=b["inf"])
             if self.world == 1:
                 return core, inf
-            all_core, wk = gather_records(core, self.n_groups_total, self.group, out=b["out"], async_op=True)
+            all_core, wk = gather_records(core, self.n_groups_total, self.group, out=b["out"], async_op=True,
+                                          padded=b["core_pad"])
             b["work"].append(wk)
             all_inf = None
             if inf is not None:
-                all_inf, wk2 = gather_records(inf, self.n_groups_total, self.group, out=b["out_inf"], async_op=True)
+                all_inf, wk2 = gather_records(inf, self.n_groups_total, self.group, out=b["out_inf"], async_op=True,
+                                              padded=b["inf_pad"])
                 b["work"].append(wk2)
         return all_core, all_inf
 

@@ -51,6 +51,9 @@ class Context:
         calls, record `record_event` right after it (see anofox_hip_context_set_accumulate_gate)."""
         err = _abi.AnofoxError()
         h = lambda ev: C.c_void_p(0 if ev is None else int(ev.cuda_event))
+        # the library holds the raw hipEvent_t handles until the next fit call consumes the (one-shot) gate: keep the
+        # torch objects alive at least that long, whatever the caller does with its own references
+        self._gate_events = (wait_event, record_event)
         self._check(self._lib.anofox_hip_context_set_accumulate_gate(self._h, h(wait_event), h(record_event), C.byref(err)), err)
 
     def synchronize(self):
@@ -98,6 +101,7 @@ class Context:
             self._h, G, p, N, C.c_void_p(row_offsets.data_ptr()), C.c_void_p(y.data_ptr()), cols,
             C.c_void_p(w.data_ptr() if w is not None else 0), options, C.c_void_p(core.data_ptr()),
             C.c_void_p(inference.data_ptr() if inference is not None else 0), C.byref(err))
+        self._gate_events = None   # consumed (or dropped) by the call above
         self._check(ok, err)
         return core, (inference if options.compute_inference else None)
 

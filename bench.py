@@ -52,26 +52,41 @@ def algorithmic_flops_per_fit(n: int, p: int) -> float:
     return 2.0 * n * (pp * (pp + 1) / 2 + pp + 1)
 
 
+def sample_windows(G: int, sample: int):
+    """Three windows of groups — head, middle and tail of the batch — `sample` groups in total (all of them when
+    the batch is smaller): the tail window lies in the LAST slab of a multi-slab launch."""
+    if G <= sample:
+        return [(0, G)]
+    k = max(1, sample // 3)
+    mid = (G - k) // 2
+    return [(0, k), (mid, mid + k), (G - (sample - 2 * k), G)]
+
+
 def parity_gate(pkg, core, inf, offs, y, x_cols, w, model, kw, p, sample):
-    """Re-check a sample of groups against the CPU oracle; returns (ok, max coef err, max diag err)."""
+    """Re-check a sample of groups (head, middle and tail of this rank's batch) against the CPU oracle; returns
+    (ok, max coef err, max diag err)."""
     import oracle  # checker only
-    S = min(sample, core.shape[0])
-    n_rows = int(offs[S].item())
-    ys = y[:n_rows].cpu().numpy()
-    xs = [c[:n_rows].cpu().numpy() for c in x_cols]
-    ws = w[:n_rows].cpu().numpy() if w is not None else None
-    rcore, rinf = oracle.fit_groups(ys, xs, offs[:S + 1].cpu().numpy(), w=ws, model=model,
-                                    n_threads=len(os.sched_getaffinity(0)), **kw)
-    c = core[:S].cpu().numpy()
-    if not np.array_equal(c[:, p + 5], rcore[:, p + 5]):
-        return False, float("inf"), float("inf")
-    scale = np.max(np.abs(rcore[:, :p + 1]), axis=1, keepdims=True)
-    cerr = float(np.max(np.abs(c[:, :p + 1] - rcore[:, :p + 1]) / np.maximum(np.abs(rcore[:, :p + 1]), 1e-3 * scale)))
-    derr = float(np.max(np.abs(c[:, p + 1:p + 4] / rcore[:, p + 1:p + 4] - 1.0)))
-    if rinf is not None:
-        gi = inf[:S].cpu().numpy()
-        derr = max(derr, float(np.max(np.abs(gi - rinf) / np.maximum(np.abs(rinf), 1e-300))))
-    return (cerr < 1e-9 and derr < 1e-6), cerr, derr
+    G = core.shape[0]
+    ok_all, cerr, derr = True, 0.0, 0.0
+    for g0, g1 in sample_windows(G, sample):
+        so = offs[g0:g1 + 1].cpu().numpy()
+        r0, r1 = int(so[0]), int(so[-1])
+        ys = y[r0:r1].cpu().numpy()
+        xs = [c[r0:r1].cpu().numpy() for c in x_cols]
+        ws = w[r0:r1].cpu().numpy() if w is not None else None
+        rcore, rinf = oracle.fit_groups(ys, xs, so - r0, w=ws, model=model,
+                                        n_threads=len(os.sched_getaffinity(0)), **kw)
+        c = core[g0:g1].cpu().numpy()
+        if not np.array_equal(c[:, p + 5], rcore[:, p + 5]):
+            return False, float("inf"), float("inf")
+        scale = np.max(np.abs(rcore[:, :p + 1]), axis=1, keepdims=True)
+        cerr = max(cerr, float(np.max(np.abs(c[:, :p + 1] - rcore[:, :p + 1]) / np.maximum(np.abs(rcore[:, :p + 1]), 1e-3 * scale))))
+        derr = max(derr, float(np.max(np.abs(c[:, p + 1:p + 4] / rcore[:, p + 1:p + 4] - 1.0))))
+        if rinf is not None:
+            gi = inf[g0:g1].cpu().numpy()
+            derr = max(derr, float(np.max(np.abs(gi - rinf) / np.maximum(np.abs(rinf), 1e-300))))
+        ok_all = ok_all and (cerr < 1e-9 and derr < 1e-6)
+    return ok_all, cerr, derr
 
 
 def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=12.0):
@@ -102,6 +117,21 @@ def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=12.0):
                       f"(dense Householder QR per group, {cores} threads), {t:.1f} s"}
 
 
+def launch_ranks(n: int) -> int:
+    """Start `n` ranks of this script (one process per GPU) through torch.distributed.run on 127.0.0.1 and wait."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,12 +154,17 @@ def main():
     ap.add_argument("--parity-sample", type=int, default=1024)
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # bare `python bench.py --gpus N`: this process becomes the launcher.  It has made no GPU call (importing
+        # torch makes none) and makes none: the N ranks are child processes, rank 0's JSON line goes straight to
+        # the inherited stdout, and the launcher exits with the children's return code.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}: launch N ranks for --gpus N "
+                         f"(or run `python bench.py --gpus N` without a launcher)")
     # ANOFOX_BENCH_REHEARSAL=1: several ranks share cuda:0 over gloo (to rehearse the N > 1 path on a 1-GPU box)
     rehearsal = os.environ.get("ANOFOX_BENCH_REHEARSAL") == "1"
     dev_index = 0 if rehearsal else local_rank
@@ -259,7 +294,7 @@ def main():
         ok = ok and cerr < 1e-9
         args.parity_sample = 0
     if args.parity_sample > 0:
-        # every rank checks the head of its own shard (the gathered block [lo:hi] must be its own records)
+        # every rank checks head, middle and tail of its own shard (the gathered block [lo:hi] must be its own records)
         mine = core_all[lo:hi]
         mine_inf = inf_all[lo:hi] if inf_all is not None else None
         ok, cerr, derr = parity_gate(pkg, mine, mine_inf, offs, y, x_cols, w, args.model, kw, p, args.parity_sample)
@@ -312,9 +347,14 @@ def main():
                        "groups_total": G, "groups_per_gpu": G_local, "rows_per_group": n, "features": p,
                        "partition": f"contiguous key ranges over {world} rank(s); all-gather of {p + 6}-double records"},
             "parity": {"ok": ok, "sample_groups_per_rank": min(args.parity_sample, G_local),
+                       "sample_windows": ([list(wd) for wd in sample_windows(G_local, args.parity_sample)]
+                                          if args.parity_sample > 0 else None),
                        "max_coef_rel_err": cerr, "max_diag_rel_err": derr},
             "roofline": {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,
+                         "traffic_source": ("profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                            "passes of this kernel on this workload; not measured in this run)"
+                                            if traffic is not None else None),
                          "kernel": kernel, "avg_launch_ms": acc_ms, "launches_per_step": kt["accumulate_count"] / args.steps,
                          "kernel_ms_per_step": acc_step_ms, "groups_refined_last_launch": refined,
                          ("algorithmic_bytes_per_step" if bound == "hbm" else "algorithmic_flops_per_step"): per_step,

@@ -296,7 +296,8 @@ ANOFOX_HIP_API bool anofox_hip_context_synchronize(AnofoxHipContext *ctx, Anofox
  * small solve / refinement kernels of batch k overlap the HBM-bound accumulate kernel of batch k + 1: the fit entry
  * points make the stream wait for `wait_event` (hipEvent_t as void*, may be NULL) before the accumulate kernel and
  * record `record_event` (may be NULL) right after it.  Chaining the events keeps the accumulate kernels of the two
- * contexts from running against each other. */
+ * contexts from running against each other.  The gate is ONE-SHOT: it applies to the next fit call on this context
+ * only and is cleared by it (the event handles stay the caller's; the library never keeps them past that call). */
 ANOFOX_HIP_API bool anofox_hip_context_set_accumulate_gate(AnofoxHipContext *ctx, void *wait_event, void *record_event,
                                             AnofoxError *out_error);
 

@@ -15,6 +15,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Multi-process GPU tests fork their ranks from a fork server that is started HERE, before anything in this
+    # process has touched the GPU: a process that has initialised HIP must never exec (or hand a forked copy of
+    # itself to) another program, and a rank forked from the clean server initialises the GPU on its own.
+    import multiprocessing as mp
+    from multiprocessing import forkserver
+    try:
+        mp.set_forkserver_preload([])
+        forkserver.ensure_running()
+    except Exception:        # pragma: no cover  (platforms without a fork server: the tests that need it skip)
+        pass
 
 
 def load_csv(rel):

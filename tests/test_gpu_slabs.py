@@ -1,0 +1,130 @@
+"""Every slab of a multi-slab launch is oracle-checked (VERDICT r1 "weak" #1).
+
+`run_wide_batch` cuts a batch into slabs of 2^30 / record_bytes groups (csrc/host_api.hip) and passes
+`group_base` > 0 to every kernel of the later slabs; the host entry point streams batches of more than 32M rows
+through the GPU in row slabs.  These tests make batches that need several slabs and compare groups from the FIRST,
+a MIDDLE and the LAST slab with the oracle, plus a whole-batch linearity property."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import COEF_RTOL, DIAG_RTOL, assert_records_match, import_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def _slab_groups(p):
+    """Groups per slab of the wide path, as csrc/host_api.hip::run_wide_batch computes it."""
+    T = (p + 15) // 16
+    rec_bytes = (T * (T + 1) // 2 * 256 + 4 * 16 * T + 8) * 8
+    return max(256, (1 << 30) // rec_bytes)
+
+
+def _windows(G, slab, k):
+    """k groups at the head of the first slab, straddling every slab boundary's far side, and at the very end."""
+    w = [(0, k)]
+    g = slab
+    while g < G:
+        w.append((g - k // 2, min(G, g + k // 2)))   # last groups of one slab and first groups of the next
+        g += slab
+    w.append((G - k, G))
+    return w
+
+
+def _check_windows(core, inf, offs, y, x_cols, w, p, model, kw, windows, what):
+    for g0, g1 in windows:
+        so = offs[g0:g1 + 1].cpu().numpy()
+        r0, r1 = int(so[0]), int(so[-1])
+        rcore, rinf = oracle.fit_groups(y[r0:r1].cpu().numpy(), [c[r0:r1].cpu().numpy() for c in x_cols], so - r0,
+                                        w=(w[r0:r1].cpu().numpy() if w is not None else None), model=model,
+                                        n_threads=8, **kw)
+        assert_records_match(core[g0:g1].cpu().numpy(), rcore, p,
+                             inf[g0:g1].cpu().numpy() if inf is not None else None, rinf,
+                             what=f"{what} groups [{g0}, {g1})")
+
+
+@pytest.mark.parametrize("p,n,slabs,model,inference", [
+    (128, 140, 2.2, "ols", True),      # cfg5's width: 13 786 groups per slab
+    (40, 48, 2.1, "wls", False),       # T = 3: 77 314 groups per slab
+    (20, 30, 1.3, "ridge", True),      # lane-per-group solve (mid path), T = 2
+])
+def test_wide_batches_beyond_one_slab_match_oracle_in_every_slab(p, n, slabs, model, inference):
+    import torch
+    pkg = import_pkg()
+    synth = import_pkg("synth")
+    slab = _slab_groups(p)
+    G = int(slab * slabs) + 7
+    assert G > slab
+    offs, y, x_cols, w = synth.make_grouped(G, n, p, weights=(model == "wls"), device="cuda:0",
+                                            chunk_groups=max(1, (1 << 22) // n))
+    kw = dict(compute_inference=inference)
+    if model == "ridge":
+        kw["alpha"] = 0.7
+    ctx = pkg.Context(0)
+    opts = pkg.RegressionOptions(**kw).batch_options(model)
+    core, inf = ctx.fit_batch_device(offs, y, x_cols, w, opts)
+    torch.cuda.synchronize()
+    assert bool((core[:, p + 5] == 0).all()) and bool((core[:, p + 4] == n).all())
+    _check_windows(core, inf, offs, y, x_cols, w, p, model, kw, _windows(G, slab, 8), f"{model} p={p}")
+    # whole batch: linearity of least squares (slopes 2 b + 3 e_1, sigma doubles) — no slab may be skipped or shifted
+    if model != "ridge":
+        y2 = 2.0 * y + 3.0 * x_cols[0] - 1.0
+        core2, _ = ctx.fit_batch_device(offs, y2, x_cols, w, pkg.RegressionOptions().batch_options(model))
+        torch.cuda.synchronize()
+        want = 2.0 * core[:, :p].clone()
+        want[:, 0] += 3.0
+        scale = want.abs().max(dim=1, keepdim=True).values
+        # near-square groups (n ~ p): the coefficients themselves carry cond(X)^2 eps, compare at 1e-7
+        tol = COEF_RTOL if n >= 4 * p else 1e-7
+        assert float(((core2[:, :p] - want).abs() / torch.maximum(want.abs(), 1e-3 * scale)).max()) < tol
+        assert float((core2[:, p + 3] / (2.0 * core[:, p + 3]) - 1.0).abs().max()) < DIAG_RTOL
+    ctx.close()
+
+
+def test_cfg5_record_slabs_at_full_group_count():
+    """BASELINE cfg5's 50 000 groups x p = 128 with full diagnostics: four record slabs.  n is cut to 160 rows so
+    the inputs fit a test's time budget (the slab logic depends on G and p only); head, every slab boundary and the
+    tail are oracle-checked."""
+    import torch
+    pkg = import_pkg()
+    synth = import_pkg("synth")
+    G, n, p = 50_000, 160, 128
+    slab = _slab_groups(p)
+    assert (G + slab - 1) // slab == 4
+    offs, y, x_cols, _ = synth.make_grouped(G, n, p, device="cuda:0", chunk_groups=2048)
+    ctx = pkg.Context(0)
+    opts = pkg.RegressionOptions(compute_inference=True).batch_options("ols")
+    core, inf = ctx.fit_batch_device(offs, y, x_cols, None, opts)
+    torch.cuda.synchronize()
+    assert bool((core[:, p + 5] == 0).all()) and bool((core[:, p + 4] == n).all())
+    _check_windows(core, inf, offs, y, x_cols, None, p, "ols", dict(compute_inference=True), _windows(G, slab, 6), "cfg5 G")
+    ctx.close()
+
+
+@pytest.mark.parametrize("p,model", [(1, "ols"), (3, "wls")])
+def test_host_entry_point_beyond_one_row_slab(p, model):
+    """anofox_hip_fit_batch_host streams more than 32M rows in several row slabs: groups of the first and of the
+    LAST slab against the oracle, and every group's row count."""
+    pkg = import_pkg()
+    rng = np.random.default_rng(5 + p)
+    n = 9000
+    G = (32 << 20) // n + 300          # > 32M rows: two slabs, the second with ~300 groups
+    ns = np.full(G, n, dtype=np.int64)
+    ns[::7] -= 13                      # ragged
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    assert N > (32 << 20)
+    x_cols = [rng.uniform(-10, 10, N) for _ in range(p)]
+    gid = np.repeat(np.arange(G), ns)
+    beta = rng.uniform(-5, 5, (G, p))
+    y = rng.uniform(-10, 10, G)[gid] + sum(beta[gid, j] * x_cols[j] for j in range(p)) + 2.0 * rng.standard_normal(N)
+    w = rng.uniform(0.5, 1.5, N) if model == "wls" else None
+    del gid
+    kw = dict(compute_inference=True)
+    core, inf = pkg.fit_batch_host(offs, y, x_cols, w, pkg.RegressionOptions(**kw).batch_options(model))
+    assert np.all(core[:, p + 5] == 0) and np.array_equal(core[:, p + 4], ns.astype(np.float64))
+    for g0, g1 in ((0, 24), (G // 2, G // 2 + 24), (G - 24, G)):
+        r0, r1 = int(offs[g0]), int(offs[g1])
+        rcore, rinf = oracle.fit_groups(y[r0:r1], [c[r0:r1] for c in x_cols], offs[g0:g1 + 1] - r0,
+                                        w=(w[r0:r1] if w is not None else None), model=model, n_threads=8, **kw)
+        assert_records_match(core[g0:g1], rcore, p, inf[g0:g1], rinf, what=f"host slabs {model} [{g0}, {g1})")
