@@ -176,6 +176,21 @@ SYMBOLS = {
     "anofox_hip_context_set_accumulate_gate": (C.c_bool, [_CTX, C.c_void_p, C.c_void_p, _ERRP]),
     "anofox_hip_context_last_refine_count": (C.c_bool, [_CTX, C.POINTER(C.c_int64), _ERRP]),
     "anofox_hip_version": (C.c_char_p, []),
+    "anofox_hip_agg_state_max_features": (C.c_size_t, []),
+    "anofox_hip_agg_state_create": (C.c_bool, [_CTX, C.c_size_t, AnofoxHipBatchOptions, C.c_int64, C.POINTER(C.c_void_p), _ERRP]),
+    "anofox_hip_agg_state_destroy": (None, [C.c_void_p]),
+    "anofox_hip_agg_state_reserve": (C.c_bool, [C.c_void_p, C.c_int64, _ERRP]),
+    "anofox_hip_agg_state_slots": (C.c_int64, [C.c_void_p]),
+    "anofox_hip_agg_state_rows": (C.c_int64, [C.c_void_p]),
+    "anofox_hip_agg_state_update_host": (C.c_bool, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, _ERRP]),
+    "anofox_hip_agg_state_update_device": (C.c_bool, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_void_p, _ERRP]),
+    "anofox_hip_agg_state_combine": (C.c_bool, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _ERRP]),
+    "anofox_hip_agg_state_finalize_host": (C.c_bool, [C.c_void_p, C.c_int64, _DP, _DP, C.POINTER(C.c_int64), _ERRP]),
+    "anofox_hip_agg_state_finalize_device": (C.c_bool, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _ERRP]),
+    "anofox_hip_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "anofox_hip_host_free": (None, [C.c_void_p]),
 }
 
 _lib = None

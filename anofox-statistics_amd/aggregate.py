@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _abi
 from .options import InvalidInputException, RegressionOptions, parse_options
-from .runtime import Context, fit_batch_host
+from .runtime import AggState, Context, fit_batch_host
 
 
 @dataclass
@@ -95,14 +95,57 @@ def _null_mask_1d(a) -> (np.ndarray, np.ndarray):
     return np.ascontiguousarray(arr, dtype=np.float64), np.zeros(arr.shape[0], dtype=bool)
 
 
+class StreamingStates:
+    """Every aggregate state of one query, kept on the GPU (runtime.AggState / anofox_hip_agg_state_*): what a
+    DuckDB shim holds once per query.  Each aggregate object created with `streaming=<this>` plays one thread-local
+    hash table: its Initialize takes slot numbers from here, its Update sends accepted rows straight to the GPU
+    state (no row buffer), its Combine merges slot pairs, its Finalize reads the solved records of its slots."""
+
+    def __init__(self, context: Optional[Context] = None):
+        self.context = context or Context()
+        self.state: Optional[AggState] = None
+        self.n_slots = 0
+        self.unrefined = 0
+        self._solved = None        # (core, inf) of all slots, computed by the first Finalize after the last change
+
+    def new_slots(self, n: int) -> np.ndarray:
+        out = np.arange(self.n_slots, self.n_slots + n, dtype=np.uint32)
+        self.n_slots += n
+        return out
+
+    def ensure(self, n_features: int, batch_options) -> AggState:
+        if self.state is None:
+            self.state = AggState(self.context, n_features, batch_options)
+        elif self.state.p != n_features:
+            raise InvalidInputException(f"Inconsistent feature count: expected {self.state.p}, got {n_features}")
+        return self.state
+
+    def touched(self):
+        self._solved = None
+
+    def solved(self):
+        if self._solved is None:
+            self.state.reserve(self.n_slots)      # slots whose rows were all skipped never reached the GPU
+            core, inf, self.unrefined = self.state.finalize(self.n_slots)
+            self._solved = (core, inf)
+        return self._solved
+
+
 class _FitAgg:
     model = "ols"
     sql_name = "anofox_stats_ols_fit_agg"
     has_weights = False
 
-    def __init__(self, options: Optional[Mapping[str, Any]] = None, context: Optional[Context] = None):
+    def __init__(self, options: Optional[Mapping[str, Any]] = None, context: Optional[Context] = None,
+                 streaming=None):
         self.options: RegressionOptions = parse_options(options)   # Bind
         self._ctx = context
+        # streaming: None/False = buffer rows on the host and fit them in one batched call at Finalize (the layout
+        # of the reference's state); True or a StreamingStates = O(p^2) state per group on the GPU
+        self._pool: Optional[StreamingStates] = None
+        if streaming:
+            self._pool = streaming if isinstance(streaming, StreamingStates) else StreamingStates(context)
+        self._slot_of: dict = {}               # key -> slot (streaming)
         self.n_features: Optional[int] = None
         self._keys: List[np.ndarray] = []      # every key seen (also of skipped rows: the group exists)
         self._rkeys: List[np.ndarray] = []     # keys of accumulated rows
@@ -154,6 +197,8 @@ class _FitAgg:
             if int(ln) != self.n_features:
                 raise InvalidInputException(
                     f"Inconsistent feature count: expected {self.n_features}, got {int(ln)}")
+        if self._pool is not None:
+            return self._update_streaming(keys, keep, yv, xa, wv if self.has_weights else None)
         self._keys.append(keys)
         if keep.any():
             self._rkeys.append(keys[keep])
@@ -163,8 +208,46 @@ class _FitAgg:
                 self._w.append(wv[keep])
         return self
 
+    def _update_streaming(self, keys, keep, yv, xa, wv):
+        """Update of the streaming state: Initialize a slot for every new key (also for keys whose rows are all
+        skipped: the group exists and comes out NULL), then hand the accepted rows to the GPU state."""
+        uk, inv = np.unique(keys, return_inverse=True)
+        new = [k for k in uk.tolist() if k not in self._slot_of]
+        if new:
+            for k, sl in zip(new, self._pool.new_slots(len(new)).tolist()):
+                self._slot_of[k] = sl
+        if keep.any():
+            slots = np.array([self._slot_of[k] for k in uk.tolist()], dtype=np.uint32)[inv]
+            st = self._pool.ensure(self.n_features, self.options.batch_options(self.model))
+            st.update(slots[keep], yv[keep], np.ascontiguousarray(xa[keep][:, :self.n_features]),
+                      None if wv is None else wv[keep], n_slots=self._pool.n_slots)
+            self._pool.touched()
+        return self
+
     # ---- Combine -----------------------------------------------------------------------------
     def combine(self, other: "_FitAgg"):
+        if self._pool is not None:
+            if other._pool is not self._pool:
+                raise InvalidInputException("streaming aggregates combine only within one StreamingStates pool")
+            if other.n_features is not None:
+                if self.n_features is None:
+                    self.n_features = other.n_features
+                elif self.n_features != other.n_features:
+                    raise InvalidInputException(
+                        f"Cannot combine states with different feature counts: {other.n_features} vs {self.n_features}")
+            src, dst = [], []
+            for k, sl in other._slot_of.items():
+                if k in self._slot_of:
+                    src.append(sl)
+                    dst.append(self._slot_of[k])
+                else:
+                    self._slot_of[k] = sl          # the target hash table adopts the source's state
+            if src and self._pool.state is not None:
+                self._pool.state.reserve(self._pool.n_slots)
+                self._pool.state.combine(src, dst)
+                self._pool.touched()
+            other._slot_of = {}
+            return self
         if other.n_features is not None:
             if self.n_features is None:
                 self.n_features = other.n_features
@@ -198,6 +281,16 @@ class _FitAgg:
         return ukeys, offsets, y, x_cols, w
 
     def finalize(self) -> FitAggResult:
+        if self._pool is not None:
+            ukeys = np.array(sorted(self._slot_of.keys()))
+            G = len(ukeys)
+            if self._pool.state is None:      # no row was ever accumulated: every group is NULL
+                core = np.full((G, 6), np.nan)
+                core[:, 5] = _abi.STATUS_NULL_TOO_FEW_ROWS
+                return result_from_records(ukeys, core, None, 0)
+            core, inf = self._pool.solved()
+            idx = np.array([self._slot_of[k] for k in ukeys.tolist()], dtype=np.int64)
+            return result_from_records(ukeys, core[idx], None if inf is None else inf[idx], self._pool.state.p)
         ukeys, offsets, y, x_cols, w = self.grouped_columns()
         G = len(ukeys)
         if self.n_features is None:       # no row was ever accumulated: every group is NULL

@@ -1,0 +1,535 @@
+// agg_state.hip — anofox_hip_agg_state_*: the aggregate state of {ols,ridge,wls}_fit_agg kept on the GPU.
+//
+// The reference's aggregate state is a per-group row buffer on the host (src/aggregate_functions/
+// ols_aggregate.cpp:19-42) that Update appends to row by row (:120-186), Combine concatenates (:189-234) and
+// Finalize hands to one FFI call per group (:249-338).  Here the state of ALL groups of a query is one object
+// holding an O(p^2) moment record per "slot" (= one DuckDB aggregate state) in HBM:
+//   update    a chunk of rows in arrival order -> ingest.hip folds it into the records (rows are not kept);
+//   combine   pairs (source slot, target slot) -> the source record is merged into the target and emptied;
+//   finalize  the unchanged solve kernel of the batch path (solve_narrow.hip) over the records.
+// Host chunks are staged through two device buffers on a copy stream, so the H2D copy of chunk k + 1 overlaps
+// the kernels of chunk k; update() returns once its inputs have been copied (the caller may reuse them).
+#include <stdlib.h>
+
+#include <memory>
+#include <unordered_set>
+
+#include "context.h"
+
+using namespace anofox;
+using namespace anofox::host;
+
+struct AnofoxHipAggState {
+	AnofoxHipContext *ctx = nullptr;
+	size_t p = 0;
+	AnofoxHipBatchOptions opt{};
+	std::mutex mu;
+	// per-slot state
+	double *moments = nullptr;
+	int64_t *n_accum = nullptr;
+	int32_t *run_start = nullptr, *run_end = nullptr;
+	int64_t capacity = 0; // slots allocated
+	int64_t n_slots = 0;  // slots in use (largest count announced by the caller)
+	int64_t rows = 0;     // rows passed to update so far
+	// per-pass scratch (one set: the passes of one state are serialised on the context's stream)
+	void *scratch = nullptr;
+	size_t scratch_bytes = 0;
+	size_t sort_temp_bytes = 0;
+	int32_t *counters = nullptr; // [0] runs of the current pass, [1] sticky out-of-range flag (own small allocation)
+	// staging of host chunks
+	struct Stage {
+		void *buf = nullptr;
+		size_t bytes = 0;
+		hipEvent_t copied = nullptr, done = nullptr;
+	} stage[2];
+	int next_stage = 0;
+	hipStream_t copy_stream = nullptr;
+	void *pair_buf = nullptr; // combine: src | dst
+	size_t pair_bytes = 0;
+};
+
+namespace anofox {
+namespace host {
+// Release everything the state holds on the device and cut it loose from its context (called by
+// anofox_hip_agg_state_destroy and by anofox_hip_context_destroy for the states that outlive their context).
+void agg_state_detach(AnofoxHipAggState *s) {
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!s->ctx) return;
+	(void)hipSetDevice(s->ctx->device);
+	(void)hipStreamSynchronize(s->ctx->stream);
+	if (s->copy_stream) {
+		(void)hipStreamSynchronize(s->copy_stream);
+		(void)hipStreamDestroy(s->copy_stream);
+		s->copy_stream = nullptr;
+	}
+	for (auto &st : s->stage) {
+		if (st.buf) (void)hipFree(st.buf);
+		if (st.copied) (void)hipEventDestroy(st.copied);
+		if (st.done) (void)hipEventDestroy(st.done);
+		st = AnofoxHipAggState::Stage();
+	}
+	void **bufs[] = {(void **)&s->moments, (void **)&s->n_accum, (void **)&s->run_start, (void **)&s->run_end, &s->scratch,
+	                 (void **)&s->counters, &s->pair_buf};
+	for (void **b : bufs) {
+		if (*b) (void)hipFree(*b);
+		*b = nullptr;
+	}
+	s->capacity = 0;
+	s->scratch_bytes = s->pair_bytes = 0;
+	s->ctx = nullptr;
+}
+} // namespace host
+} // namespace anofox
+
+namespace {
+
+// every entry point: the state must still be attached to a live context
+bool attached(AnofoxHipAggState *s, AnofoxError *e) {
+	if (s && !s->ctx) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "the aggregate state's context has been destroyed");
+		return false;
+	}
+	return true;
+}
+
+bool state_reserve(AnofoxHipAggState *s, int64_t n_slots, AnofoxError *e) {
+	if (n_slots > (int64_t)0x7fffffff) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "too many aggregate states (limit 2^31 - 1)"); return false; }
+	if (n_slots > s->n_slots) s->n_slots = n_slots;
+	if (n_slots <= s->capacity) return true;
+	int64_t cap = s->capacity * 2;
+	if (cap < n_slots) cap = n_slots;
+	if (cap < 1024) cap = 1024;
+	if (cap > (int64_t)0x7fffffff) cap = 0x7fffffff;
+	const size_t rec = (size_t)moment_record_len((int)s->p) * sizeof(double);
+	double *m = nullptr;
+	int64_t *na = nullptr;
+	int32_t *rs = nullptr, *re = nullptr;
+	if (hipMalloc((void **)&m, (size_t)cap * rec) != hipSuccess || hipMalloc((void **)&na, (size_t)cap * sizeof(int64_t)) != hipSuccess ||
+	    hipMalloc((void **)&rs, (size_t)cap * sizeof(int32_t)) != hipSuccess || hipMalloc((void **)&re, (size_t)cap * sizeof(int32_t)) != hipSuccess) {
+		(void)hipGetLastError();
+		if (m) (void)hipFree(m);
+		if (na) (void)hipFree(na);
+		if (rs) (void)hipFree(rs);
+		if (re) (void)hipFree(re);
+		set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE, "hipMalloc failed for the aggregate state");
+		return false;
+	}
+	hipStream_t st = s->ctx->stream;
+	const size_t old = (size_t)s->capacity;
+	bool bad = false;
+	if (old) {
+		bad = bad || hip_fail(hipMemcpyAsync(m, s->moments, old * rec, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync", e);
+		bad = bad || hip_fail(hipMemcpyAsync(na, s->n_accum, old * sizeof(int64_t), hipMemcpyDeviceToDevice, st), "hipMemcpyAsync", e);
+	}
+	// an empty slot is all zeros (cnt = 0)
+	bad = bad || hip_fail(hipMemsetAsync((char *)m + old * rec, 0, ((size_t)cap - old) * rec, st), "hipMemsetAsync", e);
+	bad = bad || hip_fail(hipMemsetAsync(na + old, 0, ((size_t)cap - old) * sizeof(int64_t), st), "hipMemsetAsync", e);
+	bad = bad || hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e);
+	if (bad) {
+		(void)hipFree(m); (void)hipFree(na); (void)hipFree(rs); (void)hipFree(re);
+		return false;
+	}
+	if (s->moments) (void)hipFree(s->moments);
+	if (s->n_accum) (void)hipFree(s->n_accum);
+	if (s->run_start) (void)hipFree(s->run_start);
+	if (s->run_end) (void)hipFree(s->run_end);
+	s->moments = m;
+	s->n_accum = na;
+	s->run_start = rs;
+	s->run_end = re;
+	s->capacity = cap;
+	return true;
+}
+
+// scratch of one pass: keys_in | keys_out | rows_out | run_list | piece table | sort temp
+bool state_scratch(AnofoxHipAggState *s, AnofoxError *e) {
+	if (s->scratch) return true;
+	const size_t b_n = align_up((size_t)kIngestChunkRows * sizeof(uint32_t), 256);
+	const size_t b_pt = align_up(ingest_piece_table_bytes((int)s->p), 256);
+	s->sort_temp_bytes = align_up(ingest_sort_temp_bytes(kIngestChunkRows), 256);
+	return ensure_buffer(&s->scratch, &s->scratch_bytes, 4 * b_n + b_pt + s->sort_temp_bytes, "ingest scratch", e);
+}
+
+// one pass (<= kIngestChunkRows rows) on device-resident inputs
+bool run_pass(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const double *d_y, const double *d_x, const double *d_w,
+              const uint8_t *d_valid, AnofoxError *e) {
+	if (!state_scratch(s, e)) return false;
+	const size_t b_n = align_up((size_t)kIngestChunkRows * sizeof(uint32_t), 256);
+	const size_t b_pt = align_up(ingest_piece_table_bytes((int)s->p), 256);
+	char *base = (char *)s->scratch;
+	IngestArgs a;
+	memset(&a, 0, sizeof a);
+	a.slot = d_slot;
+	a.y = d_y;
+	a.x = d_x;
+	a.w = d_w;
+	a.valid = d_valid;
+	a.n = n;
+	a.p = (int)s->p;
+	a.weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS ? 1 : 0;
+	a.center = s->opt.fit_intercept ? 1 : 0;
+	a.moments = s->moments;
+	a.n_accum = s->n_accum;
+	a.n_slots = s->n_slots;
+	a.keys_in = (uint32_t *)base;
+	a.keys_out = (uint32_t *)(base + b_n);
+	a.rows_out = (uint32_t *)(base + 2 * b_n);
+	a.run_list = (uint32_t *)(base + 3 * b_n);
+	a.piece_table = base + 4 * b_n;
+	a.sort_temp = base + 4 * b_n + b_pt;
+	a.sort_temp_bytes = s->sort_temp_bytes;
+	a.run_start = s->run_start;
+	a.run_end = s->run_end;
+	a.counters = s->counters;
+	hipStream_t st = s->ctx->stream;
+	if (hip_fail(hipMemsetAsync(a.counters, 0, sizeof(int32_t), st), "hipMemsetAsync", e)) return false;
+	if (hip_fail(hipMemsetAsync(a.piece_table, 0, 64, st), "hipMemsetAsync", e)) return false; // PieceHeader
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (s->ctx->timing) {
+		e0 = get_event(s->ctx);
+		e1 = get_event(s->ctx);
+		(void)hipEventRecord(e0, st);
+	}
+	if (hip_fail(launch_ingest_chunk(a, st), "ingest kernel launch", e)) return false;
+	if (s->ctx->timing) {
+		(void)hipEventRecord(e1, st);
+		s->ctx->acc_events.emplace_back(e0, e1); // the ingest pass is this path's "accumulate" stage
+	}
+	return true;
+}
+
+bool validate_update(AnofoxHipAggState *s, int64_t n_rows, int64_t n_slots, const void *slot, const void *y, const void *x, const void *w,
+                     AnofoxError *e) {
+	if (!s) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "state is NULL"); return false; }
+	if (n_rows < 0 || n_slots < 0) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "negative n_rows or n_slots"); return false; }
+	if (n_rows > 0 && (!slot || !y || !x)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "slot, y or x is NULL"); return false; }
+	if (n_rows > 0 && s->opt.model == ANOFOX_HIP_MODEL_WLS && !w) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "weights is NULL"); return false; }
+	if (n_rows > 0 && n_slots == 0) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "rows without any aggregate state (n_slots == 0)"); return false; }
+	return true;
+}
+
+} // namespace
+
+extern "C" {
+
+bool anofox_hip_agg_state_create(AnofoxHipContext *ctx, size_t n_features, AnofoxHipBatchOptions options, int64_t initial_slots,
+                                 AnofoxHipAggState **out_state, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!out_state) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "out_state is NULL"); return false; }
+	*out_state = nullptr;
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (n_features == 0 || n_features > anofox_hip_agg_state_max_features()) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT,
+		          "streaming aggregate states support 1.." + std::to_string(anofox_hip_agg_state_max_features()) +
+		              " features (got " + std::to_string(n_features) + "); wider designs go through the batch entry points");
+		return false;
+	}
+	if (options.model != ANOFOX_HIP_MODEL_OLS && options.model != ANOFOX_HIP_MODEL_RIDGE && options.model != ANOFOX_HIP_MODEL_WLS) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "unknown model");
+		return false;
+	}
+	if (options.compute_inference && options.hc_type != ANOFOX_HC_NONE && options.model != ANOFOX_HIP_MODEL_RIDGE) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT,
+		          "hc_type needs a second pass over the rows, which a streaming aggregate state does not keep; use the batch entry points");
+		return false;
+	}
+	if (initial_slots < 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "negative initial_slots"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	auto *s = new (std::nothrow) AnofoxHipAggState();
+	if (!s) { set_error(out_error, ANOFOX_ERROR_ALLOCATION_FAILURE, "state allocation failed"); return false; }
+	s->ctx = ctx;
+	s->p = n_features;
+	s->opt = options;
+	bool ok = !hip_fail(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking), "hipStreamCreate", out_error);
+	for (int k = 0; ok && k < 2; ++k) {
+		ok = !hip_fail(hipEventCreateWithFlags(&s->stage[k].copied, hipEventDisableTiming), "hipEventCreate", out_error) &&
+		     !hip_fail(hipEventCreateWithFlags(&s->stage[k].done, hipEventDisableTiming), "hipEventCreate", out_error);
+	}
+	ok = ok && !hip_fail(hipMalloc((void **)&s->counters, 256), "hipMalloc", out_error);
+	ok = ok && !hip_fail(hipMemsetAsync(s->counters, 0, 256, ctx->stream), "hipMemsetAsync", out_error);
+	if (ok && initial_slots > 0) {
+		ok = state_reserve(s, initial_slots, out_error);
+		s->n_slots = 0; // reserved, not yet in use
+	}
+	if (!ok) {
+		agg_state_detach(s);
+		delete s;
+		return false;
+	}
+	ctx->agg_states.push_back(s);
+	*out_state = s;
+	return true;
+}
+
+void anofox_hip_agg_state_destroy(AnofoxHipAggState *s) {
+	if (!s) return;
+	AnofoxHipContext *ctx = nullptr;
+	{
+		std::lock_guard<std::mutex> lk0(s->mu);
+		ctx = s->ctx;
+	}
+	if (ctx) {
+		{
+			std::lock_guard<std::mutex> lk(ctx->mu);
+			auto &v = ctx->agg_states;
+			for (size_t i = 0; i < v.size(); ++i)
+				if (v[i] == s) { v.erase(v.begin() + (long)i); break; }
+		}
+		agg_state_detach(s);
+	}
+	delete s;
+}
+
+size_t anofox_hip_agg_state_max_features(void) { return (size_t)kNarrowMaxP; }
+
+int64_t anofox_hip_agg_state_slots(const AnofoxHipAggState *s) { return s ? s->n_slots : 0; }
+int64_t anofox_hip_agg_state_rows(const AnofoxHipAggState *s) { return s ? s->rows : 0; }
+
+bool anofox_hip_agg_state_reserve(AnofoxHipAggState *s, int64_t n_slots, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!s || n_slots < 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL or n_slots negative"); return false; }
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
+	return state_reserve(s, n_slots, out_error);
+}
+
+bool anofox_hip_agg_state_update_device(AnofoxHipAggState *s, int64_t n_rows, int64_t n_slots, const uint32_t *d_slot, const double *d_y,
+                                        const double *d_x_rowmajor, const double *d_w, const uint8_t *d_valid, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!validate_update(s, n_rows, n_slots, d_slot, d_y, d_x_rowmajor, d_w, out_error)) return false;
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
+	if (!state_reserve(s, n_slots, out_error)) return false;
+	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
+	for (int64_t r0 = 0; r0 < n_rows; r0 += kIngestChunkRows) {
+		const int64_t n = n_rows - r0 < kIngestChunkRows ? n_rows - r0 : kIngestChunkRows;
+		if (!run_pass(s, n, d_slot + r0, d_y + r0, d_x_rowmajor + (size_t)r0 * s->p, weighted ? d_w + r0 : nullptr,
+		              d_valid ? d_valid + r0 : nullptr, out_error))
+			return false;
+	}
+	s->rows += n_rows;
+	return true;
+}
+
+bool anofox_hip_agg_state_update_host(AnofoxHipAggState *s, int64_t n_rows, int64_t n_slots, const uint32_t *slot, const double *y,
+                                      const double *x_rowmajor, const double *w, const uint8_t *valid, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!validate_update(s, n_rows, n_slots, slot, y, x_rowmajor, w, out_error)) return false;
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
+	if (!state_reserve(s, n_slots, out_error)) return false;
+	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
+	const size_t p = s->p;
+	// staging layout of one chunk: x | y | w | slot | valid
+	const size_t C = (size_t)kIngestChunkRows;
+	const size_t b_x = align_up(C * p * sizeof(double), 256), b_y = align_up(C * sizeof(double), 256);
+	const size_t b_s = align_up(C * sizeof(uint32_t), 256), b_v = align_up(C, 256);
+	const size_t total = b_x + 2 * b_y + b_s + b_v;
+	hipStream_t st = s->ctx->stream, cs = s->copy_stream;
+	for (int64_t r0 = 0; r0 < n_rows; r0 += kIngestChunkRows) {
+		const size_t n = (size_t)(n_rows - r0 < kIngestChunkRows ? n_rows - r0 : kIngestChunkRows);
+		auto &sg = s->stage[s->next_stage];
+		s->next_stage ^= 1;
+		if (!sg.buf) {
+			if (!ensure_buffer(&sg.buf, &sg.bytes, total, "ingest staging", out_error)) return false;
+		} else if (hip_fail(hipStreamWaitEvent(cs, sg.done, 0), "hipStreamWaitEvent", out_error)) { // the pass that last read this buffer
+			return false;
+		}
+		char *base = (char *)sg.buf;
+		double *d_x = (double *)base, *d_y = (double *)(base + b_x), *d_w = (double *)(base + b_x + b_y);
+		uint32_t *d_slot = (uint32_t *)(base + b_x + 2 * b_y);
+		uint8_t *d_valid = (uint8_t *)(base + b_x + 2 * b_y + b_s);
+		bool bad = hip_fail(hipMemcpyAsync(d_x, x_rowmajor + (size_t)r0 * p, n * p * sizeof(double), hipMemcpyHostToDevice, cs), "H2D x", out_error);
+		bad = bad || hip_fail(hipMemcpyAsync(d_y, y + r0, n * sizeof(double), hipMemcpyHostToDevice, cs), "H2D y", out_error);
+		if (weighted) bad = bad || hip_fail(hipMemcpyAsync(d_w, w + r0, n * sizeof(double), hipMemcpyHostToDevice, cs), "H2D w", out_error);
+		bad = bad || hip_fail(hipMemcpyAsync(d_slot, slot + r0, n * sizeof(uint32_t), hipMemcpyHostToDevice, cs), "H2D slot", out_error);
+		if (valid) bad = bad || hip_fail(hipMemcpyAsync(d_valid, valid + r0, n, hipMemcpyHostToDevice, cs), "H2D valid", out_error);
+		bad = bad || hip_fail(hipEventRecord(sg.copied, cs), "hipEventRecord", out_error);
+		bad = bad || hip_fail(hipStreamWaitEvent(st, sg.copied, 0), "hipStreamWaitEvent", out_error);
+		if (bad) return false;
+		if (!run_pass(s, (int64_t)n, d_slot, d_y, d_x, weighted ? d_w : nullptr, valid ? d_valid : nullptr, out_error)) return false;
+		if (hip_fail(hipEventRecord(sg.done, st), "hipEventRecord", out_error)) return false;
+	}
+	// the caller may reuse its buffers on return: wait for the copies (not for the kernels)
+	if (hip_fail(hipStreamSynchronize(cs), "hipStreamSynchronize", out_error)) return false;
+	s->rows += n_rows;
+	return true;
+}
+
+bool anofox_hip_agg_state_combine(AnofoxHipAggState *s, int64_t n_pairs, const uint32_t *source_slots, const uint32_t *target_slots,
+                                  AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!s || n_pairs < 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL or n_pairs negative"); return false; }
+	if (n_pairs == 0) return true;
+	if (!source_slots || !target_slots) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "slot arrays are NULL"); return false; }
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	{
+		// every pair is merged by its own wavefront: a target (or a slot that is both source and target) may appear once
+		std::unordered_set<uint32_t> seen;
+		seen.reserve((size_t)n_pairs * 2);
+		for (int64_t i = 0; i < n_pairs; ++i) {
+			const uint32_t a = source_slots[i], b = target_slots[i];
+			if ((int64_t)a >= s->n_slots || (int64_t)b >= s->n_slots) {
+				set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "combine: slot index out of range");
+				return false;
+			}
+			if (a == b) continue;
+			if (!seen.insert(a).second || !seen.insert(b).second) {
+				set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "combine: a slot may take part in one pair per call");
+				return false;
+			}
+		}
+	}
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
+	const size_t b = align_up((size_t)n_pairs * sizeof(uint32_t), 256);
+	hipStream_t st = s->ctx->stream;
+	if (2 * b > s->pair_bytes) {
+		if (hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error)) return false;
+		if (!ensure_buffer(&s->pair_buf, &s->pair_bytes, 2 * b, "combine pairs", out_error)) return false;
+	}
+	uint32_t *d_src = (uint32_t *)s->pair_buf, *d_dst = (uint32_t *)((char *)s->pair_buf + b);
+	if (hip_fail(hipMemcpyAsync(d_src, source_slots, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
+	if (hip_fail(hipMemcpyAsync(d_dst, target_slots, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
+	if (hip_fail(launch_ingest_combine(s->moments, s->n_accum, s->n_slots, d_src, d_dst, n_pairs, (int)s->p, s->opt.fit_intercept ? 1 : 0, st),
+	             "combine kernel launch", out_error))
+		return false;
+	// the pair arrays are pageable host memory: the copies above have completed on return, the kernel is stream-ordered
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
+}
+
+} // extern "C"
+
+namespace {
+
+// solve every slot [0, n) on the state's records; d_core / d_inf are device buffers
+bool run_finalize(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf, AnofoxError *e) {
+	AnofoxHipContext *ctx = s->ctx;
+	const size_t p = s->p;
+	// workspace: refine list | refine vec | counters | t memo  (the refinement passes need the rows and do not run here;
+	// the queue only counts the groups that would have taken them)
+	const size_t b_lst = align_up((size_t)n * sizeof(int32_t), 256);
+	const size_t b_vec = align_up((size_t)n * (p + 2) * sizeof(double), 256);
+	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_lst + b_vec + 256 + kTcritTableBytes, "workspace", e)) return false;
+	char *base = (char *)ctx->ws;
+	BatchArgs a;
+	memset(&a, 0, sizeof a);
+	a.n_groups = n;
+	a.p = (int)p;
+	a.model = (int)s->opt.model;
+	a.fit_intercept = s->opt.fit_intercept ? 1 : 0;
+	a.compute_inference = s->opt.compute_inference ? 1 : 0;
+	a.lambda_scaling = (int)s->opt.lambda_scaling;
+	a.hc_type = ANOFOX_HC_NONE;
+	a.confidence_level = s->opt.confidence_level;
+	a.alpha = s->opt.alpha;
+	a.moments = s->moments;
+	a.core = d_core;
+	a.inference = s->opt.compute_inference ? d_inf : nullptr;
+	a.refine_list = (int32_t *)base;
+	a.refine_vec = (double *)(base + b_lst);
+	a.refine_count = (int32_t *)(base + b_lst + b_vec);
+	a.tcrit_table = base + b_lst + b_vec + 256;
+	a.rule_counts = s->n_accum; // the aggregate's "< 2 accumulated rows -> NULL" (ols_aggregate.cpp:263-267)
+	ctx->last_refine_count = a.refine_count;
+	hipStream_t st = ctx->stream;
+	if (hip_fail(hipMemsetAsync(a.refine_count, 0, 256 + kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (ctx->timing) {
+		e0 = get_event(ctx);
+		e1 = get_event(ctx);
+		(void)hipEventRecord(e0, st);
+	}
+	if (hip_fail(launch_solve_narrow(a, st), "solve kernel launch", e)) return false;
+	if (ctx->timing) {
+		(void)hipEventRecord(e1, st);
+		ctx->predict_events.emplace_back(e0, e1); // reported as the state's finalize stage (predict_ms of the timing struct)
+	}
+	return true;
+}
+
+bool check_finalize(AnofoxHipAggState *s, int64_t n, const void *core, const void *inf, AnofoxError *e) {
+	if (!s) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "state is NULL"); return false; }
+	if (n < 0 || n > s->n_slots) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "n_slots exceeds the slots in use"); return false; }
+	if (n > 0 && !core) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "core is NULL"); return false; }
+	if (n > 0 && s->opt.compute_inference && !inf) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "inference buffer is NULL"); return false; }
+	return true;
+}
+
+// the sticky flag of ingest_keys_kernel: a row named a slot >= n_slots (its row was dropped)
+bool check_slot_flag(AnofoxHipAggState *s, AnofoxError *e) {
+	int32_t c[2] = {0, 0};
+	if (hip_fail(hipMemcpyAsync(c, s->counters, sizeof c, hipMemcpyDeviceToHost, s->ctx->stream), "hipMemcpy", e)) return false;
+	if (hip_fail(hipStreamSynchronize(s->ctx->stream), "hipStreamSynchronize", e)) return false;
+	if (c[1] != 0) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "update: a row named a slot index >= n_slots (the row was dropped)");
+		return false;
+	}
+	return true;
+}
+
+} // namespace
+
+extern "C" {
+
+bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *s, int64_t n_slots, double *d_core, double *d_inference, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!check_finalize(s, n_slots, d_core, d_inference, out_error)) return false;
+	if (n_slots == 0) return true;
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
+	return run_finalize(s, n_slots, d_core, d_inference, out_error);
+}
+
+bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, double *core, double *inference, int64_t *out_unrefined,
+                                        AnofoxError *out_error) {
+	reset_error(out_error);
+	if (out_unrefined) *out_unrefined = 0;
+	if (!check_finalize(s, n_slots, core, inference, out_error)) return false;
+	if (n_slots == 0) return true;
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	AnofoxHipContext *ctx = s->ctx;
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	const size_t p = s->p, G = (size_t)n_slots;
+	const size_t b_core = align_up(G * (p + 6) * sizeof(double), 256);
+	const size_t b_inf = s->opt.compute_inference ? align_up(G * (5 * p + 2) * sizeof(double), 256) : 0;
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_core + b_inf, "staging", out_error)) return false;
+	double *d_core = (double *)ctx->stage;
+	double *d_inf = b_inf ? (double *)((char *)ctx->stage + b_core) : nullptr;
+	if (!run_finalize(s, n_slots, d_core, d_inf, out_error)) return false;
+	hipStream_t st = ctx->stream;
+	if (hip_fail(hipMemcpyAsync(core, d_core, G * (p + 6) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;
+	if (d_inf && hip_fail(hipMemcpyAsync(inference, d_inf, G * (5 * p + 2) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H inference", out_error)) return false;
+	int32_t queued = 0;
+	if (hip_fail(hipMemcpyAsync(&queued, ctx->last_refine_count, sizeof queued, hipMemcpyDeviceToHost, st), "D2H", out_error)) return false;
+	if (!check_slot_flag(s, out_error)) return false; // (synchronises the stream)
+	if (out_unrefined) *out_unrefined = queued;
+	return true;
+}
+
+void *anofox_hip_host_alloc(size_t bytes) {
+	void *p = nullptr;
+	if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return p;
+}
+
+void anofox_hip_host_free(void *p) {
+	if (p) (void)hipHostFree(p);
+}
+
+} // extern "C"

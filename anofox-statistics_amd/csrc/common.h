@@ -349,6 +349,46 @@ struct ResidualArgs {
 };
 hipError_t launch_residuals_narrow(const ResidualArgs &a, hipStream_t stream);
 
+// ---- streaming ingest (ingest.hip): row chunks in arrival order -> per-slot moment records, p <= kNarrowMaxP ----
+// A "slot" is one aggregate state (one GROUP BY key of one hash table).  The state keeps the narrow path's moment
+// record (MomentLayout<P>) per slot plus the number of rows the aggregate's Update accepted, i.e. what the
+// reference buffers as whole rows (src/aggregate_functions/ols_aggregate.cpp:19-42,120-186) reduced to O(p^2).
+constexpr int64_t kIngestChunkRows = 1 << 20; // rows folded per pass (bounds the staging and sort buffers)
+constexpr int kIngestPieceRows = 2048;        // a run longer than this within one chunk is cut into pieces
+constexpr int kIngestMaxBig = (int)(kIngestChunkRows / kIngestPieceRows) + 8;
+constexpr int kIngestMaxPieces = 2 * (int)(kIngestChunkRows / kIngestPieceRows) + 16;
+struct IngestArgs {
+	// one chunk of rows in arrival order (device pointers)
+	const uint32_t *slot;  // [n] state index of each row
+	const double *y;       // [n]
+	const double *x;       // [n * p] row-major (DuckDB's LIST(DOUBLE) child)
+	const double *w;       // [n] or nullptr
+	const uint8_t *valid;  // [n] or nullptr: 0 = the aggregate skips the row (NULL y / NULL x list / NULL weight)
+	int64_t n;
+	int p;
+	int weighted;
+	int center; // fit_intercept
+	// state
+	double *moments;   // [n_slots * moment_record_len(p)]
+	int64_t *n_accum;  // [n_slots] rows accepted by Update (the "< 2 rows -> NULL" rule looks at this)
+	int64_t n_slots;
+	// scratch of one pass
+	uint32_t *keys_in, *keys_out, *rows_out; // [n]
+	int32_t *run_start, *run_end;            // [n_slots]
+	uint32_t *run_list;                      // [n]
+	int32_t *counters;                       // [0] runs in this chunk (zeroed per pass)  [1] sticky: a slot index was out of range
+	void *piece_table;                       // ingest_piece_table_bytes(p)
+	void *sort_temp;
+	size_t sort_temp_bytes;
+};
+size_t ingest_piece_table_bytes(int p);
+size_t ingest_sort_temp_bytes(int64_t n);
+hipError_t launch_ingest_chunk(const IngestArgs &a, hipStream_t stream);
+// merge slot src[i] into slot dst[i] (dst's rows come first, as in OlsAggCombine: ols_aggregate.cpp:189-234) and
+// empty src[i]; the dst indices of one call must be distinct
+hipError_t launch_ingest_combine(double *moments, int64_t *n_accum, int64_t n_slots, const uint32_t *src, const uint32_t *dst,
+                                 int64_t n_pairs, int p, int center, hipStream_t stream);
+
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);
 hipError_t launch_inference_wide_finish(const WideArgs &a, hipStream_t stream); // after the last solve_wide mode

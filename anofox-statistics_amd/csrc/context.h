@@ -1,0 +1,107 @@
+// context.h — the context object and the small host-side helpers shared by the translation units that implement
+// the C ABI (host_api.hip, agg_state.hip).  Internal: nothing here is exported.
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+struct AnofoxHipContext {
+	int device = 0;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	std::mutex mu;
+	// device workspace (moments, refine queue, direct RSS)
+	void *ws = nullptr;
+	size_t ws_bytes = 0;
+	// device staging for the host-pointer entry points
+	void *stage = nullptr;
+	size_t stage_bytes = 0;
+	// small auxiliary device buffer (t-quantile memo of the predict kernel)
+	void *aux = nullptr;
+	size_t aux_bytes = 0;
+	const int32_t *last_refine_count = nullptr; // device address of the most recent launch's queue counter
+	hipEvent_t gate_wait = nullptr, gate_record = nullptr; // anofox_hip_context_set_accumulate_gate
+	// Student-t critical values for df = 1..kWindowTcritCap at the confidence level of the last window call
+	void *wtab = nullptr;
+	size_t wtab_bytes = 0;
+	double wtab_conf = -1.0;
+	// timing
+	bool timing = false;
+	std::vector<hipEvent_t> free_events;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_events, solve_events, predict_events;
+	// streaming aggregate states created on this context (agg_state.hip); destroying the context releases their
+	// device memory and leaves them detached (every later call on them fails, destroy still frees the object)
+	std::vector<struct AnofoxHipAggState *> agg_states;
+};
+
+namespace anofox {
+namespace host {
+void agg_state_detach(struct AnofoxHipAggState *s); // agg_state.hip
+}
+}
+
+namespace anofox {
+namespace host {
+
+
+inline void set_error(AnofoxError *e, AnofoxErrorCode code, const std::string &msg) {
+	if (!e) return;
+	e->code = code;
+	const size_t n = msg.size() < 255 ? msg.size() : 255;
+	memcpy(e->message, msg.data(), n);
+	e->message[n] = 0;
+}
+
+inline void reset_error(AnofoxError *e) {
+	if (!e) return;
+	e->code = ANOFOX_ERROR_SUCCESS;
+	memset(e->message, 0, sizeof e->message);
+}
+
+inline bool hip_fail(hipError_t rc, const char *what, AnofoxError *e) {
+	if (rc == hipSuccess) return false;
+	set_error(e, ANOFOX_ERROR_INTERNAL, std::string("HIP error in ") + what + ": " + hipGetErrorString(rc));
+	return true;
+}
+
+constexpr int kRefineSteps = 2; // iterative-refinement updates applied to queued groups
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline bool ensure_buffer(void **buf, size_t *cap, size_t need, const char *what, AnofoxError *e) {
+	if (need <= *cap) return true;
+	if (*buf) {
+		if (hip_fail(hipFree(*buf), "hipFree", e)) return false; // hipFree synchronises the device
+		*buf = nullptr;
+		*cap = 0;
+	}
+	const size_t want = align_up(need + need / 8, 1 << 20);
+	if (hipMalloc(buf, want) != hipSuccess) {
+		(void)hipGetLastError();
+		*buf = nullptr;
+		set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE, std::string("hipMalloc failed for ") + what);
+		return false;
+	}
+	*cap = want;
+	return true;
+}
+
+inline hipEvent_t get_event(AnofoxHipContext *ctx) {
+	if (!ctx->free_events.empty()) {
+		hipEvent_t ev = ctx->free_events.back();
+		ctx->free_events.pop_back();
+		return ev;
+	}
+	hipEvent_t ev = nullptr;
+	(void)hipEventCreate(&ev);
+	return ev;
+}
+
+} // namespace host
+} // namespace anofox

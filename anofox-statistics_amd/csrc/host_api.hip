@@ -21,86 +21,11 @@
 
 using namespace anofox;
 
-struct AnofoxHipContext {
-	int device = 0;
-	hipStream_t own_stream = nullptr;
-	hipStream_t stream = nullptr;
-	std::mutex mu;
-	// device workspace (moments, refine queue, direct RSS)
-	void *ws = nullptr;
-	size_t ws_bytes = 0;
-	// device staging for the host-pointer entry points
-	void *stage = nullptr;
-	size_t stage_bytes = 0;
-	// small auxiliary device buffer (t-quantile memo of the predict kernel)
-	void *aux = nullptr;
-	size_t aux_bytes = 0;
-	const int32_t *last_refine_count = nullptr; // device address of the most recent launch's queue counter
-	hipEvent_t gate_wait = nullptr, gate_record = nullptr; // anofox_hip_context_set_accumulate_gate
-	// Student-t critical values for df = 1..kWindowTcritCap at the confidence level of the last window call
-	void *wtab = nullptr;
-	size_t wtab_bytes = 0;
-	double wtab_conf = -1.0;
-	// timing
-	bool timing = false;
-	std::vector<hipEvent_t> free_events;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> acc_events, solve_events, predict_events;
-};
+#include "context.h"
+
+using namespace anofox::host;
 
 namespace {
-
-void set_error(AnofoxError *e, AnofoxErrorCode code, const std::string &msg) {
-	if (!e) return;
-	e->code = code;
-	const size_t n = msg.size() < 255 ? msg.size() : 255;
-	memcpy(e->message, msg.data(), n);
-	e->message[n] = 0;
-}
-
-void reset_error(AnofoxError *e) {
-	if (!e) return;
-	e->code = ANOFOX_ERROR_SUCCESS;
-	memset(e->message, 0, sizeof e->message);
-}
-
-bool hip_fail(hipError_t rc, const char *what, AnofoxError *e) {
-	if (rc == hipSuccess) return false;
-	set_error(e, ANOFOX_ERROR_INTERNAL, std::string("HIP error in ") + what + ": " + hipGetErrorString(rc));
-	return true;
-}
-
-constexpr int kRefineSteps = 2; // iterative-refinement updates applied to queued groups
-
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-bool ensure_buffer(void **buf, size_t *cap, size_t need, const char *what, AnofoxError *e) {
-	if (need <= *cap) return true;
-	if (*buf) {
-		if (hip_fail(hipFree(*buf), "hipFree", e)) return false; // hipFree synchronises the device
-		*buf = nullptr;
-		*cap = 0;
-	}
-	const size_t want = align_up(need + need / 8, 1 << 20);
-	if (hipMalloc(buf, want) != hipSuccess) {
-		(void)hipGetLastError();
-		*buf = nullptr;
-		set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE, std::string("hipMalloc failed for ") + what);
-		return false;
-	}
-	*cap = want;
-	return true;
-}
-
-hipEvent_t get_event(AnofoxHipContext *ctx) {
-	if (!ctx->free_events.empty()) {
-		hipEvent_t ev = ctx->free_events.back();
-		ctx->free_events.pop_back();
-		return ev;
-	}
-	hipEvent_t ev = nullptr;
-	(void)hipEventCreate(&ev);
-	return ev;
-}
 
 struct Workspace {
 	void *seg_table; // SegHeader + tables + segment records (common.h)
@@ -402,6 +327,14 @@ void anofox_hip_context_destroy(AnofoxHipContext *ctx) {
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	(void)hipStreamSynchronize(ctx->stream);
+	{
+		std::vector<AnofoxHipAggState *> states;
+		{
+			std::lock_guard<std::mutex> lk(ctx->mu);
+			states.swap(ctx->agg_states);
+		}
+		for (auto *st : states) agg_state_detach(st);
+	}
 	for (auto &pr : ctx->acc_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 	for (auto &pr : ctx->solve_events) { (void)hipEventDestroy(pr.second); }
 	for (auto ev : ctx->free_events) (void)hipEventDestroy(ev);

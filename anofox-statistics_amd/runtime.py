@@ -213,6 +213,119 @@ class Context:
 _DP = C.POINTER(C.c_double)
 
 
+class AggState:
+    """The streaming aggregate state of {ols,ridge,wls}_fit_agg on the GPU (anofox_hip_agg_state_*): one O(p^2)
+    moment record per slot; `update` folds row chunks in, `combine` merges slots, `finalize` solves them."""
+
+    def __init__(self, ctx: Context, n_features: int, options: _abi.AnofoxHipBatchOptions, initial_slots: int = 0):
+        self._lib = _abi.load()
+        self._ctx = ctx          # keeps the context alive
+        self.p = int(n_features)
+        self.options = options
+        err = _abi.AnofoxError()
+        h = C.c_void_p()
+        if not self._lib.anofox_hip_agg_state_create(ctx._h, self.p, options, int(initial_slots), C.byref(h), C.byref(err)):
+            raise AnofoxStatsError(err.code, err.text())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.anofox_hip_agg_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def n_slots(self) -> int:
+        return int(self._lib.anofox_hip_agg_state_slots(self._h))
+
+    @property
+    def n_rows(self) -> int:
+        return int(self._lib.anofox_hip_agg_state_rows(self._h))
+
+    def reserve(self, n_slots: int):
+        err = _abi.AnofoxError()
+        if not self._lib.anofox_hip_agg_state_reserve(self._h, int(n_slots), C.byref(err)):
+            raise AnofoxStatsError(err.code, err.text())
+
+    def update(self, slot, y, x_rowmajor, w=None, valid=None, n_slots: Optional[int] = None):
+        """Host chunk (numpy): slot uint32[n], y float64[n], x_rowmajor float64[n, p], w float64[n], valid uint8[n]."""
+        sl = np.ascontiguousarray(slot, dtype=np.uint32)
+        yv = np.ascontiguousarray(y, dtype=np.float64)
+        xv = np.ascontiguousarray(x_rowmajor, dtype=np.float64)
+        n = len(yv)
+        if len(sl) != n or xv.size != n * self.p:
+            raise ValueError("slot, y and x disagree in length")
+        wv = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+        vv = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint8)
+        if n_slots is None:
+            n_slots = max(self.n_slots, int(sl.max()) + 1 if n else 0)
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_agg_state_update_host(
+            self._h, n, int(n_slots), sl.ctypes.data, yv.ctypes.data, xv.ctypes.data,
+            None if wv is None else wv.ctypes.data, None if vv is None else vv.ctypes.data, C.byref(err))
+        if not ok:
+            raise AnofoxStatsError(err.code, err.text())
+
+    def update_device(self, slot, y, x_rowmajor, w=None, valid=None, n_slots: Optional[int] = None,
+                      use_current_torch_stream: bool = True):
+        """Device chunk (CUDA tensors): slot int32/uint32-as-int32[n], y[n], x_rowmajor[n, p], w[n], valid uint8[n]."""
+        import torch
+        n = int(y.numel())
+        if n_slots is None:
+            n_slots = max(self.n_slots, int(slot.max().item()) + 1 if n else 0)
+        if use_current_torch_stream:
+            self._ctx.set_stream(torch.cuda.current_stream(y.device).cuda_stream)
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_agg_state_update_device(
+            self._h, n, int(n_slots), C.c_void_p(slot.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(x_rowmajor.data_ptr()),
+            C.c_void_p(w.data_ptr() if w is not None else 0), C.c_void_p(valid.data_ptr() if valid is not None else 0),
+            C.byref(err))
+        if not ok:
+            raise AnofoxStatsError(err.code, err.text())
+
+    def combine(self, source_slots, target_slots):
+        src = np.ascontiguousarray(source_slots, dtype=np.uint32)
+        dst = np.ascontiguousarray(target_slots, dtype=np.uint32)
+        if len(src) != len(dst):
+            raise ValueError("source and target differ in length")
+        err = _abi.AnofoxError()
+        if not self._lib.anofox_hip_agg_state_combine(self._h, len(src), src.ctypes.data, dst.ctypes.data, C.byref(err)):
+            raise AnofoxStatsError(err.code, err.text())
+
+    def finalize(self, n_slots: Optional[int] = None):
+        """-> (core[G, p+6], inference[G, 5p+2] or None, groups that would have taken the refinement passes)."""
+        G = self.n_slots if n_slots is None else int(n_slots)
+        p = self.p
+        core = np.empty((G, p + 6), dtype=np.float64)
+        inf = np.empty((G, 5 * p + 2), dtype=np.float64) if self.options.compute_inference else None
+        unref = C.c_int64()
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_agg_state_finalize_host(
+            self._h, G, core.ctypes.data_as(_DP), None if inf is None else inf.ctypes.data_as(_DP), C.byref(unref),
+            C.byref(err))
+        if not ok:
+            raise AnofoxStatsError(err.code, err.text())
+        return core, inf, int(unref.value)
+
+    def finalize_device(self, core, inference=None, n_slots: Optional[int] = None, use_current_torch_stream: bool = True):
+        import torch
+        G = self.n_slots if n_slots is None else int(n_slots)
+        if use_current_torch_stream:
+            self._ctx.set_stream(torch.cuda.current_stream(core.device).cuda_stream)
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_agg_state_finalize_device(
+            self._h, G, C.c_void_p(core.data_ptr()), C.c_void_p(inference.data_ptr() if inference is not None else 0),
+            C.byref(err))
+        if not ok:
+            raise AnofoxStatsError(err.code, err.text())
+        return core, inference
+
+
 def fit_batch_host(row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,
                    ctx: Optional[Context] = None):
     """numpy in, numpy out: (core[G, p+6], inference[G, 5p+2] or None)."""

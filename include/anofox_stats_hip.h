@@ -420,6 +420,58 @@ ANOFOX_HIP_API bool anofox_hip_residuals_batch_host(AnofoxHipContext *ctx, int64
                                      const double *const *x_cols, const double *rse, bool include_studentized,
                                      bool drop_nan_rows, double *out, double *group, AnofoxError *out_error);
 
+/*
+ * Streaming aggregate state: the Update / Combine / Finalize callbacks of the three aggregates
+ * (src/aggregate_functions/ols_aggregate.cpp:120-186,189-234,249-338; ridge_aggregate.cpp:124-345;
+ * wls_aggregate.cpp:122-362) with the state kept on the GPU.  The reference buffers every row of every group on
+ * the host until Finalize; here ONE object holds an O(p^2) moment record per "slot" (= one DuckDB aggregate state:
+ * the shim's Initialize hands out slot numbers 0, 1, 2, ...) and rows are folded in as they arrive, in any order:
+ *
+ *   update    n_rows rows in arrival order: slot[i] (state of row i), y[i], x_rowmajor[i * p .. i * p + p) (the LIST
+ *             child as DuckDB delivers it), w[i] (WLS), valid[i] (optional; 0 = the row Update skips: NULL y, NULL x
+ *             list or NULL weight, ols_aggregate.cpp:150-159, wls_aggregate.cpp:160-166).  NULL list ELEMENTS are
+ *             passed as NaN (the row filter of the fit drops such rows, ols.rs:59-66).  n_slots = number of slots
+ *             handed out so far (every slot[i] < n_slots; the state grows to it).  The feature count is fixed at
+ *             creation — the shim keeps the reference's "Inconsistent feature count" check (ols_aggregate.cpp:165-175).
+ *             _host: pageable or pinned host memory (anofox_hip_host_alloc), staged through the GPU in chunks with the
+ *             copy of one chunk overlapping the kernels of the previous one; returns when the inputs may be reused.
+ *             _device: device pointers, asynchronous on the context's stream.
+ *   combine   pairs (source slot, target slot) as Combine receives them: the source's rows count as arriving AFTER
+ *             the target's (ols_aggregate.cpp:224-233) and the source is emptied; a slot may take part in one pair
+ *             per call.
+ *   finalize  fit records of slots [0, n_slots) exactly as anofox_hip_fit_batch_* lays them out (status 100 for
+ *             fewer than 2 accumulated rows, ols_aggregate.cpp:263-267).  The rows are gone, so the batch path's
+ *             refinement passes (re-reading the rows of ill-conditioned or exactly fitting groups) cannot run:
+ *             *out_unrefined (optional) is the number of groups that would have taken them.  hc_type other than
+ *             none needs the rows as well and is rejected at creation.
+ *
+ * A state belongs to one context (device + stream); calls on one state are serialised.  n_features <=
+ * anofox_hip_agg_state_max_features() = 8.
+ */
+typedef struct AnofoxHipAggState AnofoxHipAggState;
+ANOFOX_HIP_API size_t anofox_hip_agg_state_max_features(void);
+ANOFOX_HIP_API bool anofox_hip_agg_state_create(AnofoxHipContext *ctx, size_t n_features, AnofoxHipBatchOptions options,
+                                 int64_t initial_slots, AnofoxHipAggState **out_state, AnofoxError *out_error);
+ANOFOX_HIP_API void anofox_hip_agg_state_destroy(AnofoxHipAggState *state);
+ANOFOX_HIP_API bool anofox_hip_agg_state_reserve(AnofoxHipAggState *state, int64_t n_slots, AnofoxError *out_error);
+ANOFOX_HIP_API int64_t anofox_hip_agg_state_slots(const AnofoxHipAggState *state);
+ANOFOX_HIP_API int64_t anofox_hip_agg_state_rows(const AnofoxHipAggState *state);
+ANOFOX_HIP_API bool anofox_hip_agg_state_update_host(AnofoxHipAggState *state, int64_t n_rows, int64_t n_slots, const uint32_t *slot,
+                                      const double *y, const double *x_rowmajor, const double *w, const uint8_t *valid,
+                                      AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_agg_state_update_device(AnofoxHipAggState *state, int64_t n_rows, int64_t n_slots, const uint32_t *d_slot,
+                                        const double *d_y, const double *d_x_rowmajor, const double *d_w, const uint8_t *d_valid,
+                                        AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_agg_state_combine(AnofoxHipAggState *state, int64_t n_pairs, const uint32_t *source_slots,
+                                  const uint32_t *target_slots, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *state, int64_t n_slots, double *core, double *inference,
+                                        int64_t *out_unrefined, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *state, int64_t n_slots, double *d_core, double *d_inference,
+                                          AnofoxError *out_error);
+/* Page-locked host memory for the shim's row arenas (copies from it run at the full PCIe rate and asynchronously). */
+ANOFOX_HIP_API void *anofox_hip_host_alloc(size_t bytes);
+ANOFOX_HIP_API void anofox_hip_host_free(void *ptr);
+
 /* Predictions only, from existing fit records (d_core as produced by the fit entry points). */
 ANOFOX_HIP_API bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                      const int64_t *d_row_offsets, const double *const *x_cols, const double *d_core,

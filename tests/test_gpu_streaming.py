@@ -1,0 +1,328 @@
+"""GPU tests of the streaming aggregate state (anofox_hip_agg_state_*): Update with rows
+arriving in shuffled group order across many chunks, Combine of partial states, Finalize — against the oracle's fit
+of the same rows grouped (the reference buffers the rows, src/aggregate_functions/ols_aggregate.cpp:120-338, so its
+result is the fit of each group's rows in arrival order)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import COEF_RTOL, DIAG_RTOL, assert_records_match, import_pkg, load_csv, load_json, nan_or
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return import_pkg()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context()
+    yield c
+    c.close()
+
+
+def _rows(rng, G, p, n_lo, n_hi, offset=0.0):
+    """Rows of G groups in ARRIVAL order (shuffled): slot, y, X[n, p], w."""
+    ns = rng.integers(n_lo, n_hi + 1, size=G)
+    slot = np.repeat(np.arange(G, dtype=np.uint32), ns)
+    rng.shuffle(slot)
+    N = len(slot)
+    X = rng.uniform(-10, 10, (N, p)) + offset
+    beta = rng.uniform(-5, 5, (G, p))
+    b0 = rng.uniform(-10, 10, G)
+    y = b0[slot] + np.einsum("ij,ij->i", beta[slot], X) + 2.0 * rng.standard_normal(N)
+    w = rng.uniform(0.5, 1.5, N)
+    return slot, y, X, w
+
+
+def _grouped(slot, y, X, w, G, keep=None):
+    """What the reference's state holds at Finalize: each group's accepted rows in arrival order."""
+    idx = np.arange(len(slot)) if keep is None else np.nonzero(keep)[0]
+    order = idx[np.argsort(slot[idx], kind="stable")]
+    counts = np.bincount(slot[idx], minlength=G)
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return offs, y[order], [np.ascontiguousarray(X[order, j]) for j in range(X.shape[1])], w[order]
+
+
+def _kw(model, icpt, inference=True):
+    kw = dict(fit_intercept=icpt, compute_inference=inference, confidence_level=0.9)
+    if model == "ridge":
+        kw["alpha"] = 1.5
+    return kw
+
+
+def _feed(st, slot, y, X, w, G, sizes, valid=None):
+    r0 = 0
+    k = 0
+    while r0 < len(slot):
+        n = sizes[k % len(sizes)]
+        k += 1
+        sl = slice(r0, r0 + n)
+        st.update(slot[sl], y[sl], X[sl], None if w is None else w[sl], None if valid is None else valid[sl], n_slots=G)
+        r0 += n
+
+
+@pytest.mark.parametrize("model", ["ols", "ridge", "wls"])
+@pytest.mark.parametrize("p", [1, 3, 8])
+@pytest.mark.parametrize("icpt", [True, False])
+def test_shuffled_chunks_match_oracle(pkg, ctx, model, p, icpt):
+    rng = np.random.default_rng(100 * p + 10 * len(model) + int(icpt))
+    G = 300
+    slot, y, X, w = _rows(rng, G, p, 2, 400)
+    kw = _kw(model, icpt)
+    st = pkg.AggState(ctx, p, pkg.RegressionOptions(**kw).batch_options(model))
+    wv = w if model == "wls" else None
+    _feed(st, slot, y, X, wv, G, [2048, 1, 777, 5000, 64])          # DuckDB-sized vectors and odd ones
+    core, inf, unref = st.finalize()
+    offs, yg, xg, wg = _grouped(slot, y, X, w, G)
+    rcore, rinf = oracle.fit_groups(yg, xg, offs, w=(wg if model == "wls" else None), model=model, **kw)
+    assert core.shape == (G, p + 6) and st.n_rows == len(slot)
+    zero_df = [g for g in range(G) if rcore[g, p + 5] == 0 and rcore[g, p + 4] <= p + int(icpt)]
+    assert_records_match(core, rcore, p, inf, rinf, what=f"streaming {model} p={p} icpt={icpt}", skip_diag_groups=zero_df)
+    st.close()
+
+
+@pytest.mark.parametrize("model", ["ols", "wls"])
+def test_one_call_with_millions_of_rows_and_huge_runs(pkg, ctx, model):
+    """One update call above kIngestChunkRows (sub-chunked inside the library), rows partly sorted so that single
+    groups contribute runs far longer than kIngestPieceRows (the piece path), partly shuffled."""
+    rng = np.random.default_rng(9)
+    p, G = 4, 40
+    ns = np.full(G, 30_000)
+    ns[0] = 900_000                       # one group is most of the batch: hundreds of pieces per chunk
+    ns[1] = 2                             # and tiny ones
+    ns[2] = 1
+    slot = np.repeat(np.arange(G, dtype=np.uint32), ns)      # sorted arrival: long runs
+    tail = slot[-300_000:].copy()
+    rng.shuffle(tail)
+    slot[-300_000:] = tail
+    N = len(slot)
+    assert N > (1 << 20)
+    X = rng.uniform(-10, 10, (N, p)) + 50.0
+    beta = rng.uniform(-5, 5, (G, p))
+    y = np.einsum("ij,ij->i", beta[slot], X) + 3.0 + 2.0 * rng.standard_normal(N)
+    w = rng.uniform(0.5, 1.5, N)
+    kw = _kw(model, True)
+    st = pkg.AggState(ctx, p, pkg.RegressionOptions(**kw).batch_options(model))
+    st.update(slot, y, X, w if model == "wls" else None, n_slots=G)
+    core, inf, _ = st.finalize()
+    offs, yg, xg, wg = _grouped(slot, y, X, w, G)
+    rcore, rinf = oracle.fit_groups(yg, xg, offs, w=(wg if model == "wls" else None), model=model, n_threads=8, **kw)
+    assert_records_match(core, rcore, p, inf, rinf, what=f"streaming huge runs {model}")
+    assert core[2, p + 5] == 100 and core[1, p + 5] == 6      # one row -> NULL; two rows, five parameters -> InsufficientData
+    st.close()
+
+
+def test_skipped_rows_invalid_values_and_empty_slots(pkg, ctx):
+    """valid = 0 rows are not accumulated at all (Update's NULL skip: they do not count towards the '< 2 rows -> NULL'
+    rule); NaN / inf values are accumulated rows that the fit's row filter drops (ols.rs:59-66); slots that never
+    receive an accepted row come out NULL; constant and collinear columns as in the batch path."""
+    rng = np.random.default_rng(3)
+    p, G = 3, 64
+    slot, y, X, w = _rows(rng, G, p, 1, 60)
+    N = len(slot)
+    valid = (rng.uniform(size=N) > 0.15).astype(np.uint8)
+    valid[slot == 5] = 0                               # slot 5: every row skipped -> NULL (0 accumulated rows)
+    y[rng.uniform(size=N) < 0.05] = np.nan             # accumulated, then filtered
+    X[rng.uniform(size=N) < 0.03, 1] = np.inf
+    w[rng.uniform(size=N) < 0.05] = -1.0               # WLS: non-positive weight -> filtered
+    X[slot == 7, 2] = 4.25                             # constant column -> NaN coefficient
+    X[slot == 9, 1] = 2.0 * X[slot == 9, 0] + 1.0      # collinear -> aliased
+    y[slot == 11] = np.nan                             # no valid row at all -> NoValidData
+    kw = _kw("wls", True)
+    st = pkg.AggState(ctx, p, pkg.RegressionOptions(**kw).batch_options("wls"))
+    _feed(st, slot, y, X, w, G + 3, [500, 33], valid=valid)      # 3 slots beyond the last one that gets rows
+    core, inf, _ = st.finalize()
+    assert core.shape[0] == G + 3
+    keep = valid != 0
+    offs, yg, xg, wg = _grouped(slot, y, X, w, G + 3, keep=keep)
+    rcore, rinf = oracle.fit_groups(yg, xg, offs, w=wg, model="wls", **kw)
+    zero_df = [g for g in range(G + 3) if rcore[g, p + 5] == 0 and rcore[g, p + 4] <= p + 1]
+    assert_records_match(core, rcore, p, inf, rinf, what="streaming NULLs", skip_diag_groups=zero_df)
+    assert core[5, p + 5] == 100 and np.all(core[G:, p + 5] == 100)
+    assert core[11, p + 5] == 10          # NoValidData
+    assert np.isnan(core[7, 2]) and core[7, p + 5] == 0
+    st.close()
+
+
+@pytest.mark.parametrize("model,icpt", [("ols", True), ("wls", True), ("ridge", False)])
+def test_combine_merges_partial_states(pkg, ctx, model, icpt):
+    """Three thread-local hash tables share one device state: keys overlap, Combine merges (source rows count as
+    arriving after the target's), and the result equals the oracle's fit of the concatenated buffers."""
+    rng = np.random.default_rng(17 + len(model))
+    p, G = 5, 120
+    kw = _kw(model, icpt)
+    parts = []
+    for t in range(3):
+        slot, y, X, w = _rows(rng, G, p, 0, 90, offset=20.0 * t)
+        present = rng.uniform(size=G) < 0.8                      # not every key is seen by every thread
+        m = present[slot]
+        parts.append((slot[m], y[m], X[m], w[m]))
+    st = pkg.AggState(ctx, p, pkg.RegressionOptions(**kw).batch_options(model))
+    # thread t's state of key g lives in slot t * G + g
+    for t, (slot, y, X, w) in enumerate(parts):
+        _feed(st, slot + np.uint32(t * G), y, X, w if model == "wls" else None, 3 * G, [1000, 17])
+    ar = np.arange(G, dtype=np.uint32)
+    st.combine(ar + G, ar)                 # thread 1 into thread 0
+    st.combine(ar + 2 * G, ar)             # thread 2 into thread 0
+    core, inf, _ = st.finalize()
+    slot = np.concatenate([q[0] for q in parts])
+    y = np.concatenate([q[1] for q in parts])
+    X = np.concatenate([q[2] for q in parts])
+    w = np.concatenate([q[3] for q in parts])
+    offs, yg, xg, wg = _grouped(slot, y, X, w, G)                # stable: thread 0's rows, then 1's, then 2's
+    rcore, rinf = oracle.fit_groups(yg, xg, offs, w=(wg if model == "wls" else None), model=model, **kw)
+    zero_df = [g for g in range(G) if rcore[g, p + 5] == 0 and rcore[g, p + 4] <= p + 1]
+    assert_records_match(core[:G], rcore, p, inf[:G], rinf, what=f"combine {model}", skip_diag_groups=zero_df)
+    assert np.all(core[G:, p + 5] == 100)                        # the sources were emptied
+    with pytest.raises(pkg.AnofoxStatsError):
+        st.combine([1, 1], [2, 3])                               # a slot twice in one call
+    with pytest.raises(pkg.AnofoxStatsError):
+        st.combine([1], [3 * G + 5])                             # out of range
+    st.close()
+
+
+def test_creation_and_argument_errors(pkg, ctx):
+    o = pkg.RegressionOptions().batch_options("ols")
+    with pytest.raises(pkg.AnofoxStatsError) as ei:
+        pkg.AggState(ctx, 9, o)
+    assert ei.value.code == 1 and "features" in str(ei.value)
+    with pytest.raises(pkg.AnofoxStatsError):
+        pkg.AggState(ctx, 0, o)
+    with pytest.raises(pkg.AnofoxStatsError) as ei:
+        pkg.AggState(ctx, 3, pkg.RegressionOptions(compute_inference=True, hc_type="hc3").batch_options("ols"))
+    assert "hc_type" in str(ei.value)
+    st = pkg.AggState(ctx, 2, pkg.RegressionOptions().batch_options("wls"))
+    with pytest.raises(pkg.AnofoxStatsError):
+        st.update([0], [1.0], [[1.0, 2.0]], None, n_slots=1)     # WLS without weights
+    st.close()
+    st = pkg.AggState(ctx, 2, o)
+    st.update([0, 0, 0, 7], [1.0, 2.0, 3.5, 1.0], [[1, 2], [2, 1], [3, 5], [0, 0]], n_slots=4)   # slot 7 >= n_slots
+    with pytest.raises(pkg.AnofoxStatsError) as ei:
+        st.finalize()
+    assert "slot index" in str(ei.value)
+    st.close()
+    st = pkg.AggState(ctx, 2, o)                                 # nothing ever updated
+    core, inf, _ = st.finalize()
+    assert core.shape == (0, 8) and inf is None
+    st.close()
+
+
+def test_device_chunks_and_agreement_with_the_batch_path(pkg, ctx):
+    """update_device on shuffled device-resident chunks at a size the batch path fits in milliseconds: every group
+    against the batch kernels (an independent accumulation order, so agreement is to rounding, not bit for bit), a
+    sample against the oracle."""
+    import torch
+    synth = import_pkg("synth")
+    G, n, p = 50_000, 64, 8
+    offs, y, x_cols, w = synth.make_grouped(G, n, p, weights=True, device="cuda:0")
+    N = G * n
+    perm = torch.randperm(N, device="cuda:0")
+    slot = (perm // n).to(torch.int32)
+    X = torch.stack(x_cols, dim=1)[perm].contiguous()
+    ys, ws = y[perm].contiguous(), w[perm].contiguous()
+    for model in ("ols", "wls"):
+        opts = pkg.RegressionOptions(compute_inference=True).batch_options(model)
+        st = pkg.AggState(ctx, p, opts, initial_slots=G)
+        step = 700_001
+        for r0 in range(0, N, step):
+            sl = slice(r0, min(N, r0 + step))
+            st.update_device(slot[sl], ys[sl], X[sl], ws[sl] if model == "wls" else None, n_slots=G)
+        core = torch.empty((G, p + 6), dtype=torch.float64, device="cuda:0")
+        inf = torch.empty((G, 5 * p + 2), dtype=torch.float64, device="cuda:0")
+        st.finalize_device(core, inf)
+        bcore, binf = ctx.fit_batch_device(offs, y, x_cols, w if model == "wls" else None, opts)
+        torch.cuda.synchronize()
+        assert bool((core[:, p + 5] == 0).all()) and bool((core[:, p + 4] == n).all())
+        scale = bcore[:, :p + 1].abs().max(dim=1, keepdim=True).values
+        assert float(((core[:, :p + 1] - bcore[:, :p + 1]).abs() / torch.maximum(bcore[:, :p + 1].abs(), 1e-3 * scale)).max()) < COEF_RTOL
+        assert float((core[:, p + 1:p + 4] / bcore[:, p + 1:p + 4] - 1.0).abs().max()) < DIAG_RTOL
+        assert float(((inf - binf).abs() / binf.abs().clamp_min(1e-300))[:, :2 * p].max()) < DIAG_RTOL
+        # the oracle sees a group's rows in arrival order = ascending position in the permutation
+        S = 64
+        rows = torch.nonzero(slot < S).squeeze(1)
+        so, ysr, Xs, wsr = slot[rows].cpu().numpy().astype(np.uint32), ys[rows].cpu().numpy(), X[rows].cpu().numpy(), ws[rows].cpu().numpy()
+        go, yg, xg, wg = _grouped(so, ysr, Xs, wsr, S)
+        rcore, rinf = oracle.fit_groups(yg, xg, go, w=(wg if model == "wls" else None), model=model, compute_inference=True)
+        assert_records_match(core[:S].cpu().numpy(), rcore, p, inf[:S].cpu().numpy(), rinf, what=f"streaming device {model}")
+        st.close()
+
+
+@pytest.mark.parametrize("case,xn,icpt", [("simple_linear", ["x"], True), ("multiple_regression", ["x1", "x2", "x3"], True),
+                                          ("no_intercept", ["x"], False), ("rank_deficient", ["x1", "x2"], True),
+                                          ("perfect_collinearity", ["x1", "x2"], True)])
+def test_reference_fixtures_through_the_streaming_aggregate(pkg, ctx, case, xn, icpt):
+    """The R fixtures of test/data/ols_tests through the aggregate mirror with a GPU-resident state: the fixture's
+    rows (group 1) arrive interleaved with rows of another group, in small updates; the fixture's rows keep their
+    own order."""
+    from conftest import rel_err
+    d = load_csv(f"ols_tests/input/{case}.csv")
+    e = load_json(f"ols_tests/expected/{case}.json")
+    X = np.stack([d[c] for c in xn], axis=1)
+    y = d["y"]
+    n = len(y)
+    rng = np.random.default_rng(1)
+    agg = pkg.OlsFitAgg({"intercept": icpt}, ctx, streaming=True)
+    Xa = np.concatenate([X, rng.uniform(-1, 1, (n, len(xn)))])
+    ya = np.concatenate([y, rng.uniform(-1, 1, n)])
+    keys = np.concatenate([np.full(n, 1), np.full(n, 2)])
+    order = np.argsort(np.concatenate([np.arange(n) + 0.25, rng.uniform(0, n, n)]), kind="stable")
+    for c0 in range(0, 2 * n, 37):
+        sel = order[c0:c0 + 37]
+        agg.update(keys[sel], ya[sel], Xa[sel])
+    res = agg.finalize()
+    assert list(res.keys) == [1, 2]
+    r = res.row(0)
+    assert r is not None
+    coefs = e["coefficients"] if isinstance(e["coefficients"], list) else [e["coefficients"]]
+    coefs = [nan_or(c) for c in coefs]
+    slopes = coefs[1:] if icpt else coefs
+    if icpt:
+        assert rel_err(r["intercept"], coefs[0]) < COEF_RTOL
+    else:
+        assert np.isnan(r["intercept"])
+    for got, want in zip(r["coefficients"], slopes):
+        assert (np.isnan(got) and np.isnan(want)) or rel_err(got, want) < COEF_RTOL
+    assert rel_err(r["r_squared"], e["r_squared"]) < DIAG_RTOL
+    assert rel_err(r["adj_r_squared"], e["adj_r_squared"]) < DIAG_RTOL
+    assert rel_err(r["residual_std_error"], e["sigma"]) < DIAG_RTOL
+    assert r["n_observations"] == n and r["n_features"] == len(xn)
+
+
+def test_streaming_mirror_equals_buffered_mirror_with_combine(pkg, ctx):
+    """OlsFitAgg / WlsFitAgg with streaming=<pool>: two 'threads' update disjoint row sets with NULLs in y, x and w,
+    Combine, Finalize — same SQL-level result as the buffered mirror (same keys, same NULL groups, values to 1e-9)."""
+    rng = np.random.default_rng(23)
+    n, p = 4000, 3
+    keys = rng.integers(0, 50, n)
+    X = rng.uniform(-3, 3, (n, p))
+    y = X @ np.array([1.0, -2.0, 0.5]) + 0.1 * keys + rng.standard_normal(n)
+    w = rng.uniform(0.5, 2.0, n)
+    yl = [None if rng.uniform() < 0.05 else float(v) for v in y]
+    xl = [None if rng.uniform() < 0.05 else r.tolist() for r in X]
+    wl = [None if rng.uniform() < 0.05 else float(v) for v in w]
+    keys[-3:] = [900, 901, 901]                       # a one-row group and a two-row group
+    for cls, has_w in ((pkg.OlsFitAgg, False), (pkg.WlsFitAgg, True)):
+        opts = {"compute_inference": True}
+        pool = pkg.StreamingStates(ctx)
+        a, b = cls(opts, ctx, streaming=pool), cls(opts, ctx, streaming=pool)
+        ra, rb = cls(opts, ctx), cls(opts, ctx)
+        half = n // 2
+        for agg in (a, ra):
+            for c0 in range(0, half, 512):
+                sl = slice(c0, min(half, c0 + 512))
+                agg.update(keys[sl], yl[sl], xl[sl], *([wl[sl]] if has_w else []))
+        for agg in (b, rb):
+            for c0 in range(half, n, 512):
+                sl = slice(c0, min(n, c0 + 512))
+                agg.update(keys[sl], yl[sl], xl[sl], *([wl[sl]] if has_w else []))
+        got = a.combine(b).finalize()
+        want = ra.combine(rb).finalize()
+        assert np.array_equal(got.keys, want.keys) and np.array_equal(got.is_null, want.is_null)
+        assert np.array_equal(got.status, want.status) and np.array_equal(got.n_observations, want.n_observations)
+        ok = ~want.is_null
+        for f in ("coefficients", "intercept", "r_squared", "residual_std_error", "std_errors", "t_values", "f_statistic"):
+            g, r = getattr(got, f)[ok], getattr(want, f)[ok]
+            assert np.allclose(g, r, rtol=1e-9, atol=1e-12, equal_nan=True), f
