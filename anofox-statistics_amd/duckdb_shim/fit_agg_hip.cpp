@@ -1,52 +1,154 @@
-// fit_agg_hip.cpp — DuckDB-side shim for the three aggregates.
+// fit_agg_hip.cpp — DuckDB glue of the three aggregates over the GPU-resident state.
 //
-// Drop-in replacements for the Finalize callbacks of the reference's
-//   src/aggregate_functions/ols_aggregate.cpp:249-338    (OlsAggFinalize)
-//   src/aggregate_functions/ridge_aggregate.cpp:255-345  (RidgeAggFinalize)
-//   src/aggregate_functions/wls_aggregate.cpp:268-362    (WlsAggFinalize)
-// which loop one anofox_*_fit FFI call per group state.  Here the states of one Finalize vector (up to
-// STANDARD_VECTOR_SIZE = 2048 groups) are packed into grouped columns and fitted with ONE call of
-// anofox_hip_fit_batch_host (include/anofox_stats_hip.h).  Everything else of those files — state structs, Bind,
-// Update, Combine, Destroy, registration under anofox_stats_*_fit_agg and the short aliases — stays as it is.
+// Replaces, in the reference's
+//   src/aggregate_functions/ols_aggregate.cpp    (state :19-42, Initialize :103, Destroy :108, Update :120-186,
+//                                                 Combine :189-234, Finalize :249-338)
+//   src/aggregate_functions/ridge_aggregate.cpp  (:19-43, :124-191, :194-240, :255-345)
+//   src/aggregate_functions/wls_aggregate.cpp    (:19-44, :122-201, :204-253, :268-362)
+// the per-group std::vector row buffers and the one-FFI-call-per-group Finalize.  The DuckDB state shrinks to a
+// slot number; the rows go through anofox_shim::AggArena (agg_arena.hpp: page-locked chunk buffers ->
+// anofox_hip_agg_state_update_host) into one O(p^2) moment record per slot on the GPU; Finalize reads the records of
+// one batched solve.  Bind, the result type, the options parser and the registration (names, aliases, overloads:
+// ols_aggregate.cpp:74-96,343-426) stay exactly as they are — only the five callbacks and the state size change:
 //
-// NOT COMPILED IN THIS REPOSITORY: the reference's `duckdb` submodule (headers) is not available here; written
-// against the DuckDB v1.4.5 / v1.5.5 API exactly as the reference uses it.  The three
-// wrapper functions at the bottom have the signature DuckDB expects for `aggregate_finalize_t`.
-#include <vector>
-
+//   AggregateFunction(name, args, LogicalType::ANY, AggregateFunction::StateSize<HipAggState>, HipAggInitialize,
+//                     HipAggUpdate<OlsTraits>, HipAggCombine, HipAggFinalize<OlsTraits>, nullptr, OlsAggBind, HipAggDestroy)
+//
+// and the bind data gains one member, `shared_ptr<anofox_shim::AggArena> arena`, created in Bind from the parsed
+// options and shared by Copy() (every thread of the query must reach the same state).
+//
+// NOT COMPILED IN THIS REPOSITORY: the reference's `duckdb` submodule (headers) is empty here; written against the
+// DuckDB v1.4.5 / v1.5.5 API exactly as the reference uses it.  All logic that does not need
+// DuckDB types lives in agg_arena.hpp, which IS compiled and tested here (arena_capi.cpp, tests/test_gpu_arena.py).
 #include "duckdb.hpp"
 #include "duckdb/function/aggregate_function.hpp"
 
 #include "../include/anofox_stats_ffi.h" // the reference's header: structs and enums
 #include "../include/ffi_enum_converters.hpp"
-#include "anofox_stats_hip.h"            // after the reference's header: adds only the batch API
+#include "anofox_stats_hip.h"            // after the reference's header: adds only the batch / state API
+#include "agg_arena.hpp"
 
 namespace duckdb {
 
-namespace {
+// The whole DuckDB-side aggregate state: which slot of the query's GPU state this group (of this thread's hash
+// table) owns.  -1 until the first Update touches it (Initialize has no access to the bind data).
+struct HipAggState {
+	int64_t slot;
+};
 
-// Field access differs per model only in the weights buffer and the ridge options.
+// What the three bind-data classes add (OlsAggregateBindData etc. keep their option fields):
+struct HipAggBindMixin {
+	shared_ptr<anofox_shim::AggArena> arena;
+};
+
 struct OlsTraits {
-	static constexpr AnofoxHipModel kModel = ANOFOX_HIP_MODEL_OLS;
-	template <class STATE> static const vector<double> *Weights(const STATE &) { return nullptr; }
-	template <class STATE> static void Fill(const STATE &s, AnofoxHipBatchOptions &o) { o.hc_type = ConvertHcType(s.hc_type); }
+	static constexpr bool kWeighted = false;
+	using BindData = OlsAggregateBindData; // + HipAggBindMixin
 };
 struct RidgeTraits {
-	static constexpr AnofoxHipModel kModel = ANOFOX_HIP_MODEL_RIDGE;
-	template <class STATE> static const vector<double> *Weights(const STATE &) { return nullptr; }
-	template <class STATE> static void Fill(const STATE &s, AnofoxHipBatchOptions &o) {
-		o.alpha = s.alpha;
-		o.lambda_scaling = ConvertLambdaScaling(s.lambda_scaling);
-		o.hc_type = ANOFOX_HC_NONE;
-	}
+	static constexpr bool kWeighted = false;
+	using BindData = RidgeAggregateBindData;
 };
 struct WlsTraits {
-	static constexpr AnofoxHipModel kModel = ANOFOX_HIP_MODEL_WLS;
-	template <class STATE> static const vector<double> *Weights(const STATE &s) { return &s.weights; }
-	template <class STATE> static void Fill(const STATE &s, AnofoxHipBatchOptions &o) { o.hc_type = ConvertHcType(s.hc_type); }
+	static constexpr bool kWeighted = true;
+	using BindData = WlsAggregateBindData;
 };
 
-void AppendList(Vector &list_vec, idx_t row, const double *src, idx_t n) {
+// Bind-time helper: the batch options of the query from the parsed bind data (called at the end of *AggBind).
+template <class BIND>
+AnofoxHipBatchOptions MakeHipOptions(const BIND &b, AnofoxHipModel model) {
+	AnofoxHipBatchOptions o {};
+	o.model = model;
+	o.fit_intercept = b.fit_intercept;
+	o.compute_inference = b.compute_inference;
+	o.confidence_level = b.confidence_level;
+	o.solver = ConvertSolverType(b.solver);
+	o.alpha = 1.0;
+	return o; // ridge: o.alpha = b.alpha, o.lambda_scaling = ConvertLambdaScaling(b.lambda_scaling); ols/wls: o.hc_type
+}
+
+static void HipAggInitialize(const AggregateFunction &, data_ptr_t state_p) {
+	reinterpret_cast<HipAggState *>(state_p)->slot = -1;
+}
+
+static void HipAggDestroy(Vector &, AggregateInputData &, idx_t) {
+	// nothing per state: the slots belong to the arena, which the bind data's shared_ptr releases with the query
+}
+
+// Update: ols_aggregate.cpp:120-186 / wls_aggregate.cpp:122-201 with the push_backs replaced by one arena append.
+template <class TRAITS>
+static void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, idx_t input_count, Vector &state_vector, idx_t count) {
+	auto &bind = aggr_input_data.bind_data->Cast<typename TRAITS::BindData>();
+	auto &arena = *bind.arena;
+	UnifiedVectorFormat y_data, x_data, w_data, sdata;
+	inputs[0].ToUnifiedFormat(count, y_data);
+	inputs[1].ToUnifiedFormat(count, x_data);
+	if (TRAITS::kWeighted) inputs[2].ToUnifiedFormat(count, w_data);
+	auto y_values = UnifiedVectorFormat::GetData<double>(y_data);
+	auto w_values = TRAITS::kWeighted ? UnifiedVectorFormat::GetData<double>(w_data) : nullptr;
+	auto x_list = ListVector::GetData(inputs[1]);
+	auto &x_child = ListVector::GetEntry(inputs[1]);
+	auto x_child_data = FlatVector::GetData<double>(x_child);
+	auto &x_child_validity = FlatVector::Validity(x_child);
+	state_vector.ToUnifiedFormat(count, sdata);
+	auto states = (HipAggState **)sdata.data;
+
+	anofox_shim::AggArena::Writer writer(arena); // one lock per vector
+	double row[8];
+	for (idx_t i = 0; i < count; i++) {
+		auto &state = *states[sdata.sel->get_index(i)];
+		if (state.slot < 0) state.slot = writer.NewSlot(); // the group exists even if every row of it is skipped
+		auto y_idx = y_data.sel->get_index(i);
+		if (!y_data.validity.RowIsValid(y_idx)) continue;                       // ols_aggregate.cpp:150-153
+		auto x_idx = x_data.sel->get_index(i);
+		if (!x_data.validity.RowIsValid(x_idx)) continue;                       // :157-159
+		double w = 1.0;
+		if (TRAITS::kWeighted) {
+			auto w_idx = w_data.sel->get_index(i);
+			if (!w_data.validity.RowIsValid(w_idx)) continue;                   // wls_aggregate.cpp:160-166
+			w = w_values[w_idx];
+		}
+		auto entry = x_list[x_idx];
+		if (entry.length > 8 && arena.FeatureCount() == 0)
+			throw InvalidInputException("anofox_stats fit_agg (HIP): more than 8 features need the batched Finalize path");
+		const idx_t n = entry.length <= 8 ? entry.length : 8;
+		for (idx_t j = 0; j < n; j++) // a NULL list element becomes NaN: the fit's row filter drops the row (ols.rs:59-66)
+			row[j] = x_child_validity.RowIsValid(entry.offset + j) ? x_child_data[entry.offset + j] : NAN;
+		try {
+			writer.Append((uint32_t)state.slot, y_values[y_idx], row, entry.length, w);
+		} catch (const std::invalid_argument &e) {
+			throw InvalidInputException(e.what());                              // "Inconsistent feature count: ..." (:172-175)
+		}
+	}
+}
+
+// Combine: ols_aggregate.cpp:189-234.  A source without a slot has seen no Update; a target without one adopts the
+// source's slot (the reference moves the buffers); otherwise the pair is merged on the GPU.
+static void HipAggCombine(Vector &source_vector, Vector &target_vector, AggregateInputData &aggr_input_data, idx_t count) {
+	UnifiedVectorFormat source_data, target_data;
+	source_vector.ToUnifiedFormat(count, source_data);
+	target_vector.ToUnifiedFormat(count, target_data);
+	auto sources = (HipAggState **)source_data.data;
+	auto targets = (HipAggState **)target_data.data;
+	vector<uint32_t> src, dst;
+	for (idx_t i = 0; i < count; i++) {
+		auto &source = *sources[source_data.sel->get_index(i)];
+		auto &target = *targets[target_data.sel->get_index(i)];
+		if (source.slot < 0) continue;
+		if (target.slot < 0) {
+			target.slot = source.slot;
+			source.slot = -1;
+			continue;
+		}
+		src.push_back((uint32_t)source.slot);
+		dst.push_back((uint32_t)target.slot);
+	}
+	if (src.empty()) return;
+	auto &arena = *aggr_input_data.bind_data->Cast<HipAggBindMixin>().arena;
+	arena.Combine(src.data(), dst.data(), src.size());
+}
+
+static void AppendList(Vector &list_vec, idx_t row, const double *src, idx_t n) {
 	auto entries = ListVector::GetData(list_vec);
 	auto offset = ListVector::GetListSize(list_vec);
 	ListVector::Reserve(list_vec, offset + n); // the reference's SetListInResult omits this (ols_aggregate.cpp:237-246)
@@ -57,73 +159,24 @@ void AppendList(Vector &list_vec, idx_t row, const double *src, idx_t n) {
 	ListVector::SetListSize(list_vec, offset + n);
 }
 
-template <class STATE, class TRAITS>
-void BatchedFinalize(Vector &state_vector, Vector &result, idx_t count, idx_t offset) {
+// Finalize: ols_aggregate.cpp:249-338.  The first call of the query solves every slot at once; each call then only
+// copies its <= 2048 records into the STRUCT vector (field order of GetOlsAggResultType, :74-96).
+template <class TRAITS>
+static void HipAggFinalize(Vector &state_vector, AggregateInputData &aggr_input_data, Vector &result, idx_t count, idx_t offset) {
+	auto &bind = aggr_input_data.bind_data->Cast<typename TRAITS::BindData>();
+	auto &arena = *bind.arena;
+	arena.Solve();
+	const idx_t p = arena.FeatureCount();
 	UnifiedVectorFormat sdata;
 	state_vector.ToUnifiedFormat(count, sdata);
-	auto states = (STATE **)sdata.data;
-
-	// 1. grouped columns: rows of state i are [offsets[i], offsets[i+1]); uninitialised states hold no rows and
-	//    come back with status 100 (the "< 2 rows -> NULL" rule of ols_aggregate.cpp:263-267)
-	vector<int64_t> offsets(count + 1, 0);
-	idx_t p = 0;
-	const STATE *any = nullptr;
-	for (idx_t i = 0; i < count; i++) {
-		auto &st = *states[sdata.sel->get_index(i)];
-		offsets[i + 1] = offsets[i] + (st.initialized ? (int64_t)st.y_values.size() : 0);
-		if (st.initialized) {
-			p = st.n_features;
-			any = &st;
-		}
-	}
-	if (!any) {
-		for (idx_t i = 0; i < count; i++) FlatVector::SetNull(result, i + offset, true);
-		return;
-	}
-	const idx_t n_rows = (idx_t)offsets[count];
-	vector<double> y(n_rows), w;
-	vector<vector<double>> x(p, vector<double>(n_rows));
-	const bool weighted = TRAITS::Weights(*any) != nullptr;
-	if (weighted) w.resize(n_rows);
-	for (idx_t i = 0; i < count; i++) {
-		auto &st = *states[sdata.sel->get_index(i)];
-		if (!st.initialized) continue;
-		std::copy(st.y_values.begin(), st.y_values.end(), y.begin() + offsets[i]);
-		for (idx_t j = 0; j < p; j++) std::copy(st.x_columns[j].begin(), st.x_columns[j].end(), x[j].begin() + offsets[i]);
-		if (weighted) {
-			auto *sw = TRAITS::Weights(st);
-			std::copy(sw->begin(), sw->end(), w.begin() + offsets[i]);
-		}
-	}
-	vector<const double *> x_cols(p);
-	for (idx_t j = 0; j < p; j++) x_cols[j] = x[j].data();
-
-	// 2. one GPU call for the whole vector of groups (options are per query: every state carries the bind data)
-	AnofoxHipBatchOptions opt {};
-	opt.model = TRAITS::kModel;
-	opt.fit_intercept = any->fit_intercept;
-	opt.compute_inference = any->compute_inference;
-	opt.confidence_level = any->confidence_level;
-	opt.solver = ConvertSolverType(any->solver);
-	opt.alpha = 1.0;
-	TRAITS::Fill(*any, opt);
-	vector<double> core(count * (p + 6)), inf(opt.compute_inference ? count * (5 * p + 2) : 0);
-	AnofoxError err;
-	if (!anofox_hip_fit_batch_host(/*per-thread default context*/ nullptr, (int64_t)count, p, (int64_t)n_rows,
-	                               offsets.data(), y.data(), x_cols.data(), weighted ? w.data() : nullptr, opt,
-	                               core.data(), inf.empty() ? nullptr : inf.data(), &err)) {
-		throw InvalidInputException("anofox_stats fit_agg (HIP): %s", err.message);
-	}
-
-	// 3. records -> STRUCT (field order of GetOlsAggResultType, ols_aggregate.cpp:74-96)
+	auto states = (HipAggState **)sdata.data;
 	auto &entries = StructVector::GetEntries(result);
 	for (idx_t i = 0; i < count; i++) {
-		const double *rec = &core[i * (p + 6)];
+		auto &state = *states[sdata.sel->get_index(i)];
 		const idx_t r = i + offset;
-		auto &st = *states[sdata.sel->get_index(i)];
-		if (rec[p + 5] != 0.0) { // NULL group: too few rows or a failed fit (ols_aggregate.cpp:263-267,298-301)
+		const double *rec = state.slot < 0 ? nullptr : arena.Core((uint32_t)state.slot);
+		if (!rec) { // fewer than 2 accumulated rows or a failed fit -> NULL, the query continues (:263-267,298-301)
 			FlatVector::SetNull(result, r, true);
-			st.Reset();
 			continue;
 		}
 		AppendList(*entries[0], r, rec, p);
@@ -133,28 +186,13 @@ void BatchedFinalize(Vector &state_vector, Vector &result, idx_t count, idx_t of
 		FlatVector::GetData<double>(*entries[4])[r] = rec[p + 3];
 		FlatVector::GetData<int64_t>(*entries[5])[r] = (int64_t)rec[p + 4];
 		FlatVector::GetData<int64_t>(*entries[6])[r] = (int64_t)p;
-		if (opt.compute_inference) {
-			const double *ir = &inf[i * (5 * p + 2)];
+		if (bind.compute_inference) {
+			const double *ir = arena.Inference((uint32_t)state.slot);
 			for (idx_t k = 0; k < 5; k++) AppendList(*entries[7 + k], r, ir + k * p, p); // se, t, p, ci_lower, ci_upper
 			FlatVector::GetData<double>(*entries[12])[r] = ir[5 * p];
 			FlatVector::GetData<double>(*entries[13])[r] = ir[5 * p + 1];
 		}
-		st.Reset();
 	}
-}
-
-} // namespace
-
-// aggregate_finalize_t wrappers: plug these into the AggregateFunction constructors at
-// ols_aggregate.cpp:381-386, ridge_aggregate.cpp:392-397, wls_aggregate.cpp:405-410.
-void OlsAggFinalizeHip(Vector &state_vector, AggregateInputData &, Vector &result, idx_t count, idx_t offset) {
-	BatchedFinalize<OlsAggregateState, OlsTraits>(state_vector, result, count, offset);
-}
-void RidgeAggFinalizeHip(Vector &state_vector, AggregateInputData &, Vector &result, idx_t count, idx_t offset) {
-	BatchedFinalize<RidgeAggregateState, RidgeTraits>(state_vector, result, count, offset);
-}
-void WlsAggFinalizeHip(Vector &state_vector, AggregateInputData &, Vector &result, idx_t count, idx_t offset) {
-	BatchedFinalize<WlsAggregateState, WlsTraits>(state_vector, result, count, offset);
 }
 
 } // namespace duckdb

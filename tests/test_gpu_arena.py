@@ -1,0 +1,146 @@
+"""GPU test of the DuckDB shim's arena (anofox-statistics_amd/duckdb_shim/agg_arena.hpp through arena_capi.cpp): the
+calls the glue in fit_agg_hip.cpp makes — Update vectors of <= 2048 rows from several threads with lazily initialised
+states, Combine of the threads' states, Finalize vector by vector — against the oracle's fit of the same rows."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, assert_records_match, import_pkg
+
+pytestmark = pytest.mark.gpu
+
+_DP = C.POINTER(C.c_double)
+
+
+def _lib():
+    pkg = import_pkg()           # loads libanofox_stats_hip.so first (RTLD_GLOBAL)
+    path = os.path.join(ROOT, "anofox-statistics_amd", "duckdb_shim", "libanofox_arena_capi.so")
+    assert os.path.exists(path), "build it with make -C anofox-statistics_amd/duckdb_shim (or __graft_entry__.build())"
+    lib = C.CDLL(path)
+    abi = import_pkg("_abi")
+    lib.arena_create.restype = C.c_void_p
+    lib.arena_create.argtypes = [abi.AnofoxHipBatchOptions, C.c_size_t]
+    lib.arena_destroy.argtypes = [C.c_void_p]
+    lib.arena_update.restype = C.c_int
+    lib.arena_update.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                 C.c_void_p, C.c_char_p]
+    lib.arena_combine.restype = C.c_int
+    lib.arena_combine.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]
+    lib.arena_finalize.restype = C.c_int
+    lib.arena_finalize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+    lib.arena_feature_count.restype = C.c_size_t
+    lib.arena_feature_count.argtypes = [C.c_void_p]
+    lib.arena_rows.restype = C.c_uint64
+    lib.arena_rows.argtypes = [C.c_void_p]
+    return pkg, lib
+
+
+@pytest.mark.parametrize("model,flush_rows", [("ols", 5000), ("wls", 1 << 20), ("ridge", 777)])
+def test_threads_update_combine_finalize(model, flush_rows):
+    pkg, lib = _lib()
+    rng = np.random.default_rng(len(model))
+    p, G, T = 6, 400, 3
+    kw = dict(compute_inference=True)
+    if model == "ridge":
+        kw["alpha"] = 0.5
+    arena = lib.arena_create(pkg.RegressionOptions(**kw).batch_options(model), flush_rows)
+    assert arena
+    # thread t owns a hash table: state k of thread t = key k
+    data = []
+    for t in range(T):
+        n = 30_000
+        keys = rng.integers(0, G, n).astype(np.uint32)
+        X = rng.uniform(-5, 5, (n, p)) + 3.0 * t
+        y = X @ rng.uniform(-2, 2, p) + 0.01 * keys + rng.standard_normal(n)
+        w = rng.uniform(0.5, 2.0, n)
+        accept = (rng.uniform(size=n) > 0.1).astype(np.uint8)          # NULL y / x / w rows
+        X[rng.uniform(size=n) < 0.02, 2] = np.nan                       # NULL list elements
+        data.append((keys, y, X, w, accept, np.full(G, -1, dtype=np.int64)))
+    errs = []
+
+    def run(t):
+        keys, y, X, w, accept, slots = data[t]
+        msg = C.create_string_buffer(256)
+        for c0 in range(0, len(keys), 2048):                            # STANDARD_VECTOR_SIZE
+            sl = slice(c0, c0 + 2048)
+            k, yy, xx, ww, aa = (np.ascontiguousarray(v[sl]) for v in (keys, y, X, w, accept))
+            rc = lib.arena_update(arena, len(k), k.ctypes.data, slots.ctypes.data, yy.ctypes.data, xx.ctypes.data, p,
+                                  ww.ctypes.data if model == "wls" else None, aa.ctypes.data, msg)
+            if rc != 0:
+                errs.append(msg.value.decode())
+                return
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errs, errs
+    assert lib.arena_feature_count(arena) == p
+    assert lib.arena_rows(arena) == sum(int(d[4].sum()) for d in data)
+    # Combine thread 1 and 2 into thread 0, as the glue does: adopt where the target has no slot, merge otherwise
+    tgt = data[0][5]
+    msg = C.create_string_buffer(256)
+    for t in (1, 2):
+        src_slots = data[t][5]
+        adopt = (tgt < 0) & (src_slots >= 0)
+        tgt[adopt] = src_slots[adopt]
+        both = (src_slots >= 0) & ~adopt
+        s = np.ascontiguousarray(src_slots[both], dtype=np.uint32)
+        d = np.ascontiguousarray(tgt[both], dtype=np.uint32)
+        assert lib.arena_combine(arena, s.ctypes.data, d.ctypes.data, len(s), msg) == 0, msg.value
+    # Finalize, 2048 states per call
+    have = np.nonzero(tgt >= 0)[0]
+    core = np.full((G, p + 6), np.nan)
+    inf = np.full((G, 5 * p + 2), np.nan)
+    isnull = np.ones(G, dtype=np.uint8)
+    for c0 in range(0, len(have), 2048):
+        idx = have[c0:c0 + 2048]
+        sl = np.ascontiguousarray(tgt[idx], dtype=np.uint32)
+        oc = np.empty((len(idx), p + 6))
+        oi = np.empty((len(idx), 5 * p + 2))
+        nn = np.empty(len(idx), dtype=np.uint8)
+        assert lib.arena_finalize(arena, len(idx), sl.ctypes.data, oc.ctypes.data, oi.ctypes.data, nn.ctypes.data, msg) == 0, msg.value
+        core[idx], inf[idx], isnull[idx] = oc, oi, nn
+    # the reference's buffers: thread 0's accepted rows of a key, then thread 1's, then thread 2's
+    keys = np.concatenate([d[0][d[4] != 0] for d in data])
+    y = np.concatenate([d[1][d[4] != 0] for d in data])
+    X = np.concatenate([d[2][d[4] != 0] for d in data])
+    w = np.concatenate([d[3][d[4] != 0] for d in data])
+    order = np.argsort(keys, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=G))]).astype(np.int64)
+    rcore, rinf = oracle.fit_groups(y[order], [np.ascontiguousarray(X[order, j]) for j in range(p)], offs,
+                                    w=(w[order] if model == "wls" else None), model=model, **kw)
+    ok = rcore[:, p + 5] == 0
+    assert np.array_equal(isnull == 0, ok)
+    assert_records_match(core[ok], rcore[ok], p, inf[ok], rinf[ok], what=f"arena {model}")
+    lib.arena_destroy(arena)
+
+
+def test_inconsistent_feature_count_and_empty_query():
+    pkg, lib = _lib()
+    arena = lib.arena_create(pkg.RegressionOptions().batch_options("ols"), 100)
+    slots = np.full(2, -1, dtype=np.int64)
+    msg = C.create_string_buffer(256)
+    k = np.zeros(3, dtype=np.uint32)
+    y = np.arange(3.0)
+    assert lib.arena_update(arena, 3, k.ctypes.data, slots.ctypes.data, y.ctypes.data, np.ones((3, 2)).ctypes.data, 2, None, None, msg) == 0
+    assert lib.arena_update(arena, 3, k.ctypes.data, slots.ctypes.data, y.ctypes.data, np.ones((3, 3)).ctypes.data, 3, None, None, msg) == -1
+    assert msg.value.decode() == "Inconsistent feature count: expected 2, got 3"      # ols_aggregate.cpp:172-175
+    lib.arena_destroy(arena)
+    # a query whose every row is skipped: states exist, nothing reaches the GPU, every group is NULL
+    arena = lib.arena_create(pkg.RegressionOptions().batch_options("ols"), 100)
+    slots = np.full(1, -1, dtype=np.int64)
+    acc = np.zeros(3, dtype=np.uint8)
+    assert lib.arena_update(arena, 3, k.ctypes.data, slots.ctypes.data, y.ctypes.data, np.ones((3, 2)).ctypes.data, 2, None, acc.ctypes.data, msg) == 0
+    assert slots[0] == 0
+    nn = np.zeros(1, dtype=np.uint8)
+    sl = np.zeros(1, dtype=np.uint32)
+    oc = np.empty((1, 8))
+    assert lib.arena_finalize(arena, 1, sl.ctypes.data, oc.ctypes.data, None, nn.ctypes.data, msg) == 0
+    assert nn[0] == 1
+    lib.arena_destroy(arena)
