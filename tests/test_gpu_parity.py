@@ -179,6 +179,20 @@ def test_series_known_answers(pkg, known_answers):
         _check_expect(fn((2 * i + 1).tolist(), [i.tolist()], opts), case["expect"])
 
 
+def test_cfg1_example_calls_through_the_c_symbols(pkg, known_answers):
+    """BASELINE cfg1: the eight example calls of examples/ols_single_series.sql (:27-31,49-57,78-82,98-102,113-117,
+    140-157,186,200-230) through anofox_ols_fit, against the closed form rounded as the example rounds."""
+    from test_oracle_golden import _check_example
+    cases = known_answers["ols_single_series_examples"]["cases"]
+    assert len(cases) == 11
+    for case in cases:
+        r = pkg.ols_fit(case["y"], case["x"], case["options"])
+        _check_example(r, case)
+        assert r["n_features"] == len(case["x"]) and len(r["coefficients"]) == len(case["x"])
+        if case["name"] == "ex3_full_inference":      # an exact fit: errors and p-values collapse to ~0
+            assert r["std_errors"][0] < 1e-9 and r["p_values"][0] < 1e-12 and r["f_pvalue"] < 1e-12
+
+
 def test_single_fit_error_conventions(pkg):
     a = import_pkg("_abi")
     with pytest.raises(pkg.InvalidInputException) as ei:

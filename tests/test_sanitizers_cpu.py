@@ -1,0 +1,31 @@
+"""CPU tier: AddressSanitizer + UndefinedBehaviorSanitizer builds of the oracle's C code and of the library's host
+code (GPU ASan is not available on this pool).  tests/tools/Makefile compiles csrc/host_api.hip and
+csrc/agg_state.hip as plain C++ with g++ (kernel launchers stubbed: nothing reaches them without a GPU) and
+oracle/anofox_oracle.c with gcc, each with a driver; a non-zero exit or any sanitizer report fails the test."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+OUT = "/tmp/anofox_sanitize"
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not shutil.which("g++") or not os.path.isdir("/opt/rocm/include/hip"):
+        pytest.skip("needs g++ and the HIP headers")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "tools"), f"OUT={OUT}"], stdout=subprocess.DEVNULL)
+    return OUT
+
+
+@pytest.mark.parametrize("unit", ["oracle_sanitize", "host_sanitize"])
+def test_sanitizer_unit(built, unit):
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([os.path.join(built, unit)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr
+    assert "all" in r.stdout
