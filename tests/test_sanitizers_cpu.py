@@ -23,7 +23,7 @@ def built():
 
 @pytest.mark.parametrize("unit", ["oracle_sanitize", "host_sanitize"])
 def test_sanitizer_unit(built, unit):
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     env.pop("LD_PRELOAD", None)
     r = subprocess.run([os.path.join(built, unit)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
