@@ -35,6 +35,23 @@ typedef double dbl4 __attribute__((ext_vector_type(4)));
 typedef const double __attribute__((address_space(1))) *gptr_t;
 typedef const dbl2u __attribute__((address_space(1))) *gptr2_t;
 
+// Diagnostic build only (-DANOFOX_SOLVE_STAMPS, csrc/Makefile target `diag`): wave 0 of workgroup 0 sums s_memtime
+// deltas of the phases of its chunk loop: [0] row masks known  [1] next chunk's loads issued (+ repairs)  [2] the chunk's
+// slabs (fragment reads + MFMAs + side sums)  [3] next chunk's loads landed  [4] staged into LDS  [5] barrier passed
+// [6] chunks  [7] whole group.
+#ifdef ANOFOX_SOLVE_STAMPS
+__device__ unsigned long long g_acc_stamps[8];
+#define ACC_STAMP_DECL unsigned long long st_t = 0, st_acc[6] = {0, 0, 0, 0, 0, 0}, st_n = 0; const bool st_on = blockIdx.x == 0 && WAVE == 0; const unsigned long long st_begin = __builtin_amdgcn_s_memtime()
+#define ACC_STAMP_START() do { if (st_on) st_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define ACC_STAMP(k) do { if (st_on) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_t; st_t = now_; } } while (0)
+#define ACC_STAMP_FLUSH() do { if (st_on && threadIdx.x == 0) { for (int k_ = 0; k_ < 6; ++k_) g_acc_stamps[k_] = st_acc[k_]; g_acc_stamps[6] = st_n; g_acc_stamps[7] = __builtin_amdgcn_s_memtime() - st_begin; } } while (0)
+#else
+#define ACC_STAMP_DECL do { } while (0)
+#define ACC_STAMP_START() do { } while (0)
+#define ACC_STAMP(k) do { } while (0)
+#define ACC_STAMP_FLUSH() do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kWaves = 4;
@@ -46,15 +63,37 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 
 __device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
 
+// Row masks of a chunk.  Bit layout (what the staging ballots produce without any bit shuffling): lane (colsub, rp)
+// stages rows 2 rp, 2 rp + 1, 16 + 2 rp, 17 + 2 rp; byte k of the mask holds those four row classes, bit rp within it.
+__device__ __forceinline__ int row_bit(int row) { return ((row >> 4) << 4) | ((row & 1) << 3) | ((row >> 1) & 7); }
+template <int CH>
+__device__ __forceinline__ unsigned range_mask(int64_t left) { // rows [0, left) of a chunk (wave-uniform, partial chunks only)
+	if (left >= CH) return CH == 32 ? 0xffffffffu : 0xffffu;
+	unsigned m = 0;
+	for (int r = 0; r < (int)left; ++r) m |= 1u << row_bit(r);
+	return m;
+}
+__device__ __forceinline__ int first_row_of_mask(unsigned m) { // lowest row whose bit is set (m != 0)
+	int best = 64;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const unsigned byte = (m >> (8 * k)) & 0xffu;
+		const int r = 16 * (k >> 1) + (k & 1) + 2 * (__ffs((int)byte) - 1);
+		best = (byte != 0u && r < best) ? r : best;
+	}
+	return best;
+}
+
 template <int T>
 struct WideCfg {
 	static constexpr int NT = T * (T + 1) / 2;             // upper-triangular tiles
 	static constexpr int TPW = (NT + kWaves - 1) / kWaves; // tiles per wave
 	static constexpr int OWN = (T + kWaves - 1) / kWaves;  // column blocks owned per wave
-	// rows staged per barrier: 32 where the registers allow it (6.5 TB/s at p = 96 against 6.1 with 16), 16 for the
-	// widest designs (72 accumulator registers per wave at T = 8: the extra staging registers would spill)
-	static constexpr int CH = (T <= 6) ? 32 : 16;
-	static constexpr int STRIDE = CH + 2; // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
+	// rows staged per barrier: the per-chunk costs that are latency, not work (row masks through LDS, issuing the next
+	// chunk's loads, the barrier) are as long as the MFMAs of 16 rows at T = 8, so chunks are 32 rows for every width
+	// (the weighted kernel at T = 8 would spill with the staging registers of 32 rows: 16 there)
+	static constexpr int chunk_rows(bool weighted) { return (T == 8 && weighted) ? 16 : 32; }
+	static constexpr int stride(bool weighted) { return chunk_rows(weighted) + 2; } // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
 };
 
 // One wave's share of a chunk: the slabs of MFMAs + the VALU side sums.  WAVE is a compile-time constant so
@@ -69,25 +108,36 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
                                               dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
                                               double (&sxy)[WideCfg<T>::OWN], unsigned &ncmask, double &sy,
                                               double &syy, double &sw) {
-	constexpr int kChunkRows = WideCfg<T>::CH, kLdsStride = WideCfg<T>::STRIDE, OWN = WideCfg<T>::OWN;
+	constexpr int kChunkRows = WideCfg<T>::chunk_rows(WEIGHTED), kLdsStride = WideCfg<T>::stride(WEIGHTED), OWN = WideCfg<T>::OWN;
 	const int k = lane >> 4;
 	const int i = lane & 15;
 	// without an intercept the image holds raw values; the constant-column test still compares with the first valid row
 	double fown[OWN];
 #pragma unroll
 	for (int o = 0; o < OWN; ++o) fown[o] = (!CENTER && WAVE + kWaves * o < T) ? firstcol[16 * (WAVE + kWaves * o) + i] : 0.0;
-#pragma unroll 1
-	for (int t = 0; t < kChunkRows / 4; ++t) {
+	// Software pipeline over the chunk's slabs: the fragment reads of slab t + 1 are issued BEFORE the MFMAs of slab t
+	// (two register sets, the loop is fully unrolled), so that a wave goes from one slab's MFMAs straight into the
+	// next slab's — with the reads at the top of each slab the matrix pipe idles for an LDS round trip per slab
+	// whenever the SIMD's other wave is not in its own MFMA phase (measured: 115 cycles per MFMA per SIMD against
+	// 64-68 for back-to-back issue with two waves).
+	constexpr int NS = kChunkRows / 4;
+	double d[2][T], dy[2], w[2];
+	auto read_slab = [&](int t, int s) {
 		const int row = 4 * t + k;
-		double d[T];
 #pragma unroll
-		for (int I = 0; I < T; ++I) d[I] = img[(16 * I + i) * kLdsStride + row];
-		const double dy = img[ycol * kLdsStride + row];
-		double w = 1.0;
-		if (WEIGHTED) w = img[(ycol + 1) * kLdsStride + row];
+		for (int I = 0; I < T; ++I) d[s][I] = img[(16 * I + i) * kLdsStride + row];
+		dy[s] = img[ycol * kLdsStride + row];
+		w[s] = WEIGHTED ? img[(ycol + 1) * kLdsStride + row] : 1.0;
+	};
+	read_slab(0, 0);
+#pragma unroll
+	for (int t = 0; t < NS; ++t) {
+		const int s = t & 1;
+		const int row = 4 * t + k;
+		if (t + 1 < NS) read_slab(t + 1, s ^ 1);
 		double a[T];
 #pragma unroll
-		for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? w * d[I] : d[I];
+		for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? w[s] * d[s][I] : d[s][I];
 
 		int tile = 0;
 #pragma unroll
@@ -95,7 +145,7 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 #pragma unroll
 			for (int J = I; J < T; ++J) {
 				if (tile % kWaves == WAVE)
-					acc[tile / kWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[J], acc[tile / kWaves], 0, 0, 0);
+					acc[tile / kWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[s][J], acc[tile / kWaves], 0, 0, 0);
 				++tile;
 			}
 		}
@@ -104,36 +154,41 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 			if (I % kWaves == WAVE) {
 				// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row (a zeroed row of a
 				// shifted image gives 0; a raw image needs the row's validity)
-				const double dev = CENTER ? d[I] : d[I] - fown[I / kWaves];
-				const bool moved = !(fabs(dev) < 1e-10) && (CENTER || ((rowmask >> row) & 1u));
+				const double dev = CENTER ? d[s][I] : d[s][I] - fown[I / kWaves];
+				const bool moved = !(fabs(dev) < 1e-10) && (CENTER || ((rowmask >> row_bit(row)) & 1u));
 				ncmask |= moved ? (1u << I) : 0u;
 				sx[I / kWaves] += a[I];
-				sxy[I / kWaves] = fma(a[I], dy, sxy[I / kWaves]);
+				sxy[I / kWaves] = fma(a[I], dy[s], sxy[I / kWaves]);
 			}
 		}
 		if (WAVE == 0) {
-			const double wdy = WEIGHTED ? w * dy : dy;
+			const double wdy = WEIGHTED ? w[s] * dy[s] : dy[s];
 			sy += wdy;
-			syy = fma(wdy, dy, syy);
-			if (WEIGHTED) sw += w; // unweighted: the row count, taken from the masks
+			syy = fma(wdy, dy[s], syy);
+			if (WEIGHTED) sw += w[s]; // unweighted: the row count, taken from the masks
 		}
 	}
 }
 
 // The rows [lo, hi) of one group — or of one segment of a very large group, then with the group's first valid
 // row handed in (`forced_first`: x per column, y at index 16 T) — into one moment record at `rec`, by a workgroup.
-template <int T, bool WEIGHTED, bool CENTER>
-__device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
-                                                     const double *forced_first) {
+// WAVE (this wavefront's number within the workgroup) is a template parameter of the WHOLE row loop, not only of
+// compute_chunk: with a per-chunk `switch (wave)` the four arms get different register assignments for the 72
+// accumulator registers and the compiler copies all of them in and out around every chunk (2 x 36 v_mov_b64 behind
+// the last MFMA of each 16-row chunk, ~20 % of the chunk's matrix-core time).  The barriers inside are executed the
+// same number of times by every wave, from four copies of the loop.
+template <int T, int WAVE, bool WEIGHTED, bool CENTER>
+__device__ __forceinline__ void wide_accumulate_rows_wave(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
+                                                          const double *forced_first) {
 	using Cfg = WideCfg<T>;
-	constexpr int kChunkRows = Cfg::CH, kLdsStride = Cfg::STRIDE;
+	constexpr int kChunkRows = Cfg::chunk_rows(WEIGHTED), kLdsStride = Cfg::stride(WEIGHTED);
 	constexpr bool kWideChunk = kChunkRows == 32;
 	constexpr unsigned kFullMask = kWideChunk ? 0xffffffffu : 0xffffu;
 	constexpr int P16 = 16 * T;
 	const int p = args.p;
 	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
 	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	constexpr int wave = WAVE;
 	const int64_t nrows = hi - lo;
 
 	extern __shared__ double lds[];
@@ -164,11 +219,29 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 	}
 	__syncthreads();
 
-	// staging assignment: load instruction q of this wave covers columns 8*(wave + 4q) .. +7; lane -> (col, row pair)
+	// staging assignment: load instruction q of this wave covers columns 8*(wave + 4q) .. +7; lane -> (col, row pair).
+	// Everything a lane needs to know about its load slots lives in registers (column pointer, LDS destination, flags):
+	// with the pointers parked in LDS every load of a chunk waited for its own ds_read round trip, ~1000 cycles per
+	// chunk of pure latency (phase stamps, scripts/dbg_acc_stamps.py).
 	constexpr int kMaxLoads = (P16 + 2 + 7) / 8 / kWaves + 1;
 	const int colsub = lane >> 3;
 	const int rp = lane & 7;
 	const int n_loads_total = (ncol + 7) / 8; // load slots: 8 source columns each
+	gptr_t colp[kMaxLoads]; // this lane's column of slot q, at the group's first row + 2 rp
+	int dcol[kMaxLoads];    // element offset of (image column, row 2 rp) within an image
+	unsigned actbits = 0;   // bit q: the column exists (slots beyond ncol read y again and store into a spare column)
+	unsigned wbits = 0;     // bit q: the column is the weight column
+#pragma unroll
+	for (int q = 0; q < kMaxLoads; ++q) {
+		const int src = 8 * (wave + kWaves * q) + colsub;
+		const bool active = src < ncol;
+		int col = src < p ? src : ycol + (src - p); // x in place, y / w after 16 T
+		if (!active) col = ycol + 2 + (colsub % 6); // spare columns 16T+2 .. 16T+7: nothing reads them
+		dcol[q] = col * kLdsStride + 2 * rp;
+		colp[q] = reinterpret_cast<gptr_t>(colbase[src < ncol_pad ? src : ncol_pad - 1]) + 2 * rp;
+		actbits |= active ? (1u << q) : 0u;
+		wbits |= (WEIGHTED && src == p + 1) ? (1u << q) : 0u;
+	}
 
 	dbl4 acc[Cfg::TPW];
 #pragma unroll
@@ -197,34 +270,35 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 	};
 	// issue the loads of one chunk (global -> registers); consumed by stage_store
 	auto stage_load = [&](int64_t chunk, Stage &sg) {
-		const int64_t r0 = chunk * kChunkRows + 2 * rp; // row within the group
-		const bool full = (chunk + 1) * kChunkRows <= nrows; // wave-uniform: every row of the chunk exists
+		const int64_t c0 = chunk * kChunkRows;              // first row of the chunk within the group
+		const bool full = c0 + kChunkRows <= nrows;         // wave-uniform: every row of the chunk exists
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
-			const int li = wave + kWaves * q;
 			sg.v0[q] = sg.v1[q] = sg.v2[q] = sg.v3[q] = 0.0;
-			if (li < n_loads_total) { // wave-uniform
-				const gptr_t b = reinterpret_cast<gptr_t>(colbase[8 * li + colsub]);
+			if (wave + kWaves * q < n_loads_total) { // wave-uniform
+				const gptr_t b = colp[q] + c0;
 				if (full) {
-					const dbl2u va = *reinterpret_cast<gptr2_t>(b + r0);
+					const dbl2u va = *reinterpret_cast<gptr2_t>(b);
 					sg.v0[q] = va.x;
 					sg.v1[q] = va.y;
 					if (kWideChunk) {
-						const dbl2u vb = *reinterpret_cast<gptr2_t>(b + r0 + 16);
+						const dbl2u vb = *reinterpret_cast<gptr2_t>(b + 16);
 						sg.v2[q] = vb.x;
 						sg.v3[q] = vb.y;
 					}
 				} else {
-					if (r0 < nrows) sg.v0[q] = b[r0];
-					if (r0 + 1 < nrows) sg.v1[q] = b[r0 + 1];
-					if (kWideChunk && r0 + 16 < nrows) sg.v2[q] = b[r0 + 16];
-					if (kWideChunk && r0 + 17 < nrows) sg.v3[q] = b[r0 + 17];
+					const int64_t r0 = c0 + 2 * rp;
+					if (r0 < nrows) sg.v0[q] = b[0];
+					if (r0 + 1 < nrows) sg.v1[q] = b[1];
+					if (kWideChunk && r0 + 16 < nrows) sg.v2[q] = b[16];
+					if (kWideChunk && r0 + 17 < nrows) sg.v3[q] = b[17];
 				}
 			}
 		}
 	};
 	// registers -> LDS image `buf` (shifted by fq; rows past the end of the group as zeros), plus this wave's partial
-	// row-validity mask (ols.rs:59-66, wls.rs:76-86)
+	// row-validity mask (ols.rs:59-66, wls.rs:76-86).  Straight-line code: lanes whose column does not exist store into
+	// a spare column and count as valid.
 	auto stage_store = [&](int64_t chunk, int buf, const Stage &sg) {
 		bool ok0 = true, ok1 = true, ok2 = true, ok3 = true;
 		double *img = image + buf * ncol_pad * kLdsStride;
@@ -232,49 +306,41 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 		const bool in0 = 2 * rp < left, in1 = 2 * rp + 1 < left, in2 = 2 * rp + 16 < left, in3 = 2 * rp + 17 < left;
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
-			const int li = wave + kWaves * q;
-			if (li < n_loads_total) {
-				const int src = 8 * li + colsub;
-				if (src < ncol) {
-					bool f0 = isfinite(sg.v0[q]), f1 = isfinite(sg.v1[q]), f2 = isfinite(sg.v2[q]), f3 = isfinite(sg.v3[q]);
-					if (WEIGHTED && src == p + 1) {
-						f0 = f0 && sg.v0[q] > 0.0;
-						f1 = f1 && sg.v1[q] > 0.0;
-						f2 = f2 && sg.v2[q] > 0.0;
-						f3 = f3 && sg.v3[q] > 0.0;
-					}
-					ok0 = ok0 && f0;
-					ok1 = ok1 && f1;
-					ok2 = ok2 && f2;
-					ok3 = ok3 && f3;
-					const int col = src < p ? src : ycol + (src - p);
-					double *dst = img + col * kLdsStride + 2 * rp;
-					dst[0] = in0 ? sg.v0[q] - fq[q] : 0.0;
-					dst[1] = in1 ? sg.v1[q] - fq[q] : 0.0;
-					if (kWideChunk) {
-						dst[16] = in2 ? sg.v2[q] - fq[q] : 0.0;
-						dst[17] = in3 ? sg.v3[q] - fq[q] : 0.0;
-					}
+			if (wave + kWaves * q < n_loads_total) { // wave-uniform
+				const bool inactive = !((actbits >> q) & 1u);
+				const bool isw = WEIGHTED && ((wbits >> q) & 1u);
+				bool f0 = isfinite(sg.v0[q]), f1 = isfinite(sg.v1[q]), f2 = isfinite(sg.v2[q]), f3 = isfinite(sg.v3[q]);
+				if (WEIGHTED) {
+					f0 = f0 && !(isw && !(sg.v0[q] > 0.0));
+					f1 = f1 && !(isw && !(sg.v1[q] > 0.0));
+					f2 = f2 && !(isw && !(sg.v2[q] > 0.0));
+					f3 = f3 && !(isw && !(sg.v3[q] > 0.0));
+				}
+				ok0 = ok0 && (f0 || inactive);
+				ok1 = ok1 && (f1 || inactive);
+				ok2 = ok2 && (f2 || inactive);
+				ok3 = ok3 && (f3 || inactive);
+				double *dst = img + dcol[q];
+				dst[0] = in0 ? sg.v0[q] - fq[q] : 0.0;
+				dst[1] = in1 ? sg.v1[q] - fq[q] : 0.0;
+				if (kWideChunk) {
+					dst[16] = in2 ? sg.v2[q] - fq[q] : 0.0;
+					dst[17] = in3 ? sg.v3[q] - fq[q] : 0.0;
 				}
 			}
 		}
-		// fold the 8 column sub-groups: bit = row of the chunk, set when the row is valid in every column this wave staged
-		unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1), b2 = __ballot(ok2), b3 = __ballot(ok3);
+		// fold the 8 column sub-groups: byte k of the mask = rows {2j, 2j+1, 16+2j, 17+2j}[k], j = bit (row_bit below)
+		unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
 		b0 &= b0 >> 32; b0 &= b0 >> 16; b0 &= b0 >> 8;
 		b1 &= b1 >> 32; b1 &= b1 >> 16; b1 &= b1 >> 8;
-		b2 &= b2 >> 32; b2 &= b2 >> 16; b2 &= b2 >> 8;
-		b3 &= b3 >> 32; b3 &= b3 >> 16; b3 &= b3 >> 8;
-		unsigned m = 0;
-#pragma unroll
-		for (int r = 0; r < 8; ++r) {
-			m |= ((unsigned)(b0 >> r) & 1u) << (2 * r);
-			m |= ((unsigned)(b1 >> r) & 1u) << (2 * r + 1);
-			if (kWideChunk) {
-				m |= ((unsigned)(b2 >> r) & 1u) << (16 + 2 * r);
-				m |= ((unsigned)(b3 >> r) & 1u) << (17 + 2 * r);
-			}
+		unsigned m = ((unsigned)b0 & 0xffu) | (((unsigned)b1 & 0xffu) << 8);
+		if (kWideChunk) {
+			unsigned long long b2 = __ballot(ok2), b3 = __ballot(ok3);
+			b2 &= b2 >> 32; b2 &= b2 >> 16; b2 &= b2 >> 8;
+			b3 &= b3 >> 32; b3 &= b3 >> 16; b3 &= b3 >> 8;
+			m |= (((unsigned)b2 & 0xffu) << 16) | (((unsigned)b3 & 0xffu) << 24);
 		}
-		if (left < kChunkRows) m &= (left <= 0) ? 0u : ((1u << left) - 1u); // rows past the end of the group are invalid
+		if (left < kChunkRows) m &= range_mask<kChunkRows>(left); // rows past the end of the group are invalid
 		if (lane == 0) maskslot[buf * kWaves + wave] = m;
 	};
 	// Rare repairs of a staged image, each lane on the elements it staged itself (so reads precede writes in program
@@ -284,42 +350,42 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 		double *img = image + buf * ncol_pad * kLdsStride;
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
-			const int li = wave + kWaves * q;
-			if (li < n_loads_total) {
-				const int src = 8 * li + colsub;
-				if (src < ncol) {
-					const int col = src < p ? src : ycol + (src - p);
-					double *dst = img + col * kLdsStride + 2 * rp;
-					const double f = shift ? fq[q] : 0.0;
+			if (wave + kWaves * q < n_loads_total && ((actbits >> q) & 1u)) {
+				double *dst = img + dcol[q];
+				const double f = shift ? fq[q] : 0.0;
 #pragma unroll
-					for (int e = 0; e < (kWideChunk ? 4 : 2); ++e) {
-						const int row = 2 * rp + (e & 1) + 16 * (e >> 1);
-						const double cur = dst[(e & 1) + 16 * (e >> 1)];
-						dst[(e & 1) + 16 * (e >> 1)] = ((rowmask >> row) & 1u) ? cur - f : 0.0;
-					}
+				for (int e = 0; e < (kWideChunk ? 4 : 2); ++e) {
+					const int bit = 16 * (e >> 1) + 8 * (e & 1) + rp; // row_bit(2 rp + (e & 1) + 16 (e >> 1))
+					const double cur = dst[(e & 1) + 16 * (e >> 1)];
+					dst[(e & 1) + 16 * (e >> 1)] = ((rowmask >> bit) & 1u) ? cur - f : 0.0;
 				}
 			}
 		}
 	};
 
-	// One chunk.  The loads run one chunk ahead (two ahead, in a second register set, measured the same at p = 48..112:
-	// the kernel is not waiting for HBM) and are stored to the other image once this chunk's MFMAs are issued.
+	// One chunk.  The loads run one chunk ahead and are stored to the other image once this chunk's MFMAs are issued.
+	ACC_STAMP_DECL;
 	auto iteration = [&](int64_t c, Stage &ahead) {
+		ACC_STAMP_START();
 		const int buf = (int)(c & 1);
 		const double *img = image + buf * ncol_pad * kLdsStride;
 		unsigned rowmask = maskslot[buf * kWaves + 0] & maskslot[buf * kWaves + 1] & maskslot[buf * kWaves + 2] &
 		                   maskslot[buf * kWaves + 3];
 		rowmask = __builtin_amdgcn_readfirstlane(rowmask);
+		ACC_STAMP(0);
 		const int64_t left = nrows - c * kChunkRows;
-		const unsigned rangemask = left >= kChunkRows ? kFullMask : ((1u << left) - 1u);
+		const unsigned rangemask = left >= kChunkRows ? kFullMask : range_mask<kChunkRows>(left);
 		if (c + 1 < n_chunks) stage_load(c + 1, ahead); // in flight while this chunk's MFMAs run
 
 		const bool found_first = !have_first && rowmask != 0u; // wave-uniform
-		if (found_first || (rowmask != rangemask && rowmask != 0u)) {
+		// (a chunk without any valid row is zeroed as well and goes through the MFMAs like every other chunk: skipping
+		// its compute step would put the 72 accumulator registers behind a branch, and the compiler then copies all of
+		// them at the join — 36 v_mov_b64 waiting on the last MFMA of EVERY chunk)
+		if (found_first || rowmask != rangemask) {
 			if (found_first) {
 				// the group's first valid row: remember its values (the shift when CENTER, the reference point of the
 				// constant-column test, part of the record) and shift this chunk, which was staged unshifted
-				const int r = __ffs((int)rowmask) - 1;
+				const int r = first_row_of_mask(rowmask);
 #pragma unroll
 				for (int q = 0; q < kMaxLoads; ++q) {
 					const int li = wave + kWaves * q;
@@ -339,17 +405,21 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 		}
 		have_first = have_first || found_first;
 
-		if (rowmask != 0u) {
-			cnt += __popc(rowmask);
-			switch (wave) {
-			case 0: compute_chunk<T, 0, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			case 1: compute_chunk<T, 1, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			case 2: compute_chunk<T, 2, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			default: compute_chunk<T, 3, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw); break;
-			}
-		}
+		cnt += __popc(rowmask);
+		ACC_STAMP(1);
+		compute_chunk<T, WAVE, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw);
+		ACC_STAMP(2);
+#ifdef ANOFOX_SOLVE_STAMPS
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+		ACC_STAMP(3);
 		if (c + 1 < n_chunks) stage_store(c + 1, buf ^ 1, ahead);
+		ACC_STAMP(4);
 		__syncthreads();
+		ACC_STAMP(5);
+#ifdef ANOFOX_SOLVE_STAMPS
+		++st_n;
+#endif
 	};
 
 	Stage sg;
@@ -360,6 +430,7 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 	__syncthreads();
 	for (int64_t c = 0; c < n_chunks; ++c) iteration(c, sg);
 
+	ACC_STAMP_FLUSH();
 	// ---- write the moment record ----
 	// tiles: tile-major, 256 doubles each, element (row, col) at row*16 + col
 	{
@@ -411,6 +482,17 @@ __device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64
 			sc[3] = (double)cnt;
 			sc[4] = firstcol[ycol];
 		}
+	}
+}
+
+template <int T, bool WEIGHTED, bool CENTER>
+__device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
+                                                     const double *forced_first) {
+	switch (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) {
+	case 0: wide_accumulate_rows_wave<T, 0, WEIGHTED, CENTER>(args, lo, hi, rec, forced_first); break;
+	case 1: wide_accumulate_rows_wave<T, 1, WEIGHTED, CENTER>(args, lo, hi, rec, forced_first); break;
+	case 2: wide_accumulate_rows_wave<T, 2, WEIGHTED, CENTER>(args, lo, hi, rec, forced_first); break;
+	default: wide_accumulate_rows_wave<T, 3, WEIGHTED, CENTER>(args, lo, hi, rec, forced_first); break;
 	}
 }
 
@@ -475,7 +557,7 @@ hipError_t launch_T(const WideArgs &a, hipStream_t stream) {
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
 	const int ncol_pad = wide_ncol_pad(a.p, weighted);
-	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::STRIDE * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
+	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::stride(weighted) * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
 	const dim3 grid((unsigned)a.n_groups), block(256);
 	const dim3 seg_grid((unsigned)kWideSegMaxSegments); // idle unless some group exceeded seg_rows
 #define ANOFOX_WIDE_LAUNCH(W, C)                                                                                  \
@@ -495,6 +577,12 @@ hipError_t launch_T(const WideArgs &a, hipStream_t stream) {
 }
 
 } // namespace
+
+#ifdef ANOFOX_SOLVE_STAMPS
+extern "C" __attribute__((visibility("default"))) int anofox_hip_diag_acc_stamps(unsigned long long *out8) {
+	return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_acc_stamps), 8 * sizeof(unsigned long long));
+}
+#endif
 
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;

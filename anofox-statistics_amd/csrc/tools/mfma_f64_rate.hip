@@ -22,6 +22,78 @@ __global__ __launch_bounds__(256) void rate_kernel(double *out, int iters, long 
 	if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;
 }
 
+// The same with operands that CHANGE from one instruction to the next (eight random doubles per lane, cycled): the
+// accumulate kernel feeds the matrix cores random data, and switching activity counts against the power limit.
+// PATTERN: which registers feed consecutive instructions
+//   0  A and B differ from instruction to instruction        1  the same A for all, B differs
+//   2  A == B (one register for both operands), differing     3  consecutive PAIRS share A, B differs
+//   4  the accumulate kernel's order at p = 128, wave 0: tiles (0,0) (0,4) (1,1) (1,5) (2,3) (3,3) (3,7) (4,7) (6,6)
+template <int NACC, int PATTERN>
+__global__ __launch_bounds__(256) void rate_kernel_random(double *out, int iters, long long *cycles, const double *src) {
+	dbl4 acc[NACC];
+	for (int i = 0; i < NACC; ++i) acc[i] = (dbl4){0, 0, 0, 0};
+	double a[8], b[8];
+	for (int i = 0; i < 8; ++i) {
+		a[i] = src[(threadIdx.x * 16 + i) & 4095];
+		b[i] = src[(threadIdx.x * 16 + 8 + i) & 4095];
+	}
+	const long long t0 = __builtin_amdgcn_s_memtime();
+	for (int it = 0; it < iters; it += 8) { // operand registers picked at compile time: the loop body is MFMAs only
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+#pragma unroll
+			for (int i = 0; i < NACC; ++i)
+			{
+				constexpr int TI[9] = {0, 0, 1, 1, 2, 3, 3, 4, 6}, TJ[9] = {0, 4, 1, 5, 3, 3, 7, 7, 6};
+				double x = a[(i + k) & 7], y = b[(i * 3 + k) & 7];
+				if (PATTERN == 1) x = a[0];
+				if (PATTERN == 2) y = x;
+				if (PATTERN == 3) x = a[((i >> 1) + k) & 7];
+				if (PATTERN == 4) { x = a[TI[i % 9]]; y = a[TJ[i % 9]]; }
+				acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[i], 0, 0, 0);
+			}
+		}
+	}
+	const long long t1 = __builtin_amdgcn_s_memtime();
+	double s = 0;
+	for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+	if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;
+}
+
+template <int NACC, int PATTERN>
+void run_random(int blocks, int threads, const char *label) {
+	double *out, *src;
+	long long *cyc;
+	(void)hipMalloc(&out, (size_t)blocks * threads * sizeof(double));
+	(void)hipMalloc(&src, 4096 * sizeof(double));
+	(void)hipMalloc(&cyc, sizeof(long long));
+	double h[4096];
+	unsigned long long x = 88172645463325252ull;
+	for (int i = 0; i < 4096; ++i) {
+		x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+		h[i] = ((double)(x >> 11) / 9007199254740992.0) * 20.0 - 10.0;
+	}
+	(void)hipMemcpy(src, h, sizeof h, hipMemcpyHostToDevice);
+	const int iters = 20000; // a multiple of 8: the operand index (i + it) & 7 is resolved by unrolling
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0);
+	(void)hipEventCreate(&e1);
+	hipLaunchKernelGGL((rate_kernel_random<NACC, PATTERN>), dim3(blocks), dim3(threads), 0, 0, out, 104, cyc, src);
+	(void)hipDeviceSynchronize();
+	(void)hipEventRecord(e0);
+	hipLaunchKernelGGL((rate_kernel_random<NACC, PATTERN>), dim3(blocks), dim3(threads), 0, 0, out, iters, cyc, src);
+	(void)hipEventRecord(e1);
+	(void)hipDeviceSynchronize();
+	float ms;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	const double flops = ((double)blocks * threads / 64) * (double)iters * NACC * 2.0 * 16 * 16 * 4;
+	printf("%-28s acc=%2d  RANDOM operands                      chip %.2f TFLOP/s   %.3f ms\n", label, NACC, flops / (ms * 1e-3) / 1e12, ms);
+	(void)hipFree(out);
+	(void)hipFree(src);
+	(void)hipFree(cyc);
+}
+
 template <int NACC>
 void run(int blocks, int threads, const char *label) {
 	double *out;
@@ -57,5 +129,12 @@ int main() {
 	run<9>(256, 256, "1 wave/SIMD, 9 acc");
 	run<9>(512, 256, "2 waves/SIMD, 9 acc");
 	run<4>(1024, 256, "4 waves/SIMD, 4 acc");
+	run_random<9, 0>(256, 256, "1 wave/SIMD, 9 acc");
+	run_random<9, 0>(512, 256, "2 waves/SIMD, 9 acc");
+	run_random<4, 0>(1024, 256, "4 waves/SIMD, 4 acc");
+	run_random<9, 1>(512, 256, "2 w/SIMD same A");
+	run_random<9, 2>(512, 256, "2 w/SIMD A == B");
+	run_random<9, 3>(512, 256, "2 w/SIMD pairs share A");
+	run_random<9, 4>(512, 256, "2 w/SIMD kernel tile order");
 	return 0;
 }
