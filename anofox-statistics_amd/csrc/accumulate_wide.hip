@@ -106,8 +106,8 @@ struct WideCfg {
 template <int T, int WAVE, bool WEIGHTED, bool CENTER>
 __device__ __forceinline__ void compute_chunk(const double *img, const double *firstcol, int ycol, int lane, unsigned rowmask,
                                               dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
-                                              double (&sxy)[WideCfg<T>::OWN], unsigned &ncmask, double &sy,
-                                              double &syy, double &sw) {
+                                              double (&sxy)[WideCfg<T>::OWN], double (&dmax)[WideCfg<T>::OWN], unsigned &ncmask,
+                                              double &sy, double &syy, double &sw) {
 	constexpr int kChunkRows = WideCfg<T>::chunk_rows(WEIGHTED), kLdsStride = WideCfg<T>::stride(WEIGHTED), OWN = WideCfg<T>::OWN;
 	const int k = lane >> 4;
 	const int i = lane & 15;
@@ -154,9 +154,15 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 			if (I % kWaves == WAVE) {
 				// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row (a zeroed row of a
 				// shifted image gives 0; a raw image needs the row's validity)
-				const double dev = CENTER ? d[s][I] : d[s][I] - fown[I / kWaves];
-				const bool moved = !(fabs(dev) < 1e-10) && (CENTER || ((rowmask >> row_bit(row)) & 1u));
-				ncmask |= moved ? (1u << I) : 0u;
+				if (CENTER) {
+					// shifted image: |x - x_first| itself, 0 on rows that do not take part — keep the largest (one v_max_f64;
+					// the compare / select / or per slab it replaces sat in the MFMA waves' instruction stream)
+					dmax[I / kWaves] = fmax(dmax[I / kWaves], fabs(d[s][I]));
+				} else {
+					const double dev = d[s][I] - fown[I / kWaves];
+					const bool moved = !(fabs(dev) < 1e-10) && ((rowmask >> row_bit(row)) & 1u);
+					ncmask |= moved ? (1u << I) : 0u;
+				}
 				sx[I / kWaves] += a[I];
 				sxy[I / kWaves] = fma(a[I], dy[s], sxy[I / kWaves]);
 			}
@@ -246,9 +252,9 @@ __device__ __forceinline__ void wide_accumulate_rows_wave(const WideArgs &args, 
 	dbl4 acc[Cfg::TPW];
 #pragma unroll
 	for (int t = 0; t < Cfg::TPW; ++t) acc[t] = (dbl4){0.0, 0.0, 0.0, 0.0};
-	double sx[Cfg::OWN], sxy[Cfg::OWN];
+	double sx[Cfg::OWN], sxy[Cfg::OWN], dmax[Cfg::OWN];
 #pragma unroll
-	for (int o = 0; o < Cfg::OWN; ++o) sx[o] = sxy[o] = 0.0;
+	for (int o = 0; o < Cfg::OWN; ++o) sx[o] = sxy[o] = dmax[o] = 0.0;
 	unsigned ncmask = 0;
 	double sy = 0.0, syy = 0.0, sw = 0.0;
 	bool have_first = forced_first != nullptr; // wave-uniform
@@ -300,35 +306,48 @@ __device__ __forceinline__ void wide_accumulate_rows_wave(const WideArgs &args, 
 	// row-validity mask (ols.rs:59-66, wls.rs:76-86).  Straight-line code: lanes whose column does not exist store into
 	// a spare column and count as valid.
 	auto stage_store = [&](int64_t chunk, int buf, const Stage &sg) {
-		bool ok0 = true, ok1 = true, ok2 = true, ok3 = true;
 		double *img = image + buf * ncol_pad * kLdsStride;
 		const int64_t left = nrows - chunk * kChunkRows; // rows of the group in this chunk (wave-uniform)
-		const bool in0 = 2 * rp < left, in1 = 2 * rp + 1 < left, in2 = 2 * rp + 16 < left, in3 = 2 * rp + 17 < left;
+		// A row is valid when every value is finite (ols.rs:59-66): z_k = sum_q 0 * v_k[q] is NaN exactly when one of the
+		// lane's values of row class k is not finite — one FMA per value and one compare per row class instead of a class
+		// test and two scalar mask updates per value.  (Lanes of columns that do not exist hold y values: harmless.)
+		double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+		bool wbad0 = false, wbad1 = false, wbad2 = false, wbad3 = false; // wls.rs:76-86: w > 0
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
 			if (wave + kWaves * q < n_loads_total) { // wave-uniform
-				const bool inactive = !((actbits >> q) & 1u);
-				const bool isw = WEIGHTED && ((wbits >> q) & 1u);
-				bool f0 = isfinite(sg.v0[q]), f1 = isfinite(sg.v1[q]), f2 = isfinite(sg.v2[q]), f3 = isfinite(sg.v3[q]);
-				if (WEIGHTED) {
-					f0 = f0 && !(isw && !(sg.v0[q] > 0.0));
-					f1 = f1 && !(isw && !(sg.v1[q] > 0.0));
-					f2 = f2 && !(isw && !(sg.v2[q] > 0.0));
-					f3 = f3 && !(isw && !(sg.v3[q] > 0.0));
-				}
-				ok0 = ok0 && (f0 || inactive);
-				ok1 = ok1 && (f1 || inactive);
-				ok2 = ok2 && (f2 || inactive);
-				ok3 = ok3 && (f3 || inactive);
-				double *dst = img + dcol[q];
-				dst[0] = in0 ? sg.v0[q] - fq[q] : 0.0;
-				dst[1] = in1 ? sg.v1[q] - fq[q] : 0.0;
+				z0 = fma(sg.v0[q], 0.0, z0);
+				z1 = fma(sg.v1[q], 0.0, z1);
 				if (kWideChunk) {
-					dst[16] = in2 ? sg.v2[q] - fq[q] : 0.0;
-					dst[17] = in3 ? sg.v3[q] - fq[q] : 0.0;
+					z2 = fma(sg.v2[q], 0.0, z2);
+					z3 = fma(sg.v3[q], 0.0, z3);
+				}
+				if (WEIGHTED) {
+					const bool isw = (wbits >> q) & 1u;
+					wbad0 = wbad0 || (isw && !(sg.v0[q] > 0.0));
+					wbad1 = wbad1 || (isw && !(sg.v1[q] > 0.0));
+					wbad2 = wbad2 || (isw && !(sg.v2[q] > 0.0));
+					wbad3 = wbad3 || (isw && !(sg.v3[q] > 0.0));
+				}
+				double *dst = img + dcol[q];
+				if (left >= kChunkRows) { // wave-uniform: every row of the chunk exists
+					dst[0] = sg.v0[q] - fq[q];
+					dst[1] = sg.v1[q] - fq[q];
+					if (kWideChunk) {
+						dst[16] = sg.v2[q] - fq[q];
+						dst[17] = sg.v3[q] - fq[q];
+					}
+				} else { // the group's last chunk: rows past its end as zeros
+					dst[0] = 2 * rp < left ? sg.v0[q] - fq[q] : 0.0;
+					dst[1] = 2 * rp + 1 < left ? sg.v1[q] - fq[q] : 0.0;
+					if (kWideChunk) {
+						dst[16] = 2 * rp + 16 < left ? sg.v2[q] - fq[q] : 0.0;
+						dst[17] = 2 * rp + 17 < left ? sg.v3[q] - fq[q] : 0.0;
+					}
 				}
 			}
 		}
+		const bool ok0 = !isnan(z0) && !wbad0, ok1 = !isnan(z1) && !wbad1, ok2 = !isnan(z2) && !wbad2, ok3 = !isnan(z3) && !wbad3;
 		// fold the 8 column sub-groups: byte k of the mask = rows {2j, 2j+1, 16+2j, 17+2j}[k], j = bit (row_bit below)
 		unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
 		b0 &= b0 >> 32; b0 &= b0 >> 16; b0 &= b0 >> 8;
@@ -407,7 +426,7 @@ __device__ __forceinline__ void wide_accumulate_rows_wave(const WideArgs &args, 
 
 		cnt += __popc(rowmask);
 		ACC_STAMP(1);
-		compute_chunk<T, WAVE, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, ncmask, sy, syy, sw);
+		compute_chunk<T, WAVE, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, dmax, ncmask, sy, syy, sw);
 		ACC_STAMP(2);
 #ifdef ANOFOX_SOLVE_STAMPS
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -456,7 +475,7 @@ __device__ __forceinline__ void wide_accumulate_rows_wave(const WideArgs &args, 
 			double a = sx[I / kWaves], b = sxy[I / kWaves];
 			a += shfl_xor_d(a, 16); a += shfl_xor_d(a, 32);
 			b += shfl_xor_d(b, 16); b += shfl_xor_d(b, 32);
-			unsigned nc = (ncmask >> I) & 1u;
+			unsigned nc = CENTER ? (dmax[I / kWaves] >= 1e-10 ? 1u : 0u) : ((ncmask >> I) & 1u);
 			nc |= __shfl_xor((int)nc, 16, 64);
 			nc |= __shfl_xor((int)nc, 32, 64);
 			if (lane < 16) {
