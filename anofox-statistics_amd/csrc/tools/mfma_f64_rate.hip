@@ -61,6 +61,65 @@ __global__ __launch_bounds__(256) void rate_kernel_random(double *out, int iters
 	if (threadIdx.x == 0 && blockIdx.x == 0) *cycles = t1 - t0;
 }
 
+// How much matrix-core time does ordinary vector work cost?  9 MFMAs (distinct operands) plus NV independent
+// v_fma_f64 per loop trip, in the same wave.
+template <int NV>
+__global__ __launch_bounds__(256) void rate_kernel_mixed(double *out, int iters, const double *src) {
+	dbl4 acc[9];
+	for (int i = 0; i < 9; ++i) acc[i] = (dbl4){0, 0, 0, 0};
+	double a[8], b[8], v[8];
+	for (int i = 0; i < 8; ++i) {
+		a[i] = src[(threadIdx.x * 16 + i) & 4095];
+		b[i] = src[(threadIdx.x * 16 + 8 + i) & 4095];
+		v[i] = a[i] * 0.001;
+	}
+	for (int it = 0; it < iters; it += 8) {
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+#pragma unroll
+			for (int i = 0; i < 9; ++i) {
+				acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(i + k) & 7], b[(i * 3 + k) & 7], acc[i], 0, 0, 0);
+#pragma unroll
+				for (int j = 0; j < NV / 9 + ((i < NV % 9) ? 1 : 0); ++j) v[(i + j) & 7] = fma(v[(i + j) & 7], 0.999999, a[(i + j + k) & 7]);
+			}
+		}
+	}
+	double s = 0;
+	for (int i = 0; i < 9; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+	for (int i = 0; i < 8; ++i) s += v[i];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int NV>
+void run_mixed(int blocks) {
+	double *out, *src;
+	(void)hipMalloc(&out, (size_t)blocks * 256 * sizeof(double));
+	(void)hipMalloc(&src, 4096 * sizeof(double));
+	double h[4096];
+	unsigned long long x = 88172645463325252ull;
+	for (int i = 0; i < 4096; ++i) {
+		x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+		h[i] = ((double)(x >> 11) / 9007199254740992.0) * 20.0 - 10.0;
+	}
+	(void)hipMemcpy(src, h, sizeof h, hipMemcpyHostToDevice);
+	const int iters = 20000;
+	hipEvent_t e0, e1;
+	(void)hipEventCreate(&e0);
+	(void)hipEventCreate(&e1);
+	hipLaunchKernelGGL(rate_kernel_mixed<NV>, dim3(blocks), dim3(256), 0, 0, out, 104, src);
+	(void)hipDeviceSynchronize();
+	(void)hipEventRecord(e0);
+	hipLaunchKernelGGL(rate_kernel_mixed<NV>, dim3(blocks), dim3(256), 0, 0, out, iters, src);
+	(void)hipEventRecord(e1);
+	(void)hipDeviceSynchronize();
+	float ms;
+	(void)hipEventElapsedTime(&ms, e0, e1);
+	const double flops = ((double)blocks * 4) * (double)iters * 9 * 2.0 * 16 * 16 * 4;
+	printf("%d waves/SIMD, 9 MFMA + %3d v_fma_f64 per trip   chip %.2f TFLOP/s (MFMA only)   %.3f ms\n", blocks / 256, NV, flops / (ms * 1e-3) / 1e12, ms);
+	(void)hipFree(out);
+	(void)hipFree(src);
+}
+
 template <int NACC, int PATTERN>
 void run_random(int blocks, int threads, const char *label) {
 	double *out, *src;
@@ -136,5 +195,12 @@ int main() {
 	run_random<9, 2>(512, 256, "2 w/SIMD A == B");
 	run_random<9, 3>(512, 256, "2 w/SIMD pairs share A");
 	run_random<9, 4>(512, 256, "2 w/SIMD kernel tile order");
+	run_mixed<0>(512);
+	run_mixed<9>(512);
+	run_mixed<18>(512);
+	run_mixed<36>(512);
+	run_mixed<72>(512);
+	run_mixed<36>(256);
+	run_mixed<36>(1024);
 	return 0;
 }
