@@ -34,10 +34,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # vector rate); FP64 MFMA runs at half of it on MI355X (AMD datasheet: 78.6 TFLOP/s FP64 matrix = FP64 vector).
 FP64_MFMA_PEAK_TFLOPS = 78.6
 # Measured on the MI355X boxes of this pool (not datasheet): a plain 16-B/lane streaming read reaches 6.05-6.39 TB/s
-# (csrc/tools/hbm_read_rate, profiles/r01_hbm_read_rate.txt) and a pure v_mfma_f64_16x16x4_f64 loop 47 TFLOP/s
-# (csrc/tools/mfma_f64_rate).  Reported next to `peak`; `frac` stays achieved / peak.
+# (csrc/tools/hbm_read_rate, profiles/r01_hbm_read_rate.txt) and a pure v_mfma_f64_16x16x4_f64 loop whose instructions
+# take DIFFERENT operand registers 68-72 TFLOP/s (csrc/tools/mfma_f64_rate, profiles/r02_mfma_f64_rate.txt; round 1's
+# 47 TFLOP/s came from a loop that fed every instruction the same two registers).  Reported next to `peak`; `frac`
+# stays achieved / peak.
 MEASURED_STREAM_READ_GBS = 6390.0
-MEASURED_MFMA_F64_TFLOPS = 47.0
+MEASURED_MFMA_F64_TFLOPS = 72.0
 
 
 def algorithmic_bytes_per_fit(n: int, p: int, weighted: bool, inference: bool) -> int:
