@@ -306,6 +306,9 @@ __device__ __forceinline__ int64_t register_overflow_rows(void *table, int64_t s
 }
 #endif
 hipError_t launch_predict(const PredictArgs &a, hipStream_t stream);
+// out[g] = { rss, aic, bic } from the fit records (predict.hip)
+hipError_t launch_information_criteria(const double *core, int64_t n_groups, int p, int fit_intercept, int wls, double *out,
+                                       hipStream_t stream);
 
 // expanding-window fit + predict (window_narrow.hip), p <= kNarrowMaxP
 struct WindowArgs {

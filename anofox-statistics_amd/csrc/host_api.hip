@@ -506,6 +506,50 @@ bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, si
 	return run_predict(ctx, n_groups, n_features, n_rows, d_row_offsets, x_cols, d_core, confidence_level, d_pred, out_error);
 }
 
+bool anofox_hip_information_criteria_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, const double *d_core,
+                                                  AnofoxHipBatchOptions options, double *d_out, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (n_groups < 0 || n_features == 0 || n_features > (size_t)kWideMaxP) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "invalid n_groups / n_features");
+		return false;
+	}
+	if (n_groups > 0 && (!d_core || !d_out)) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "core or out is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	return !hip_fail(launch_information_criteria(d_core, n_groups, (int)n_features, options.fit_intercept ? 1 : 0,
+	                                             options.model == ANOFOX_HIP_MODEL_WLS ? 1 : 0, d_out, ctx->stream),
+	                 "information criteria kernel launch", out_error);
+}
+
+bool anofox_hip_information_criteria_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, const double *core,
+                                                AnofoxHipBatchOptions options, double *out, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) {
+		ctx = default_context(out_error);
+		if (!ctx) return false;
+	}
+	if (n_groups < 0 || n_features == 0 || n_features > (size_t)kWideMaxP) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "invalid n_groups / n_features");
+		return false;
+	}
+	if (n_groups == 0) return true;
+	if (!core || !out) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "core or out is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	const size_t G = (size_t)n_groups, b_core = align_up(G * (n_features + 6) * sizeof(double), 256);
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_core + G * 3 * sizeof(double), "staging", out_error)) return false;
+	double *d_core = (double *)ctx->stage, *d_out = (double *)((char *)ctx->stage + b_core);
+	hipStream_t st = ctx->stream;
+	if (hip_fail(hipMemcpyAsync(d_core, core, G * (n_features + 6) * sizeof(double), hipMemcpyHostToDevice, st), "H2D core", out_error)) return false;
+	if (hip_fail(launch_information_criteria(d_core, n_groups, (int)n_features, options.fit_intercept ? 1 : 0,
+	                                         options.model == ANOFOX_HIP_MODEL_WLS ? 1 : 0, d_out, st),
+	             "information criteria kernel launch", out_error))
+		return false;
+	if (hip_fail(hipMemcpyAsync(out, d_out, G * 3 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H", out_error)) return false;
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
+}
+
 bool anofox_hip_fit_predict_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                          const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
                                          const double *d_w, const int64_t *d_train_counts, AnofoxHipBatchOptions options,

@@ -274,6 +274,53 @@ hipError_t launch_predict_p(const PredictArgs &a, hipStream_t stream) {
 
 } // namespace
 
+namespace {
+
+// Information criteria of every fit of a batch, from the fit records alone (information_criteria.rs:15-33,67-85):
+//   k   = estimated parameters = coefficients that are not NaN (+ 1 with an intercept)
+//   rss = residual_std_error^2 (n - k)         (the record's sigma is sqrt(rss / (n - k)), ols.rs:183)
+//   aic = n ln(rss / n) + 2 k,   bic = n ln(rss / n) + k ln n;   rss == 0 -> -inf;   NULL group or n == k -> NaN
+// out[g] = { rss, aic, bic }.  One thread per group.
+__global__ __launch_bounds__(256) void information_criteria_kernel(const double *core, int64_t n_groups, int p, int icpt, int wls,
+                                                                   double *out) {
+	const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g >= n_groups) return;
+	const double *c = core + g * (int64_t)(p + 6);
+	const double nanv = __builtin_nan("");
+	double rss = nanv, aic = nanv, bic = nanv;
+	if (c[p + 5] == 0.0) {
+		int k = icpt ? 1 : 0;
+		for (int j = 0; j < p; ++j) k += isnan(c[j]) ? 0 : 1;
+		const double n = c[p + 4], rse = c[p + 3];
+		// the intercept-only shortcut reports sqrt(sum w (y - ybar)^2 / sum w) for WLS (wls.rs:126-135): the weight
+		// total is not in the record, so rss cannot be recovered there
+		const bool wls_icpt_only = wls && k == (icpt ? 1 : 0);
+		if (n > (double)k && !wls_icpt_only && !isnan(rse)) {
+			rss = rse * rse * (n - (double)k);
+			if (rss == 0.0) {
+				aic = bic = -__builtin_inf();
+			} else {
+				const double base = n * log(rss / n);
+				aic = base + 2.0 * (double)k;
+				bic = base + (double)k * log(n);
+			}
+		}
+	}
+	out[3 * g] = rss;
+	out[3 * g + 1] = aic;
+	out[3 * g + 2] = bic;
+}
+
+} // namespace
+
+hipError_t launch_information_criteria(const double *core, int64_t n_groups, int p, int fit_intercept, int wls, double *out,
+                                       hipStream_t stream) {
+	if (n_groups <= 0) return hipSuccess;
+	hipLaunchKernelGGL(information_criteria_kernel, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, stream, core, n_groups, p,
+	                   fit_intercept, wls, out);
+	return hipGetLastError();
+}
+
 hipError_t launch_predict(const PredictArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
 	hipLaunchKernelGGL(predict_margin_kernel, dim3((unsigned)((a.n_groups + 255) / 256)), dim3(256), 0, stream, a);

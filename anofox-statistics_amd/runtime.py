@@ -156,6 +156,20 @@ class Context:
         self._check(ok, err)
         return pred
 
+    def information_criteria_device(self, core, options: _abi.AnofoxHipBatchOptions, out=None, use_current_torch_stream: bool = True):
+        """CUDA fit records [G, p+6] -> out[G, 3] = {rss, aic, bic}; asynchronous."""
+        import torch
+        G, p = int(core.shape[0]), int(core.shape[1]) - 6
+        if out is None:
+            out = torch.empty((G, 3), dtype=torch.float64, device=core.device)
+        if use_current_torch_stream:
+            self.set_stream(torch.cuda.current_stream(core.device).cuda_stream)
+        err = _abi.AnofoxError()
+        ok = self._lib.anofox_hip_information_criteria_batch_device(self._h, G, p, C.c_void_p(core.data_ptr()), options,
+                                                                    C.c_void_p(out.data_ptr()), C.byref(err))
+        self._check(ok, err)
+        return out
+
     def last_refine_count(self) -> int:
         """Groups of the most recent fit launch that took the on-device refinement passes (diagnostic)."""
         n = C.c_int64()
@@ -374,6 +388,20 @@ def fit_predict_batch_host(row_offsets, y, x_cols: Sequence, w, options: _abi.An
     if not ok:
         raise AnofoxStatsError(err.code, err.text())
     return core, pred
+
+
+def information_criteria_host(core, options: _abi.AnofoxHipBatchOptions, ctx: Optional[Context] = None):
+    """numpy fit records [G, p+6] -> out[G, 3] = {rss, aic, bic} (anofox_hip_information_criteria_batch_host)."""
+    lib = _abi.load()
+    c = np.ascontiguousarray(core, dtype=np.float64)
+    G, p = c.shape[0], c.shape[1] - 6
+    out = np.empty((G, 3), dtype=np.float64)
+    err = _abi.AnofoxError()
+    ok = lib.anofox_hip_information_criteria_batch_host(ctx._h if ctx is not None else None, G, p, c.ctypes.data_as(_DP), options,
+                                                        out.ctypes.data_as(_DP), C.byref(err))
+    if not ok:
+        raise AnofoxStatsError(err.code, err.text())
+    return out
 
 
 FRAME_UNBOUNDED = 2 ** 63 - 1        # ANOFOX_HIP_FRAME_UNBOUNDED

@@ -321,6 +321,22 @@ ANOFOX_HIP_API bool anofox_hip_fit_batch_host(AnofoxHipContext *ctx, int64_t n_g
                                AnofoxError *out_error);
 
 /*
+ * Information criteria as batched outputs of the fit records: what the SQL functions
+ * aic(rss, n, k) / bic(rss, n, k) (src/scalar_functions/aic_bic.cpp:12-110 over
+ * crates/anofox-stats-core/src/diagnostics/information_criteria.rs:15-33,67-85) give when they are applied to every
+ * group's fit with k = estimated parameters (coefficients that are not NaN, + 1 with an intercept) and
+ * rss = residual_std_error^2 (n_observations - k):  out[g] = { rss, aic, bic },  aic = n ln(rss / n) + 2 k,
+ * bic = n ln(rss / n) + k ln n,  rss == 0 -> -inf (:24-26),  NaN for NULL groups and for n == k.
+ * `core` = records of anofox_hip_fit_batch_* fitted with the same `options` (fit_intercept and model are used).
+ */
+ANOFOX_HIP_API bool anofox_hip_information_criteria_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features,
+                                                  const double *d_core, AnofoxHipBatchOptions options, double *d_out,
+                                                  AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_information_criteria_batch_host(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features,
+                                                const double *core, AnofoxHipBatchOptions options, double *out,
+                                                AnofoxError *out_error);
+
+/*
  * fit + predict in one batch: the `*_fit_predict_agg` aggregates (src/aggregate_functions/ols_predict_aggregate.cpp:
  * 322-425, ridge/wls likewise).  Every row of every group gets {yhat, yhat_lower, yhat_upper} (d_pred, [n_rows x 3],
  * NaN = SQL NULL); rows whose y is NaN (the aggregate's NULL y = "prediction row") or that hold a non-finite

@@ -1440,3 +1440,52 @@ def test_residuals_device_full_size_properties(pkg, ctx):
                                          [c[:S * n].cpu().numpy() for c in x_cols], offs[:S + 1].cpu().numpy(),
                                          rse=rse[:S].cpu().numpy())
     _assert_residuals_match(out[:S * n].cpu().numpy(), grp[:S].cpu().numpy(), rout, rgrp, "device sample")
+
+
+# --------------------------------------------------------------------------------------------------
+# information criteria as batched outputs of the fit records
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model,p,icpt", [("ols", 3, True), ("ols", 8, False), ("wls", 5, True), ("ridge", 12, True), ("ols", 40, True)])
+def test_information_criteria_batch_matches_reference_formula(pkg, ctx, model, p, icpt):
+    """out[g] = {rss, aic, bic}: rss against the residuals of the oracle's coefficients summed in numpy, aic / bic
+    against information_criteria.rs:15-33,67-85 (oracle.aic / oracle.bic) on (rss, n, k)."""
+    rng = np.random.default_rng(31 * p + len(model))
+    G = 40
+    offs, y, x_cols, w = _random_groups(rng, G, p, p + 3, 300)
+    # degenerate groups: a constant column (k shrinks), a one-row group (NULL), an exact fit (rss -> 0)
+    x_cols[0][offs[1]:offs[2]] = 2.5
+    lo, hi = offs[3], offs[4]
+    y[lo:hi] = (1.0 if icpt else 0.0) + sum((j + 1) * x_cols[j][lo:hi] for j in range(p))
+    kw = dict(fit_intercept=icpt)
+    if model == "ridge":
+        kw["alpha"] = 0.3
+    wv = w if model == "wls" else None
+    opts = _opts(pkg, model, **kw)
+    core, _ = pkg.fit_batch_host(offs, y, x_cols, wv, opts, ctx=ctx)
+    out = pkg.information_criteria_host(core, opts, ctx=ctx)
+    rcore, _ = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
+    X = np.stack(x_cols, axis=1)
+    for g in range(G):
+        if rcore[g, p + 5] != 0:
+            assert np.all(np.isnan(out[g]))
+            continue
+        sl = slice(offs[g], offs[g + 1])
+        b = np.nan_to_num(rcore[g, :p], nan=0.0)
+        res = y[sl] - (rcore[g, p] if icpt else 0.0) - X[sl] @ b
+        rss = float(np.sum((w[sl] if model == "wls" else 1.0) * res * res))
+        k = int(np.sum(~np.isnan(rcore[g, :p]))) + int(icpt)
+        n = int(rcore[g, p + 4])
+        if n == k:
+            assert np.all(np.isnan(out[g]))
+            continue
+        if g == 3 and model != "ridge":      # exact fit: rss is rounding noise, the criteria are hugely negative (or -inf)
+            assert out[g, 0] < 1e-18 * np.sum(y[sl] ** 2) and out[g, 1] < -20 * n
+            continue
+        assert abs(out[g, 0] / rss - 1.0) < DIAG_RTOL, (g, out[g, 0], rss)
+        assert abs(out[g, 1] - oracle.aic(rss, n, k)[1]) <= 1e-6 * max(1.0, abs(out[g, 1]))
+        assert abs(out[g, 2] - oracle.bic(rss, n, k)[1]) <= 1e-6 * max(1.0, abs(out[g, 2]))
+    # device entry point: same numbers
+    import torch
+    d = ctx.information_criteria_device(torch.from_numpy(core).cuda(), opts)
+    torch.cuda.synchronize()
+    assert np.array_equal(np.nan_to_num(d.cpu().numpy(), nan=-7.0), np.nan_to_num(out, nan=-7.0))
