@@ -18,7 +18,7 @@ from .aggregate import (StreamingStates, FitAggResult, FitPredictAggResult, OlsF
                         result_from_records, ols_fit_predict, ridge_fit_predict, wls_fit_predict, vif_agg,
                         residuals_diagnostics_agg)
 from .options import InvalidInputException, RegressionOptions, parse_options  # noqa: E402
-from .runtime import AggState, Context, information_criteria_host, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host, fit_predict_window_host, vif_batch_host, residuals_batch_host  # noqa: E402
+from .runtime import AggState, Context, information_criteria_host, fit_predict_frames_host, fit_batch_host, fit_predict_batch_host, fit_predict_expanding_host, fit_predict_window_host, vif_batch_host, residuals_batch_host  # noqa: E402
 from .scalar import aic, bic, ols_fit, predict, predict_with_interval, ridge_fit, t_critical, vif, wls_fit, residuals_diagnostics  # noqa: E402
 
 # the scalar functions under their SQL names (src/table_functions/{ols,ridge,wls}_fit.cpp, predict.cpp,
@@ -35,7 +35,7 @@ SQL_FUNCTIONS.update({
 })
 
 __all__ = [
-    "AggState", "StreamingStates", "information_criteria_host", "AnofoxStatsError", "Context", "FitAggResult", "InvalidInputException", "OlsFitAgg", "RegressionOptions",
+    "AggState", "StreamingStates", "information_criteria_host", "fit_predict_frames_host", "AnofoxStatsError", "Context", "FitAggResult", "InvalidInputException", "OlsFitAgg", "RegressionOptions",
     "RidgeFitAgg", "SQL_FUNCTIONS", "WlsFitAgg", "aic", "bic", "fit_batch_host", "ols_fit", "ols_fit_agg",
     "parse_options", "result_from_records", "ridge_fit", "ridge_fit_agg", "wls_fit", "wls_fit_agg",
     "FitPredictAggResult", "OlsFitPredictAgg", "RidgeFitPredictAgg", "WlsFitPredictAgg", "fit_predict_batch_host",

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (gl >= args.n_groups) return;
 	const int64_t lo = args.row_offsets[args.group_base + gl];
-	const int64_t hi = args.row_offsets[args.group_base + gl + 1];
+	const int64_t hi = group_row_end(args, args.group_base + gl);
 	if (args.seg_table && hi - lo > args.seg_rows) {
 		if (wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments)) return;
 	}

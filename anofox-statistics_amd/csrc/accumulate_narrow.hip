@@ -206,7 +206,7 @@ template <int P, bool WEIGHTED, bool CENTER, bool PF>
 __device__ __forceinline__ void accumulate_group(const BatchArgs &args, int64_t g, int lane) {
 	using L = MomentLayout<P>;
 	const int64_t lo = args.row_offsets[g];
-	const int64_t hi = args.row_offsets[g + 1];
+	const int64_t hi = group_row_end(args, g);
 	if (args.seg_table && hi - lo > args.seg_rows) {
 		// a single wavefront streams at ~5 GB/s: hand the group to accumulate_segments_kernel in pieces (unless the
 		// tables are full, which only happens when the caller understated n_rows: then it stays with this wave)

@@ -519,7 +519,7 @@ template <int T, bool WEIGHTED, bool CENTER>
 __global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) {
 	const int64_t g = blockIdx.x;
 	const int64_t lo = args.row_offsets[args.group_base + g];
-	const int64_t hi = args.row_offsets[args.group_base + g + 1];
+	const int64_t hi = group_row_end(args, args.group_base + g);
 	if (args.seg_table && hi - lo > args.seg_rows) {
 		// four waves stream a group at ~25 GB/s: hand it to accumulate_wide_segments_kernel in pieces
 		__shared__ int registered;

@@ -75,7 +75,11 @@ struct BatchArgs {
 	// segments of seg_rows rows, one wavefront each, and merged; seg_table == nullptr disables it
 	void *seg_table;
 	int64_t seg_rows;
+	// optional [G]: group g owns rows [row_offsets[g], row_ends[g]) instead of [row_offsets[g], row_offsets[g+1]) —
+	// row ranges may then overlap (window frames fitted as a batch of "virtual groups", frames.hip)
+	const int64_t *row_ends;
 };
+inline __host__ __device__ int64_t group_row_end(const BatchArgs &a, int64_t g) { return a.row_ends ? a.row_ends[g] : a.row_offsets[g + 1]; }
 
 // Segment bookkeeping of the narrow accumulate kernel.  seg_rows >= ceil(n_rows / kSegTargetWaves), so fewer than
 // kSegTargetWaves groups can exceed it and their segments number fewer than 2 kSegTargetWaves: fixed-size tables.
@@ -152,7 +156,9 @@ struct WideArgs {
 	// valid row as its shift, found when the group is registered, so that merging is a plain sum)
 	void *seg_table;
 	int64_t seg_rows;
+	const int64_t *row_ends; // optional [G_total], see BatchArgs
 };
+inline __host__ __device__ int64_t group_row_end(const WideArgs &a, int64_t g) { return a.row_ends ? a.row_ends[g] : a.row_offsets[g + 1]; }
 
 // wide-record segment table: SegHeader | SegBigGroup[kSegMaxBig] | SegEntry[kSegMaxSegments] |
 //   first[kSegMaxBig][16 T + 2] (x at the group's first valid row, then y) | records[kSegMaxSegments][record_len]
@@ -391,6 +397,31 @@ hipError_t launch_ingest_chunk(const IngestArgs &a, hipStream_t stream);
 // empty src[i]; the dst indices of one call must be distinct
 hipError_t launch_ingest_combine(double *moments, int64_t *n_accum, int64_t n_slots, const uint32_t *src, const uint32_t *dst,
                                  int64_t n_pairs, int p, int center, hipStream_t stream);
+
+// ---- window frames as a batch of virtual groups (frames.hip): any p <= kWideMaxP, any frame ----
+struct FrameArgs {
+	const double *y;
+	const double *x_table[kWideMaxP];
+	int64_t n_frames;
+	int p;
+	int fit_intercept;
+	double confidence_level;
+	const int64_t *lo, *hi;   // frame e = rows [lo[e], hi[e]); the row predicted is hi[e] - 1
+	const int64_t *ynn;       // [n_rows + 1] prefix count of rows whose y is not NaN
+	int64_t *rule_counts;     // [n_frames] out: training rows when MORE than p + [intercept] exist, else 0 (-> NULL)
+	const double *core;       // [n_frames * (p + 6)] fit records of the frames
+	const double *tcrit;      // [tcrit_cap + 1], launch_tcrit_table
+	int tcrit_cap;
+	double *pred;             // [n_frames * 3]
+	const int32_t *list;      // optional: frame e of this batch is output row list[e] (pred index), else e
+};
+size_t frames_scan_temp_bytes(int64_t n_rows);
+hipError_t launch_frames_ynn(const double *y, int64_t n_rows, int64_t *ynn, void *temp, size_t temp_bytes, hipStream_t stream);
+// ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING -> lo / hi per row (clipped to the partition)
+hipError_t launch_frames_from_rows_spec(const int64_t *row_offsets, int64_t n_groups, int64_t n_rows, int64_t start_preceding,
+                                        int64_t end_preceding, int64_t *lo, int64_t *hi, hipStream_t stream);
+hipError_t launch_frames_rule(const FrameArgs &a, hipStream_t stream);
+hipError_t launch_frames_predict(const FrameArgs &a, hipStream_t stream);
 
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);

@@ -1,0 +1,157 @@
+// frames.hip — window functions over ANY frame and any width as a batch of "virtual groups".
+//
+// The reference's window functions (src/window_functions/ols_fit_predict.cpp:110-324; ridge_fit_predict.cpp,
+// wls_fit_predict.cpp) run the aggregate's Update / Finalize over every frame DuckDB hands them — ROWS, RANGE or
+// GROUPS, any number of features.  window_narrow.hip covers ROWS frames for p <= 8 with in-register solves; this
+// file covers everything else, and the frames window_narrow.hip flags as ill-conditioned: frame e is the row range
+// [lo[e], hi[e]) and becomes group e of an ordinary batch fit whose row ranges may overlap (BatchArgs::row_ends),
+// so the three accumulate / solve families (and their refinement passes) apply unchanged.  What is specific:
+//   ynn     prefix count of rows whose y is not NULL (NaN): the training rows of a frame in O(1);
+//   rule    the window's NULL rule: a frame needs MORE than p + [intercept] training rows
+//           (ols_fit_predict.cpp:257-262) — frames that fail get rule count 0, which the solve kernels turn into
+//           status 100 like the aggregate's "fewer than 2 rows";
+//   spec    frame bounds of ROWS BETWEEN a PRECEDING AND b PRECEDING per row, clipped to the partition;
+//   predict x of the LAST row of the frame (ols_fit_predict.cpp:157-162) with the simplified interval of
+//           anofox_predict_with_interval (lib.rs:2264-2349): yhat -+ t sigma sqrt(1 + 1/n).
+// Cost: O(frame) rows per output row (the reference refits every frame from scratch as well).
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "common.h"
+
+namespace anofox {
+
+namespace {
+
+struct NotNan {
+	__host__ __device__ int64_t operator()(double v) const { return v == v ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(256) void frames_spec_kernel(const int64_t *row_offsets, int64_t n_groups, int64_t n_rows, int64_t start_p,
+                                                          int64_t end_p, int64_t *lo_out, int64_t *hi_out) {
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= n_rows) return;
+	// partition of row e: the last g with row_offsets[g] <= e
+	int64_t a = 0, b = n_groups;
+	while (b - a > 1) {
+		const int64_t m = (a + b) >> 1;
+		if (row_offsets[m] <= e) a = m;
+		else b = m;
+	}
+	const int64_t plo = row_offsets[a], phi = row_offsets[a + 1];
+	int64_t first = start_p == kFrameUnbounded ? plo : e - start_p;
+	int64_t last = end_p == -kFrameUnbounded ? phi - 1 : e - end_p;
+	if (first < plo) first = plo;
+	if (last > phi - 1) last = phi - 1;
+	const bool empty = last < first || e < plo || e >= phi;
+	lo_out[e] = empty ? e : first;
+	hi_out[e] = empty ? e : last + 1;
+}
+
+__global__ __launch_bounds__(256) void frames_rule_kernel(FrameArgs a) {
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= a.n_frames) return;
+	const int64_t lo = a.lo[e], hi = a.hi[e];
+	int64_t nt = 0;
+	if (hi > lo) nt = a.ynn[hi] - a.ynn[lo];
+	a.rule_counts[e] = nt > (int64_t)(a.p + (a.fit_intercept ? 1 : 0)) ? nt : 0;
+}
+
+// critical value for an integer df: table lookup; beyond the table the Cornish-Fisher series (as window_narrow.hip)
+__device__ __forceinline__ double frames_tcrit(const FrameArgs &a, double df) {
+	const int i = (int)df;
+	if (i <= a.tcrit_cap) return a.tcrit[i];
+	const double z = a.tcrit[0], z2 = z * z, r = 1.0 / df;
+	const double g1 = z * (z2 + 1.0) * 0.25;
+	const double g2 = z * ((5.0 * z2 + 16.0) * z2 + 3.0) * (1.0 / 96.0);
+	const double g3 = z * (((3.0 * z2 + 19.0) * z2 + 17.0) * z2 - 15.0) * (1.0 / 384.0);
+	return z + r * (g1 + r * (g2 + r * g3));
+}
+
+__global__ __launch_bounds__(256) void frames_predict_kernel(FrameArgs a) {
+	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= a.n_frames) return;
+	const int p = a.p;
+	const double *c = a.core + e * (int64_t)(p + 6);
+	const double nanv = __builtin_nan("");
+	double yhat = nanv, ylo = nanv, yhi = nanv;
+	const int64_t hi = a.hi[e];
+	if (c[p + 5] == 0.0 && hi > a.lo[e]) {
+		const int64_t r = hi - 1; // the frame's last row
+		const double b0 = c[p];
+		double v = isnan(b0) ? 0.0 : b0; // lib.rs:2264-2349: NaN intercept / coefficients contribute 0
+		for (int j = 0; j < p; ++j) {
+			const double bj = c[j];
+			if (!isnan(bj)) v = fma(bj, a.x_table[j][r], v);
+		}
+		if (isfinite(v)) {
+			yhat = ylo = yhi = v;
+			const double rse = c[p + 3], n = c[p + 4];
+			const double used = (double)p + (isnan(b0) ? 0.0 : 1.0);
+			if (!isnan(rse) && rse > 0.0 && n > (double)p + 1.0 && n > used) {
+				const double t = frames_tcrit(a, n - used);
+				if (!isnan(t)) {
+					const double margin = t * rse * sqrt(1.0 + 1.0 / n);
+					ylo = v - margin;
+					yhi = v + margin;
+				}
+			}
+		}
+	}
+	double *out = a.pred + (a.list ? (int64_t)a.list[e] : e) * 3;
+	out[0] = yhat;
+	out[1] = ylo;
+	out[2] = yhi;
+}
+
+} // namespace
+
+size_t frames_scan_temp_bytes(int64_t n_rows) {
+	size_t temp = 0;
+	const double *y = nullptr;
+	int64_t *out = nullptr;
+	(void)rocprim::exclusive_scan(nullptr, temp, rocprim::make_transform_iterator(y, NotNan()), out, (int64_t)0, (size_t)n_rows + 1,
+	                              rocprim::plus<int64_t>(), (hipStream_t) nullptr);
+	return temp;
+}
+
+// ynn[i] = number of rows r < i with y[r] not NaN, i = 0 .. n_rows.  (The scan reads one element past y's rows to
+// produce ynn[n_rows]: y is therefore expected to be followed by readable memory — the callers pass a padded copy or
+// scan n_rows elements and finish the last entry with a one-thread kernel.)
+__global__ void frames_ynn_last_kernel(const double *y, int64_t n_rows, int64_t *ynn) {
+	if (n_rows > 0) ynn[n_rows] = ynn[n_rows - 1] + (y[n_rows - 1] == y[n_rows - 1] ? 1 : 0);
+	else ynn[0] = 0;
+}
+
+hipError_t launch_frames_ynn(const double *y, int64_t n_rows, int64_t *ynn, void *temp, size_t temp_bytes, hipStream_t stream) {
+	if (n_rows > 0) {
+		size_t tb = temp_bytes;
+		hipError_t rc = rocprim::exclusive_scan(temp, tb, rocprim::make_transform_iterator(y, NotNan()), ynn, (int64_t)0, (size_t)n_rows,
+		                                        rocprim::plus<int64_t>(), stream);
+		if (rc != hipSuccess) return rc;
+	}
+	hipLaunchKernelGGL(frames_ynn_last_kernel, dim3(1), dim3(1), 0, stream, y, n_rows, ynn);
+	return hipGetLastError();
+}
+
+hipError_t launch_frames_from_rows_spec(const int64_t *row_offsets, int64_t n_groups, int64_t n_rows, int64_t start_preceding,
+                                        int64_t end_preceding, int64_t *lo, int64_t *hi, hipStream_t stream) {
+	if (n_rows <= 0) return hipSuccess;
+	hipLaunchKernelGGL(frames_spec_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, row_offsets, n_groups, n_rows,
+	                   start_preceding, end_preceding, lo, hi);
+	return hipGetLastError();
+}
+
+hipError_t launch_frames_rule(const FrameArgs &a, hipStream_t stream) {
+	if (a.n_frames <= 0) return hipSuccess;
+	hipLaunchKernelGGL(frames_rule_kernel, dim3((unsigned)((a.n_frames + 255) / 256)), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_frames_predict(const FrameArgs &a, hipStream_t stream) {
+	if (a.n_frames <= 0) return hipSuccess;
+	hipLaunchKernelGGL(frames_predict_kernel, dim3((unsigned)((a.n_frames + 255) / 256)), dim3(256), 0, stream, a);
+	return hipGetLastError();
+}
+
+} // namespace anofox

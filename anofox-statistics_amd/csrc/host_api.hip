@@ -100,6 +100,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.core = d_core;
 	a.inference = opt.compute_inference ? d_inf : nullptr;
 	a.rule_counts = d_rule_counts;
+	a.row_ends = ctx->frame_ends;
 
 	hipStream_t st = ctx->stream;
 	a.seg_table = base + b_mom + b_rss + b_lst + 256 + kTcritTableBytes;
@@ -195,6 +196,7 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	a.rule_counts = d_rule_counts;
 	a.seg_table = ws.seg_table;
 	a.seg_rows = seg_rows_for(n_rows);
+	a.row_ends = ctx->frame_ends;
 
 	hipStream_t st = ctx->stream;
 	// refine counter + t table + the header of the segment table (contiguous)
@@ -215,7 +217,8 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 	if (ctx->timing) (void)hipEventRecord(e0, st); // (again: the accumulate kernel starts after the gate)
 	// batches of small groups (<= 128 rows on average): several groups per wavefront, the long ones through a list
 	static const bool small_on = !(getenv("ANOFOX_ACC_SMALL") && atoi(getenv("ANOFOX_ACC_SMALL")) == 0); // A/B switch
-	const int segw = (small_on && n_rows > 0 && G < (int64_t)0x7fffffff) ? accumulate_small_segment_width((double)n_rows / (double)G) : 0;
+	// (window frames: overlapping row ranges given by row_ends — the packed kernel reads row_offsets[g + 1])
+	const int segw = (small_on && !a.row_ends && n_rows > 0 && G < (int64_t)0x7fffffff) ? accumulate_small_segment_width((double)n_rows / (double)G) : 0;
 	if (segw) {
 		int32_t *big_count = ws.refine_count + 4; // zeroed with the other counters; the list borrows the (still unused) refine queue
 		if (hip_fail(launch_accumulate_small(a, segw, ws.refine_list, big_count, st), "accumulate kernel launch", e)) return false;
@@ -339,6 +342,7 @@ void anofox_hip_context_destroy(AnofoxHipContext *ctx) {
 	for (auto &pr : ctx->solve_events) { (void)hipEventDestroy(pr.second); }
 	for (auto ev : ctx->free_events) (void)hipEventDestroy(ev);
 	if (ctx->ws) (void)hipFree(ctx->ws);
+	if (ctx->frames_buf) (void)hipFree(ctx->frames_buf);
 	if (ctx->stage) (void)hipFree(ctx->stage);
 	if (ctx->aux) (void)hipFree(ctx->aux);
 	if (ctx->wtab) (void)hipFree(ctx->wtab);
@@ -645,10 +649,108 @@ bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int64_t n_groups, 
 
 namespace {
 
+// ---- window frames as virtual groups (frames.hip): any width, any frame, with the fit path's refinement ----
+constexpr int64_t kFrameSlab = 1 << 20; // frames fitted per pass (bounds the record scratch: (p + 6) doubles each)
+
+struct FrameScratch {
+	int64_t *ynn;   // [n_rows + 1]
+	void *scan_tmp;
+	size_t scan_tmp_bytes;
+	int64_t *lo, *hi; // [n_rows] (frames computed from a ROWS spec), else nullptr
+	int64_t *rule;  // [slab]
+	double *core;   // [slab * (p + 6)]
+};
+
+bool carve_frames(AnofoxHipContext *ctx, int64_t n_rows, int64_t n_frames, size_t p, bool need_bounds, FrameScratch *fs, AnofoxError *e) {
+	const int64_t slab = n_frames < kFrameSlab ? n_frames : kFrameSlab;
+	const size_t b_ynn = align_up(((size_t)n_rows + 2) * sizeof(int64_t), 256);
+	const size_t b_tmp = align_up(frames_scan_temp_bytes(n_rows) + 256, 256);
+	const size_t b_bnd = need_bounds ? align_up((size_t)n_rows * sizeof(int64_t), 256) : 0;
+	const size_t b_rule = align_up((size_t)slab * sizeof(int64_t), 256);
+	const size_t b_core = align_up((size_t)slab * (p + 6) * sizeof(double), 256);
+	if (!ensure_buffer(&ctx->frames_buf, &ctx->frames_bytes, b_ynn + b_tmp + 2 * b_bnd + b_rule + b_core, "window frame scratch", e)) return false;
+	char *base = (char *)ctx->frames_buf;
+	fs->ynn = (int64_t *)base;
+	fs->scan_tmp = base + b_ynn;
+	fs->scan_tmp_bytes = b_tmp;
+	fs->lo = need_bounds ? (int64_t *)(base + b_ynn + b_tmp) : nullptr;
+	fs->hi = need_bounds ? (int64_t *)(base + b_ynn + b_tmp + b_bnd) : nullptr;
+	fs->rule = (int64_t *)(base + b_ynn + b_tmp + 2 * b_bnd);
+	fs->core = (double *)(base + b_ynn + b_tmp + 2 * b_bnd + b_rule);
+	return true;
+}
+
+// Fit every frame [d_lo[e], d_hi[e]) as a group and predict its last row into d_pred[(d_list ? d_list[e] : e)].
+bool run_frames(AnofoxHipContext *ctx, const FrameScratch &fs, int64_t n_frames, size_t p, int64_t n_rows, const double *d_y,
+                const double *const *x_cols, const double *d_w, const int64_t *d_lo, const int64_t *d_hi, AnofoxHipBatchOptions opt,
+                double *d_pred, const int32_t *d_list, AnofoxError *e) {
+	if (n_frames == 0) return true;
+	opt.compute_inference = false; // the window functions fit without inference (ols_fit_predict.cpp:296)
+	opt.hc_type = ANOFOX_HC_NONE;
+	if (!ensure_buffer(&ctx->wtab, &ctx->wtab_bytes, (size_t)(kWindowTcritCap + 1) * sizeof(double), "t table", e)) return false;
+	hipStream_t st = ctx->stream;
+	if (ctx->wtab_conf != opt.confidence_level) {
+		if (hip_fail(launch_tcrit_table((double *)ctx->wtab, kWindowTcritCap, 0.5 * (1.0 + opt.confidence_level), st), "t table kernel launch", e)) return false;
+		ctx->wtab_conf = opt.confidence_level;
+	}
+	FrameArgs a;
+	memset(&a, 0, sizeof a);
+	a.y = d_y;
+	for (size_t j = 0; j < p; ++j) a.x_table[j] = x_cols[j];
+	a.p = (int)p;
+	a.fit_intercept = opt.fit_intercept ? 1 : 0;
+	a.confidence_level = opt.confidence_level;
+	a.ynn = fs.ynn;
+	a.rule_counts = fs.rule;
+	a.core = fs.core;
+	a.tcrit = (const double *)ctx->wtab;
+	a.tcrit_cap = kWindowTcritCap;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (ctx->timing) {
+		e0 = get_event(ctx);
+		e1 = get_event(ctx);
+		(void)hipEventRecord(e0, st);
+	}
+	const bool was_timing = ctx->timing;
+	ctx->timing = false; // the passes below are reported as one "predict" interval, not as accumulate / solve launches
+	bool ok = true;
+	for (int64_t s0 = 0; ok && s0 < n_frames; s0 += kFrameSlab) {
+		const int64_t S = n_frames - s0 < kFrameSlab ? n_frames - s0 : kFrameSlab;
+		a.n_frames = S;
+		a.lo = d_lo + s0;
+		a.hi = d_hi + s0;
+		a.pred = d_list ? d_pred : d_pred + 3 * s0;
+		a.list = d_list ? d_list + s0 : nullptr;
+		ok = !hip_fail(launch_frames_rule(a, st), "frame rule kernel launch", e);
+		ctx->frame_ends = a.hi;
+		ok = ok && run_device_batch(ctx, S, p, n_rows, a.lo, d_y, x_cols, d_w, opt, fs.core, nullptr, e, fs.rule);
+		ctx->frame_ends = nullptr;
+		ok = ok && !hip_fail(launch_frames_predict(a, st), "frame predict kernel launch", e);
+	}
+	ctx->timing = was_timing;
+	if (ctx->timing) {
+		(void)hipEventRecord(e1, st);
+		ctx->predict_events.emplace_back(e0, e1);
+	}
+	return ok;
+}
+
 bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, const int64_t *d_off, const double *d_y,
                 const double *const *x_cols, const double *d_w, const AnofoxHipWindowFrame &frame,
                 const AnofoxHipBatchOptions &opt, double *d_pred, AnofoxError *e) {
 	if (G == 0) return true;
+	if (p > (size_t)kNarrowMaxP) {
+		// wider than the in-register window kernels: every frame becomes a virtual group of the batch fit (frames.hip)
+		if (n_rows == 0) return true;
+		FrameScratch fs;
+		if (!carve_frames(ctx, n_rows, n_rows, p, true, &fs, e)) return false;
+		hipStream_t st = ctx->stream;
+		if (hip_fail(launch_frames_ynn(d_y, n_rows, fs.ynn, fs.scan_tmp, fs.scan_tmp_bytes, st), "frame scan launch", e)) return false;
+		if (hip_fail(launch_frames_from_rows_spec(d_off, G, n_rows, frame.start_preceding, frame.end_preceding, fs.lo, fs.hi, st),
+		             "frame bounds kernel launch", e))
+			return false;
+		return run_frames(ctx, fs, n_rows, p, n_rows, d_y, x_cols, d_w, fs.lo, fs.hi, opt, d_pred, nullptr, e);
+	}
 	if (!ensure_buffer(&ctx->wtab, &ctx->wtab_bytes, (size_t)(kWindowTcritCap + 1) * sizeof(double), "t table", e)) return false;
 	hipStream_t st = ctx->stream;
 	if (ctx->wtab_conf != opt.confidence_level) {
@@ -697,8 +799,8 @@ bool validate_window(AnofoxHipContext *ctx, int64_t G, size_t p, const void *off
 		return false;
 	}
 	if (G < 0 || p == 0 || !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "invalid n_groups / n_features / x"); return false; }
-	if (p > (size_t)kNarrowMaxP) {
-		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "the window path supports at most " + std::to_string(kNarrowMaxP) + " features");
+	if (p > (size_t)kWideMaxP) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "the window path supports at most " + std::to_string(kWideMaxP) + " features");
 		return false;
 	}
 	if (G > 0 && (!off || !y || !pred)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "row_offsets, y or pred is NULL"); return false; }
@@ -720,6 +822,93 @@ bool anofox_hip_fit_predict_window_device(AnofoxHipContext *ctx, int64_t n_group
 	std::lock_guard<std::mutex> lk(ctx->mu);
 	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
 	return run_window(ctx, n_groups, n_features, n_rows, d_row_offsets, d_y, x_cols, d_w, frame, options, d_pred, out_error);
+}
+
+namespace {
+bool validate_frames(AnofoxHipContext *ctx, int64_t n_rows, size_t p, const void *y, const double *const *x_cols, const void *w,
+                     const void *lo, const void *hi, const AnofoxHipBatchOptions &opt, const void *pred, AnofoxError *e) {
+	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
+	if (n_rows < 0 || p == 0 || p > (size_t)kWideMaxP || !x_cols) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "invalid n_rows / n_features / x"); return false; }
+	if (n_rows > 0 && (!y || !lo || !hi || !pred)) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "y, frame bounds or pred is NULL"); return false; }
+	for (size_t j = 0; j < p; ++j)
+		if (n_rows > 0 && !x_cols[j]) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "x column pointer is NULL"); return false; }
+	if (opt.model != ANOFOX_HIP_MODEL_OLS && opt.model != ANOFOX_HIP_MODEL_RIDGE && opt.model != ANOFOX_HIP_MODEL_WLS) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "unknown model");
+		return false;
+	}
+	if (opt.model == ANOFOX_HIP_MODEL_WLS && n_rows > 0 && !w) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "weights is NULL"); return false; }
+	return true;
+}
+} // namespace
+
+bool anofox_hip_fit_predict_frames_device(AnofoxHipContext *ctx, int64_t n_rows, size_t n_features, const double *d_y,
+                                          const double *const *x_cols, const double *d_w, const int64_t *d_frame_lo,
+                                          const int64_t *d_frame_hi, AnofoxHipBatchOptions options, double *d_pred,
+                                          AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!validate_frames(ctx, n_rows, n_features, d_y, x_cols, d_w, d_frame_lo, d_frame_hi, options, d_pred, out_error)) return false;
+	if (n_rows == 0) return true;
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	FrameScratch fs;
+	if (!carve_frames(ctx, n_rows, n_rows, n_features, false, &fs, out_error)) return false;
+	if (hip_fail(launch_frames_ynn(d_y, n_rows, fs.ynn, fs.scan_tmp, fs.scan_tmp_bytes, ctx->stream), "frame scan launch", out_error)) return false;
+	return run_frames(ctx, fs, n_rows, n_features, n_rows, d_y, x_cols, d_w, d_frame_lo, d_frame_hi, options, d_pred, nullptr, out_error);
+}
+
+bool anofox_hip_fit_predict_frames_host(AnofoxHipContext *ctx, int64_t n_rows, size_t n_features, const double *y,
+                                        const double *const *x_cols, const double *w, const int64_t *frame_lo,
+                                        const int64_t *frame_hi, AnofoxHipBatchOptions options, double *pred, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx) {
+		ctx = default_context(out_error);
+		if (!ctx) return false;
+	}
+	if (!validate_frames(ctx, n_rows, n_features, y, x_cols, w, frame_lo, frame_hi, options, pred, out_error)) return false;
+	if (n_rows == 0) return true;
+	for (int64_t e = 0; e < n_rows; ++e)
+		if (frame_lo[e] < 0 || frame_hi[e] > n_rows || (frame_hi[e] > frame_lo[e] && frame_lo[e] >= n_rows)) {
+			set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "frame bounds must lie within [0, n_rows]");
+			return false;
+		}
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	const size_t p = n_features, R = (size_t)n_rows;
+	const bool weighted = options.model == ANOFOX_HIP_MODEL_WLS;
+	const size_t ncol = p + 1 + (weighted ? 1 : 0);
+	const size_t b_col = align_up((R + 2) * sizeof(double), 256), b_bnd = align_up(R * sizeof(int64_t), 256);
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, ncol * b_col + 2 * b_bnd + align_up(R * 3 * sizeof(double) + 8, 256), "staging", out_error))
+		return false;
+	char *cur = (char *)ctx->stage;
+	hipStream_t st = ctx->stream;
+	const double *d_x[kWideMaxP];
+	for (size_t j = 0; j < p; ++j) {
+		if (hip_fail(hipMemcpyAsync(cur, x_cols[j], R * sizeof(double), hipMemcpyHostToDevice, st), "H2D x", out_error)) return false;
+		d_x[j] = (const double *)cur;
+		cur += b_col;
+	}
+	if (hip_fail(hipMemcpyAsync(cur, y, R * sizeof(double), hipMemcpyHostToDevice, st), "H2D y", out_error)) return false;
+	const double *d_y = (const double *)cur;
+	cur += b_col;
+	const double *d_w = nullptr;
+	if (weighted) {
+		if (hip_fail(hipMemcpyAsync(cur, w, R * sizeof(double), hipMemcpyHostToDevice, st), "H2D w", out_error)) return false;
+		d_w = (const double *)cur;
+		cur += b_col;
+	}
+	int64_t *d_lo = (int64_t *)cur;
+	cur += b_bnd;
+	int64_t *d_hi = (int64_t *)cur;
+	cur += b_bnd;
+	double *d_pred = (double *)cur;
+	if (hip_fail(hipMemcpyAsync(d_lo, frame_lo, R * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D frame_lo", out_error)) return false;
+	if (hip_fail(hipMemcpyAsync(d_hi, frame_hi, R * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D frame_hi", out_error)) return false;
+	FrameScratch fs;
+	if (!carve_frames(ctx, n_rows, n_rows, p, false, &fs, out_error)) return false;
+	if (hip_fail(launch_frames_ynn(d_y, n_rows, fs.ynn, fs.scan_tmp, fs.scan_tmp_bytes, st), "frame scan launch", out_error)) return false;
+	if (!run_frames(ctx, fs, n_rows, p, n_rows, d_y, d_x, d_w, d_lo, d_hi, options, d_pred, nullptr, out_error)) return false;
+	if (hip_fail(hipMemcpyAsync(pred, d_pred, R * 3 * sizeof(double), hipMemcpyDeviceToHost, st), "D2H pred", out_error)) return false;
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
 }
 
 bool anofox_hip_fit_predict_expanding_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
@@ -774,7 +963,7 @@ bool anofox_hip_fit_predict_window_host(AnofoxHipContext *ctx, int64_t n_groups,
 	int64_t *d_off = (int64_t *)cur;
 	cur += b_off;
 	if (hip_fail(hipMemcpyAsync(d_off, row_offsets, (G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D offsets", out_error)) return false;
-	const double *d_x[kNarrowMaxP];
+	const double *d_x[kWideMaxP];
 	for (size_t j = 0; j < p; ++j) {
 		if (R > 0 && hip_fail(hipMemcpyAsync(cur, x_cols[j], R * sizeof(double), hipMemcpyHostToDevice, st), "H2D x", out_error)) return false;
 		d_x[j] = (const double *)cur;

@@ -324,7 +324,7 @@ __device__ __forceinline__ void residual_grad_wave(const BatchArgs &args, int64_
 #pragma unroll
 		for (int k = 0; k < kNarrowMaxP + 2; ++k) acc[k] = 0.0;
 		const double b0 = args.fit_intercept ? core[p] : 0.0;
-		const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+		const int64_t lo = args.row_offsets[g], hi = group_row_end(args, g);
 		for (int64_t r = lo + lane; r < hi; r += 64) {
 			const double yv = args.y[r];
 			bool ok = isfinite(yv);

@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 		const double b0 = args.fit_intercept ? core[p] : 0.0;
 		const double shift = (tid < p && args.fit_intercept) ? vec[2 * P16 + tid] : 0.0; // x at the first valid row
 		const double *mycol = tid < p ? args.x_table[tid] : nullptr;
-		const int64_t lo = args.row_offsets[g], hi = args.row_offsets[g + 1];
+		const int64_t lo = args.row_offsets[g], hi = group_row_end(args, g);
 		double rss = 0.0, gs = 0.0, gj = 0.0;
 		for (int64_t r0 = lo; r0 < hi; r0 += 256) {
 			const int64_t r = r0 + tid;

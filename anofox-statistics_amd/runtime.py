@@ -444,6 +444,29 @@ def fit_predict_window_host(row_offsets, y, x_cols: Sequence, w, options: _abi.A
     return pred
 
 
+def fit_predict_frames_host(y, x_cols: Sequence, w, frame_lo, frame_hi, options: _abi.AnofoxHipBatchOptions,
+                            ctx: Optional[Context] = None):
+    """Window fit + predict over explicit frames: frame of row e = rows [frame_lo[e], frame_hi[e]).  numpy in / out:
+    pred[N, 3]."""
+    lib = _abi.load()
+    yv = np.ascontiguousarray(y, dtype=np.float64)
+    cols = [np.ascontiguousarray(c, dtype=np.float64) for c in x_cols]
+    wv = None if w is None else np.ascontiguousarray(w, dtype=np.float64)
+    lo = np.ascontiguousarray(frame_lo, dtype=np.int64)
+    hi = np.ascontiguousarray(frame_hi, dtype=np.int64)
+    p, N = len(cols), len(yv)
+    pred = np.empty((N, 3), dtype=np.float64)
+    colp = (_DP * max(p, 1))(*[c.ctypes.data_as(_DP) for c in cols])
+    err = _abi.AnofoxError()
+    ok = lib.anofox_hip_fit_predict_frames_host(
+        ctx._h if ctx is not None else None, N, p, yv.ctypes.data_as(_DP), colp, None if wv is None else wv.ctypes.data_as(_DP),
+        lo.ctypes.data_as(C.POINTER(C.c_int64)), hi.ctypes.data_as(C.POINTER(C.c_int64)), options, pred.ctypes.data_as(_DP),
+        C.byref(err))
+    if not ok:
+        raise AnofoxStatsError(err.code, err.text())
+    return pred
+
+
 def vif_batch_host(row_offsets, x_cols: Sequence, ctx: Optional[Context] = None):
     """numpy in, numpy out: out[G, p+1] = {vif[p], status} (status 100 = fewer than 3 rows -> SQL NULL)."""
     lib = _abi.load()

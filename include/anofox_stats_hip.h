@@ -361,7 +361,8 @@ ANOFOX_HIP_API bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *ctx, int
  * d_pred[3*e .. 3*e+2] = {yhat, yhat_lower, yhat_upper} of x_e from the fit on rows 0..e of e's partition
  * (rows with NaN y — the window's NULL y — or non-finite features do not train); NaN = SQL NULL (at most
  * p + [intercept] training rows so far, failed fit, or non-finite prediction).  A frame ending at 1 PRECEDING is
- * this output shifted down by one row within the partition.  n_features <= 8.
+ * this output shifted down by one row within the partition.  n_features <= 8 run the in-register window kernels,
+ * wider designs the virtual-group path (anofox_hip_fit_predict_frames_*).
  */
 ANOFOX_HIP_API bool anofox_hip_fit_predict_expanding_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                              const int64_t *d_row_offsets, const double *d_y, const double *const *x_cols,
@@ -396,6 +397,25 @@ ANOFOX_HIP_API bool anofox_hip_fit_predict_window_host(AnofoxHipContext *ctx, in
                                         const int64_t *row_offsets, const double *y, const double *const *x_cols,
                                         const double *w, AnofoxHipWindowFrame frame, AnofoxHipBatchOptions options,
                                         double *pred, AnofoxError *out_error);
+
+/*
+ * The same window functions over EXPLICIT frames — RANGE and GROUPS frames, EXCLUDE clauses, anything DuckDB's window
+ * executor resolves to a row range per output row (src/window_functions/ols_fit_predict.cpp:110-324 receives the
+ * frame's rows whatever the frame type): frame of row e = rows [frame_lo[e], frame_hi[e]) of the (already ordered)
+ * input, hi exclusive; an empty frame (hi <= lo) is NULL.  Trains on the frame's rows with non-NULL (non-NaN) y,
+ * predicts the x of the frame's LAST row hi - 1, NULL unless MORE than p + [intercept] training rows exist (:257-262).
+ * Every frame is fitted as a group of the batch path (its refinement passes included), so any n_features <=
+ * anofox_hip_max_features() and any frame shape work; cost O(frame) per output row.  The ROWS entry points above use
+ * this path for n_features > 8 and for the frames the in-register kernels flag as ill-conditioned.
+ */
+ANOFOX_HIP_API bool anofox_hip_fit_predict_frames_device(AnofoxHipContext *ctx, int64_t n_rows, size_t n_features, const double *d_y,
+                                          const double *const *x_cols, const double *d_w, const int64_t *d_frame_lo,
+                                          const int64_t *d_frame_hi, AnofoxHipBatchOptions options, double *d_pred,
+                                          AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_fit_predict_frames_host(AnofoxHipContext *ctx, int64_t n_rows, size_t n_features, const double *y,
+                                        const double *const *x_cols, const double *w, const int64_t *frame_lo,
+                                        const int64_t *frame_hi, AnofoxHipBatchOptions options, double *pred,
+                                        AnofoxError *out_error);
 
 /*
  * Grouped variance inflation factors: the Finalize loop of vif_agg (src/aggregate_functions/vif_aggregate.cpp:
