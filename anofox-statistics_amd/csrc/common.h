@@ -336,6 +336,12 @@ struct WindowArgs {
 	int64_t frame_start;
 	int64_t frame_end;
 	double avg_rows; // rows per partition on average (0 = unknown)
+	// Output rows whose fit was ill-conditioned (smallest Cholesky pivot ratio < 1e-3, or rss / tss < 1e-7: the moment
+	// identity has cancelled) are appended here; the host refits them through the virtual-group path (frames.hip),
+	// whose refinement passes restore QR-level accuracy.  nullptr = no flagging.
+	int32_t *flag_list;
+	int32_t *flag_count;
+	int32_t flag_cap;
 };
 constexpr int kWindowTcritCap = 65536;
 constexpr int64_t kFrameUnbounded = ANOFOX_HIP_FRAME_UNBOUNDED;
@@ -407,7 +413,7 @@ struct FrameArgs {
 	int fit_intercept;
 	double confidence_level;
 	const int64_t *lo, *hi;   // frame e = rows [lo[e], hi[e]); the row predicted is hi[e] - 1
-	const int64_t *ynn;       // [n_rows + 1] prefix count of rows whose y is not NaN
+	const int64_t *ynn;       // [n_rows + 1] prefix count of rows whose y is not NaN; nullptr = count each frame directly
 	int64_t *rule_counts;     // [n_frames] out: training rows when MORE than p + [intercept] exist, else 0 (-> NULL)
 	const double *core;       // [n_frames * (p + 6)] fit records of the frames
 	const double *tcrit;      // [tcrit_cap + 1], launch_tcrit_table
@@ -418,8 +424,10 @@ struct FrameArgs {
 size_t frames_scan_temp_bytes(int64_t n_rows);
 hipError_t launch_frames_ynn(const double *y, int64_t n_rows, int64_t *ynn, void *temp, size_t temp_bytes, hipStream_t stream);
 // ROWS BETWEEN start_preceding PRECEDING AND end_preceding PRECEDING -> lo / hi per row (clipped to the partition)
+// (list != nullptr: bounds of the rows list[0 .. n_list) only, written to lo[k] / hi[k])
 hipError_t launch_frames_from_rows_spec(const int64_t *row_offsets, int64_t n_groups, int64_t n_rows, int64_t start_preceding,
-                                        int64_t end_preceding, int64_t *lo, int64_t *hi, hipStream_t stream);
+                                        int64_t end_preceding, int64_t *lo, int64_t *hi, hipStream_t stream,
+                                        const int32_t *list = nullptr, int64_t n_list = 0);
 hipError_t launch_frames_rule(const FrameArgs &a, hipStream_t stream);
 hipError_t launch_frames_predict(const FrameArgs &a, hipStream_t stream);
 

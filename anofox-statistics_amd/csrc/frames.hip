@@ -28,9 +28,15 @@ struct NotNan {
 };
 
 __global__ __launch_bounds__(256) void frames_spec_kernel(const int64_t *row_offsets, int64_t n_groups, int64_t n_rows, int64_t start_p,
-                                                          int64_t end_p, int64_t *lo_out, int64_t *hi_out) {
-	const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (e >= n_rows) return;
+                                                          int64_t end_p, int64_t *lo_out, int64_t *hi_out, const int32_t *list,
+                                                          int64_t n_list) {
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= (list ? n_list : n_rows)) return;
+	const int64_t e = list ? (int64_t)list[k] : k;
+	if (e < 0 || e >= n_rows) { // (a list entry out of range: an empty frame)
+		lo_out[k] = hi_out[k] = 0;
+		return;
+	}
 	// partition of row e: the last g with row_offsets[g] <= e
 	int64_t a = 0, b = n_groups;
 	while (b - a > 1) {
@@ -44,8 +50,8 @@ __global__ __launch_bounds__(256) void frames_spec_kernel(const int64_t *row_off
 	if (first < plo) first = plo;
 	if (last > phi - 1) last = phi - 1;
 	const bool empty = last < first || e < plo || e >= phi;
-	lo_out[e] = empty ? e : first;
-	hi_out[e] = empty ? e : last + 1;
+	lo_out[k] = empty ? e : first;
+	hi_out[k] = empty ? e : last + 1;
 }
 
 __global__ __launch_bounds__(256) void frames_rule_kernel(FrameArgs a) {
@@ -53,7 +59,11 @@ __global__ __launch_bounds__(256) void frames_rule_kernel(FrameArgs a) {
 	if (e >= a.n_frames) return;
 	const int64_t lo = a.lo[e], hi = a.hi[e];
 	int64_t nt = 0;
-	if (hi > lo) nt = a.ynn[hi] - a.ynn[lo];
+	if (hi > lo) {
+		if (a.ynn) nt = a.ynn[hi] - a.ynn[lo];
+		else // few frames (the refits of flagged rows): count directly instead of scanning every row of the input
+			for (int64_t r = lo; r < hi; ++r) nt += a.y[r] == a.y[r] ? 1 : 0;
+	}
 	a.rule_counts[e] = nt > (int64_t)(a.p + (a.fit_intercept ? 1 : 0)) ? nt : 0;
 }
 
@@ -135,10 +145,12 @@ hipError_t launch_frames_ynn(const double *y, int64_t n_rows, int64_t *ynn, void
 }
 
 hipError_t launch_frames_from_rows_spec(const int64_t *row_offsets, int64_t n_groups, int64_t n_rows, int64_t start_preceding,
-                                        int64_t end_preceding, int64_t *lo, int64_t *hi, hipStream_t stream) {
-	if (n_rows <= 0) return hipSuccess;
-	hipLaunchKernelGGL(frames_spec_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, row_offsets, n_groups, n_rows,
-	                   start_preceding, end_preceding, lo, hi);
+                                        int64_t end_preceding, int64_t *lo, int64_t *hi, hipStream_t stream, const int32_t *list,
+                                        int64_t n_list) {
+	const int64_t n = list ? n_list : n_rows;
+	if (n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(frames_spec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, row_offsets, n_groups, n_rows,
+	                   start_preceding, end_preceding, lo, hi, list, n_list);
 	return hipGetLastError();
 }
 

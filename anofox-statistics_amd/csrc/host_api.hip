@@ -406,6 +406,14 @@ bool anofox_hip_context_last_refine_count(AnofoxHipContext *ctx, int64_t *out_co
 	return true;
 }
 
+bool anofox_hip_context_last_window_refit_count(AnofoxHipContext *ctx, int64_t *out_count, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!ctx || !out_count) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context or out_count is NULL"); return false; }
+	std::lock_guard<std::mutex> lk(ctx->mu);
+	*out_count = ctx->last_window_flagged;
+	return true;
+}
+
 bool anofox_hip_context_collect_timing(AnofoxHipContext *ctx, AnofoxHipKernelTimes *out, AnofoxError *out_error) {
 	reset_error(out_error);
 	if (!ctx || !out) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "context or out is NULL"); return false; }
@@ -775,6 +783,16 @@ bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, cons
 	a.frame_start = frame.start_preceding;
 	a.frame_end = frame.end_preceding;
 	a.avg_rows = (n_rows > 0 && G > 0) ? (double)n_rows / (double)G : 0.0;
+	// ill-conditioned frames are flagged by the kernel and refitted below with the fit path's refinement passes
+	static const bool flag_on = !(getenv("ANOFOX_WIN_FLAG") && atoi(getenv("ANOFOX_WIN_FLAG")) == 0); // A/B switch for measurements
+	const bool flagging = flag_on && n_rows > 0 && n_rows < (int64_t)0x7fffffff;
+	if (flagging) {
+		if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, 256 + (size_t)n_rows * sizeof(int32_t), "window flag list", e)) return false;
+		a.flag_count = (int32_t *)ctx->aux;
+		a.flag_list = (int32_t *)((char *)ctx->aux + 256);
+		a.flag_cap = (int32_t)n_rows;
+		if (hip_fail(hipMemsetAsync(a.flag_count, 0, sizeof(int32_t), st), "hipMemsetAsync", e)) return false;
+	}
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	if (ctx->timing) {
 		e0 = get_event(ctx);
@@ -786,7 +804,22 @@ bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, cons
 		(void)hipEventRecord(e1, st);
 		ctx->predict_events.emplace_back(e0, e1);
 	}
-	return true;
+	if (!flagging) return true;
+	// (the one host synchronisation of this path: how many frames were flagged — usually none)
+	int32_t n_flag = 0;
+	if (hip_fail(hipMemcpyAsync(&n_flag, a.flag_count, sizeof n_flag, hipMemcpyDeviceToHost, st), "D2H flag count", e)) return false;
+	if (hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e)) return false;
+	ctx->last_window_flagged = n_flag;
+	if (n_flag <= 0) return true;
+	if (n_flag > a.flag_cap) n_flag = a.flag_cap;
+	FrameScratch fs;
+	if (!carve_frames(ctx, n_rows, n_flag, p, true, &fs, e)) return false;
+	if ((int64_t)n_flag * 64 < n_rows) fs.ynn = nullptr; // few frames: their training rows are counted directly
+	else if (hip_fail(launch_frames_ynn(d_y, n_rows, fs.ynn, fs.scan_tmp, fs.scan_tmp_bytes, st), "frame scan launch", e)) return false;
+	if (hip_fail(launch_frames_from_rows_spec(d_off, G, n_rows, frame.start_preceding, frame.end_preceding, fs.lo, fs.hi, st, a.flag_list, n_flag),
+	             "frame bounds kernel launch", e))
+		return false;
+	return run_frames(ctx, fs, n_flag, p, n_rows, d_y, x_cols, d_w, fs.lo, fs.hi, opt, d_pred, a.flag_list, e);
 }
 
 bool validate_window(AnofoxHipContext *ctx, int64_t G, size_t p, const void *off, const void *y, const double *const *x_cols,

@@ -59,7 +59,22 @@ struct PrefixFit {
 	double rse;
 	double nobs;
 	bool ok;
+	bool suspect; // ill-conditioned or cancelled: to be refitted with refinement (WindowArgs::flag_list)
 };
+
+// Called by every lane of the wavefront (convergent); lanes with `flag` append their row: one atomic per wavefront.
+__device__ __forceinline__ void window_flag_row(const WindowArgs &a, bool flag, int64_t row) {
+	if (!a.flag_list) return;
+	const unsigned long long b = __ballot(flag);
+	if (b == 0ull) return;
+	const int lane = threadIdx.x & 63;
+	const int leader = __ffsll((long long)b) - 1;
+	int base = 0;
+	if (lane == leader) base = atomicAdd(a.flag_count, (int)__popcll(b));
+	base = __shfl(base, leader, 64);
+	const int k = base + (int)__popcll(b & ((1ull << lane) - 1ull));
+	if (flag && k < a.flag_cap) a.flag_list[k] = (int32_t)row;
+}
 
 // Fit from the moments of one prefix; rec uses the MomentLayout<P> of the accumulate kernel.
 template <int P>
@@ -68,6 +83,7 @@ __device__ __forceinline__ void fit_from_moments(const double (&rec)[MomentLayou
 	using L = MomentLayout<P>;
 	const double nanv = __builtin_nan("");
 	out.ok = false;
+	out.suspect = false;
 	out.intercept = out.rse = out.nobs = nanv;
 #pragma unroll
 	for (int j = 0; j < P; ++j) out.coef[j] = nanv;
@@ -115,6 +131,7 @@ __device__ __forceinline__ void fit_from_moments(const double (&rec)[MomentLayou
 	double diag0[P];
 #pragma unroll
 	for (int j = 0; j < P; ++j) diag0[j] = A[j][j];
+	bool small_pivot = false; // some accepted pivot below 1e-3 of its diagonal entry (no division: this runs per row)
 #pragma unroll
 	for (int j = 0; j < P; ++j) {
 		double d = A[j][j];
@@ -122,6 +139,7 @@ __device__ __forceinline__ void fit_from_moments(const double (&rec)[MomentLayou
 		for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
 		const bool ok = active[j] && (d > kAliasTolX * diag0[j]) && (d > 0.0);
 		active[j] = ok;
+		small_pivot = small_pivot || (ok && d < 1e-3 * diag0[j]);
 		const double ljj = ok ? sqrt(d) : 1.0;
 		A[j][j] = ljj;
 		const double inv = 1.0 / ljj;
@@ -156,7 +174,10 @@ __device__ __forceinline__ void fit_from_moments(const double (&rec)[MomentLayou
 		bb += beta[i] * beta[i];
 	}
 	double rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
-	if (rss < 0.0) rss = 0.0; // exact fits: the moment identity can round below zero (no residual pass here)
+	// the same triggers as the fit path's refinement queue (solve_narrow.hip): the normal equations have squared a
+	// large condition number, or rss = tss - |z|^2 has cancelled
+	out.suspect = small_pivot || !(rss > 1e-7 * tss);
+	if (rss < 0.0) rss = 0.0; // exact fits: the moment identity can round below zero (flagged above)
 	const double df = cnt - (double)(rank + (icpt ? 1 : 0));
 	double b0 = nanv;
 	if (icpt) {
@@ -246,6 +267,7 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 	for (int a = 0; a < Z; ++a) first[a] = 0.0;
 	bool have_first = false;
 	double fin[3] = {nanv, nanv, nanv};
+	bool fin_suspect = false;
 
 	for (int64_t base = lo; __ballot(base < hi) != 0ull; base += SEGW) { // until every segment of the wave is done
 		const int64_t r = base + sl;
@@ -319,9 +341,11 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 
 		// Finalize of the window aggregate for the frame ending at this row
 		double yhat = nanv, ylo = nanv, yhi = nanv;
+		bool suspect = false;
 		if (in && xfinite && n_y > (double)(P + (icpt ? 1 : 0))) {       // ols_fit_predict.cpp:257-262 (strictly more)
 			PrefixFit<P> f;
 			fit_from_moments<P>(rec, args.model, icpt, args.alpha, args.lambda_scaling, f);
+			suspect = f.ok && f.suspect;
 			if (f.ok) {
 				double v = isnan(f.intercept) ? 0.0 : f.intercept;
 #pragma unroll
@@ -344,6 +368,7 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 			}
 		}
 		const int64_t b = args.frame_end; // frame ends b rows before the current row: row r + b gets this result
+		window_flag_row(args, suspect && in && r + b < hi && r + b >= lo, r + b);
 		if (in) {
 			if (r + b < hi && r + b >= lo) { // b < 0 (FOLLOWING): the frame of row r + b ends here
 				double *out = args.pred + (r + b) * 3;
@@ -363,6 +388,8 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 			fin[0] = has_last ? f0 : fin[0];
 			fin[1] = has_last ? f1 : fin[1];
 			fin[2] = has_last ? f2 : fin[2];
+			const double fs = seg_pick<SEGW>(suspect ? 1.0 : 0.0, src);
+			fin_suspect = has_last ? (fs != 0.0) : fin_suspect;
 		}
 	}
 	if (args.frame_end < 0 && hi > lo) { // frames reaching past the partition's end stop at its last row: same result
@@ -374,16 +401,19 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 			out[1] = fin[1];
 			out[2] = fin[2];
 		}
+		if (fin_suspect) // (segment-uniform; every lane takes part in the ballots of the same number of trips)
+			for (int64_t t = t0; __ballot(t < hi) != 0ull; t += SEGW) window_flag_row(args, t + sl < hi, t + sl);
 	}
 }
 
 // Shared tail of both kernels: Finalize of the window aggregate for one frame (moments in rec), predicting z.
 template <int P>
 __device__ __forceinline__ void predict_from_moments(const WindowArgs &args, const double (&rec)[MomentLayout<P>::REC], bool icpt,
-                                                     const double (&z)[P + 1], double &yhat, double &ylo, double &yhi) {
+                                                     const double (&z)[P + 1], double &yhat, double &ylo, double &yhi, bool &suspect) {
 	PrefixFit<P> f;
 	fit_from_moments<P>(rec, args.model, icpt, args.alpha, args.lambda_scaling, f);
 	if (!f.ok) return;
+	suspect = f.suspect;
 	double v = isnan(f.intercept) ? 0.0 : f.intercept;
 #pragma unroll
 	for (int j = 0; j < P; ++j) v = fma(isnan(f.coef[j]) ? 0.0 : f.coef[j], isnan(f.coef[j]) ? 0.0 : z[j], v);
@@ -493,6 +523,7 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 			}
 		}
 		double yhat = nanv, ylo = nanv, yhi = nanv;
+		bool suspect = false;
 		if (any_live && xfl && n_y > (double)(P + (icpt ? 1 : 0))) { // ols_fit_predict.cpp:253-262
 			double rec[L::REC];
 #pragma unroll
@@ -502,7 +533,7 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 			rec[L::OFF_SW] = sw;
 			rec[L::OFF_CNT] = cnt;
 			rec[L::OFF_MASK] = (double)mask;
-			predict_from_moments<P>(args, rec, icpt, z, yhat, ylo, yhi);
+			predict_from_moments<P>(args, rec, icpt, z, yhat, ylo, yhi, suspect);
 		}
 		if (in) {
 			double *out = args.pred + e * 3;
@@ -510,6 +541,7 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 			out[1] = ylo;
 			out[2] = yhi;
 		}
+		window_flag_row(args, suspect && in, e);
 	}
 }
 

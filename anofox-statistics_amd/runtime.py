@@ -170,6 +170,13 @@ class Context:
         self._check(ok, err)
         return out
 
+    def last_window_refit_count(self) -> int:
+        """Output rows of the most recent window call that were refitted with refinement (diagnostic)."""
+        n = C.c_int64()
+        err = _abi.AnofoxError()
+        self._check(self._lib.anofox_hip_context_last_window_refit_count(self._h, C.byref(n), C.byref(err)), err)
+        return int(n.value)
+
     def last_refine_count(self) -> int:
         """Groups of the most recent fit launch that took the on-device refinement passes (diagnostic)."""
         n = C.c_int64()

@@ -531,6 +531,10 @@ ANOFOX_HIP_API bool anofox_hip_context_collect_timing(AnofoxHipContext *ctx, Ano
  * the last slab) were queued for the on-device refinement passes.  Synchronises the context's stream. */
 ANOFOX_HIP_API bool anofox_hip_context_last_refine_count(AnofoxHipContext *ctx, int64_t *out_count, AnofoxError *out_error);
 
+/* Diagnostic: output rows of the context's most recent window call (n_features <= 8) whose frame the in-register
+ * kernel flagged as ill-conditioned and that were refitted through the virtual-group path with refinement. */
+ANOFOX_HIP_API bool anofox_hip_context_last_window_refit_count(AnofoxHipContext *ctx, int64_t *out_count, AnofoxError *out_error);
+
 /* Library / build identification, e.g. "anofox_stats_hip 0.1 gfx950". */
 ANOFOX_HIP_API const char *anofox_hip_version(void);
 

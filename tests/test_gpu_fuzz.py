@@ -188,6 +188,13 @@ def test_fuzz_window_frames(pkg, ctx, seed):
     assert np.array_equal(np.isnan(pred[:, 0]), np.isnan(ref[:, 0])), f"NULL pattern {what}"
     m = ~np.isnan(ref[:, 0])
     if m.any():
-        err = np.abs(pred[m, 0] - ref[m, 0]) / np.maximum(np.abs(ref[m, 0]), 1.0)
-        # frames with barely more rows than parameters are ill-conditioned; the window kernels have no refinement pass
-        assert np.quantile(err, 0.9) < 1e-8 and err.max() < 1e-3, (what, np.quantile(err, 0.9), err.max())
+        # every row, yhat AND the interval bounds: ill-conditioned frames (barely more rows than parameters, exact fits)
+        # are flagged by the in-register kernel and refitted with the fit path's refinement passes
+        scale = np.maximum(np.abs(ref[m, 0]), 1.0)
+        err = np.abs(pred[m, 0] - ref[m, 0]) / scale
+        assert err.max() < 1e-8, (what, err.max())
+        for k in (1, 2):
+            fin = np.isfinite(ref[m, k])
+            assert np.array_equal(np.isfinite(pred[m, k]), fin), what
+            e2 = np.abs(pred[m, k][fin] - ref[m, k][fin]) / np.maximum(np.abs(ref[m, k][fin]), scale[fin])
+            assert e2.size == 0 or e2.max() < 1e-6, (what, k, e2.max())
