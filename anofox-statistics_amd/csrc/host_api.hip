@@ -1622,9 +1622,9 @@ bool validate_residuals(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_ro
                         const void *y_hat, const double *const *x_cols, const void *out, const void *group, AnofoxError *e) {
 	if (!ctx) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "context is NULL"); return false; }
 	if (G < 0 || n_rows < 0) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "negative n_groups or n_rows"); return false; }
-	if (p > (size_t)kNarrowMaxP) {
+	if (p > (size_t)kResidualsMaxP) {
 		set_error(e, ANOFOX_ERROR_INVALID_INPUT,
-		          "n_features = " + std::to_string(p) + " exceeds the supported maximum of " + std::to_string(kNarrowMaxP) +
+		          "n_features = " + std::to_string(p) + " exceeds the supported maximum of " + std::to_string(kResidualsMaxP) +
 		              " for residual diagnostics");
 		return false;
 	}
@@ -1644,7 +1644,7 @@ bool run_residuals(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_
 	a.row_offsets = d_off;
 	a.y = d_y;
 	a.y_hat = d_y_hat;
-	for (size_t j = 0; j < p; ++j) a.x[j] = x_cols[j];
+	for (size_t j = 0; j < p && j < (size_t)kNarrowMaxP; ++j) a.x[j] = x_cols[j];
 	a.rse = d_rse;
 	a.out = d_out;
 	a.group_out = d_group;
@@ -1652,6 +1652,13 @@ bool run_residuals(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_
 	a.p = (int)p;
 	a.include_studentized = include_studentized ? 1 : 0;
 	a.drop_nan_rows = drop_nan_rows ? 1 : 0;
+	if (p > (size_t)kNarrowMaxP) {
+		// 9 .. 32 features: workgroup-per-group kernel; its column pointers travel through a small device table
+		if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, (size_t)kResidualsMaxP * sizeof(double *), "residual column table", e)) return false;
+		// (x_cols is pageable host memory: the runtime has read it into its staging buffer when the call returns)
+		if (hip_fail(hipMemcpyAsync(ctx->aux, x_cols, p * sizeof(double *), hipMemcpyHostToDevice, ctx->stream), "H2D column table", e)) return false;
+		return !hip_fail(launch_residuals_mid(a, (const double *const *)ctx->aux, ctx->stream), "residuals kernel launch", e);
+	}
 	return !hip_fail(launch_residuals_narrow(a, ctx->stream), "residuals kernel launch", e);
 }
 
@@ -1720,7 +1727,7 @@ bool residuals_host(AnofoxHipContext *ctx, int64_t n_groups, size_t p, int64_t n
 
 extern "C" {
 
-size_t anofox_hip_residuals_max_features(void) { return (size_t)kNarrowMaxP; }
+size_t anofox_hip_residuals_max_features(void) { return (size_t)kResidualsMaxP; }
 
 bool anofox_hip_residuals_batch_device(AnofoxHipContext *ctx, int64_t n_groups, size_t n_features, int64_t n_rows,
                                        const int64_t *d_row_offsets, const double *d_y, const double *d_y_hat,

@@ -214,7 +214,7 @@ ANOFOX_HIP_API void anofox_free_vif(double *vif);
  * (lib.rs:1752-1920 over crates/anofox-stats-core/src/diagnostics/residuals.rs:30-145): raw = y - y_hat;
  * standardized = raw / s when residual_std_error s is not NaN; with x and include_studentized the leverage
  * h_i = x~_i' (X~'X~)^-1 x~_i of the intercept-augmented design and studentized = raw / (s sqrt(max(1 - h, 1e-10))).
- * A rank-deficient design yields no leverage (has_leverage = false).  Runs on the GPU; x_count <= 8. */
+ * A rank-deficient design yields no leverage (has_leverage = false).  Runs on the GPU; x_count <= 32. */
 typedef struct {
 	double *raw;
 	double *standardized;
@@ -441,7 +441,8 @@ ANOFOX_HIP_API bool anofox_hip_vif_batch_host(AnofoxHipContext *ctx, int64_t n_g
  * y_hat is NaN are left out, as the aggregate's Update does (:154-163; their records are all NaN); the aggregate
  * itself returns NULL for groups with fewer than 3 used rows (:223) and passes no residual standard error (:232),
  * so d_rse (one value per group, NaN = none) may be NULL.  x_cols / n_features may be NULL / 0 (no leverage);
- * n_features <= anofox_hip_residuals_max_features() = 8.
+ * n_features <= anofox_hip_residuals_max_features() = 32 (up to 8: one wavefront per group, residuals_narrow.hip;
+ * 9 .. 32: one workgroup per group, residuals_mid.hip).
  */
 #define ANOFOX_HIP_RESIDUALS_HAS_STANDARDIZED 1
 #define ANOFOX_HIP_RESIDUALS_HAS_STUDENTIZED 2

@@ -1291,7 +1291,7 @@ def _assert_residuals_match(out, grp, rout, rgrp, what):
     assert np.max(np.abs(out[m] - rout[m]) / scale, initial=0.0) < 1e-9, what
 
 
-@pytest.mark.parametrize("p", [0, 1, 3, 8])
+@pytest.mark.parametrize("p", [0, 1, 3, 8, 9, 16, 32])
 def test_residuals_batch_matches_oracle(pkg, ctx, p):
     """Tolerance 1e-9 relative on every part (the stated bar is 1e-6 for diagnostics)."""
     rng = np.random.default_rng(4100 + p)
@@ -1357,6 +1357,37 @@ def test_residuals_rank_deficient_empty_and_poisoned_groups(pkg, ctx):
     assert np.array_equal(out[:, :2], rout[:, :2])
 
 
+def test_residuals_mid_width_rank_deficient_and_poisoned_groups(pkg, ctx):
+    """9 .. 32 features (one workgroup per group, residuals_mid.hip): collinear and constant columns give no leverage,
+    a NaN feature value in a used row poisons the group's leverage, empty and tiny groups, everything else against
+    the oracle."""
+    rng = np.random.default_rng(12)
+    p, ns = 12, [60, 60, 60, 5, 0, 60, 300]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    X = rng.uniform(-3, 3, (N, p)) + 10.0
+    X[offs[0]:offs[1], 7] = 2.0 * X[offs[0]:offs[1], 2] - 1.0          # exactly collinear
+    X[offs[1]:offs[2], 4] = 4.0                                          # constant: collinear with the intercept
+    X[offs[5] + 9, 3] = np.nan                                           # NaN feature value in a used row
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    y = rng.standard_normal(N)
+    y_hat = y + 0.1 * rng.standard_normal(N)
+    y[offs[6] + 5] = np.nan                                              # a skipped row
+    rse = np.full(len(ns), 0.1)
+    out, grp = pkg.residuals_batch_host(offs, y, y_hat, x_cols, rse, ctx=ctx)
+    rout, rgrp = oracle.residuals_groups(y, y_hat, x_cols, offs, rse=rse)
+    assert list(grp[:, 0]) == [60, 60, 60, 5, 0, 60, 299]
+    assert list(grp[:, 1].astype(int)) == [1, 1, 7, 1, 1, 7, 7]
+    for g in (2, 6):
+        lo, hi = offs[g], offs[g + 1]
+        assert np.allclose(out[lo:hi], rout[lo:hi], rtol=1e-9, atol=0, equal_nan=True)
+    lo, hi = offs[5], offs[6]
+    assert np.all(np.isnan(out[lo:hi, 3]))                               # poisoned leverage, flag still set
+    assert np.array_equal(np.nan_to_num(out[:, :2], nan=-7.0), np.nan_to_num(rout[:, :2], nan=-7.0))
+    with pytest.raises(pkg.AnofoxStatsError):
+        pkg.residuals_batch_host(offs, y, y_hat, [x_cols[0]] * 33, rse, ctx=ctx)
+
+
 def test_residuals_reference_structural_tests(pkg, ctx):
     """test/sql/diagnostics/test_residuals_diagnostics_agg.test (reg_data, reg_data_with_x), the scalar form of
     test/sql/scalar/test_diagnostics_scalar.test:126-140 and the unit tests of residuals.rs:204-263."""
@@ -1413,9 +1444,13 @@ def test_compute_residuals_c_symbol_errors(pkg):
     assert [res.raw[i] for i in range(3)] == [0.0, 0.0, 0.0]
     lib.anofox_free_residuals(C.byref(res))
     assert not res.raw and res.len == 0
-    xs = (abi.AnofoxDataArray * 9)(*[a3] * 9)
-    assert not lib.anofox_compute_residuals(a3, a3, xs, 9, 1.0, True, C.byref(res), C.byref(err))
-    assert err.code == 1 and "maximum of 8" in err.text()
+    xs = (abi.AnofoxDataArray * 33)(*[a3] * 33)
+    assert not lib.anofox_compute_residuals(a3, a3, xs, 33, 1.0, True, C.byref(res), C.byref(err))
+    assert err.code == 1 and "maximum of 32" in err.text()
+    xs = (abi.AnofoxDataArray * 9)(*[a3] * 9)          # nine identical columns: accepted, rank deficient -> no leverage
+    assert lib.anofox_compute_residuals(a3, a3, xs, 9, 1.0, True, C.byref(res), C.byref(err))
+    assert res.len == 3 and not res.has_leverage
+    lib.anofox_free_residuals(C.byref(res))
 
 
 def test_residuals_device_full_size_properties(pkg, ctx):
