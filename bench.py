@@ -329,7 +329,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and not args.vif:
             try:
-                traffic = json.load(open(tpath)).get(f"{args.model}_G{G_local}_n{n}_p{p}")
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"{args.model}_G{G_local}_n{n}_p{p}")
+                if traffic is None and not (args.inference and p <= 8) and tj.get(f"{args.model}_n{n}_p{p}_bytes_per_group"):
+                    traffic = tj[f"{args.model}_n{n}_p{p}_bytes_per_group"] * G_local     # per step, like `achieved`
             except Exception:
                 traffic = None
         extra = {}
