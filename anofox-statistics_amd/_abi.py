@@ -176,6 +176,12 @@ SYMBOLS = {
     "anofox_hip_context_set_accumulate_gate": (C.c_bool, [_CTX, C.c_void_p, C.c_void_p, _ERRP]),
     "anofox_hip_context_last_refine_count": (C.c_bool, [_CTX, C.POINTER(C.c_int64), _ERRP]),
     "anofox_hip_version": (C.c_char_p, []),
+    "anofox_hip_comm_unique_id": (C.c_bool, [C.c_void_p, _ERRP]),
+    "anofox_hip_comm_create": (C.c_bool, [_CTX, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), _ERRP]),
+    "anofox_hip_comm_destroy": (None, [C.c_void_p]),
+    "anofox_hip_comm_world_size": (C.c_int, [C.c_void_p]),
+    "anofox_hip_comm_rank": (C.c_int, [C.c_void_p]),
+    "anofox_hip_gather_records_device": (C.c_bool, [C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p, _ERRP]),
     "anofox_hip_context_last_window_refit_count": (C.c_bool, [_CTX, C.POINTER(C.c_int64), _ERRP]),
     "anofox_hip_fit_predict_frames_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p,
                                                         C.c_void_p, C.c_void_p, AnofoxHipBatchOptions, C.c_void_p, _ERRP]),

@@ -514,6 +514,29 @@ ANOFOX_HIP_API bool anofox_hip_predict_batch_device(AnofoxHipContext *ctx, int64
                                      const int64_t *d_row_offsets, const double *const *x_cols, const double *d_core,
                                      double confidence_level, double *d_pred, AnofoxError *out_error);
 
+/*
+ * Multi-GPU (no reference counterpart): the path shards by GROUP BY key — one process per GPU fits its
+ * own keys with no data-path communication — and ONE collective assembles the result: an RCCL all-gather of the
+ * fixed-size f64 records over xGMI.  These entry points are that exchange step without Python: rank 0 calls
+ * anofox_hip_comm_unique_id and ships the 128 bytes to the other ranks by whatever channel the host has; every rank
+ * calls anofox_hip_comm_create on its own context (collective: returns when all ranks have joined); after a fit,
+ * anofox_hip_gather_records_device gathers `records_per_rank` records of `record_len` doubles from every rank into
+ * d_all[world_size * records_per_rank * record_len] on every rank, rank r's block at r * records_per_rank (shards are
+ * padded to the same count; pad records with NaN), stream-ordered behind the fit kernels of the communicator's
+ * context.  RCCL is loaded at run time by the first of these calls (dlopen): the library has no link-time dependency
+ * on it.
+ */
+#define ANOFOX_HIP_COMM_ID_BYTES 128
+typedef struct AnofoxHipComm AnofoxHipComm;
+ANOFOX_HIP_API bool anofox_hip_comm_unique_id(uint8_t *out_id /* [ANOFOX_HIP_COMM_ID_BYTES] */, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_comm_create(AnofoxHipContext *ctx, int world_size, int rank, const uint8_t *id, AnofoxHipComm **out_comm,
+                            AnofoxError *out_error);
+ANOFOX_HIP_API void anofox_hip_comm_destroy(AnofoxHipComm *comm);
+ANOFOX_HIP_API int anofox_hip_comm_world_size(const AnofoxHipComm *comm);
+ANOFOX_HIP_API int anofox_hip_comm_rank(const AnofoxHipComm *comm);
+ANOFOX_HIP_API bool anofox_hip_gather_records_device(AnofoxHipComm *comm, const double *d_local, int64_t records_per_rank,
+                                      size_t record_len, double *d_all, AnofoxError *out_error);
+
 /* Measurement hooks (bench.py): when enabled, every accumulate-kernel launch of this context is
  * bracketed by HIP events on the launch stream. */
 typedef struct {

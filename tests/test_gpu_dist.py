@@ -182,3 +182,36 @@ def _run_bench(out):
         rc = subprocess.call([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--groups", "20000",
                               "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], stdout=f, env=env)
     sys.exit(rc)
+
+
+def test_c_abi_gather_on_a_single_rank_communicator():
+    """anofox_hip_comm_* / anofox_hip_gather_records_device (RCCL behind the C ABI): with the one GPU of this box a
+    communicator of world size 1 — unique id, init, an all-gather that is stream-ordered behind a fit on the same
+    context, destroy.  (N > 1 ranks need N GPUs: the driver's scaling run.)"""
+    import ctypes as C
+    import torch
+    pkg = import_pkg()
+    abi = import_pkg("_abi")
+    synth = import_pkg("synth")
+    lib = abi.load()
+    err = abi.AnofoxError()
+    uid = (C.c_uint8 * 128)()
+    assert lib.anofox_hip_comm_unique_id(uid, C.byref(err)), err.text()
+    ctx = pkg.Context(0)
+    comm = C.c_void_p()
+    assert lib.anofox_hip_comm_create(ctx._h, 1, 0, uid, C.byref(comm), C.byref(err)), err.text()
+    assert lib.anofox_hip_comm_world_size(comm) == 1 and lib.anofox_hip_comm_rank(comm) == 0
+    G, n, p = 4000, 200, 8
+    offs, y, x_cols, _ = synth.make_grouped(G, n, p, device="cuda:0")
+    opts = pkg.RegressionOptions().batch_options("ols")
+    core, _ = ctx.fit_batch_device(offs, y, x_cols, None, opts)
+    out = torch.full((G, p + 6), float("nan"), dtype=torch.float64, device="cuda:0")
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert lib.anofox_hip_gather_records_device(comm, C.c_void_p(core.data_ptr()), G, p + 6, C.c_void_p(out.data_ptr()), C.byref(err)), err.text()
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int64), core.view(torch.int64))
+    assert not lib.anofox_hip_gather_records_device(None, None, 1, 1, None, C.byref(err)) and err.code == 1
+    assert not lib.anofox_hip_comm_create(ctx._h, 2, 5, uid, C.byref(C.c_void_p()), C.byref(err)) and err.code == 1
+    lib.anofox_hip_comm_destroy(comm)
+    lib.anofox_hip_comm_destroy(None)
+    ctx.close()
