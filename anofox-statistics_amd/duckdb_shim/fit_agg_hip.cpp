@@ -94,7 +94,7 @@ static void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, i
 	auto states = (HipAggState **)sdata.data;
 
 	anofox_shim::AggArena::Writer writer(arena); // one lock per vector
-	double row[8];
+	double row[128]; // anofox_hip_max_features(); up to 8 features stream into the GPU state, wider designs are buffered
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
 		if (state.slot < 0) state.slot = writer.NewSlot(); // the group exists even if every row of it is skipped
@@ -109,9 +109,8 @@ static void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, i
 			w = w_values[w_idx];
 		}
 		auto entry = x_list[x_idx];
-		if (entry.length > 8 && arena.FeatureCount() == 0)
-			throw InvalidInputException("anofox_stats fit_agg (HIP): more than 8 features need the batched Finalize path");
-		const idx_t n = entry.length <= 8 ? entry.length : 8;
+		if (entry.length > 128) throw InvalidInputException("anofox_stats fit_agg (HIP): at most 128 features are supported");
+		const idx_t n = entry.length;
 		for (idx_t j = 0; j < n; j++) // a NULL list element becomes NaN: the fit's row filter drops the row (ols.rs:59-66)
 			row[j] = x_child_validity.RowIsValid(entry.offset + j) ? x_child_data[entry.offset + j] : NAN;
 		try {

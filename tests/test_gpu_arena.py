@@ -39,12 +39,17 @@ def _lib():
     return pkg, lib
 
 
-@pytest.mark.parametrize("model,flush_rows", [("ols", 5000), ("wls", 1 << 20), ("ridge", 777)])
-def test_threads_update_combine_finalize(model, flush_rows):
+@pytest.mark.parametrize("model,flush_rows,p,hc", [("ols", 5000, 6, None), ("wls", 1 << 20, 6, None), ("ridge", 777, 6, None),
+                                                   ("ols", 5000, 12, None), ("wls", 5000, 20, None), ("ols", 5000, 4, "hc1")])
+def test_threads_update_combine_finalize(model, flush_rows, p, hc):
+    """p <= 8 without HC errors: rows stream into the GPU-resident state; wider designs and HC errors: the arena buffers
+    the rows in host chunks and makes one batched call at Solve — same calls, same results."""
     pkg, lib = _lib()
-    rng = np.random.default_rng(len(model))
-    p, G, T = 6, 400, 3
+    rng = np.random.default_rng(len(model) + p)
+    G, T = 400, 3
     kw = dict(compute_inference=True)
+    if hc:
+        kw["hc_type"] = hc
     if model == "ridge":
         kw["alpha"] = 0.5
     arena = lib.arena_create(pkg.RegressionOptions(**kw).batch_options(model), flush_rows)
