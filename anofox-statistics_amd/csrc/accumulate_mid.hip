@@ -16,6 +16,10 @@
 //     otherwise 4 ballots give the row mask (the 16 lanes of a kk group hold the 16 columns of a block) and
 //     invalid rows are removed with bit masks;
 //   * four groups per 256-thread workgroup, no LDS, no barrier;
+//   * (measured and removed in round 2: the same kernel with the step buffers in a per-wave LDS ring filled by
+//     global_load_lds_dwordx4, 3-8 steps ahead and no VGPR staging — correct, but slower at p = 9 / 16 / 24-wls
+//     (3.1 / 4.1 / 3.1 TB/s against 3.8 / 4.7 / 3.5 here) and level at p = 32: one DMA instruction covers 8 columns,
+//     so 10, 17 or 26 columns waste 37 / 29 / 19 % of the lanes, and the ring's LDS caps the CU at 8 waves)
 //   * a group with more than seg_rows rows (>= 1/2048 of the batch) is cut into segments, one wavefront each
 //     (accumulate_mid_segments_kernel, idle otherwise), all shifted by the group's first valid row, and the wave
 //     that finishes the last segment sums the segment records.
@@ -117,13 +121,105 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 	}
 }
 
+// Row validity of one 16-row step starting at row r0 (ols.rs:59-66, wls.rs:76-86), then the step itself.  Common case
+// first: a full step whose 16 rows all pass.
+template <int T, bool WEIGHTED, bool CENTER>
+__device__ __forceinline__ void mid_process_step(MidState<T> &st, const double (&x)[T][4], const double (&y)[4], const double (&w)[4],
+                                                 int64_t r0, int64_t hi, int kk, int lj) {
+	bool ok_all = true;
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		ok_all = ok_all && isfinite(y[m]);
+		if (WEIGHTED) ok_all = ok_all && isfinite(w[m]) && (w[m] > 0.0);
+#pragma unroll
+		for (int I = 0; I < T; ++I) ok_all = ok_all && isfinite(x[I][m]);
+	}
+	if (r0 + 16 <= hi && __ballot(ok_all) == ~0ull) {
+		mid_step<T, WEIGHTED, CENTER, true>(st, x, y, w, 0xFFFFu, kk, lj);
+		return;
+	}
+	unsigned rowmask = 0; // bit = row of the step
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		bool ok = isfinite(y[m]) && (r0 + mid_row(kk, m) < hi);
+		if (WEIGHTED) ok = ok && isfinite(w[m]) && (w[m] > 0.0);
+#pragma unroll
+		for (int I = 0; I < T; ++I) ok = ok && isfinite(x[I][m]);
+		const unsigned long long b = __ballot(ok);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) rowmask |= (((b >> (16 * k)) & 0xFFFFull) == 0xFFFFull) ? (1u << mid_row(k, m)) : 0u;
+	}
+	rowmask = __builtin_amdgcn_readfirstlane(rowmask);
+	if (rowmask == 0u) return;
+	mid_step<T, WEIGHTED, CENTER, false>(st, x, y, w, rowmask, kk, lj);
+}
+
+template <int T>
+__device__ __forceinline__ void mid_init_state(MidState<T> &st, const bool (&real)[T], const double *forced_first, int lj) {
+	constexpr int P16 = 16 * T, NT = T * (T + 1) / 2;
+#pragma unroll
+	for (int t = 0; t < NT; ++t) st.acc[t] = mid_dbl4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+	for (int I = 0; I < T; ++I) st.sx[I] = st.sxy[I] = st.first[I] = 0.0;
+	st.ncmask = 0;
+	st.sy = st.syy = st.sw = st.first_y = 0.0;
+	st.have_first = false;
+	st.cnt = 0;
+	if (forced_first) {
+#pragma unroll
+		for (int I = 0; I < T; ++I) st.first[I] = real[I] ? forced_first[16 * I + lj] : 0.0;
+		st.first_y = forced_first[P16];
+		st.have_first = true;
+	}
+}
+
+// the moment record, layout of accumulate_wide.hip
+template <int T>
+__device__ __forceinline__ void mid_write_record(const MidState<T> &st, const bool (&real)[T], double *rec, int lane) {
+	constexpr int P16 = 16 * T, NT = T * (T + 1) / 2;
+	const int kk = lane >> 4, lj = lane & 15;
+#pragma unroll
+	for (int t = 0; t < NT; ++t) {
+		double *tp = rec + (int64_t)t * 256; // tile-major, element (row, col) at row * 16 + col
+#pragma unroll
+		for (int r = 0; r < 4; ++r) tp[(kk + 4 * r) * 16 + lj] = st.acc[t][r];
+	}
+	double *vec = rec + (int64_t)NT * 256;
+#pragma unroll
+	for (int I = 0; I < T; ++I) { // reduce over the four kk groups (lanes l, l^16, l^32, l^48)
+		double a = st.sx[I], b = st.sxy[I];
+		a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+		b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+		unsigned nc = (st.ncmask >> I) & 1u;
+		nc |= (unsigned)__shfl_xor((int)nc, 16, 64);
+		nc |= (unsigned)__shfl_xor((int)nc, 32, 64);
+		if (lane < 16) {
+			vec[0 * P16 + 16 * I + lane] = a;
+			vec[1 * P16 + 16 * I + lane] = b;
+			vec[2 * P16 + 16 * I + lane] = st.first[I];
+			vec[3 * P16 + 16 * I + lane] = (real[I] && nc) ? 1.0 : 0.0;
+		}
+	}
+	// every lane of a kk group holds the same partial of the y moments: lanes 0, 16, 32, 48
+	double sy = st.sy, syy = st.syy, sw = st.sw;
+	sy += __shfl_xor(sy, 16, 64); sy += __shfl_xor(sy, 32, 64);
+	syy += __shfl_xor(syy, 16, 64); syy += __shfl_xor(syy, 32, 64);
+	sw += __shfl_xor(sw, 16, 64); sw += __shfl_xor(sw, 32, 64);
+	if (lane == 0) {
+		double *sc = vec + 4 * P16;
+		sc[0] = sy;
+		sc[1] = syy;
+		sc[2] = sw;
+		sc[3] = (double)st.cnt;
+		sc[4] = st.first_y;
+	}
+}
+
 // The rows [lo, hi) of one group — or of one segment of a very large group, then with the group's first valid
 // row handed in (`forced_first`: x per column, y at index 16 T) — into one wide moment record at `rec`.
 template <int T, bool WEIGHTED, bool CENTER>
 __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
                                                     const double *forced_first, int lane) {
-	constexpr int P16 = 16 * T;
-	constexpr int NT = T * (T + 1) / 2;
 	const int p = args.p;
 	const int kk = lane >> 4, lj = lane & 15;
 
@@ -139,20 +235,7 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 	const mid_gptr_t wcol = (mid_gptr_t)(uintptr_t)args.w;
 
 	MidState<T> st;
-#pragma unroll
-	for (int t = 0; t < NT; ++t) st.acc[t] = mid_dbl4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-	for (int I = 0; I < T; ++I) st.sx[I] = st.sxy[I] = st.first[I] = 0.0;
-	st.ncmask = 0;
-	st.sy = st.syy = st.sw = st.first_y = 0.0;
-	st.have_first = false;
-	st.cnt = 0;
-	if (forced_first) {
-#pragma unroll
-		for (int I = 0; I < T; ++I) st.first[I] = real[I] ? forced_first[16 * I + lj] : 0.0;
-		st.first_y = forced_first[P16];
-		st.have_first = true;
-	}
+	mid_init_state<T>(st, real, forced_first, lj);
 
 	// S steps (16 S rows) per loop trip, the next trip's loads in flight: per column a wave asks for 128 S
 	// contiguous bytes at a time (DRAM locality: a single 128-byte line per stream and trip ran at ~4 TB/s)
@@ -202,72 +285,11 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 			const double (&x)[T][4] = xs[q];
 			const double (&y)[4] = ys[q];
 			const double (&w)[4] = ws[q];
-			// row validity (ols.rs:59-66, wls.rs:76-86).  Common case first: a full step whose 16 rows all pass
-			bool ok_all = true;
-#pragma unroll
-			for (int m = 0; m < 4; ++m) {
-				ok_all = ok_all && isfinite(y[m]);
-				if (WEIGHTED) ok_all = ok_all && isfinite(w[m]) && (w[m] > 0.0);
-#pragma unroll
-				for (int I = 0; I < T; ++I) ok_all = ok_all && isfinite(x[I][m]);
-			}
-			if (r0 + 16 <= hi && __ballot(ok_all) == ~0ull) {
-				mid_step<T, WEIGHTED, CENTER, true>(st, x, y, w, 0xFFFFu, kk, lj);
-				continue;
-			}
-			unsigned rowmask = 0; // bit = row of the step
-#pragma unroll
-			for (int m = 0; m < 4; ++m) {
-				bool ok = isfinite(y[m]) && (r0 + mid_row(kk, m) < hi);
-				if (WEIGHTED) ok = ok && isfinite(w[m]) && (w[m] > 0.0);
-#pragma unroll
-				for (int I = 0; I < T; ++I) ok = ok && isfinite(x[I][m]);
-				const unsigned long long b = __ballot(ok);
-#pragma unroll
-				for (int k = 0; k < 4; ++k) rowmask |= (((b >> (16 * k)) & 0xFFFFull) == 0xFFFFull) ? (1u << mid_row(k, m)) : 0u;
-			}
-			rowmask = __builtin_amdgcn_readfirstlane(rowmask);
-			if (rowmask == 0u) continue;
-			mid_step<T, WEIGHTED, CENTER, false>(st, x, y, w, rowmask, kk, lj);
+			mid_process_step<T, WEIGHTED, CENTER>(st, x, y, w, r0, hi, kk, lj);
 		}
 	}
 
-	// ---- the moment record, layout of accumulate_wide.hip ----
-#pragma unroll
-	for (int t = 0; t < NT; ++t) {
-		double *tp = rec + (int64_t)t * 256; // tile-major, element (row, col) at row * 16 + col
-#pragma unroll
-		for (int r = 0; r < 4; ++r) tp[(kk + 4 * r) * 16 + lj] = st.acc[t][r];
-	}
-	double *vec = rec + (int64_t)NT * 256;
-#pragma unroll
-	for (int I = 0; I < T; ++I) { // reduce over the four kk groups (lanes l, l^16, l^32, l^48)
-		double a = st.sx[I], b = st.sxy[I];
-		a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-		b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
-		unsigned nc = (st.ncmask >> I) & 1u;
-		nc |= (unsigned)__shfl_xor((int)nc, 16, 64);
-		nc |= (unsigned)__shfl_xor((int)nc, 32, 64);
-		if (lane < 16) {
-			vec[0 * P16 + 16 * I + lane] = a;
-			vec[1 * P16 + 16 * I + lane] = b;
-			vec[2 * P16 + 16 * I + lane] = st.first[I];
-			vec[3 * P16 + 16 * I + lane] = (real[I] && nc) ? 1.0 : 0.0;
-		}
-	}
-	// every lane of a kk group holds the same partial of the y moments: lanes 0, 16, 32, 48
-	double sy = st.sy, syy = st.syy, sw = st.sw;
-	sy += __shfl_xor(sy, 16, 64); sy += __shfl_xor(sy, 32, 64);
-	syy += __shfl_xor(syy, 16, 64); syy += __shfl_xor(syy, 32, 64);
-	sw += __shfl_xor(sw, 16, 64); sw += __shfl_xor(sw, 32, 64);
-	if (lane == 0) {
-		double *sc = vec + 4 * P16;
-		sc[0] = sy;
-		sc[1] = syy;
-		sc[2] = sw;
-		sc[3] = (double)st.cnt;
-		sc[4] = st.first_y;
-	}
+	mid_write_record<T>(st, real, rec, lane);
 }
 
 template <int T, bool WEIGHTED, bool CENTER>
