@@ -492,7 +492,7 @@ bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *s, int64_t n_slots,
 }
 
 bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, double *core, double *inference, int64_t *out_unrefined,
-                                        AnofoxError *out_error) {
+                                        int32_t *out_unrefined_slots, AnofoxError *out_error) {
 	reset_error(out_error);
 	if (out_unrefined) *out_unrefined = 0;
 	if (!check_finalize(s, n_slots, core, inference, out_error)) return false;
@@ -516,6 +516,10 @@ bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, d
 	if (hip_fail(hipMemcpyAsync(&queued, ctx->last_refine_count, sizeof queued, hipMemcpyDeviceToHost, st), "D2H", out_error)) return false;
 	if (!check_slot_flag(s, out_error)) return false; // (synchronises the stream)
 	if (out_unrefined) *out_unrefined = queued;
+	if (out_unrefined_slots && queued > 0) { // the queue itself: the first words of the workspace (run_finalize)
+		const int64_t n = queued < n_slots ? queued : n_slots;
+		if (hip_fail(hipMemcpy(out_unrefined_slots, ctx->ws, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H", out_error)) return false;
+	}
 	return true;
 }
 

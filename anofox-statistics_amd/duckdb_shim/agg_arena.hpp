@@ -101,7 +101,7 @@ public:
 			core_.resize((size_t)n_slots_ * (p_ + 6));
 			if (opt_.compute_inference) inf_.resize((size_t)n_slots_ * (5 * p_ + 2));
 			AnofoxError err;
-			if (!anofox_hip_agg_state_finalize_host(state_, n_slots_, core_.data(), inf_.empty() ? nullptr : inf_.data(), &unrefined_, &err))
+			if (!anofox_hip_agg_state_finalize_host(state_, n_slots_, core_.data(), inf_.empty() ? nullptr : inf_.data(), &unrefined_, nullptr, &err))
 				Throw(err);
 		}
 		solved_ = true;

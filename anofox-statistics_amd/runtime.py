@@ -325,12 +325,14 @@ class AggState:
         core = np.empty((G, p + 6), dtype=np.float64)
         inf = np.empty((G, 5 * p + 2), dtype=np.float64) if self.options.compute_inference else None
         unref = C.c_int64()
+        slots = np.empty(max(G, 1), dtype=np.int32)
         err = _abi.AnofoxError()
         ok = self._lib.anofox_hip_agg_state_finalize_host(
             self._h, G, core.ctypes.data_as(_DP), None if inf is None else inf.ctypes.data_as(_DP), C.byref(unref),
-            C.byref(err))
+            slots.ctypes.data, C.byref(err))
         if not ok:
             raise AnofoxStatsError(err.code, err.text())
+        self.unrefined_slots = np.sort(slots[:int(unref.value)])   # groups that would have taken the refinement passes
         return core, inf, int(unref.value)
 
     def finalize_device(self, core, inference=None, n_slots: Optional[int] = None, use_current_torch_stream: bool = True):

@@ -479,8 +479,11 @@ ANOFOX_HIP_API bool anofox_hip_residuals_batch_host(AnofoxHipContext *ctx, int64
  *   finalize  fit records of slots [0, n_slots) exactly as anofox_hip_fit_batch_* lays them out (status 100 for
  *             fewer than 2 accumulated rows, ols_aggregate.cpp:263-267).  The rows are gone, so the batch path's
  *             refinement passes (re-reading the rows of ill-conditioned or exactly fitting groups) cannot run:
- *             *out_unrefined (optional) is the number of groups that would have taken them.  hc_type other than
- *             none needs the rows as well and is rejected at creation.
+ *             *out_unrefined (optional) is the number of groups that would have taken them — smallest Cholesky
+ *             pivot ratio below 1e-3 or rss / tss below 1e-7: their coefficients carry cond^2 eps and their sigma / r^2
+ *             the cancellation of rss = tss - |z|^2 — and out_unrefined_slots (optional, room for n_slots entries)
+ *             receives their slot numbers, in no particular order.  hc_type other than none needs the rows as well and
+ *             is rejected at creation.
  *
  * A state belongs to one context (device + stream); calls on one state are serialised.  n_features <=
  * anofox_hip_agg_state_max_features() = 8.
@@ -502,7 +505,7 @@ ANOFOX_HIP_API bool anofox_hip_agg_state_update_device(AnofoxHipAggState *state,
 ANOFOX_HIP_API bool anofox_hip_agg_state_combine(AnofoxHipAggState *state, int64_t n_pairs, const uint32_t *source_slots,
                                   const uint32_t *target_slots, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *state, int64_t n_slots, double *core, double *inference,
-                                        int64_t *out_unrefined, AnofoxError *out_error);
+                                        int64_t *out_unrefined, int32_t *out_unrefined_slots, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *state, int64_t n_slots, double *d_core, double *d_inference,
                                           AnofoxError *out_error);
 /* Page-locked host memory for the shim's row arenas (copies from it run at the full PCIe rate and asynchronously). */

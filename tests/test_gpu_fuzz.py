@@ -4,6 +4,7 @@ Every case draws its own shape, scales, NULL / NaN / inf pattern, degenerate col
 records of the HIP path must agree with the oracle's to the north-star tolerances (coefficients 1e-9, diagnostics
 1e-6), including the NaN patterns and status words.  Groups with zero residual degrees of freedom are compared on
 coefficients only (their diagnostics are ratios of rounding noise)."""
+import json
 import os
 
 import numpy as np
@@ -16,6 +17,12 @@ pytestmark = pytest.mark.gpu
 
 # ANOFOX_FUZZ_SCALE=10 multiplies the number of seeds (an occasional deep sweep; the default run stays at seconds)
 _SCALE = max(1, int(os.environ.get("ANOFOX_FUZZ_SCALE", "1")))
+# Groups the streaming state reports as unrefined (pivot ratio < 1e-3 or rss / tss < 1e-7; the rows are gone at Finalize,
+# so the batch path's refinement passes cannot run).  Measured over the 600-seed sweep (profiles/r02_stream_unrefined.md):
+# 108 of 11832 fitted groups; coefficients still within 1.6e-10, sigma within 5.3e-6 (the group with 1 - r^2 = 5.6e-11:
+# rss = tss - |z|^2 keeps eps / (1 - r^2) of its digits).  Coefficients are therefore held to the ordinary tolerance and
+# only sigma and what is derived from it (standard errors, t, p, interval bounds, adjusted r^2) to this looser one.
+UNREFINED_DIAG_RTOL = 1e-4
 
 SIZES = [0, 1, 2, 3, 4, 5, 7, 9, 17, 50, 63, 64, 65, 127, 128, 129, 200, 256, 257, 400]
 
@@ -198,3 +205,128 @@ def test_fuzz_window_frames(pkg, ctx, seed):
             assert np.array_equal(np.isfinite(pred[m, k]), fin), what
             e2 = np.abs(pred[m, k][fin] - ref[m, k][fin]) / np.maximum(np.abs(ref[m, k][fin]), scale[fin])
             assert e2.size == 0 or e2.max() < 1e-6, (what, k, e2.max())
+
+
+@pytest.mark.parametrize("seed", range(30 * _SCALE))
+def test_fuzz_streaming_state(pkg, ctx, seed):
+    """The GPU-resident aggregate state on random shapes: rows of all groups shuffled, fed in chunks of random sizes
+    with skipped rows, NaN / inf values, non-positive weights, constant and aliased columns — against the oracle's fit
+    of each group's accepted rows in arrival order.  Designs are kept moderately conditioned: the streaming state
+    has no refinement pass (rows are gone at Finalize)."""
+    rng = np.random.default_rng(50_000 + seed)
+    p = int(rng.integers(1, 9))
+    G = int(rng.integers(1, 80))
+    ns = rng.choice(SIZES + [p, p + 1, p + 2, 2 * p + 3, 3000], size=G)
+    slot = np.repeat(np.arange(G, dtype=np.uint32), ns)
+    rng.shuffle(slot)
+    N = len(slot)
+    if N == 0:
+        return
+    model = ["ols", "ridge", "wls"][int(rng.integers(0, 3))]
+    col_scale = 10.0 ** rng.uniform(-0.5, 0.5, p)
+    X = rng.standard_normal((N, p)) * col_scale + rng.choice([0.0, 1.0, 3.0], p) * col_scale
+    beta = rng.uniform(-3, 3, (G, p)) / col_scale
+    y = rng.uniform(-5, 5, G)[slot] + np.einsum("ij,ij->i", X, beta[slot]) + rng.standard_normal(N) * 10.0 ** rng.uniform(-2, 1)
+    w = rng.uniform(0.2, 3.0, N)
+    for g in range(G):
+        rows = np.nonzero(slot == g)[0]
+        if len(rows) == 0:
+            continue
+        kind = rng.integers(0, 10)
+        if kind == 0:
+            X[rows, rng.integers(0, p)] = rng.uniform(-3, 3)
+        elif kind == 1 and p >= 2:
+            a, b = rng.choice(p, 2, replace=False)
+            X[rows, max(a, b)] = 2.0 * X[rows, min(a, b)]
+        elif kind == 2:
+            y[rng.choice(rows, size=max(1, len(rows) // 6), replace=False)] = np.nan
+        elif kind == 3:
+            X[rng.choice(rows, size=max(1, len(rows) // 8), replace=False), rng.integers(0, p)] = rng.choice([np.nan, np.inf, -np.inf])
+        elif kind == 4:
+            w[rng.choice(rows, size=max(1, len(rows) // 5), replace=False)] = rng.choice([0.0, -1.0, np.nan, np.inf])
+    valid = (rng.random(N) > 0.1).astype(np.uint8)
+    kw = dict(fit_intercept=bool(rng.integers(0, 2)), compute_inference=bool(rng.integers(0, 2)),
+              confidence_level=float(rng.choice([0.8, 0.9, 0.95, 0.99])))
+    if model == "ridge":
+        kw["alpha"] = float(10.0 ** rng.uniform(-2, 1))
+        kw["lambda_scaling"] = str(rng.choice(["raw", "glmnet"]))
+    st = pkg.AggState(ctx, p, pkg.RegressionOptions(**kw).batch_options(model))
+    r0 = 0
+    while r0 < N:
+        n = int(rng.choice([1, 7, 64, 500, 2048, 10_000]))
+        sl = slice(r0, r0 + n)
+        st.update(slot[sl], y[sl], X[sl], w[sl] if model == "wls" else None, valid[sl], n_slots=G)
+        r0 += n
+    core, inf, _ = st.finalize(G)
+    unrefined = set(int(v) for v in st.unrefined_slots)     # pivot ratio < 1e-3 or rss / tss < 1e-7: the batch path would refine
+    st.close()
+    keep = np.nonzero(valid)[0]
+    order = keep[np.argsort(slot[keep], kind="stable")]
+    offs = np.concatenate([[0], np.cumsum(np.bincount(slot[keep], minlength=G))]).astype(np.int64)
+    x_cols = [np.ascontiguousarray(X[order, j]) for j in range(p)]
+    wv = w[order] if model == "wls" else None
+    rcore, rinf = oracle.fit_groups(y[order], x_cols, offs, w=wv, model=model, **kw)
+    n_par = np.sum(~np.isnan(rcore[:, :p]), axis=1) + (1 if kw["fit_intercept"] else 0)
+    zero_df = {g for g in range(G) if rcore[g, p + 5] == 0 and rcore[g, p + 4] - n_par[g] <= 0}
+    with np.errstate(all="ignore"):
+        Xo = np.where(np.isfinite(X[order]), X[order], 0.0)
+        xbar = np.stack([np.abs(Xo[offs[g]:offs[g + 1]]).mean(0) if offs[g + 1] > offs[g] else np.zeros(p) for g in range(G)])
+    u = np.array(sorted(unrefined), dtype=np.int64)
+    rest = np.setdiff1d(np.arange(G), u)
+    if os.environ.get("ANOFOX_FUZZ_STATS") and u.size:      # how far off the unrefined groups are (scripts / DESIGN.md)
+        oku = u[(rcore[u, p + 5] == 0) & ~np.isin(u, sorted(zero_df))]
+        with np.errstate(all="ignore"):
+            sc = np.nanmax(np.abs(rcore[oku][:, :p + 1]), axis=1, keepdims=True) if oku.size else np.zeros((0, 1))
+            dc = np.abs(core[oku][:, :p + 1] - rcore[oku][:, :p + 1]) / np.maximum(np.abs(rcore[oku][:, :p + 1]), 1e-3 * sc)
+            ds = np.abs(core[oku, p + 3] - rcore[oku, p + 3]) / np.abs(rcore[oku, p + 3])
+            dr = np.abs(core[oku, p + 1] - rcore[oku, p + 1])
+        with open(os.environ["ANOFOX_FUZZ_STATS"], "a") as fh:
+            fh.write(json.dumps({"seed": seed, "groups": int(np.sum(rcore[:, p + 5] == 0)), "unrefined": int(oku.size),
+                                 "coef_rel": float(np.nanmax(dc)) if dc.size else 0.0,
+                                 "rse_rel": float(np.nanmax(ds)) if ds.size else 0.0,
+                                 "r2_abs": float(np.nanmax(dr)) if dr.size else 0.0,
+                                 "min_one_minus_r2": float(np.nanmin(1.0 - rcore[oku, p + 1])) if oku.size else 1.0}) + "\n")
+
+    def check(idx, **tol):
+        assert_records_match(core[idx], rcore[idx], p, None if inf is None else inf[idx], None if rinf is None else rinf[idx],
+                             what=f"streaming seed {seed} {model} p={p} {kw}", xbar=xbar[idx],
+                             skip_diag_groups=[k for k, g in enumerate(idx) if int(g) in zero_df], **tol)
+
+    rtol = 1e-9 if model != "ridge" or kw.get("lambda_scaling") == "raw" else 1e-8
+    check(rest, coef_rtol=rtol)
+    if u.size:      # no refinement passes for these: the cancellation of tss - |z|^2 shows in sigma
+        check(u, coef_rtol=rtol, diag_rtol=UNREFINED_DIAG_RTOL)
+
+
+@pytest.mark.parametrize("seed", range(20 * _SCALE))
+def test_fuzz_wide_window_frames(pkg, ctx, seed):
+    """*_fit_predict OVER (... ROWS ...) with 9..24 features: every frame a virtual group of the batch path."""
+    rng = np.random.default_rng(60_000 + seed)
+    p = int(rng.integers(9, 25))
+    G = int(rng.integers(1, 4))
+    ns = rng.choice([0, 1, p, p + 2, 2 * p + 5, 3 * p + 20], size=G)
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    if N == 0:
+        return
+    X = rng.uniform(-5, 5, (N, p))
+    y = 1.0 + X @ rng.uniform(-2, 2, p) + 0.3 * rng.standard_normal(N)
+    y[rng.random(N) < 0.1] = np.nan
+    X[rng.random(N) < 0.01, int(rng.integers(0, p))] = np.nan
+    w = rng.uniform(0.3, 2.0, N)
+    b = int(rng.choice([0, 0, 1, 3, -1, -4])) if rng.random() < 0.9 else None
+    a = None if rng.random() < 0.4 else (b if b is not None else -5) + int(rng.integers(p, 4 * p))
+    model = ["ols", "ridge", "wls"][int(rng.integers(0, 3))]
+    kw = dict(fit_intercept=bool(rng.integers(0, 2)), confidence_level=0.9)
+    if model == "ridge":
+        kw["alpha"] = float(10.0 ** rng.uniform(-2, 0.5))
+    wv = w if model == "wls" else None
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    pred = pkg.fit_predict_window_host(offs, y, x_cols, wv, pkg.RegressionOptions(**kw).batch_options(model), (a, b), ctx=ctx)
+    ref = oracle.fit_predict_window(y, x_cols, offs, w=wv, start_preceding=a, end_preceding=b, model=model, **kw)
+    what = f"wide window seed {seed} {model} p={p} frame=({a},{b}) {kw}"
+    assert np.array_equal(np.isnan(pred[:, 0]), np.isnan(ref[:, 0])), f"NULL pattern {what}"
+    m = ~np.isnan(ref[:, 0])
+    if m.any():
+        scale = np.maximum(np.abs(ref[m, 0]), 1.0)
+        assert (np.abs(pred[m, 0] - ref[m, 0]) / scale).max() < 1e-8, what

@@ -38,6 +38,13 @@ STUB(launch_refine_fused_narrow(const BatchArgs &, int, hipStream_t))
 STUB(launch_vif_narrow(const double *, const int64_t *, int64_t, int, int64_t, double *, hipStream_t))
 STUB(launch_vif_from_core(const double *, const int64_t *, int64_t, int, int, int, int64_t, double *, hipStream_t))
 STUB(launch_hc_narrow(const BatchArgs &, double *, void *, hipStream_t))
+STUB(launch_information_criteria(const double *, int64_t, int, int, int, double *, hipStream_t))
+STUB(launch_residuals_mid(const ResidualArgs &, const double *const *, hipStream_t))
+STUB(launch_frames_ynn(const double *, int64_t, int64_t *, void *, size_t, hipStream_t))
+STUB(launch_frames_from_rows_spec(const int64_t *, int64_t, int64_t, int64_t, int64_t, int64_t *, int64_t *, hipStream_t, const int32_t *, int64_t))
+STUB(launch_frames_rule(const FrameArgs &, hipStream_t))
+STUB(launch_frames_predict(const FrameArgs &, hipStream_t))
+size_t frames_scan_temp_bytes(int64_t) { return 4096; }
 size_t ingest_piece_table_bytes(int) { return 4096; }
 size_t ingest_sort_temp_bytes(int64_t) { return 4096; }
 bool accumulate_mid_supports(int p) { return p > 8 && p <= 32; }
@@ -167,7 +174,7 @@ int main() {
 		CHECK(anofox_hip_agg_state_slots(nullptr) == 0 && anofox_hip_agg_state_rows(nullptr) == 0);
 		anofox_hip_agg_state_destroy(nullptr);
 		CHECK(!anofox_hip_agg_state_update_host(nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, &err));
-		CHECK(!anofox_hip_agg_state_finalize_host(nullptr, 0, nullptr, nullptr, nullptr, &err));
+		CHECK(!anofox_hip_agg_state_finalize_host(nullptr, 0, nullptr, nullptr, nullptr, nullptr, &err));
 		CHECK(!anofox_hip_agg_state_combine(nullptr, 1, nullptr, nullptr, &err));
 		CHECK(anofox_hip_core_record_len(8) == 14 && anofox_hip_inference_record_len(8) == 42 && anofox_hip_max_features() == 128);
 		CHECK(anofox_hip_agg_state_max_features() == 8 && anofox_hip_vif_record_len(5) == 6);
