@@ -19,9 +19,11 @@ pytestmark = pytest.mark.gpu
 _SCALE = max(1, int(os.environ.get("ANOFOX_FUZZ_SCALE", "1")))
 # Groups the streaming state reports as unrefined (pivot ratio < 1e-3 or rss / tss < 1e-7; the rows are gone at Finalize,
 # so the batch path's refinement passes cannot run).  Measured over the 600-seed sweep (profiles/r02_stream_unrefined.md):
-# 108 of 11832 fitted groups; coefficients still within 1.6e-10, sigma within 5.3e-6 (the group with 1 - r^2 = 5.6e-11:
-# rss = tss - |z|^2 keeps eps / (1 - r^2) of its digits).  Coefficients are therefore held to the ordinary tolerance and
-# only sigma and what is derived from it (standard errors, t, p, interval bounds, adjusted r^2) to this looser one.
+# 974 of 11832 fitted groups, 866 of them exact interpolations (rows == parameters, rss / tss ~ 0 always trips the test).
+# Worst coefficient error 1.2e-8 (a square 8 x 8 system: cond^2 eps with nothing to refine it), worst sigma error 5.3e-6
+# (the group with 1 - r^2 = 5.6e-11: rss = tss - |z|^2 keeps eps / (1 - r^2) of its digits).  The bounds below are those
+# measurements with two orders of margin, not guarantees: both errors grow with the conditioning of the group.
+UNREFINED_COEF_RTOL = 1e-6
 UNREFINED_DIAG_RTOL = 1e-4
 
 SIZES = [0, 1, 2, 3, 4, 5, 7, 9, 17, 50, 63, 64, 65, 127, 128, 129, 200, 256, 257, 400]
@@ -274,14 +276,15 @@ def test_fuzz_streaming_state(pkg, ctx, seed):
     u = np.array(sorted(unrefined), dtype=np.int64)
     rest = np.setdiff1d(np.arange(G), u)
     if os.environ.get("ANOFOX_FUZZ_STATS") and u.size:      # how far off the unrefined groups are (scripts / DESIGN.md)
-        oku = u[(rcore[u, p + 5] == 0) & ~np.isin(u, sorted(zero_df))]
+        okc = u[rcore[u, p + 5] == 0]                       # coefficients: every fitted group, zero-df ones included
+        oku = okc[~np.isin(okc, sorted(zero_df))]           # diagnostics: groups with residual degrees of freedom
         with np.errstate(all="ignore"):
-            sc = np.nanmax(np.abs(rcore[oku][:, :p + 1]), axis=1, keepdims=True) if oku.size else np.zeros((0, 1))
-            dc = np.abs(core[oku][:, :p + 1] - rcore[oku][:, :p + 1]) / np.maximum(np.abs(rcore[oku][:, :p + 1]), 1e-3 * sc)
+            sc = np.nanmax(np.abs(rcore[okc][:, :p + 1]), axis=1, keepdims=True) if okc.size else np.zeros((0, 1))
+            dc = np.abs(core[okc][:, :p + 1] - rcore[okc][:, :p + 1]) / np.maximum(np.abs(rcore[okc][:, :p + 1]), 1e-3 * sc)
             ds = np.abs(core[oku, p + 3] - rcore[oku, p + 3]) / np.abs(rcore[oku, p + 3])
             dr = np.abs(core[oku, p + 1] - rcore[oku, p + 1])
         with open(os.environ["ANOFOX_FUZZ_STATS"], "a") as fh:
-            fh.write(json.dumps({"seed": seed, "groups": int(np.sum(rcore[:, p + 5] == 0)), "unrefined": int(oku.size),
+            fh.write(json.dumps({"seed": seed, "groups": int(np.sum(rcore[:, p + 5] == 0)), "unrefined": int(okc.size), "unrefined_zero_df": int(okc.size - oku.size),
                                  "coef_rel": float(np.nanmax(dc)) if dc.size else 0.0,
                                  "rse_rel": float(np.nanmax(ds)) if ds.size else 0.0,
                                  "r2_abs": float(np.nanmax(dr)) if dr.size else 0.0,
@@ -294,8 +297,8 @@ def test_fuzz_streaming_state(pkg, ctx, seed):
 
     rtol = 1e-9 if model != "ridge" or kw.get("lambda_scaling") == "raw" else 1e-8
     check(rest, coef_rtol=rtol)
-    if u.size:      # no refinement passes for these: the cancellation of tss - |z|^2 shows in sigma
-        check(u, coef_rtol=rtol, diag_rtol=UNREFINED_DIAG_RTOL)
+    if u.size:      # no refinement passes for these: cond^2 eps on the coefficients, the cancellation of tss - |z|^2 on sigma
+        check(u, coef_rtol=UNREFINED_COEF_RTOL, diag_rtol=UNREFINED_DIAG_RTOL)
 
 
 @pytest.mark.parametrize("seed", range(20 * _SCALE))
