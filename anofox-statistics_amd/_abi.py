@@ -194,6 +194,9 @@ SYMBOLS = {
     "anofox_hip_agg_state_create": (C.c_bool, [_CTX, C.c_size_t, AnofoxHipBatchOptions, C.c_int64, C.POINTER(C.c_void_p), _ERRP]),
     "anofox_hip_agg_state_destroy": (None, [C.c_void_p]),
     "anofox_hip_agg_state_reserve": (C.c_bool, [C.c_void_p, C.c_int64, _ERRP]),
+    "anofox_hip_agg_state_retain_rows": (C.c_bool, [C.c_void_p, C.c_size_t, _ERRP]),
+    "anofox_hip_agg_state_retaining": (C.c_int, [C.c_void_p]),
+    "anofox_hip_agg_state_retained_bytes": (C.c_size_t, [C.c_void_p]),
     "anofox_hip_agg_state_slots": (C.c_int64, [C.c_void_p]),
     "anofox_hip_agg_state_rows": (C.c_int64, [C.c_void_p]),
     "anofox_hip_agg_state_update_host": (C.c_bool, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,

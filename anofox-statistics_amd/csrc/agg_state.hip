@@ -7,12 +7,15 @@
 //   update    a chunk of rows in arrival order -> ingest.hip folds it into the records (rows are not kept);
 //   combine   pairs (source slot, target slot) -> the source record is merged into the target and emptied;
 //   finalize  the unchanged solve kernel of the batch path (solve_narrow.hip) over the records.
+// Optionally (anofox_hip_agg_state_retain_rows) Update also appends the chunk to a row log in HBM (rowlog.hip), and
+// Finalize refits from it exactly the groups its solve queued for refinement, through the unchanged batch path.
 // Host chunks are staged through two device buffers on a copy stream, so the H2D copy of chunk k + 1 overlaps
 // the kernels of chunk k; update() returns once its inputs have been copied (the caller may reuse them).
 #include <stdlib.h>
 
 #include <memory>
 #include <unordered_set>
+#include <vector>
 
 #include "context.h"
 
@@ -46,6 +49,16 @@ struct AnofoxHipAggState {
 	hipStream_t copy_stream = nullptr;
 	void *pair_buf = nullptr; // combine: src | dst
 	size_t pair_bytes = 0;
+	// optional row log (anofox_hip_agg_state_retain_rows): slabs in arrival order
+	bool retain = false;       // asked for
+	bool log_dropped = false;  // ... and given up because the budget was exceeded
+	size_t log_budget = 0, log_bytes = 0;
+	int64_t log_rows = 0;
+	std::vector<RowLogSlab> slabs;
+	void *refit_idx = nullptr, *refit_rows = nullptr; // Finalize's refit scratch
+	size_t refit_idx_bytes = 0, refit_rows_bytes = 0;
+	void *remap_buf = nullptr;
+	size_t remap_bytes = 0;
 };
 
 namespace anofox {
@@ -68,14 +81,22 @@ void agg_state_detach(AnofoxHipAggState *s) {
 		if (st.done) (void)hipEventDestroy(st.done);
 		st = AnofoxHipAggState::Stage();
 	}
+	for (auto &sl : s->slabs) {
+		void *parts[] = {sl.x, sl.y, sl.w, sl.slot, sl.valid};
+		for (void *q : parts)
+			if (q) (void)hipFree(q);
+	}
+	s->slabs.clear();
+	s->log_bytes = 0;
+	s->log_rows = 0;
 	void **bufs[] = {(void **)&s->moments, (void **)&s->n_accum, (void **)&s->run_start, (void **)&s->run_end, &s->scratch,
-	                 (void **)&s->counters, &s->pair_buf};
+	                 (void **)&s->counters, &s->pair_buf, &s->refit_idx, &s->refit_rows, &s->remap_buf};
 	for (void **b : bufs) {
 		if (*b) (void)hipFree(*b);
 		*b = nullptr;
 	}
 	s->capacity = 0;
-	s->scratch_bytes = s->pair_bytes = 0;
+	s->scratch_bytes = s->pair_bytes = s->refit_idx_bytes = s->refit_rows_bytes = s->remap_bytes = 0;
 	s->ctx = nullptr;
 }
 } // namespace host
@@ -150,6 +171,83 @@ bool state_scratch(AnofoxHipAggState *s, AnofoxError *e) {
 	return ensure_buffer(&s->scratch, &s->scratch_bytes, 4 * b_n + b_pt + s->sort_temp_bytes, "ingest scratch", e);
 }
 
+size_t log_row_bytes(const AnofoxHipAggState *s) {
+	return s->p * sizeof(double) + sizeof(double) + (s->opt.model == ANOFOX_HIP_MODEL_WLS ? sizeof(double) : 0) + sizeof(uint32_t) + 1;
+}
+
+void log_free(AnofoxHipAggState *s) {
+	(void)hipStreamSynchronize(s->ctx->stream);
+	for (auto &sl : s->slabs) {
+		void *parts[] = {sl.x, sl.y, sl.w, sl.slot, sl.valid};
+		for (void *q : parts)
+			if (q) (void)hipFree(q);
+	}
+	s->slabs.clear();
+	s->log_bytes = 0;
+	s->log_rows = 0;
+}
+
+// Append one chunk (device pointers, stream-ordered after whatever produced them) to the row log.  Exceeding the
+// budget is not an error: the log is dropped and Finalize reports the unrefined groups as it does without one.
+bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const double *d_y, const double *d_x, const double *d_w,
+                const uint8_t *d_valid, AnofoxError *e) {
+	if (!s->retain || s->log_dropped || n <= 0) return true;
+	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
+	const size_t p = s->p, rb = log_row_bytes(s);
+	hipStream_t st = s->ctx->stream;
+	int64_t done = 0;
+	while (done < n) {
+		if (s->slabs.empty() || s->slabs.back().rows == s->slabs.back().cap) {
+			// slabs grow geometrically from 64 Ki rows to 16 Mi rows, never beyond what the budget still allows
+			int64_t cap = s->slabs.empty() ? 65536 : s->slabs.back().cap * 2;
+			if (cap > (int64_t)1 << 24) cap = (int64_t)1 << 24;
+			const size_t left = s->log_budget > s->log_bytes ? s->log_budget - s->log_bytes : 0;
+			if ((size_t)cap * rb > left) cap = (int64_t)(left / rb);
+			if (cap < n - done && (size_t)(n - done) * rb <= left) cap = n - done;
+			if (cap <= 0 || cap < n - done) { // the rest of this chunk does not fit: stop retaining
+				log_free(s);
+				s->log_dropped = true;
+				return true;
+			}
+			RowLogSlab sl{};
+			sl.cap = cap;
+			sl.first_row = s->log_rows;
+			bool ok = hipMalloc((void **)&sl.x, (size_t)cap * p * sizeof(double)) == hipSuccess &&
+			          hipMalloc((void **)&sl.y, (size_t)cap * sizeof(double)) == hipSuccess &&
+			          (!weighted || hipMalloc((void **)&sl.w, (size_t)cap * sizeof(double)) == hipSuccess) &&
+			          hipMalloc((void **)&sl.slot, (size_t)cap * sizeof(uint32_t)) == hipSuccess &&
+			          hipMalloc((void **)&sl.valid, (size_t)cap) == hipSuccess;
+			if (!ok) { // out of device memory: same outcome as an exceeded budget
+				(void)hipGetLastError();
+				void *parts[] = {sl.x, sl.y, sl.w, sl.slot, sl.valid};
+				for (void *q : parts)
+					if (q) (void)hipFree(q);
+				log_free(s);
+				s->log_dropped = true;
+				return true;
+			}
+			s->slabs.push_back(sl);
+			s->log_bytes += (size_t)cap * rb;
+		}
+		RowLogSlab &sl = s->slabs.back();
+		const int64_t m = (n - done) < (sl.cap - sl.rows) ? (n - done) : (sl.cap - sl.rows);
+		const size_t at = (size_t)sl.rows;
+		bool bad = hip_fail(hipMemcpyAsync(sl.x + at * p, d_x + (size_t)done * p, (size_t)m * p * sizeof(double), hipMemcpyDeviceToDevice, st), "row log", e);
+		bad = bad || hip_fail(hipMemcpyAsync(sl.y + at, d_y + done, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st), "row log", e);
+		if (weighted) bad = bad || hip_fail(hipMemcpyAsync(sl.w + at, d_w + done, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st), "row log", e);
+		bad = bad || hip_fail(hipMemcpyAsync(sl.slot + at, d_slot + done, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, st), "row log", e);
+		if (d_valid)
+			bad = bad || hip_fail(hipMemcpyAsync(sl.valid + at, d_valid + done, (size_t)m, hipMemcpyDeviceToDevice, st), "row log", e);
+		else
+			bad = bad || hip_fail(hipMemsetAsync(sl.valid + at, 1, (size_t)m, st), "row log", e);
+		if (bad) return false;
+		sl.rows += m;
+		s->log_rows += m;
+		done += m;
+	}
+	return true;
+}
+
 // one pass (<= kIngestChunkRows rows) on device-resident inputs
 bool run_pass(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const double *d_y, const double *d_x, const double *d_w,
               const uint8_t *d_valid, AnofoxError *e) {
@@ -195,7 +293,7 @@ bool run_pass(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const dou
 		(void)hipEventRecord(e1, st);
 		s->ctx->acc_events.emplace_back(e0, e1); // the ingest pass is this path's "accumulate" stage
 	}
-	return true;
+	return log_append(s, n, d_slot, d_y, d_x, d_w, d_valid, e);
 }
 
 bool validate_update(AnofoxHipAggState *s, int64_t n_rows, int64_t n_slots, const void *slot, const void *y, const void *x, const void *w,
@@ -295,6 +393,24 @@ bool anofox_hip_agg_state_reserve(AnofoxHipAggState *s, int64_t n_slots, AnofoxE
 	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
 	return state_reserve(s, n_slots, out_error);
 }
+
+bool anofox_hip_agg_state_retain_rows(AnofoxHipAggState *s, size_t max_bytes, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!s) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL"); return false; }
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	if (s->rows > 0) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "retain_rows has to be called before the first update");
+		return false;
+	}
+	s->retain = max_bytes > 0;
+	s->log_budget = max_bytes;
+	s->log_dropped = false;
+	return true;
+}
+
+int anofox_hip_agg_state_retaining(const AnofoxHipAggState *s) { return s && s->retain && !s->log_dropped ? 1 : 0; }
+size_t anofox_hip_agg_state_retained_bytes(const AnofoxHipAggState *s) { return s ? s->log_bytes : 0; }
 
 bool anofox_hip_agg_state_update_device(AnofoxHipAggState *s, int64_t n_rows, int64_t n_slots, const uint32_t *d_slot, const double *d_y,
                                         const double *d_x_rowmajor, const double *d_w, const uint8_t *d_valid, AnofoxError *out_error) {
@@ -402,6 +518,12 @@ bool anofox_hip_agg_state_combine(AnofoxHipAggState *s, int64_t n_pairs, const u
 	if (hip_fail(launch_ingest_combine(s->moments, s->n_accum, s->n_slots, d_src, d_dst, n_pairs, (int)s->p, s->opt.fit_intercept ? 1 : 0, st),
 	             "combine kernel launch", out_error))
 		return false;
+	if (s->retain && !s->log_dropped && s->log_rows > 0) { // the sources' rows in the log now belong to the targets
+		if (!ensure_buffer(&s->remap_buf, &s->remap_bytes, (size_t)s->n_slots * sizeof(uint32_t), "row log remap", out_error)) return false;
+		if (hip_fail(launch_rowlog_remap((uint32_t *)s->remap_buf, s->n_slots, d_src, d_dst, n_pairs, s->slabs.data(), (int)s->slabs.size(), st),
+		             "row log remap launch", out_error))
+			return false;
+	}
 	// the pair arrays are pageable host memory: the copies above have completed on return, the kernel is stream-ordered
 	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
 }
@@ -456,6 +578,82 @@ bool run_finalize(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf
 	return true;
 }
 
+// After run_finalize: how many groups its solve queued for refinement, and — with a row log — their refit through
+// the batch path (rowlog.hip's header has the steps).  *remaining = the groups still unrefined afterwards; when it
+// is not 0 their slot numbers are still the first *remaining words of the context's workspace.
+// Synchronises the stream (the two counts have to reach the host).
+bool refit_queued(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf, int64_t *remaining, AnofoxError *e) {
+	AnofoxHipContext *ctx = s->ctx;
+	hipStream_t st = ctx->stream;
+	int32_t queued = 0;
+	if (hip_fail(hipMemcpyAsync(&queued, ctx->last_refine_count, sizeof queued, hipMemcpyDeviceToHost, st), "D2H", e)) return false;
+	if (hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e)) return false;
+	if (queued > n) queued = (int32_t)n;
+	*remaining = queued;
+	if (queued == 0 || !s->retain || s->log_dropped || s->log_rows == 0) return true;
+	const int64_t K = queued;
+	const size_t p = s->p;
+	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
+	// index scratch: sorted slots | dense map | counter | slab table | sort temp for K keys
+	const size_t b_sorted = align_up((size_t)K * sizeof(int32_t), 256), b_dense = align_up((size_t)n * sizeof(int32_t), 256);
+	const size_t b_tab = align_up(s->slabs.size() * sizeof(RowLogSlab), 256), b_t1 = align_up(rowlog_sort_temp_bytes(K), 256);
+	if (!ensure_buffer(&s->refit_idx, &s->refit_idx_bytes, b_sorted + b_dense + 256 + b_tab + b_t1, "refit scratch", e)) return false;
+	char *ib = (char *)s->refit_idx;
+	int32_t *d_sorted = (int32_t *)ib, *d_dense = (int32_t *)(ib + b_sorted);
+	unsigned long long *d_counter = (unsigned long long *)(ib + b_sorted + b_dense);
+	RowLogSlab *d_tab = (RowLogSlab *)(ib + b_sorted + b_dense + 256);
+	void *d_t1 = ib + b_sorted + b_dense + 256 + b_tab;
+	bool bad = hip_fail(launch_rowlog_sort_slots((const int32_t *)ctx->ws, d_sorted, K, d_t1, b_t1, st), "refit sort", e);
+	bad = bad || hip_fail(launch_rowlog_dense(d_sorted, K, d_dense, n, st), "refit mark", e);
+	bad = bad || hip_fail(hipMemsetAsync(d_counter, 0, 256, st), "hipMemsetAsync", e);
+	bad = bad || hip_fail(hipMemcpyAsync(d_tab, s->slabs.data(), s->slabs.size() * sizeof(RowLogSlab), hipMemcpyHostToDevice, st), "H2D", e);
+	for (size_t k = 0; !bad && k < s->slabs.size(); ++k) {
+		const RowLogSlab &sl = s->slabs[k];
+		bad = hip_fail(launch_rowlog_select(false, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, nullptr, st), "refit count", e);
+	}
+	unsigned long long m_rows = 0;
+	bad = bad || hip_fail(hipMemcpyAsync(&m_rows, d_counter, sizeof m_rows, hipMemcpyDeviceToHost, st), "D2H", e);
+	bad = bad || hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e); // (also: the slab table copy has left the vector)
+	if (bad) return false;
+	if (m_rows == 0) return true; // nothing logged for them (cannot happen for a fitted group): leave them reported
+	const size_t M = (size_t)m_rows;
+	// row scratch: keys a | keys b | y | w | x columns | offsets | core | inference | sort temp for M keys
+	const size_t b_k = align_up(M * sizeof(uint64_t), 256), b_c = align_up(M * sizeof(double), 256);
+	const size_t b_off = align_up((size_t)(K + 1) * sizeof(int64_t), 256), b_core = align_up((size_t)K * (p + 6) * sizeof(double), 256);
+	const size_t b_inf = s->opt.compute_inference ? align_up((size_t)K * (5 * p + 2) * sizeof(double), 256) : 0;
+	const size_t b_t2 = align_up(rowlog_sort_temp_bytes((int64_t)M), 256);
+	if (!ensure_buffer(&s->refit_rows, &s->refit_rows_bytes, 2 * b_k + (2 + p) * b_c + b_off + b_core + b_inf + b_t2, "refit scratch", e)) return false;
+	char *rb = (char *)s->refit_rows;
+	uint64_t *d_ka = (uint64_t *)rb, *d_kb = (uint64_t *)(rb + b_k);
+	double *d_y = (double *)(rb + 2 * b_k), *d_w = (double *)(rb + 2 * b_k + b_c), *d_x = (double *)(rb + 2 * b_k + 2 * b_c);
+	int64_t *d_off = (int64_t *)(rb + 2 * b_k + (2 + p) * b_c);
+	double *d_core2 = (double *)((char *)d_off + b_off);
+	double *d_inf2 = b_inf ? (double *)((char *)d_core2 + b_core) : nullptr;
+	void *d_t2 = (char *)d_core2 + b_core + b_inf;
+	bad = hip_fail(hipMemsetAsync(d_counter, 0, 256, st), "hipMemsetAsync", e);
+	for (size_t k = 0; !bad && k < s->slabs.size(); ++k) {
+		const RowLogSlab &sl = s->slabs[k];
+		bad = hip_fail(launch_rowlog_select(true, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, d_ka, st), "refit fill", e);
+	}
+	bad = bad || hip_fail(launch_rowlog_sort_keys(d_ka, d_kb, (int64_t)M, K, d_t2, b_t2, st), "refit sort", e);
+	// (columns are b_c bytes apart, not M doubles: every column starts 256-byte aligned)
+	const size_t col_stride = b_c / sizeof(double);
+	bad = bad || hip_fail(launch_rowlog_gather(d_kb, (int64_t)M, K, d_tab, (int)s->slabs.size(), (int)p, weighted ? 1 : 0, d_y, d_x, col_stride, d_w,
+	                                           d_off, st),
+	                      "refit gather", e);
+	if (bad) return false;
+	const double *x_cols[kNarrowMaxP];
+	for (size_t j = 0; j < p; ++j) x_cols[j] = d_x + j * col_stride;
+	AnofoxHipBatchOptions opt = s->opt;
+	opt.hc_type = ANOFOX_HC_NONE;
+	if (!refit_groups_device(ctx, K, p, (int64_t)M, d_off, d_y, x_cols, weighted ? d_w : nullptr, opt, d_core2, d_inf2, e)) return false;
+	bad = hip_fail(launch_rowlog_scatter(d_core2, d_sorted, K, (int)(p + 6), d_core, st), "refit scatter", e);
+	if (d_inf2) bad = bad || hip_fail(launch_rowlog_scatter(d_inf2, d_sorted, K, (int)(5 * p + 2), d_inf, st), "refit scatter", e);
+	if (bad) return false;
+	*remaining = 0;
+	return true;
+}
+
 bool check_finalize(AnofoxHipAggState *s, int64_t n, const void *core, const void *inf, AnofoxError *e) {
 	if (!s) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "state is NULL"); return false; }
 	if (n < 0 || n > s->n_slots) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "n_slots exceeds the slots in use"); return false; }
@@ -488,7 +686,10 @@ bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *s, int64_t n_slots,
 	if (!attached(s, out_error)) return false;
 	std::lock_guard<std::mutex> lk(s->ctx->mu);
 	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
-	return run_finalize(s, n_slots, d_core, d_inference, out_error);
+	if (!run_finalize(s, n_slots, d_core, d_inference, out_error)) return false;
+	if (!s->retain) return true; // (no log: nothing to refit, and no reason to synchronise)
+	int64_t remaining = 0;
+	return refit_queued(s, n_slots, d_core, d_inference, &remaining, out_error);
 }
 
 bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, double *core, double *inference, int64_t *out_unrefined,
@@ -509,16 +710,15 @@ bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, d
 	double *d_core = (double *)ctx->stage;
 	double *d_inf = b_inf ? (double *)((char *)ctx->stage + b_core) : nullptr;
 	if (!run_finalize(s, n_slots, d_core, d_inf, out_error)) return false;
+	int64_t queued = 0;
+	if (!refit_queued(s, n_slots, d_core, d_inf, &queued, out_error)) return false;
 	hipStream_t st = ctx->stream;
 	if (hip_fail(hipMemcpyAsync(core, d_core, G * (p + 6) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;
 	if (d_inf && hip_fail(hipMemcpyAsync(inference, d_inf, G * (5 * p + 2) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H inference", out_error)) return false;
-	int32_t queued = 0;
-	if (hip_fail(hipMemcpyAsync(&queued, ctx->last_refine_count, sizeof queued, hipMemcpyDeviceToHost, st), "D2H", out_error)) return false;
 	if (!check_slot_flag(s, out_error)) return false; // (synchronises the stream)
 	if (out_unrefined) *out_unrefined = queued;
 	if (out_unrefined_slots && queued > 0) { // the queue itself: the first words of the workspace (run_finalize)
-		const int64_t n = queued < n_slots ? queued : n_slots;
-		if (hip_fail(hipMemcpy(out_unrefined_slots, ctx->ws, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H", out_error)) return false;
+		if (hip_fail(hipMemcpy(out_unrefined_slots, ctx->ws, (size_t)queued * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H", out_error)) return false;
 	}
 	return true;
 }

@@ -407,6 +407,28 @@ hipError_t launch_ingest_chunk(const IngestArgs &a, hipStream_t stream);
 hipError_t launch_ingest_combine(double *moments, int64_t *n_accum, int64_t n_slots, const uint32_t *src, const uint32_t *dst,
                                  int64_t n_pairs, int p, int center, hipStream_t stream);
 
+// ---- row log of a streaming aggregate state (rowlog.hip): the rows kept for the refit of queued groups ----
+constexpr unsigned kRowLogRowBits = 40; // global row number inside a sort key (group index above it)
+struct RowLogSlab {
+	double *x;       // [cap * p] row-major
+	double *y;       // [cap]
+	double *w;       // [cap] or nullptr
+	uint32_t *slot;  // [cap]
+	uint8_t *valid;  // [cap]
+	int64_t first_row, rows, cap;
+};
+size_t rowlog_sort_temp_bytes(int64_t n);
+hipError_t launch_rowlog_sort_slots(const int32_t *in, int32_t *out, int64_t n, void *temp, size_t temp_bytes, hipStream_t st);
+hipError_t launch_rowlog_dense(const int32_t *sorted_slots, int64_t k_n, int32_t *dense, int64_t n_slots, hipStream_t st);
+hipError_t launch_rowlog_select(bool fill, const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row, const int32_t *dense,
+                                int64_t n_slots, unsigned long long *counter, uint64_t *keys, hipStream_t st);
+hipError_t launch_rowlog_sort_keys(const uint64_t *in, uint64_t *out, int64_t m, int64_t k_n, void *temp, size_t temp_bytes, hipStream_t st);
+hipError_t launch_rowlog_gather(const uint64_t *keys, int64_t m, int64_t k_n, const RowLogSlab *d_slabs, int n_slabs, int p, int weighted,
+                                double *y, double *x_cols, size_t col_stride, double *w, int64_t *offs, hipStream_t st);
+hipError_t launch_rowlog_scatter(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, hipStream_t st);
+hipError_t launch_rowlog_remap(uint32_t *remap, int64_t n_slots, const uint32_t *src, const uint32_t *dst, int64_t n_pairs,
+                               const RowLogSlab *h_slabs, int n_slabs, hipStream_t st);
+
 // ---- window frames as a batch of virtual groups (frames.hip): any p <= kWideMaxP, any frame ----
 struct FrameArgs {
 	const double *y;

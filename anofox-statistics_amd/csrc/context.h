@@ -48,6 +48,11 @@ struct AnofoxHipContext {
 namespace anofox {
 namespace host {
 void agg_state_detach(struct AnofoxHipAggState *s); // agg_state.hip
+// host_api.hip: the device batch path (accumulate -> solve -> refine) on device-resident inputs, enqueued on the
+// context's stream; used by agg_state.hip to refit the queued groups of a state from its row log
+bool refit_groups_device(AnofoxHipContext *ctx, int64_t n_groups, size_t p, int64_t n_rows, const int64_t *d_row_offsets,
+                         const double *d_y, const double *const *x_cols, const double *d_w, const AnofoxHipBatchOptions &opt,
+                         double *d_core, double *d_inf, AnofoxError *e);
 }
 }
 

@@ -290,6 +290,16 @@ AnofoxHipContext *default_context(AnofoxError *e) {
 
 } // namespace
 
+namespace anofox {
+namespace host {
+bool refit_groups_device(AnofoxHipContext *ctx, int64_t n_groups, size_t p, int64_t n_rows, const int64_t *d_row_offsets,
+                         const double *d_y, const double *const *x_cols, const double *d_w, const AnofoxHipBatchOptions &opt,
+                         double *d_core, double *d_inf, AnofoxError *e) {
+	return run_device_batch(ctx, n_groups, p, n_rows, d_row_offsets, d_y, x_cols, d_w, opt, d_core, d_inf, e);
+}
+} // namespace host
+} // namespace anofox
+
 extern "C" {
 
 const char *anofox_hip_version(void) { return "anofox_stats_hip 0.1 gfx950"; }

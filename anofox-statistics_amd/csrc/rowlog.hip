@@ -1,0 +1,187 @@
+// rowlog.hip — the optional row log of a streaming aggregate state (agg_state.hip, anofox_hip_agg_state_retain_rows).
+//
+// The reference's aggregate state IS a row buffer (src/aggregate_functions/ols_aggregate.cpp:19-42); the streaming
+// state replaces it by O(p^2) moments, which is what makes Update cheap — and what leaves Finalize without the rows
+// the batch path's refinement passes re-read for ill-conditioned or (nearly) exactly fitting groups.  With 288 GB of
+// HBM the rows can simply stay: Update appends every chunk to slabs in arrival order (device-to-device copies, no
+// kernel), and Finalize pulls out the rows of exactly the groups its solve queued for refinement:
+//   mark      dense[slot] = k for the k-th queued slot (ascending), -1 elsewhere
+//   count     rows of the log that belong to a queued slot (one pass over the 4-byte slot column)
+//   fill      key = k << 40 | global row number, appended through a wave-aggregated counter
+//   sort      rocPRIM radix sort of the keys: groups contiguous, arrival order inside a group, whatever order the
+//             appends happened in
+//   gather    key -> slab row -> y / w / x columns of an ordinary batch (column-major), row_offsets by binary search
+// and hands that batch to the unchanged batch path (accumulate -> solve -> refine), whose records replace the
+// streaming ones.  Combine re-labels the source slots' rows in the log (one pass over the slot column).
+#include <hip/hip_runtime.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace anofox {
+
+namespace {
+
+constexpr int kLogBlock = 256;
+constexpr uint64_t kRowMask = (1ull << kRowLogRowBits) - 1;
+
+__global__ void rowlog_dense_kernel(const int32_t *sorted_slots, int64_t k_n, int32_t *dense) {
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < k_n) dense[sorted_slots[k]] = (int32_t)k;
+}
+
+__global__ void rowlog_remap_kernel(uint32_t *slot, int64_t n, const uint32_t *remap, int64_t n_slots) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const uint32_t s = slot[i];
+		if ((int64_t)s < n_slots) {
+			const uint32_t t = remap[s];
+			if (t != s) slot[i] = t;
+		}
+	}
+}
+
+__global__ void rowlog_remap_init_kernel(uint32_t *remap, int64_t n_slots) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_slots) remap[i] = (uint32_t)i;
+}
+
+__global__ void rowlog_remap_pairs_kernel(uint32_t *remap, const uint32_t *src, const uint32_t *dst, int64_t n_pairs) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n_pairs) remap[src[i]] = dst[i];
+}
+
+// FILL = false: count the selected rows;  FILL = true: append their keys
+template <bool FILL>
+__global__ void rowlog_select_kernel(const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row, const int32_t *dense,
+                                     int64_t n_slots, unsigned long long *counter, uint64_t *keys) {
+	const int lane = threadIdx.x & 63;
+	for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+		const int64_t i = i0 + lane;
+		int32_t k = -1;
+		if (i < n && valid[i]) {
+			const uint32_t s = slot[i];
+			if ((int64_t)s < n_slots) k = dense[s];
+		}
+		const uint64_t m = __ballot(k >= 0);
+		if (m == 0) continue;
+		const int cnt = __popcll(m);
+		unsigned long long at = 0;
+		if (lane == 0) at = atomicAdd(counter, (unsigned long long)cnt);
+		at = __shfl(at, 0);
+		if (FILL && k >= 0) keys[at + (unsigned long long)__popcll(m & ((1ull << lane) - 1))] = ((uint64_t)k << kRowLogRowBits) | (uint64_t)(base_row + i);
+	}
+}
+
+__device__ __forceinline__ int slab_of_row(const RowLogSlab *slabs, int n_slabs, int64_t row) {
+	int lo = 0, hi = n_slabs - 1;
+	while (lo < hi) { // last slab whose first row is <= row
+		const int mid = (lo + hi + 1) >> 1;
+		if (slabs[mid].first_row <= row) lo = mid; else hi = mid - 1;
+	}
+	return lo;
+}
+
+__global__ void rowlog_gather_kernel(const uint64_t *keys, int64_t m, const RowLogSlab *slabs, int n_slabs, int p, int weighted, double *y,
+                                     double *x_cols, size_t col_stride, double *w) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= m) return;
+	const int64_t row = (int64_t)(keys[i] & kRowMask);
+	const RowLogSlab sl = slabs[slab_of_row(slabs, n_slabs, row)];
+	const int64_t r = row - sl.first_row;
+	y[i] = sl.y[r];
+	if (weighted) w[i] = sl.w[r];
+	const double *xr = sl.x + (size_t)r * (size_t)p;
+	for (int j = 0; j < p; ++j) x_cols[(size_t)j * col_stride + (size_t)i] = xr[j];
+}
+
+// offs[k] = first position whose key belongs to group >= k (k = 0 .. k_n)
+__global__ void rowlog_offsets_kernel(const uint64_t *keys, int64_t m, int64_t k_n, int64_t *offs) {
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k > k_n) return;
+	const uint64_t want = (uint64_t)k << kRowLogRowBits;
+	int64_t lo = 0, hi = m;
+	while (lo < hi) {
+		const int64_t mid = (lo + hi) >> 1;
+		if (keys[mid] < want) lo = mid + 1; else hi = mid;
+	}
+	offs[k] = lo;
+}
+
+__global__ void rowlog_scatter_kernel(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst) {
+	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= k_n * len) return;
+	const int64_t k = t / len;
+	const int j = (int)(t - k * len);
+	dst[(size_t)sorted_slots[k] * (size_t)len + (size_t)j] = src[t];
+}
+
+inline unsigned grid_for(int64_t n, int64_t cap = 1 << 16) {
+	int64_t g = (n + kLogBlock - 1) / kLogBlock;
+	if (g < 1) g = 1;
+	if (g > cap) g = cap;
+	return (unsigned)g;
+}
+
+} // namespace
+
+size_t rowlog_sort_temp_bytes(int64_t n) {
+	size_t a = 0, b = 0;
+	uint64_t *k64 = nullptr;
+	int32_t *k32 = nullptr;
+	(void)rocprim::radix_sort_keys(nullptr, a, k64, k64, (size_t)n, 0u, 64u, (hipStream_t) nullptr);
+	(void)rocprim::radix_sort_keys(nullptr, b, k32, k32, (size_t)n, 0u, 32u, (hipStream_t) nullptr);
+	return a > b ? a : b;
+}
+
+hipError_t launch_rowlog_sort_slots(const int32_t *in, int32_t *out, int64_t n, void *temp, size_t temp_bytes, hipStream_t st) {
+	return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0u, 31u, st); // slot numbers are < 2^31
+}
+
+hipError_t launch_rowlog_dense(const int32_t *sorted_slots, int64_t k_n, int32_t *dense, int64_t n_slots, hipStream_t st) {
+	hipError_t rc = hipMemsetAsync(dense, 0xff, (size_t)n_slots * sizeof(int32_t), st);
+	if (rc != hipSuccess) return rc;
+	rowlog_dense_kernel<<<grid_for(k_n, 1 << 30), kLogBlock, 0, st>>>(sorted_slots, k_n, dense);
+	return hipGetLastError();
+}
+
+hipError_t launch_rowlog_select(bool fill, const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row, const int32_t *dense,
+                                int64_t n_slots, unsigned long long *counter, uint64_t *keys, hipStream_t st) {
+	if (n <= 0) return hipSuccess;
+	if (fill)
+		rowlog_select_kernel<true><<<grid_for(n, 4096), kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys);
+	else
+		rowlog_select_kernel<false><<<grid_for(n, 4096), kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys);
+	return hipGetLastError();
+}
+
+hipError_t launch_rowlog_sort_keys(const uint64_t *in, uint64_t *out, int64_t m, int64_t k_n, void *temp, size_t temp_bytes, hipStream_t st) {
+	unsigned end_bit = kRowLogRowBits;
+	while (end_bit < 64 && ((uint64_t)k_n >> (end_bit - kRowLogRowBits)) != 0) ++end_bit;
+	return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)m, 0u, end_bit, st);
+}
+
+hipError_t launch_rowlog_gather(const uint64_t *keys, int64_t m, int64_t k_n, const RowLogSlab *d_slabs, int n_slabs, int p, int weighted,
+                                double *y, double *x_cols, size_t col_stride, double *w, int64_t *offs, hipStream_t st) {
+	if (m > 0) rowlog_gather_kernel<<<grid_for(m, 1 << 30), kLogBlock, 0, st>>>(keys, m, d_slabs, n_slabs, p, weighted, y, x_cols, col_stride, w);
+	rowlog_offsets_kernel<<<grid_for(k_n + 1, 1 << 30), kLogBlock, 0, st>>>(keys, m, k_n, offs);
+	return hipGetLastError();
+}
+
+hipError_t launch_rowlog_scatter(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, hipStream_t st) {
+	if (k_n <= 0) return hipSuccess;
+	rowlog_scatter_kernel<<<grid_for(k_n * len, 1 << 30), kLogBlock, 0, st>>>(src, sorted_slots, k_n, len, dst);
+	return hipGetLastError();
+}
+
+hipError_t launch_rowlog_remap(uint32_t *remap, int64_t n_slots, const uint32_t *src, const uint32_t *dst, int64_t n_pairs,
+                               const RowLogSlab *h_slabs, int n_slabs, hipStream_t st) {
+	rowlog_remap_init_kernel<<<grid_for(n_slots, 1 << 30), kLogBlock, 0, st>>>(remap, n_slots);
+	rowlog_remap_pairs_kernel<<<grid_for(n_pairs, 1 << 30), kLogBlock, 0, st>>>(remap, src, dst, n_pairs);
+	for (int k = 0; k < n_slabs; ++k)
+		if (h_slabs[k].rows > 0)
+			rowlog_remap_kernel<<<grid_for(h_slabs[k].rows, 4096), kLogBlock, 0, st>>>(h_slabs[k].slot, h_slabs[k].rows, remap, n_slots);
+	return hipGetLastError();
+}
+
+} // namespace anofox

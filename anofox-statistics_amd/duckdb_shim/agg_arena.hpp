@@ -22,6 +22,7 @@
 // repository (duckdb_shim/arena_capi.cpp + tests/test_gpu_arena.py).  fit_agg_hip.cpp is the thin DuckDB glue on top.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -38,8 +39,14 @@ namespace anofox_shim {
 class AggArena {
 public:
 	// flush_rows: rows per page-locked chunk buffer (1M rows = 76 MB at p = 8: one ingest pass of the library)
-	explicit AggArena(AnofoxHipBatchOptions options, size_t flush_rows = (size_t)1 << 20) : opt_(options), cap_(flush_rows) {
+	// retain_bytes: HBM the device state may spend on keeping the rows (anofox_hip_agg_state_retain_rows), so that
+	//   Finalize refits ill-conditioned and nearly exactly fitting groups as the batch path does; the reference keeps
+	//   every row on the host anyway (ols_aggregate.cpp:19-42).  0 = moments only.  Default 64 GiB of the 288;
+	//   ANOFOX_HIP_RETAIN_BYTES overrides it.  A query that outgrows it continues without the log (Unrefined() > 0).
+	explicit AggArena(AnofoxHipBatchOptions options, size_t flush_rows = (size_t)1 << 20, size_t retain_bytes = (size_t)64 << 30)
+	    : opt_(options), cap_(flush_rows), retain_bytes_(retain_bytes) {
 		if (cap_ == 0) cap_ = 1;
+		if (const char *v = getenv("ANOFOX_HIP_RETAIN_BYTES")) retain_bytes_ = (size_t)strtoull(v, nullptr, 10);
 	}
 	AggArena(const AggArena &) = delete;
 	AggArena &operator=(const AggArena &) = delete;
@@ -58,6 +65,7 @@ public:
 	size_t FeatureCount() const { return p_; } // 0 until the first accepted row
 	uint64_t RowsAccepted() const { return rows_; }
 	int64_t Unrefined() const { return unrefined_; }
+	bool RetainingRows() const { return state_ && anofox_hip_agg_state_retaining(state_) != 0; }
 
 	// One Update call: holds the arena's lock for the lifetime of the object.
 	class Writer {
@@ -135,6 +143,7 @@ private:
 			            (opt_.compute_inference && opt_.hc_type != ANOFOX_HC_NONE && opt_.model != ANOFOX_HIP_MODEL_RIDGE);
 			if (!buffered_) {
 				if (!anofox_hip_agg_state_create(ctx_, p_, opt_, 0, &state_, &err)) Throw(err);
+				if (retain_bytes_ && !anofox_hip_agg_state_retain_rows(state_, retain_bytes_, &err)) Throw(err);
 				AllocBuffers();
 			}
 		}
@@ -269,6 +278,7 @@ private:
 	// solved records
 	bool solved_ = false;
 	int64_t unrefined_ = 0;
+	size_t retain_bytes_ = 0;
 	std::vector<double> core_, inf_;
 };
 

@@ -79,5 +79,8 @@ ARENA_API int arena_finalize(void *a, size_t n, const uint32_t *slot, double *ou
 }
 ARENA_API size_t arena_feature_count(void *a) { return static_cast<AggArena *>(a)->FeatureCount(); }
 ARENA_API uint64_t arena_rows(void *a) { return static_cast<AggArena *>(a)->RowsAccepted(); }
+// after a Finalize: groups the device state could not refit (0 while it keeps the rows), and whether it still does
+ARENA_API int64_t arena_unrefined(void *a) { return static_cast<AggArena *>(a)->Unrefined(); }
+ARENA_API int arena_retaining(void *a) { return static_cast<AggArena *>(a)->RetainingRows() ? 1 : 0; }
 
 } // extern "C"

@@ -238,7 +238,10 @@ class AggState:
     """The streaming aggregate state of {ols,ridge,wls}_fit_agg on the GPU (anofox_hip_agg_state_*): one O(p^2)
     moment record per slot; `update` folds row chunks in, `combine` merges slots, `finalize` solves them."""
 
-    def __init__(self, ctx: Context, n_features: int, options: _abi.AnofoxHipBatchOptions, initial_slots: int = 0):
+    def __init__(self, ctx: Context, n_features: int, options: _abi.AnofoxHipBatchOptions, initial_slots: int = 0,
+                 retain_bytes: int = 0):
+        """retain_bytes > 0: also keep the rows in HBM (up to that many bytes) so that finalize can refit the groups
+        the moments alone cannot resolve accurately (anofox_hip_agg_state_retain_rows)."""
         self._lib = _abi.load()
         self._ctx = ctx          # keeps the context alive
         self.p = int(n_features)
@@ -248,6 +251,18 @@ class AggState:
         if not self._lib.anofox_hip_agg_state_create(ctx._h, self.p, options, int(initial_slots), C.byref(h), C.byref(err)):
             raise AnofoxStatsError(err.code, err.text())
         self._h = h
+        self.unrefined_slots = np.empty(0, dtype=np.int32)
+        if retain_bytes:
+            if not self._lib.anofox_hip_agg_state_retain_rows(self._h, int(retain_bytes), C.byref(err)):
+                raise AnofoxStatsError(err.code, err.text())
+
+    @property
+    def retaining(self) -> bool:
+        return bool(self._lib.anofox_hip_agg_state_retaining(self._h))
+
+    @property
+    def retained_bytes(self) -> int:
+        return int(self._lib.anofox_hip_agg_state_retained_bytes(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -484,6 +484,13 @@ ANOFOX_HIP_API bool anofox_hip_residuals_batch_host(AnofoxHipContext *ctx, int64
  *             the cancellation of rss = tss - |z|^2 — and out_unrefined_slots (optional, room for n_slots entries)
  *             receives their slot numbers, in no particular order.  hc_type other than none needs the rows as well and
  *             is rejected at creation.
+ *   retain_rows(max_bytes)  (optional, before the first update) keeps every chunk in a row log in HBM as well — p + 2 (+ 1
+ *             with weights) doubles and 5 bytes per row, up to max_bytes — and Finalize then refits exactly the groups
+ *             its solve queued, through the batch path (accumulate, solve, refinement passes) on their logged rows:
+ *             *out_unrefined is 0 and every group has the batch entry points' accuracy.  Combine re-labels the source
+ *             slots' logged rows.  Exceeding max_bytes (or device memory) is not an error: the log is dropped,
+ *             anofox_hip_agg_state_retaining() turns 0 and Finalize reports the queued groups as without a log.
+ *             finalize_device synchronises the stream once when a log is kept (it does not otherwise).
  *
  * A state belongs to one context (device + stream); calls on one state are serialised.  n_features <=
  * anofox_hip_agg_state_max_features() = 8.
@@ -494,6 +501,9 @@ ANOFOX_HIP_API bool anofox_hip_agg_state_create(AnofoxHipContext *ctx, size_t n_
                                  int64_t initial_slots, AnofoxHipAggState **out_state, AnofoxError *out_error);
 ANOFOX_HIP_API void anofox_hip_agg_state_destroy(AnofoxHipAggState *state);
 ANOFOX_HIP_API bool anofox_hip_agg_state_reserve(AnofoxHipAggState *state, int64_t n_slots, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_agg_state_retain_rows(AnofoxHipAggState *state, size_t max_bytes, AnofoxError *out_error);
+ANOFOX_HIP_API int anofox_hip_agg_state_retaining(const AnofoxHipAggState *state);          /* 1 while a row log is kept */
+ANOFOX_HIP_API size_t anofox_hip_agg_state_retained_bytes(const AnofoxHipAggState *state);  /* HBM held by the log */
 ANOFOX_HIP_API int64_t anofox_hip_agg_state_slots(const AnofoxHipAggState *state);
 ANOFOX_HIP_API int64_t anofox_hip_agg_state_rows(const AnofoxHipAggState *state);
 ANOFOX_HIP_API bool anofox_hip_agg_state_update_host(AnofoxHipAggState *state, int64_t n_rows, int64_t n_slots, const uint32_t *slot,

@@ -36,6 +36,10 @@ def _lib():
     lib.arena_feature_count.argtypes = [C.c_void_p]
     lib.arena_rows.restype = C.c_uint64
     lib.arena_rows.argtypes = [C.c_void_p]
+    lib.arena_unrefined.restype = C.c_int64
+    lib.arena_unrefined.argtypes = [C.c_void_p]
+    lib.arena_retaining.restype = C.c_int
+    lib.arena_retaining.argtypes = [C.c_void_p]
     return pkg, lib
 
 
@@ -148,4 +152,49 @@ def test_inconsistent_feature_count_and_empty_query():
     oc = np.empty((1, 8))
     assert lib.arena_finalize(arena, 1, sl.ctypes.data, oc.ctypes.data, None, nn.ctypes.data, msg) == 0
     assert nn[0] == 1
+    lib.arena_destroy(arena)
+
+
+@pytest.mark.parametrize("retain", [True, False])
+def test_arena_keeps_rows_for_the_groups_moments_cannot_resolve(retain, monkeypatch):
+    """Keys whose fit is nearly exact (noise 1e-6 on a signal of order 10): from the moments alone sigma is lost
+    (rss = tss - |z|^2 cancels); the arena lets the device state keep the rows (64 GiB by default) and Finalize refits
+    those keys through the batch path.  ANOFOX_HIP_RETAIN_BYTES=0 switches that off — and shows what it buys."""
+    if not retain:
+        monkeypatch.setenv("ANOFOX_HIP_RETAIN_BYTES", "0")
+    pkg, lib = _lib()
+    rng = np.random.default_rng(77)
+    G, p, n = 300, 5, 60_000
+    kw = dict(compute_inference=True)
+    arena = lib.arena_create(pkg.RegressionOptions(**kw).batch_options("ols"), 5000)
+    keys = rng.integers(0, G, n).astype(np.uint32)
+    X = rng.uniform(-5, 5, (n, p)) + 2.0
+    beta = rng.uniform(-3, 3, (G, p))
+    exact = np.arange(G) % 3 == 0
+    y = np.einsum("ij,ij->i", beta[keys], X) + 7.0 + np.where(exact[keys], 1e-6, 1.0) * rng.standard_normal(n)
+    slots = np.full(G, -1, dtype=np.int64)
+    msg = C.create_string_buffer(256)
+    for c0 in range(0, n, 2048):
+        sl = slice(c0, c0 + 2048)
+        k, yy, xx = (np.ascontiguousarray(v[sl]) for v in (keys, y, X))
+        assert lib.arena_update(arena, len(k), k.ctypes.data, slots.ctypes.data, yy.ctypes.data, xx.ctypes.data, p, None, None, msg) == 0, msg.value
+    assert bool(lib.arena_retaining(arena)) == retain
+    sl = np.ascontiguousarray(slots, dtype=np.uint32)
+    core = np.empty((G, p + 6))
+    inf = np.empty((G, 5 * p + 2))
+    nn = np.empty(G, dtype=np.uint8)
+    assert lib.arena_finalize(arena, G, sl.ctypes.data, core.ctypes.data, inf.ctypes.data, nn.ctypes.data, msg) == 0, msg.value
+    order = np.argsort(keys, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(keys, minlength=G))]).astype(np.int64)
+    rcore, rinf = oracle.fit_groups(y[order], [np.ascontiguousarray(X[order, j]) for j in range(p)], offs, model="ols", **kw)
+    if retain:
+        assert lib.arena_unrefined(arena) == 0
+        assert_records_match(core, rcore, p, inf, rinf, what="arena, rows kept")
+    else:
+        assert lib.arena_unrefined(arena) >= int(exact.sum())
+        easy = ~exact
+        assert_records_match(core[easy], rcore[easy], p, inf[easy], rinf[easy], what="arena, moments only, easy keys")
+        with np.errstate(all="ignore"):
+            d = np.abs(core[exact, p + 3] - rcore[exact, p + 3]) / rcore[exact, p + 3]
+        assert np.nanmax(np.where(np.isnan(d), np.inf, d)) > 1e-3          # sigma of the nearly exact keys is not usable
     lib.arena_destroy(arena)

@@ -252,14 +252,16 @@ def test_fuzz_streaming_state(pkg, ctx, seed):
     if model == "ridge":
         kw["alpha"] = float(10.0 ** rng.uniform(-2, 1))
         kw["lambda_scaling"] = str(rng.choice(["raw", "glmnet"]))
-    st = pkg.AggState(ctx, p, pkg.RegressionOptions(**kw).batch_options(model))
+    retain = seed % 2 == 1      # odd seeds keep the row log: Finalize refits what it queued, nothing stays unrefined
+    st = pkg.AggState(ctx, p, pkg.RegressionOptions(**kw).batch_options(model), retain_bytes=(1 << 28) if retain else 0)
     r0 = 0
     while r0 < N:
         n = int(rng.choice([1, 7, 64, 500, 2048, 10_000]))
         sl = slice(r0, r0 + n)
         st.update(slot[sl], y[sl], X[sl], w[sl] if model == "wls" else None, valid[sl], n_slots=G)
         r0 += n
-    core, inf, _ = st.finalize(G)
+    core, inf, n_unref = st.finalize(G)
+    assert n_unref == len(st.unrefined_slots) and (not retain or n_unref == 0)
     unrefined = set(int(v) for v in st.unrefined_slots)     # pivot ratio < 1e-3 or rss / tss < 1e-7: the batch path would refine
     st.close()
     keep = np.nonzero(valid)[0]

@@ -2,6 +2,8 @@
 arriving in shuffled group order across many chunks, Combine of partial states, Finalize — against the oracle's fit
 of the same rows grouped (the reference buffers the rows, src/aggregate_functions/ols_aggregate.cpp:120-338, so its
 result is the fit of each group's rows in arrival order)."""
+import warnings
+
 import numpy as np
 import pytest
 
@@ -326,3 +328,150 @@ def test_streaming_mirror_equals_buffered_mirror_with_combine(pkg, ctx):
         for f in ("coefficients", "intercept", "r_squared", "residual_std_error", "std_errors", "t_values", "f_statistic"):
             g, r = getattr(got, f)[ok], getattr(want, f)[ok]
             assert np.allclose(g, r, rtol=1e-9, atol=1e-12, equal_nan=True), f
+
+
+# ---- the optional row log: Finalize refits the groups its solve queued (anofox_hip_agg_state_retain_rows) ----
+
+def _hard_rows(rng, G, p, n_lo, n_hi):
+    """Groups the moments alone do not resolve to the ordinary tolerances: nearly collinear columns (pivot ratio far
+    below 1e-3), nearly exact fits (rss / tss ~ 1e-12), square systems (rows == parameters) — mixed with easy ones."""
+    ns = rng.integers(n_lo, n_hi + 1, size=G)
+    kind = rng.integers(0, 4, size=G)
+    ns[kind == 3] = p + 1                                     # exact interpolation with an intercept
+    slot = np.repeat(np.arange(G, dtype=np.uint32), ns)
+    rng.shuffle(slot)
+    N = len(slot)
+    X = rng.uniform(-10, 10, (N, p)) + 5.0
+    if p >= 2:
+        near = kind[slot] == 1
+        # cond(A) ~ 3e4
+        X[near, p - 1] = X[near, 0] * 1.5 + 1e-3 * rng.standard_normal(int(near.sum()))
+    beta = rng.uniform(-5, 5, (G, p))
+    noise = np.where(kind[slot] == 2, 1e-6, 1.0) * rng.standard_normal(N)
+    y = rng.uniform(-10, 10, G)[slot] + np.einsum("ij,ij->i", beta[slot], X) + noise
+    w = rng.uniform(0.5, 1.5, N)
+    return slot, y, X, w, kind
+
+
+def _coef_err(a, b, p):
+    with np.errstate(all="ignore"), warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)          # unfitted groups: all-NaN rows
+        sc = np.nanmax(np.abs(b[:, :p + 1]), axis=1, keepdims=True)
+        return np.nanmax(np.abs(a[:, :p + 1] - b[:, :p + 1]) / np.maximum(np.abs(b[:, :p + 1]), 1e-3 * sc), axis=1)
+
+
+@pytest.mark.parametrize("model", ["ols", "ridge", "wls"])
+@pytest.mark.parametrize("p", [2, 5, 8])
+def test_retained_rows_refit_the_queued_groups(pkg, ctx, model, p):
+    """Measured on MI355X for ols p = 8 (scripts/diag_retained.py, profiles/r02_stream_unrefined.md):
+       nearly collinear groups (cond 3e4)  coefficients  4.2e-5 without the log, 6.1e-9 with it (= the batch path, bit for bit)
+       nearly exact fits (noise 1e-6)      sigma         2.3 (relative!) without the log, 5.2e-9 with it."""
+    rng = np.random.default_rng(4000 + 10 * p + len(model))
+    G = 200
+    slot, y, X, w, kind = _hard_rows(rng, G, p, p + 3, 300)
+    valid = (rng.random(len(slot)) > 0.05).astype(np.uint8)
+    kw = _kw(model, True)
+    if model == "ridge":
+        kw["alpha"] = 1e-6                                    # (a large penalty would regularise the hard groups away)
+    opts = pkg.RegressionOptions(**kw).batch_options(model)
+    wv = w if model == "wls" else None
+    offs, yg, xg, wg = _grouped(slot, y, X, w, G, keep=valid)
+    rcore, rinf = oracle.fit_groups(yg, xg, offs, w=(wg if model == "wls" else None), model=model, **kw)
+    fitted = rcore[:, p + 5] == 0
+    zero_df = {g for g in range(G) if fitted[g] and rcore[g, p + 4] <= p + 1}
+
+    plain = pkg.AggState(ctx, p, opts)
+    _feed(plain, slot, y, X, wv, G, [2048, 1, 777, 5000, 64], valid=valid)
+    pcore, _, unref_plain = plain.finalize()
+    assert unref_plain > G // 4 and not plain.retaining and len(plain.unrefined_slots) == unref_plain
+    plain.close()
+
+    st = pkg.AggState(ctx, p, opts, retain_bytes=1 << 30)
+    _feed(st, slot, y, X, wv, G, [2048, 1, 777, 5000, 64], valid=valid)
+    assert st.retaining and st.retained_bytes >= len(slot) * (8 * (p + 1) + 5)
+    core, inf, unref = st.finalize()
+    assert unref == 0 and len(st.unrefined_slots) == 0
+
+    def check(a_core, a_inf, idx, what, **tol):
+        idx = np.asarray(idx)
+        assert_records_match(core[idx], a_core[idx], p, inf[idx], a_inf[idx], what=f"{what} {model} p={p}",
+                             skip_diag_groups=[k for k, g in enumerate(idx) if int(g) in zero_df], **tol)
+
+    # the refit IS the batch entry point's path on a sub-batch: same records (bit for bit on the refitted groups,
+    # rounding-level on the others, whose moments were summed in another order)
+    bcore, binf = ctx.fit_batch_host(offs, yg, xg, wg if model == "wls" else None, opts)
+    check(bcore, binf, np.arange(G), "retained vs batch", coef_rtol=1e-10, diag_rtol=1e-8)
+    # against the oracle: ordinary tolerances, except the coefficients of the cond 3e4 groups, where the batch path
+    # itself sits at 6e-9 (per-coefficient error with a 1e-3 normwise floor; 7e-12 normwise = cond eps)
+    collinear = np.nonzero(kind == 1)[0] if p >= 2 else np.empty(0, dtype=int)
+    check(rcore, rinf, np.setdiff1d(np.arange(G), collinear), "retained")
+    if collinear.size:
+        check(rcore, rinf, collinear, "retained, collinear", coef_rtol=1e-7)
+    # and the log is what bought that: without it the same groups are orders of magnitude further off
+    m1 = fitted & (kind == 1)
+    m2 = fitted & (kind == 2) & ~np.isin(np.arange(G), sorted(zero_df))
+    assert _coef_err(pcore, rcore, p)[m1].max() > 100 * _coef_err(core, rcore, p)[m1].max()
+
+    def sigma_err(c):    # (without the log rss = tss - |z|^2 can even come out negative: sigma = NaN where the oracle has a number)
+        d = np.abs(c[m2, p + 3] - rcore[m2, p + 3]) / rcore[m2, p + 3]
+        return np.max(np.where(np.isnan(d), np.inf, d))
+
+    assert sigma_err(pcore) > 100 * sigma_err(core) and sigma_err(core) < 1e-6
+    core2, inf2, unref2 = st.finalize()                        # Finalize does not consume the state or its log
+    assert unref2 == 0 and np.array_equal(core, core2, equal_nan=True) and np.array_equal(inf, inf2, equal_nan=True)
+    st.close()
+
+
+def test_retained_rows_follow_combine_and_span_slabs(pkg, ctx):
+    """More rows than the first slab holds (65536), two partial states per key merged by Combine: the refit sees the
+    rows of both under the target's slot; torch-side finalize_device takes the same path."""
+    import torch
+    rng = np.random.default_rng(4100)
+    p, G = 4, 600
+    kw = _kw("ols", True)
+    parts = [_hard_rows(rng, G, p, p + 3, 250)[:4] for _ in range(2)]
+    assert sum(len(q[0]) for q in parts) > 100_000
+    st = pkg.AggState(ctx, p, pkg.RegressionOptions(**kw).batch_options("ols"), retain_bytes=1 << 30)
+    for t, (slot, y, X, w) in enumerate(parts):
+        _feed(st, slot + np.uint32(t * G), y, X, None, 2 * G, [30_000, 2048, 3])
+    ar = np.arange(G, dtype=np.uint32)
+    st.combine(ar + G, ar)
+    core, inf, unref = st.finalize()
+    slot = np.concatenate([q[0] for q in parts])
+    y = np.concatenate([q[1] for q in parts])
+    X = np.concatenate([q[2] for q in parts])
+    offs, yg, xg, _ = _grouped(slot, y, X, np.ones(len(slot)), G)
+    rcore, rinf = oracle.fit_groups(yg, xg, offs, model="ols", **kw)
+    assert unref == 0
+    assert_records_match(core[:G], rcore, p, inf[:G], rinf, what="retained + combine")
+    assert np.all(core[G:, p + 5] == 100)
+    dcore = torch.empty((2 * G, p + 6), dtype=torch.float64, device="cuda")
+    dinf = torch.empty((2 * G, 5 * p + 2), dtype=torch.float64, device="cuda")
+    st.finalize_device(dcore, dinf)
+    torch.cuda.synchronize()
+    assert np.array_equal(dcore.cpu().numpy(), core, equal_nan=True) and np.array_equal(dinf.cpu().numpy(), inf, equal_nan=True)
+    st.close()
+
+
+def test_row_log_budget_and_call_order(pkg, ctx):
+    rng = np.random.default_rng(4200)
+    p, G = 3, 50
+    slot, y, X, w, _ = _hard_rows(rng, G, p, p + 3, 200)
+    kw = _kw("ols", True)
+    opts = pkg.RegressionOptions(**kw).batch_options("ols")
+    ref = pkg.AggState(ctx, p, opts)
+    _feed(ref, slot, y, X, None, G, [512])
+    rcore, rinf, runref = ref.finalize()
+    rlist = ref.unrefined_slots.copy()
+    ref.close()
+    st = pkg.AggState(ctx, p, opts, retain_bytes=1000 * (8 * (p + 1) + 5))     # room for 1000 rows only
+    _feed(st, slot, y, X, None, G, [512])
+    assert len(slot) > 1000 and not st.retaining and st.retained_bytes == 0    # dropped, not an error
+    core, inf, unref = st.finalize()
+    assert unref == runref > 0 and np.array_equal(st.unrefined_slots, rlist)
+    assert np.array_equal(core, rcore, equal_nan=True) and np.array_equal(inf, rinf, equal_nan=True)
+    lib = pkg._abi.load()
+    err = pkg._abi.AnofoxError()
+    import ctypes
+    assert not lib.anofox_hip_agg_state_retain_rows(st._h, 1 << 20, ctypes.byref(err)) and "before the first update" in err.text()
+    st.close()

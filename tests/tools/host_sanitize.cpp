@@ -45,6 +45,14 @@ STUB(launch_frames_from_rows_spec(const int64_t *, int64_t, int64_t, int64_t, in
 STUB(launch_frames_rule(const FrameArgs &, hipStream_t))
 STUB(launch_frames_predict(const FrameArgs &, hipStream_t))
 size_t frames_scan_temp_bytes(int64_t) { return 4096; }
+STUB(launch_rowlog_sort_slots(const int32_t *, int32_t *, int64_t, void *, size_t, hipStream_t))
+STUB(launch_rowlog_dense(const int32_t *, int64_t, int32_t *, int64_t, hipStream_t))
+STUB(launch_rowlog_select(bool, const uint32_t *, const uint8_t *, int64_t, int64_t, const int32_t *, int64_t, unsigned long long *, uint64_t *, hipStream_t))
+STUB(launch_rowlog_sort_keys(const uint64_t *, uint64_t *, int64_t, int64_t, void *, size_t, hipStream_t))
+STUB(launch_rowlog_gather(const uint64_t *, int64_t, int64_t, const RowLogSlab *, int, int, int, double *, double *, size_t, double *, int64_t *, hipStream_t))
+STUB(launch_rowlog_scatter(const double *, const int32_t *, int64_t, int, double *, hipStream_t))
+STUB(launch_rowlog_remap(uint32_t *, int64_t, const uint32_t *, const uint32_t *, int64_t, const RowLogSlab *, int, hipStream_t))
+size_t rowlog_sort_temp_bytes(int64_t) { return 4096; }
 size_t ingest_piece_table_bytes(int) { return 4096; }
 size_t ingest_sort_temp_bytes(int64_t) { return 4096; }
 bool accumulate_mid_supports(int p) { return p > 8 && p <= 32; }
@@ -172,6 +180,8 @@ int main() {
 		CHECK(!anofox_hip_agg_state_create(nullptr, 3, bo, 0, &st, &err) && st == nullptr);
 		CHECK(!anofox_hip_agg_state_create(ctx, 3, bo, 0, nullptr, &err));
 		CHECK(anofox_hip_agg_state_slots(nullptr) == 0 && anofox_hip_agg_state_rows(nullptr) == 0);
+		CHECK(!anofox_hip_agg_state_retain_rows(nullptr, 1 << 20, &err));
+		CHECK(anofox_hip_agg_state_retaining(nullptr) == 0 && anofox_hip_agg_state_retained_bytes(nullptr) == 0);
 		anofox_hip_agg_state_destroy(nullptr);
 		CHECK(!anofox_hip_agg_state_update_host(nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, &err));
 		CHECK(!anofox_hip_agg_state_finalize_host(nullptr, 0, nullptr, nullptr, nullptr, nullptr, &err));
