@@ -51,25 +51,53 @@ __global__ void rowlog_remap_pairs_kernel(uint32_t *remap, const uint32_t *src, 
 	if (i < n_pairs) remap[src[i]] = dst[i];
 }
 
-// FILL = false: count the selected rows;  FILL = true: append their keys
+// FILL = false: count the selected rows;  FILL = true: append their keys.
+// One workgroup owns kSelectTile consecutive rows and makes ONE atomic on the shared counter for them (a wave-level
+// append measured 12 ms for 64 M shuffled rows with 1 % selected: 370 k same-address atomics per pass); the keys of
+// a tile land in one contiguous range, in any tile order — the sort that follows does not care.
+constexpr int kSelectItems = 16;
+constexpr int kSelectTile = kLogBlock * kSelectItems;
+
+__device__ __forceinline__ int32_t rowlog_group_of(const uint32_t *slot, const uint8_t *valid, int64_t i, int64_t n, const int32_t *dense,
+                                                   int64_t n_slots) {
+	if (i >= n || !valid[i]) return -1;
+	const uint32_t s = slot[i];
+	return (int64_t)s < n_slots ? dense[s] : -1;
+}
+
 template <bool FILL>
-__global__ void rowlog_select_kernel(const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row, const int32_t *dense,
-                                     int64_t n_slots, unsigned long long *counter, uint64_t *keys) {
-	const int lane = threadIdx.x & 63;
-	for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
-		const int64_t i = i0 + lane;
-		int32_t k = -1;
-		if (i < n && valid[i]) {
-			const uint32_t s = slot[i];
-			if ((int64_t)s < n_slots) k = dense[s];
-		}
+__global__ void __launch_bounds__(kLogBlock) rowlog_select_kernel(const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row,
+                                                                  const int32_t *dense, int64_t n_slots, unsigned long long *counter,
+                                                                  uint64_t *keys) {
+	__shared__ unsigned long long s_base;
+	__shared__ int s_wave[kLogBlock / 64];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	// wave w of the block reads rows tile0 + (it * 4 + w) * 64 + lane
+	const int64_t tile0 = (int64_t)blockIdx.x * kSelectTile;
+	int mine = 0; // selected rows of this wave (uniform)
+#pragma unroll 4
+	for (int it = 0; it < kSelectItems; ++it) {
+		const int64_t i = tile0 + (int64_t)((it * (kLogBlock / 64) + wave) * 64 + lane);
+		mine += __popcll(__ballot(rowlog_group_of(slot, valid, i, n, dense, n_slots) >= 0));
+	}
+	if (lane == 0) s_wave[wave] = mine;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		int total = 0;
+		for (int w = 0; w < kLogBlock / 64; ++w) total += s_wave[w];
+		s_base = total ? atomicAdd(counter, (unsigned long long)total) : 0ull;
+	}
+	if (!FILL) return;
+	__syncthreads();
+	unsigned long long at = s_base;
+	for (int w = 0; w < wave; ++w) at += (unsigned long long)s_wave[w];
+	if (mine == 0) return;
+	for (int it = 0; it < kSelectItems; ++it) {
+		const int64_t i = tile0 + (int64_t)((it * (kLogBlock / 64) + wave) * 64 + lane);
+		const int32_t k = rowlog_group_of(slot, valid, i, n, dense, n_slots);
 		const uint64_t m = __ballot(k >= 0);
-		if (m == 0) continue;
-		const int cnt = __popcll(m);
-		unsigned long long at = 0;
-		if (lane == 0) at = atomicAdd(counter, (unsigned long long)cnt);
-		at = __shfl(at, 0);
-		if (FILL && k >= 0) keys[at + (unsigned long long)__popcll(m & ((1ull << lane) - 1))] = ((uint64_t)k << kRowLogRowBits) | (uint64_t)(base_row + i);
+		if (k >= 0) keys[at + (unsigned long long)__popcll(m & ((1ull << lane) - 1))] = ((uint64_t)k << kRowLogRowBits) | (uint64_t)(base_row + i);
+		at += (unsigned long long)__popcll(m);
 	}
 }
 
@@ -148,10 +176,11 @@ hipError_t launch_rowlog_dense(const int32_t *sorted_slots, int64_t k_n, int32_t
 hipError_t launch_rowlog_select(bool fill, const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row, const int32_t *dense,
                                 int64_t n_slots, unsigned long long *counter, uint64_t *keys, hipStream_t st) {
 	if (n <= 0) return hipSuccess;
+	const unsigned tiles = (unsigned)((n + kSelectTile - 1) / kSelectTile); // n <= 2^24 rows per slab
 	if (fill)
-		rowlog_select_kernel<true><<<grid_for(n, 4096), kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys);
+		rowlog_select_kernel<true><<<tiles, kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys);
 	else
-		rowlog_select_kernel<false><<<grid_for(n, 4096), kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys);
+		rowlog_select_kernel<false><<<tiles, kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys);
 	return hipGetLastError();
 }
 

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--model", default="ols", choices=["ols", "ridge", "wls"])
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--chunk", type=int, default=1 << 22, help="rows per update call")
+    ap.add_argument("--hard-frac", type=float, default=0.0,
+                    help="fraction of the groups made nearly exact fits (noise 1e-7): Finalize queues them for refinement")
+    ap.add_argument("--retain-gib", type=float, default=0.0, help="row log budget (anofox_hip_agg_state_retain_rows); 0 = off")
     args = ap.parse_args()
     pkg = importlib.import_module("anofox-statistics_amd")
     synth = importlib.import_module("anofox-statistics_amd.synth")
@@ -36,6 +39,11 @@ def main():
     offs, y, x_cols, w = synth.make_grouped(G, n, p, weights=weighted, device=dev)
     N = G * n
     X = torch.stack(x_cols, dim=1).contiguous()
+    n_hard = int(args.hard_frac * G)
+    if n_hard:
+        g = torch.Generator(device=dev).manual_seed(5)
+        b = torch.rand(p, device=dev, dtype=torch.float64, generator=g) * 4 - 2
+        y[:n_hard * n] = X[:n_hard * n] @ b + 3.0 + 1e-7 * torch.randn(n_hard * n, device=dev, dtype=torch.float64, generator=g)
     ctx = pkg.Context(0)
     opts = pkg.RegressionOptions().batch_options(args.model)
     bytes_row = 8 * (p + 1) + (8 if weighted else 0) + 4
@@ -57,7 +65,7 @@ def main():
             for _ in range(args.steps):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                st = pkg.AggState(ctx, p, opts, initial_slots=G)
+                st = pkg.AggState(ctx, p, opts, initial_slots=G, retain_bytes=int(args.retain_gib * (1 << 30)))
                 t1 = time.perf_counter()
                 for r0 in range(0, N, args.chunk):
                     r1 = min(N, r0 + args.chunk)
@@ -74,8 +82,10 @@ def main():
                 t2 = time.perf_counter()
                 core, _, unref = st.finalize()
                 t3 = time.perf_counter()
+                st_bytes = st.retained_bytes
                 st.close()
-                rec = {"create_ms": (t1 - t0) * 1e3, "update_ms": (t2 - t1) * 1e3, "finalize_ms": (t3 - t2) * 1e3}
+                rec = {"create_ms": (t1 - t0) * 1e3, "update_ms": (t2 - t1) * 1e3, "finalize_ms": (t3 - t2) * 1e3,
+                       "groups_unrefined": int(unref), "retained_GB": st_bytes / 1e9}
                 if best is None or rec["update_ms"] < best["update_ms"]:
                     best = rec
             best["rows_per_sec"] = N / (best["update_ms"] * 1e-3)
@@ -100,7 +110,7 @@ def main():
         ok = bool(np.array_equal(c[:, p + 5], rcore[:, p + 5]) and cerr < 1e-9 and derr < 1e-6)
         print(json.dumps({"metric": "ingest_rows_per_sec", "arrival_order": order, "model": args.model,
                           "groups": G, "rows_per_group": n, "features": p, "rows": N, "bytes_per_row": bytes_row,
-                          "update_chunk_rows": args.chunk, **{k: v for k, v in res.items()},
+                          "update_chunk_rows": args.chunk, "retain_gib": args.retain_gib, "hard_groups": n_hard, **{k: v for k, v in res.items()},
                           "groups_unrefined": unref,
                           "parity": {"ok": ok, "sample_groups": S, "max_coef_rel_err": cerr, "max_diag_rel_err": derr}}), flush=True)
         del hs, hx, hy, hw
