@@ -1,619 +1,30 @@
-// accumulate_wide.hip — moment accumulation for wide designs (8 < p <= 128) on the FP64 matrix cores.
-//
-// Same role as accumulate_narrow.hip (it replaces the reference's row buffering + dense decomposition,
-// src/aggregate_functions/ols_aggregate.cpp:120-186,249-296 and crates/anofox-stats-core/src/models/ols.rs:59-87,
-// 149-161), for designs whose (p+1)(p+2)/2 moments no longer fit a lane's registers.  The X'WX block is a
-// symmetric rank-n update and goes to v_mfma_f64_16x16x4_f64; X'Wy, the column sums, y'Wy and the
-// constant-column / finite-row predicates stay on the VALU (they are O(p) per row).
-//
-// Mapping: one 256-thread workgroup (4 wavefronts) per group.
-//   * A chunk is 32 (16 for p > 96) consecutive rows of every column (x_1..x_p, y, [w]).  The four waves load it coalesced
-//     (each load instruction: 8 columns x 128 contiguous bytes) one chunk ahead into registers and write it to
-//     a double-buffered LDS image laid out [column][18 doubles] (conflict-free for the fragment reads below); the
-//     image holds the values already shifted by the group's first valid row, with the rows that do not take part
-//     zeroed (the staging lanes do both; the chunk that contains the first valid row, and chunks with an invalid
-//     row, are repaired in place once the row masks of all four waves are known).
-//   * A slab is 4 rows.  For the 16-column block I, lane l of a wave reads the fragment element
-//     (row 4t + (l>>4), column 16I + (l&15)) with one ds_read_b64; the same register is the MFMA's A operand
-//     for tile row I and the B operand for tile column I:  M[16I+i][16J+j] += sum_k w_k d[k][16I+i] d[k][16J+j].
-//   * The T(T+1)/2 upper-triangular 16x16 tiles are dealt round-robin to the four waves (9 tiles = 72
-//     accumulator registers each at p = 128), so every wave issues the same number of MFMAs per slab.
-//   * Column block I is "owned" by wave I % 4, which also accumulates sum w d, sum w d dy and the
-//     constant-column flags for those 16 columns; wave 0 accumulates the y moments.
-//
-// Roofline: FP64 MFMA (matrix-core) bound for p >= ~48: 2*256*4 flop per instruction, T(T+1)/2 instructions
-// per 4 rows; HBM traffic 8(p+1) B per row is read once.
-#include "common.h"
+// accumulate_wide.hip — moment accumulation for wide designs (8 < p <= 128) on the FP64 matrix cores: the launcher,
+// and the kernels of 1..4 column tiles.  The kernels themselves are in accumulate_wide_impl.h; 5..8 tiles are compiled
+// by accumulate_wide_t5.hip .. accumulate_wide_t8.hip (one translation unit each, so that make -j builds them side by side).
+#include "accumulate_wide_impl.h"
 
 namespace anofox {
 
-typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
-typedef double dbl4 __attribute__((ext_vector_type(4)));
-// column base pointers are parked in LDS as integers and turned back into *global* pointers, so that the
-// loads through them are global_load (a generic pointer read from memory would give flat_load, whose
-// s_waitcnt vmcnt(0) lgkmcnt(0) serialises every load behind the previous one)
-typedef const double __attribute__((address_space(1))) *gptr_t;
-typedef const dbl2u __attribute__((address_space(1))) *gptr2_t;
-
-// Diagnostic build only (-DANOFOX_SOLVE_STAMPS, csrc/Makefile target `diag`): wave 0 of workgroup 0 sums s_memtime
-// deltas of the phases of its chunk loop: [0] row masks known  [1] next chunk's loads issued (+ repairs)  [2] the chunk's
-// slabs (fragment reads + MFMAs + side sums)  [3] next chunk's loads landed  [4] staged into LDS  [5] barrier passed
-// [6] chunks  [7] whole group.
-#ifdef ANOFOX_SOLVE_STAMPS
-__device__ unsigned long long g_acc_stamps[8];
-#define ACC_STAMP_DECL unsigned long long st_t = 0, st_acc[6] = {0, 0, 0, 0, 0, 0}, st_n = 0; const bool st_on = blockIdx.x == 0 && WAVE == 0; const unsigned long long st_begin = __builtin_amdgcn_s_memtime()
-#define ACC_STAMP_START() do { if (st_on) st_t = __builtin_amdgcn_s_memtime(); } while (0)
-#define ACC_STAMP(k) do { if (st_on) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_t; st_t = now_; } } while (0)
-#define ACC_STAMP_FLUSH() do { if (st_on && threadIdx.x == 0) { for (int k_ = 0; k_ < 6; ++k_) g_acc_stamps[k_] = st_acc[k_]; g_acc_stamps[6] = st_n; g_acc_stamps[7] = __builtin_amdgcn_s_memtime() - st_begin; } } while (0)
-#else
-#define ACC_STAMP_DECL do { } while (0)
-#define ACC_STAMP_START() do { } while (0)
-#define ACC_STAMP(k) do { } while (0)
-#define ACC_STAMP_FLUSH() do { } while (0)
-#endif
-
-namespace {
-
-constexpr int kWaves = 4;
-
-__device__ __forceinline__ double readlane_d(double v, int src) {
-	return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
-	                        __builtin_amdgcn_readlane(__double2loint(v), src));
-}
-
-__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
-
-// Row masks of a chunk.  Bit layout (what the staging ballots produce without any bit shuffling): lane (colsub, rp)
-// stages rows 2 rp, 2 rp + 1, 16 + 2 rp, 17 + 2 rp; byte k of the mask holds those four row classes, bit rp within it.
-__device__ __forceinline__ int row_bit(int row) { return ((row >> 4) << 4) | ((row & 1) << 3) | ((row >> 1) & 7); }
-template <int CH>
-__device__ __forceinline__ unsigned range_mask(int64_t left) { // rows [0, left) of a chunk (wave-uniform, partial chunks only)
-	if (left >= CH) return CH == 32 ? 0xffffffffu : 0xffffu;
-	unsigned m = 0;
-	for (int r = 0; r < (int)left; ++r) m |= 1u << row_bit(r);
-	return m;
-}
-__device__ __forceinline__ int first_row_of_mask(unsigned m) { // lowest row whose bit is set (m != 0)
-	int best = 64;
-#pragma unroll
-	for (int k = 0; k < 4; ++k) {
-		const unsigned byte = (m >> (8 * k)) & 0xffu;
-		const int r = 16 * (k >> 1) + (k & 1) + 2 * (__ffs((int)byte) - 1);
-		best = (byte != 0u && r < best) ? r : best;
-	}
-	return best;
-}
-
-template <int T>
-struct WideCfg {
-	static constexpr int NT = T * (T + 1) / 2;             // upper-triangular tiles
-	static constexpr int TPW = (NT + kWaves - 1) / kWaves; // tiles per wave
-	static constexpr int OWN = (T + kWaves - 1) / kWaves;  // column blocks owned per wave
-	// rows staged per barrier: the per-chunk costs that are latency, not work (row masks through LDS, issuing the next
-	// chunk's loads, the barrier) are as long as the MFMAs of 16 rows at T = 8, so chunks are 32 rows for every width
-	// (the weighted kernel at T = 8 would spill with the staging registers of 32 rows: 16 there)
-	static constexpr int chunk_rows(bool weighted) { return (T == 8 && weighted) ? 16 : 32; }
-	static constexpr int stride(bool weighted) { return chunk_rows(weighted) + 2; } // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
-};
-
-// One wave's share of a chunk: the slabs of MFMAs + the VALU side sums.  WAVE is a compile-time constant so
-// that the tile list unrolls into straight-line MFMAs.  `img` is the chunk's LDS image, already in the form the
-// matrix cores consume: shifted by the group's first valid row (CENTER) and with every row that does not take part
-// (non-finite value, w <= 0, past the end of the group) zeroed in ALL columns by the staging side — so a fragment
-// goes from ds_read_b64 straight into the MFMA and the only VALU work left per slab is the side sums of the column
-// blocks this wave owns.  (Shifting and masking inside the slab loop cost ~5 VALU instructions per block in each of
-// the four waves.)
-template <int T, int WAVE, bool WEIGHTED, bool CENTER>
-__device__ __forceinline__ void compute_chunk(const double *img, const double *firstcol, int ycol, int lane, unsigned rowmask,
-                                              dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
-                                              double (&sxy)[WideCfg<T>::OWN], double (&dmax)[WideCfg<T>::OWN], unsigned &ncmask,
-                                              double &sy, double &syy, double &sw) {
-	constexpr int kChunkRows = WideCfg<T>::chunk_rows(WEIGHTED), kLdsStride = WideCfg<T>::stride(WEIGHTED), OWN = WideCfg<T>::OWN;
-	const int k = lane >> 4;
-	const int i = lane & 15;
-	// without an intercept the image holds raw values; the constant-column test still compares with the first valid row
-	double fown[OWN];
-#pragma unroll
-	for (int o = 0; o < OWN; ++o) fown[o] = (!CENTER && WAVE + kWaves * o < T) ? firstcol[16 * (WAVE + kWaves * o) + i] : 0.0;
-	// Software pipeline over the chunk's slabs: the fragment reads of slab t + 1 are issued BEFORE the MFMAs of slab t
-	// (two register sets, the loop is fully unrolled), so that a wave goes from one slab's MFMAs straight into the
-	// next slab's — with the reads at the top of each slab the matrix pipe idles for an LDS round trip per slab
-	// whenever the SIMD's other wave is not in its own MFMA phase (measured: 115 cycles per MFMA per SIMD against
-	// 64-68 for back-to-back issue with two waves).
-	constexpr int NS = kChunkRows / 4;
-	double d[2][T], dy[2], w[2];
-	auto read_slab = [&](int t, int s) {
-		const int row = 4 * t + k;
-#pragma unroll
-		for (int I = 0; I < T; ++I) d[s][I] = img[(16 * I + i) * kLdsStride + row];
-		dy[s] = img[ycol * kLdsStride + row];
-		w[s] = WEIGHTED ? img[(ycol + 1) * kLdsStride + row] : 1.0;
-	};
-	read_slab(0, 0);
-#pragma unroll
-	for (int t = 0; t < NS; ++t) {
-		const int s = t & 1;
-		const int row = 4 * t + k;
-		if (t + 1 < NS) read_slab(t + 1, s ^ 1);
-		double a[T];
-#pragma unroll
-		for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? w[s] * d[s][I] : d[s][I];
-
-		int tile = 0;
-#pragma unroll
-		for (int I = 0; I < T; ++I) {
-#pragma unroll
-			for (int J = I; J < T; ++J) {
-				if (tile % kWaves == WAVE)
-					acc[tile / kWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[s][J], acc[tile / kWaves], 0, 0, 0);
-				++tile;
-			}
-		}
-#pragma unroll
-		for (int I = 0; I < T; ++I) {
-			if (I % kWaves == WAVE) {
-				// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row (a zeroed row of a
-				// shifted image gives 0; a raw image needs the row's validity)
-				if (CENTER) {
-					// shifted image: |x - x_first| itself, 0 on rows that do not take part — keep the largest (one v_max_f64;
-					// the compare / select / or per slab it replaces sat in the MFMA waves' instruction stream)
-					dmax[I / kWaves] = fmax(dmax[I / kWaves], fabs(d[s][I]));
-				} else {
-					const double dev = d[s][I] - fown[I / kWaves];
-					const bool moved = !(fabs(dev) < 1e-10) && ((rowmask >> row_bit(row)) & 1u);
-					ncmask |= moved ? (1u << I) : 0u;
-				}
-				sx[I / kWaves] += a[I];
-				sxy[I / kWaves] = fma(a[I], dy[s], sxy[I / kWaves]);
-			}
-		}
-		if (WAVE == 0) {
-			const double wdy = WEIGHTED ? w[s] * dy[s] : dy[s];
-			sy += wdy;
-			syy = fma(wdy, dy[s], syy);
-			if (WEIGHTED) sw += w[s]; // unweighted: the row count, taken from the masks
-		}
-	}
-}
-
-// The rows [lo, hi) of one group — or of one segment of a very large group, then with the group's first valid
-// row handed in (`forced_first`: x per column, y at index 16 T) — into one moment record at `rec`, by a workgroup.
-// WAVE (this wavefront's number within the workgroup) is a template parameter of the WHOLE row loop, not only of
-// compute_chunk: with a per-chunk `switch (wave)` the four arms get different register assignments for the 72
-// accumulator registers and the compiler copies all of them in and out around every chunk (2 x 36 v_mov_b64 behind
-// the last MFMA of each 16-row chunk, ~20 % of the chunk's matrix-core time).  The barriers inside are executed the
-// same number of times by every wave, from four copies of the loop.
-template <int T, int WAVE, bool WEIGHTED, bool CENTER>
-__device__ __forceinline__ void wide_accumulate_rows_wave(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
-                                                          const double *forced_first) {
-	using Cfg = WideCfg<T>;
-	constexpr int kChunkRows = Cfg::chunk_rows(WEIGHTED), kLdsStride = Cfg::stride(WEIGHTED);
-	constexpr bool kWideChunk = kChunkRows == 32;
-	constexpr unsigned kFullMask = kWideChunk ? 0xffffffffu : 0xffffu;
-	constexpr int P16 = 16 * T;
-	const int p = args.p;
-	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
-	const int lane = threadIdx.x & 63;
-	constexpr int wave = WAVE;
-	const int64_t nrows = hi - lo;
-
-	extern __shared__ double lds[];
-	// layout: image[2][ncol_pad][STRIDE] | colbase[ncol_pad] (as pointers) | firstcol[ncol_pad] | rowmask partials [2][4]
-	// image columns: x_0..x_{p-1} | zeros up to 16T | y | w | padding to a multiple of 8
-	const int ncol_pad = wide_ncol_pad(p, WEIGHTED);
-	const int ycol = P16;
-	double *image = lds;
-	unsigned long long *colbase = reinterpret_cast<unsigned long long *>(lds + 2 * ncol_pad * kLdsStride);
-	double *firstcol = reinterpret_cast<double *>(colbase + ncol_pad); // value at the group's first valid row, by image column
-	unsigned *maskslot = reinterpret_cast<unsigned *>(firstcol + ncol_pad);
-
-	// source column c (x_0.., y, w) is staged by load slot c; slot -> image column: x in place, y/w after 16T
-	for (int c = threadIdx.x; c < ncol_pad; c += 256) {
-		const double *b = args.y; // unused slots read y again and are dropped at the store
-		if (c < p) b = args.x_table[c];
-		else if (WEIGHTED && c == p + 1) b = args.w;
-		colbase[c] = reinterpret_cast<unsigned long long>(b + lo);
-		double f = 0.0;
-		if (forced_first) f = c < P16 ? forced_first[c] : (c == ycol ? forced_first[P16] : 0.0);
-		firstcol[c] = f;
-	}
-	// zero the padding columns p .. 16T-1 of both buffers once; nothing writes them afterwards
-	for (int idx = threadIdx.x; idx < 2 * (P16 - p) * kLdsStride; idx += 256) {
-		const int bufi = idx / ((P16 - p) * kLdsStride);
-		const int rem = idx - bufi * (P16 - p) * kLdsStride;
-		image[bufi * ncol_pad * kLdsStride + p * kLdsStride + rem] = 0.0;
-	}
-	__syncthreads();
-
-	// staging assignment: load instruction q of this wave covers columns 8*(wave + 4q) .. +7; lane -> (col, row pair).
-	// Everything a lane needs to know about its load slots lives in registers (column pointer, LDS destination, flags):
-	// with the pointers parked in LDS every load of a chunk waited for its own ds_read round trip, ~1000 cycles per
-	// chunk of pure latency (phase stamps, scripts/dbg_acc_stamps.py).
-	constexpr int kMaxLoads = (P16 + 2 + 7) / 8 / kWaves + 1;
-	const int colsub = lane >> 3;
-	const int rp = lane & 7;
-	const int n_loads_total = (ncol + 7) / 8; // load slots: 8 source columns each
-	gptr_t colp[kMaxLoads]; // this lane's column of slot q, at the group's first row + 2 rp
-	int dcol[kMaxLoads];    // element offset of (image column, row 2 rp) within an image
-	unsigned actbits = 0;   // bit q: the column exists (slots beyond ncol read y again and store into a spare column)
-	unsigned wbits = 0;     // bit q: the column is the weight column
-#pragma unroll
-	for (int q = 0; q < kMaxLoads; ++q) {
-		const int src = 8 * (wave + kWaves * q) + colsub;
-		const bool active = src < ncol;
-		int col = src < p ? src : ycol + (src - p); // x in place, y / w after 16 T
-		if (!active) col = ycol + 2 + (colsub % 6); // spare columns 16T+2 .. 16T+7: nothing reads them
-		dcol[q] = col * kLdsStride + 2 * rp;
-		colp[q] = reinterpret_cast<gptr_t>(colbase[src < ncol_pad ? src : ncol_pad - 1]) + 2 * rp;
-		actbits |= active ? (1u << q) : 0u;
-		wbits |= (WEIGHTED && src == p + 1) ? (1u << q) : 0u;
-	}
-
-	dbl4 acc[Cfg::TPW];
-#pragma unroll
-	for (int t = 0; t < Cfg::TPW; ++t) acc[t] = (dbl4){0.0, 0.0, 0.0, 0.0};
-	double sx[Cfg::OWN], sxy[Cfg::OWN], dmax[Cfg::OWN];
-#pragma unroll
-	for (int o = 0; o < Cfg::OWN; ++o) sx[o] = sxy[o] = dmax[o] = 0.0;
-	unsigned ncmask = 0;
-	double sy = 0.0, syy = 0.0, sw = 0.0;
-	bool have_first = forced_first != nullptr; // wave-uniform
-	int cnt = 0;
-	// the shift the staging side applies to the columns THIS lane stages (0 until the first valid row is known, 0 for
-	// the weight column and when there is no intercept)
-	double fq[kMaxLoads];
-#pragma unroll
-	for (int q = 0; q < kMaxLoads; ++q) {
-		fq[q] = 0.0;
-		const int src = 8 * (wave + kWaves * q) + colsub;
-		if (CENTER && forced_first && src <= p) fq[q] = src < p ? forced_first[src] : forced_first[P16];
-	}
-
-	const int64_t n_chunks = (nrows + kChunkRows - 1) / kChunkRows;
-	// staging registers of one chunk: rows 2 rp, 2 rp + 1 (v0, v1) and 16 + 2 rp, 17 + 2 rp (v2, v3) of this lane's columns
-	struct Stage {
-		double v0[kMaxLoads], v1[kMaxLoads], v2[kMaxLoads], v3[kMaxLoads];
-	};
-	// issue the loads of one chunk (global -> registers); consumed by stage_store
-	auto stage_load = [&](int64_t chunk, Stage &sg) {
-		const int64_t c0 = chunk * kChunkRows;              // first row of the chunk within the group
-		const bool full = c0 + kChunkRows <= nrows;         // wave-uniform: every row of the chunk exists
-#pragma unroll
-		for (int q = 0; q < kMaxLoads; ++q) {
-			sg.v0[q] = sg.v1[q] = sg.v2[q] = sg.v3[q] = 0.0;
-			if (wave + kWaves * q < n_loads_total) { // wave-uniform
-				const gptr_t b = colp[q] + c0;
-				if (full) {
-					const dbl2u va = *reinterpret_cast<gptr2_t>(b);
-					sg.v0[q] = va.x;
-					sg.v1[q] = va.y;
-					if (kWideChunk) {
-						const dbl2u vb = *reinterpret_cast<gptr2_t>(b + 16);
-						sg.v2[q] = vb.x;
-						sg.v3[q] = vb.y;
-					}
-				} else {
-					const int64_t r0 = c0 + 2 * rp;
-					if (r0 < nrows) sg.v0[q] = b[0];
-					if (r0 + 1 < nrows) sg.v1[q] = b[1];
-					if (kWideChunk && r0 + 16 < nrows) sg.v2[q] = b[16];
-					if (kWideChunk && r0 + 17 < nrows) sg.v3[q] = b[17];
-				}
-			}
-		}
-	};
-	// registers -> LDS image `buf` (shifted by fq; rows past the end of the group as zeros), plus this wave's partial
-	// row-validity mask (ols.rs:59-66, wls.rs:76-86).  Straight-line code: lanes whose column does not exist store into
-	// a spare column and count as valid.
-	auto stage_store = [&](int64_t chunk, int buf, const Stage &sg) {
-		double *img = image + buf * ncol_pad * kLdsStride;
-		const int64_t left = nrows - chunk * kChunkRows; // rows of the group in this chunk (wave-uniform)
-		// A row is valid when every value is finite (ols.rs:59-66): z_k = sum_q 0 * v_k[q] is NaN exactly when one of the
-		// lane's values of row class k is not finite — one FMA per value and one compare per row class instead of a class
-		// test and two scalar mask updates per value.  (Lanes of columns that do not exist hold y values: harmless.)
-		double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-		bool wbad0 = false, wbad1 = false, wbad2 = false, wbad3 = false; // wls.rs:76-86: w > 0
-#pragma unroll
-		for (int q = 0; q < kMaxLoads; ++q) {
-			if (wave + kWaves * q < n_loads_total) { // wave-uniform
-				z0 = fma(sg.v0[q], 0.0, z0);
-				z1 = fma(sg.v1[q], 0.0, z1);
-				if (kWideChunk) {
-					z2 = fma(sg.v2[q], 0.0, z2);
-					z3 = fma(sg.v3[q], 0.0, z3);
-				}
-				if (WEIGHTED) {
-					const bool isw = (wbits >> q) & 1u;
-					wbad0 = wbad0 || (isw && !(sg.v0[q] > 0.0));
-					wbad1 = wbad1 || (isw && !(sg.v1[q] > 0.0));
-					wbad2 = wbad2 || (isw && !(sg.v2[q] > 0.0));
-					wbad3 = wbad3 || (isw && !(sg.v3[q] > 0.0));
-				}
-				double *dst = img + dcol[q];
-				if (left >= kChunkRows) { // wave-uniform: every row of the chunk exists
-					dst[0] = sg.v0[q] - fq[q];
-					dst[1] = sg.v1[q] - fq[q];
-					if (kWideChunk) {
-						dst[16] = sg.v2[q] - fq[q];
-						dst[17] = sg.v3[q] - fq[q];
-					}
-				} else { // the group's last chunk: rows past its end as zeros
-					dst[0] = 2 * rp < left ? sg.v0[q] - fq[q] : 0.0;
-					dst[1] = 2 * rp + 1 < left ? sg.v1[q] - fq[q] : 0.0;
-					if (kWideChunk) {
-						dst[16] = 2 * rp + 16 < left ? sg.v2[q] - fq[q] : 0.0;
-						dst[17] = 2 * rp + 17 < left ? sg.v3[q] - fq[q] : 0.0;
-					}
-				}
-			}
-		}
-		const bool ok0 = !isnan(z0) && !wbad0, ok1 = !isnan(z1) && !wbad1, ok2 = !isnan(z2) && !wbad2, ok3 = !isnan(z3) && !wbad3;
-		// fold the 8 column sub-groups: byte k of the mask = rows {2j, 2j+1, 16+2j, 17+2j}[k], j = bit (row_bit below)
-		unsigned long long b0 = __ballot(ok0), b1 = __ballot(ok1);
-		b0 &= b0 >> 32; b0 &= b0 >> 16; b0 &= b0 >> 8;
-		b1 &= b1 >> 32; b1 &= b1 >> 16; b1 &= b1 >> 8;
-		unsigned m = ((unsigned)b0 & 0xffu) | (((unsigned)b1 & 0xffu) << 8);
-		if (kWideChunk) {
-			unsigned long long b2 = __ballot(ok2), b3 = __ballot(ok3);
-			b2 &= b2 >> 32; b2 &= b2 >> 16; b2 &= b2 >> 8;
-			b3 &= b3 >> 32; b3 &= b3 >> 16; b3 &= b3 >> 8;
-			m |= (((unsigned)b2 & 0xffu) << 16) | (((unsigned)b3 & 0xffu) << 24);
-		}
-		if (left < kChunkRows) m &= range_mask<kChunkRows>(left); // rows past the end of the group are invalid
-		if (lane == 0) maskslot[buf * kWaves + wave] = m;
-	};
-	// Rare repairs of a staged image, each lane on the elements it staged itself (so reads precede writes in program
-	// order): `shift` — the chunk was staged before the group's first valid row was known, subtract it now; and every
-	// row that is in range but invalid (NaN / inf somewhere, w <= 0) becomes zero in all columns.
-	auto repair_image = [&](int buf, unsigned rowmask, bool shift) {
-		double *img = image + buf * ncol_pad * kLdsStride;
-#pragma unroll
-		for (int q = 0; q < kMaxLoads; ++q) {
-			if (wave + kWaves * q < n_loads_total && ((actbits >> q) & 1u)) {
-				double *dst = img + dcol[q];
-				const double f = shift ? fq[q] : 0.0;
-#pragma unroll
-				for (int e = 0; e < (kWideChunk ? 4 : 2); ++e) {
-					const int bit = 16 * (e >> 1) + 8 * (e & 1) + rp; // row_bit(2 rp + (e & 1) + 16 (e >> 1))
-					const double cur = dst[(e & 1) + 16 * (e >> 1)];
-					dst[(e & 1) + 16 * (e >> 1)] = ((rowmask >> bit) & 1u) ? cur - f : 0.0;
-				}
-			}
-		}
-	};
-
-	// One chunk.  The loads run one chunk ahead and are stored to the other image once this chunk's MFMAs are issued.
-	ACC_STAMP_DECL;
-	auto iteration = [&](int64_t c, Stage &ahead) {
-		ACC_STAMP_START();
-		const int buf = (int)(c & 1);
-		const double *img = image + buf * ncol_pad * kLdsStride;
-		unsigned rowmask = maskslot[buf * kWaves + 0] & maskslot[buf * kWaves + 1] & maskslot[buf * kWaves + 2] &
-		                   maskslot[buf * kWaves + 3];
-		rowmask = __builtin_amdgcn_readfirstlane(rowmask);
-		ACC_STAMP(0);
-		const int64_t left = nrows - c * kChunkRows;
-		const unsigned rangemask = left >= kChunkRows ? kFullMask : range_mask<kChunkRows>(left);
-		if (c + 1 < n_chunks) stage_load(c + 1, ahead); // in flight while this chunk's MFMAs run
-
-		const bool found_first = !have_first && rowmask != 0u; // wave-uniform
-		// (a chunk without any valid row is zeroed as well and goes through the MFMAs like every other chunk: skipping
-		// its compute step would put the 72 accumulator registers behind a branch, and the compiler then copies all of
-		// them at the join — 36 v_mov_b64 waiting on the last MFMA of EVERY chunk)
-		if (found_first || rowmask != rangemask) {
-			if (found_first) {
-				// the group's first valid row: remember its values (the shift when CENTER, the reference point of the
-				// constant-column test, part of the record) and shift this chunk, which was staged unshifted
-				const int r = first_row_of_mask(rowmask);
-#pragma unroll
-				for (int q = 0; q < kMaxLoads; ++q) {
-					const int li = wave + kWaves * q;
-					if (li < n_loads_total) {
-						const int src = 8 * li + colsub;
-						if (src <= p) { // x columns and y; the weight column is never shifted
-							const int col = src < p ? src : ycol;
-							const double f = img[col * kLdsStride + r];
-							if (rp == 0) firstcol[col] = f;
-							if (CENTER) fq[q] = f;
-						}
-					}
-				}
-			}
-			repair_image(buf, rowmask, CENTER && found_first);
-			__syncthreads();
-		}
-		have_first = have_first || found_first;
-
-		cnt += __popc(rowmask);
-		ACC_STAMP(1);
-		compute_chunk<T, WAVE, WEIGHTED, CENTER>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, dmax, ncmask, sy, syy, sw);
-		ACC_STAMP(2);
-#ifdef ANOFOX_SOLVE_STAMPS
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-		ACC_STAMP(3);
-		if (c + 1 < n_chunks) stage_store(c + 1, buf ^ 1, ahead);
-		ACC_STAMP(4);
-		__syncthreads();
-		ACC_STAMP(5);
-#ifdef ANOFOX_SOLVE_STAMPS
-		++st_n;
-#endif
-	};
-
-	Stage sg;
-	if (n_chunks > 0) {
-		stage_load(0, sg);
-		stage_store(0, 0, sg);
-	}
-	__syncthreads();
-	for (int64_t c = 0; c < n_chunks; ++c) iteration(c, sg);
-
-	ACC_STAMP_FLUSH();
-	// ---- write the moment record ----
-	// tiles: tile-major, 256 doubles each, element (row, col) at row*16 + col
-	{
-		int tile = 0;
-#pragma unroll
-		for (int I = 0; I < T; ++I) {
-#pragma unroll
-			for (int J = I; J < T; ++J) {
-				if (tile % kWaves == wave) {
-					double *tp = rec + (int64_t)tile * 256;
-#pragma unroll
-					for (int r = 0; r < 4; ++r) tp[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[tile / kWaves][r];
-				}
-				++tile;
-			}
-		}
-	}
-	double *vec = rec + (int64_t)Cfg::NT * 256;
-	// column sums: reduce over the four k-groups (lanes l, l^16, l^32, l^48)
-#pragma unroll
-	for (int I = 0; I < T; ++I) {
-		if (I % kWaves == wave) {
-			double a = sx[I / kWaves], b = sxy[I / kWaves];
-			a += shfl_xor_d(a, 16); a += shfl_xor_d(a, 32);
-			b += shfl_xor_d(b, 16); b += shfl_xor_d(b, 32);
-			unsigned nc = CENTER ? (dmax[I / kWaves] >= 1e-10 ? 1u : 0u) : ((ncmask >> I) & 1u);
-			nc |= __shfl_xor((int)nc, 16, 64);
-			nc |= __shfl_xor((int)nc, 32, 64);
-			if (lane < 16) {
-				vec[0 * P16 + 16 * I + lane] = a;
-				vec[1 * P16 + 16 * I + lane] = b;
-				vec[2 * P16 + 16 * I + lane] = firstcol[16 * I + lane]; // padding columns: 0
-				vec[3 * P16 + 16 * I + lane] = (double)nc;
-			}
-		}
-	}
-	if (wave == 0) {
-		// every lane of a k-group holds the same partial: take lanes 0, 16, 32, 48
-		double a = sy, b = syy, c2 = sw;
-		a += shfl_xor_d(a, 16); a += shfl_xor_d(a, 32);
-		b += shfl_xor_d(b, 16); b += shfl_xor_d(b, 32);
-		c2 += shfl_xor_d(c2, 16); c2 += shfl_xor_d(c2, 32);
-		if (!WEIGHTED) c2 = (double)cnt;
-		if (lane == 0) {
-			double *sc = vec + 4 * P16;
-			sc[0] = a;
-			sc[1] = b;
-			sc[2] = c2;
-			sc[3] = (double)cnt;
-			sc[4] = firstcol[ycol];
-		}
-	}
-}
-
-template <int T, bool WEIGHTED, bool CENTER>
-__device__ __forceinline__ void wide_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
-                                                     const double *forced_first) {
-	switch (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) {
-	case 0: wide_accumulate_rows_wave<T, 0, WEIGHTED, CENTER>(args, lo, hi, rec, forced_first); break;
-	case 1: wide_accumulate_rows_wave<T, 1, WEIGHTED, CENTER>(args, lo, hi, rec, forced_first); break;
-	case 2: wide_accumulate_rows_wave<T, 2, WEIGHTED, CENTER>(args, lo, hi, rec, forced_first); break;
-	default: wide_accumulate_rows_wave<T, 3, WEIGHTED, CENTER>(args, lo, hi, rec, forced_first); break;
-	}
-}
-
-template <int T, bool WEIGHTED, bool CENTER>
-__global__ __launch_bounds__(256, 2) void accumulate_wide_kernel(WideArgs args) {
-	const int64_t g = blockIdx.x;
-	const int64_t lo = args.row_offsets[args.group_base + g];
-	const int64_t hi = group_row_end(args, args.group_base + g);
-	if (args.seg_table && hi - lo > args.seg_rows) {
-		// four waves stream a group at ~25 GB/s: hand it to accumulate_wide_segments_kernel in pieces
-		__shared__ int registered;
-		if (threadIdx.x < 64) {
-			const bool ok = wide_register_big_group(args, g, lo, hi, T, (int)threadIdx.x, kWideSegMaxBig, kWideSegMaxSegments);
-			if (threadIdx.x == 0) registered = ok ? 1 : 0;
-		}
-		__syncthreads();
-		if (registered) return; // (tables full: the workgroup accumulates the group itself)
-	}
-	wide_accumulate_rows<T, WEIGHTED, CENTER>(args, lo, hi, args.moments + g * (int64_t)wide_record_len(T), nullptr);
-}
-
-// One workgroup per registered segment; every segment of a group uses the group's first valid row as its shift,
-// so the workgroup that completes the last one merges by plain (ordered) sums.
-template <int T, bool WEIGHTED, bool CENTER>
-__global__ __launch_bounds__(256, 2) void accumulate_wide_segments_kernel(WideArgs args) {
-	constexpr int P16 = 16 * T;
-	constexpr int NT = T * (T + 1) / 2;
-	const int reclen = wide_record_len(T);
-	const int v = blockIdx.x;
-	SegHeader *h = wseg_header(args.seg_table);
-	const int total = h->seg_total; // reservations never exceed the capacity
-	if (v >= total) return;
-	const SegEntry e = wseg_entries(args.seg_table, kWideSegMaxBig)[v];
-	if (e.slot < 0) return; // reserved but unclaimed
-	SegBigGroup *b = wseg_big(args.seg_table) + e.slot;
-	const double *ff = wseg_first(args.seg_table, kWideSegMaxBig, kWideSegMaxSegments) + (size_t)e.slot * (P16 + 2);
-	double *recs = wseg_records(args.seg_table, T, kWideSegMaxBig, kWideSegMaxSegments);
-	wide_accumulate_rows<T, WEIGHTED, CENTER>(args, e.lo, e.hi, recs + (int64_t)v * reclen, ff);
-	__shared__ int last;
-	__threadfence(); // this segment's record before the counter
-	__syncthreads();
-	if (threadIdx.x == 0) last = (atomicAdd(&b->done, 1) == b->nseg - 1) ? 1 : 0;
-	__syncthreads();
-	if (!last) return;
-	__threadfence(); // every other segment's record after the counter
-	const double *src = recs + (int64_t)b->base * reclen;
-	double *dst = args.moments + b->g * (int64_t)reclen;
-	const int vec0 = NT * 256;
-	for (int k = threadIdx.x; k < reclen; k += 256) {
-		const bool is_first = (k >= vec0 + 2 * P16 && k < vec0 + 3 * P16) || k == vec0 + 4 * P16 + 4; // first x / first y: shared
-		const bool is_flag = k >= vec0 + 3 * P16 && k < vec0 + 4 * P16;                                   // non-constant flags: OR
-		double acc = 0.0;
-		for (int t = 0; t < b->nseg; ++t) acc += src[(int64_t)t * reclen + k];
-		if (is_first) acc = src[k];
-		if (is_flag) acc = acc > 0.0 ? 1.0 : 0.0;
-		dst[k] = acc;
-	}
-}
-
-template <int T>
-hipError_t launch_T(const WideArgs &a, hipStream_t stream) {
-	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
-	const bool center = a.fit_intercept != 0;
-	const int ncol_pad = wide_ncol_pad(a.p, weighted);
-	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::stride(weighted) * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
-	const dim3 grid((unsigned)a.n_groups), block(256);
-	const dim3 seg_grid((unsigned)kWideSegMaxSegments); // idle unless some group exceeded seg_rows
-#define ANOFOX_WIDE_LAUNCH(W, C)                                                                                  \
-	do {                                                                                                          \
-		hipLaunchKernelGGL((accumulate_wide_kernel<T, W, C>), grid, block, lds, stream, a);                       \
-		if (a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, W, C>), seg_grid, block, lds, stream, a); \
-	} while (0)
-	if (weighted) {
-		if (center) ANOFOX_WIDE_LAUNCH(true, true);
-		else ANOFOX_WIDE_LAUNCH(true, false);
-	} else {
-		if (center) ANOFOX_WIDE_LAUNCH(false, true);
-		else ANOFOX_WIDE_LAUNCH(false, false);
-	}
-#undef ANOFOX_WIDE_LAUNCH
-	return hipGetLastError();
-}
-
-} // namespace
-
-#ifdef ANOFOX_SOLVE_STAMPS
-extern "C" __attribute__((visibility("default"))) int anofox_hip_diag_acc_stamps(unsigned long long *out8) {
-	return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_acc_stamps), 8 * sizeof(unsigned long long));
-}
-#endif
+template hipError_t launch_accumulate_wide_T<1>(const WideArgs &, hipStream_t);
+template hipError_t launch_accumulate_wide_T<2>(const WideArgs &, hipStream_t);
+template hipError_t launch_accumulate_wide_T<3>(const WideArgs &, hipStream_t);
+template hipError_t launch_accumulate_wide_T<4>(const WideArgs &, hipStream_t);
+extern template hipError_t launch_accumulate_wide_T<5>(const WideArgs &, hipStream_t);
+extern template hipError_t launch_accumulate_wide_T<6>(const WideArgs &, hipStream_t);
+extern template hipError_t launch_accumulate_wide_T<7>(const WideArgs &, hipStream_t);
+extern template hipError_t launch_accumulate_wide_T<8>(const WideArgs &, hipStream_t);
 
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
 	switch (wide_tiles(a.p)) {
-	case 1: return launch_T<1>(a, stream);
-	case 2: return launch_T<2>(a, stream);
-	case 3: return launch_T<3>(a, stream);
-	case 4: return launch_T<4>(a, stream);
-	case 5: return launch_T<5>(a, stream);
-	case 6: return launch_T<6>(a, stream);
-	case 7: return launch_T<7>(a, stream);
-	case 8: return launch_T<8>(a, stream);
+	case 1: return launch_accumulate_wide_T<1>(a, stream);
+	case 2: return launch_accumulate_wide_T<2>(a, stream);
+	case 3: return launch_accumulate_wide_T<3>(a, stream);
+	case 4: return launch_accumulate_wide_T<4>(a, stream);
+	case 5: return launch_accumulate_wide_T<5>(a, stream);
+	case 6: return launch_accumulate_wide_T<6>(a, stream);
+	case 7: return launch_accumulate_wide_T<7>(a, stream);
+	case 8: return launch_accumulate_wide_T<8>(a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -157,6 +157,7 @@ struct WideArgs {
 	void *seg_table;
 	int64_t seg_rows;
 	const int64_t *row_ends; // optional [G_total], see BatchArgs
+	int no_fast_path;        // accumulate_wide: 1 = skip the speculative version (A/B switch ANOFOX_WIDE_FAST=0, tests)
 };
 inline __host__ __device__ int64_t group_row_end(const WideArgs &a, int64_t g) { return a.row_ends ? a.row_ends[g] : a.row_offsets[g + 1]; }
 

@@ -101,6 +101,8 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.inference = opt.compute_inference ? d_inf : nullptr;
 	a.rule_counts = d_rule_counts;
 	a.row_ends = ctx->frame_ends;
+	static const bool wide_fast_on = !(getenv("ANOFOX_WIDE_FAST") && atoi(getenv("ANOFOX_WIDE_FAST")) == 0); // A/B switch
+	a.no_fast_path = wide_fast_on ? 0 : 1;
 
 	hipStream_t st = ctx->stream;
 	a.seg_table = base + b_mom + b_rss + b_lst + 256 + kTcritTableBytes;
@@ -109,7 +111,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	for (int64_t g0 = 0; g0 < G; g0 += slab) {
 		a.group_base = g0;
 		a.n_groups = (G - g0 < slab) ? G - g0 : slab;
-		if (hip_fail(hipMemsetAsync(a.refine_count, 0, sizeof(int32_t), st), "hipMemsetAsync", e)) return false;
+		if (hip_fail(hipMemsetAsync(a.refine_count, 0, 64, st), "hipMemsetAsync", e)) return false; // [0] refine queue, [8] accumulate_wide's redo list
 		if (a.seg_table && hip_fail(hipMemsetAsync(a.seg_table, 0, sizeof(SegHeader), st), "hipMemsetAsync", e)) return false;
 		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
 		if (ctx->timing) {
