@@ -825,6 +825,54 @@ def test_wide_edge_cases_match_oracle(pkg, ctx):
             assert_records_match(core, rcore, p, inf, rinf, what=f"wide edge {model} icpt={icpt}", skip_diag_groups=zero_df)
 
 
+@pytest.mark.parametrize("p", [40, 128])
+def test_wide_speculative_kernel_and_its_fallback(pkg, ctx, p):
+    """p > 32, OLS with an intercept: accumulate_wide's speculative kernel (every row valid, first row as the shift,
+    constant columns read off the diagonal of the moments) and the groups it has to hand to the full kernel — a NaN /
+    inf anywhere, an invalid first row, columns in the band where sum d^2 does not decide |x - x_first| < 1e-10 —
+    next to groups it keeps, of every chunk-count shape (0, 1, 2 rows; exactly k x 32 rows; one row more or less)."""
+    rng = np.random.default_rng(1000 + p)
+    groups = []
+
+    def add(n, mutate=None):
+        X = rng.uniform(-10, 10, (n, p))
+        y = 1.0 + X @ rng.uniform(-2, 2, p) + rng.standard_normal(n)
+        if mutate:
+            mutate(X, y)
+        groups.append((X, y))
+
+    big = 3 * p + 40
+    base = 32 * ((p + 2 + 31) // 32)            # a whole number of 32-row chunks with enough rows to fit
+    for n in (0, 1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 128, 129, base + 31, base + 32, base + 33, base + 64, base + 65,
+              big, 2 * big + 1):
+        add(n)
+    add(big, lambda X, y: X.__setitem__((slice(None), 3), 7.0))                          # constant column: kept, flagged from M_jj = 0
+    # constant within 1e-10 but not exactly: sum d^2 = n / 2 * 2.5e-21 lies between 1e-20 and n 1e-20, where the diagonal
+    # of the moments does not decide — the full kernel's per-row test does.  (A column that moves by MORE than 1e-10
+    # in a few rows only is outside this test: it is "not constant" for ols.rs:76-87 and then a matter of the rank
+    # tolerances, which the oracle takes against the uncentred and the Cholesky against the centred column norm.)
+    add(big, lambda X, y: X.__setitem__((slice(None), p - 1), -2.0 + 5e-11 * (np.arange(big) % 2)))
+    add(big, lambda X, y: X.__setitem__((0, 7), np.nan))                                  # invalid first row
+    add(big, lambda X, y: y.__setitem__(70, np.nan))                                      # NaN in a middle chunk
+    add(big, lambda X, y: X.__setitem__((big - 1, p - 2), np.inf))                        # inf in the last row
+    add(big, lambda X, y: X.__setitem__((slice(0, 40), slice(None)), np.nan))             # first chunk entirely invalid
+    add(big, lambda X, y: X.__setitem__((slice(None), p // 2), 2 * X[:, 0] - X[:, 1] + 3))   # aliased column
+    add(big, lambda X, y: X.__setitem__((slice(None), slice(None)), X * 1e150))           # squares overflow: moments inf -> full kernel, same answer
+    ns = [len(g[1]) for g in groups]
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    X = np.concatenate([g[0] for g in groups])
+    y = np.concatenate([g[1] for g in groups])
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    kw = dict(fit_intercept=True, compute_inference=True)
+    core, inf = _host_fit(pkg, ctx, "ols", offs, y, x_cols, None, **kw)
+    rcore, rinf = oracle.fit_groups(y, x_cols, offs, n_threads=8, **_oracle_kw("ols", kw))
+    zero_df = [g for g in range(len(ns)) if rcore[g, p + 5] == 0 and rcore[g, p + 4] <= p + 1]
+    skip = zero_df + [len(ns) - 1]            # (the overflow group: status and NaN pattern only)
+    with np.errstate(all="ignore"):
+        assert_records_match(core, rcore, p, inf, rinf, what=f"wide speculative p={p}", skip_diag_groups=skip)
+    assert (rcore[:, p + 5] == 0).sum() >= 14
+
+
 def test_wide_exact_fit_uses_residual_pass(pkg, ctx):
     rng = np.random.default_rng(9)
     p, n = 12, 200
