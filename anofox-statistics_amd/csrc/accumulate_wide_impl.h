@@ -64,7 +64,7 @@ namespace {
 #endif
 constexpr int kWaves = ANOFOX_WIDE_WAVES;   // wavefronts per workgroup (4 or 8: a translation unit's choice)
 constexpr int kThreads = 64 * kWaves;
-constexpr int kWavesPerSimd = kWaves == 8 ? 4 : 2; // two workgroups per CU either way
+constexpr int kWavesPerSimd = kWaves / 2; // two workgroups per CU either way
 static_assert(kWaves == 4 || kWaves == 8, "4 or 8 wavefronts per workgroup");
 constexpr int kWideRedoCounter = 8; // word of the refine counter block that counts the speculative kernel's give-ups
 constexpr int kWideFastMinT = 3;    // (narrower designs go through accumulate_mid.hip)
@@ -348,25 +348,18 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	};
 	// The same without a single branch, for the steady state of the chunk loop (full chunks only): slots that do not
 	// exist load y and are stored into a spare column, like the columns that do not exist.  With the wave-uniform
-	// branches of stage_load_piece in the loop the compiler could not count the loads in flight and put s_waitcnt
-	// vmcnt(0) in front of every use: each slot then waited for the loads issued a moment before it, a full memory
-	// latency per slot.
+	// branches of stage_load_piece in the loop the compiler cannot count the loads in flight and puts s_waitcnt
+	// vmcnt(0) in front of every use.  It also loses count across the loop's back edge, so the steady loop keeps no
+	// load in flight from one iteration to the next: all of a chunk's loads go out behind slab 0 and are consumed
+	// behind the last slabs of the same iteration, each behind an exact vmcnt.  (Loads kept in flight across
+	// iterations, with the loads and waits as volatile asm naming their own count, measured the same at p = 128 —
+	// and broke as soon as the compiler had a reason to copy a register whose load had not landed.)
 	auto stage_load_piece_steady = [&](int64_t chunk, Stage &sg, int q) {
-		// The loads and the wait in front of their use are written as volatile asm, so that the wait can name the number
-		// of loads that may still be in flight (the two of each of the kMaxLoads - 1 slots issued since): the compiler's
-		// own bookkeeping loses count at the loop's back edge and waits for vmcnt(0).
 		const gptr_t b = colp[q] + chunk * kChunkRows;
-		asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sg.a[q]) : "v"(b));
-		if (kWideChunk) asm volatile("global_load_dwordx4 %0, %1, off offset:128" : "=v"(sg.b[q]) : "v"(b));
+		sg.a[q] = *reinterpret_cast<gptr2_t>(b);
+		if (kWideChunk) sg.b[q] = *reinterpret_cast<gptr2_t>(b + 16);
 	};
-	// the registers of slot q as they will be once its loads (and nothing younger) have landed
-	auto stage_wait_steady = [&](Stage &sg, int q) {
-		constexpr int kYounger = (kMaxLoads - 1) * (kWideChunk ? 2 : 1);
-		if (kWideChunk)
-			asm volatile("s_waitcnt vmcnt(%2)" : "+v"(sg.a[q]), "+v"(sg.b[q]) : "n"(kYounger));
-		else
-			asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sg.a[q]) : "n"(kYounger));
-	};
+
 	// registers -> LDS image `buf` (shifted by fq; rows past the end of the group as zeros), plus this wave's partial
 	// row-validity mask (ols.rs:59-66, wls.rs:76-86).  Straight-line code: lanes whose column does not exist store into
 	// a spare column and count as valid.
@@ -495,7 +488,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 
 	// One chunk.  The loads run one chunk ahead and are stored to the other image once this chunk's MFMAs are issued.
 	ACC_STAMP_DECL;
-	// steady = std::true_type: chunks c, c + 1 and c + 2 are full (the branch-free staging pieces)
+	// steady = std::true_type: chunks c and c + 1 are full (the branch-free staging pieces)
 	auto iteration = [&](auto steady, int64_t c, Stage &ahead) {
 		constexpr bool STEADY = decltype(steady)::value;
 		ACC_STAMP_START();
@@ -543,34 +536,43 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 
 		cnt += __popc(rowmask);
 		ACC_STAMP(1);
-		// The next chunk is staged BETWEEN the slabs of this one: load slot q (in registers since the previous chunk) is
-		// shifted and written to the other image behind slab q NS / kMaxLoads, and its registers are reloaded right away
-		// with the chunk after that — every load has a whole chunk of MFMAs to land in (issued behind slab 0 and stored
-		// three slabs later they did not: 1.4 us at two waves per SIMD is less than the loaded HBM latency).  The row
-		// mask follows behind the last slab.  With the staging as a phase of its own a wave spent 35 % of a chunk in it:
-		// its ~100 vector / LDS instructions each wait for a gap in the MFMA stream of the SIMD's other wave (phase
-		// stamps), while its own matrix work stands still.
+		// The next chunk is staged BETWEEN the slabs of this one.  Steady state: its loads go out behind slab 0, load slot
+		// q is shifted and written to the other image behind one of the last slabs, the row mask follows behind the
+		// last slab.  (Outside the steady state — a partial chunk ahead — the generic pieces do the same one chunk
+		// further ahead, behind whatever waits the compiler chooses.)  With the staging as a phase of its own a wave
+		// spent 35 % of a chunk in it: its ~100 vector / LDS instructions each wait for a gap in the MFMA stream of the
+		// SIMD's other wave (phase stamps), while its own matrix work stands still.
 		constexpr int NS = kChunkRows / 4;
 		StoreState ss;
 		stage_store_begin(ss);
 		compute_chunk<T, WAVE, WEIGHTED, CENTER, FAST>(img, firstcol, ycol, lane, rowmask, acc, sx, sxy, dmax, ncmask, sy, syy, sw, [&](int t) {
+			if (STEADY) {
+				if (t == 0) {
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int q = 0; q < kMaxLoads; ++q) stage_load_piece_steady(c + 1, ahead, q);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+#pragma unroll
+				for (int q = 0; q < kMaxLoads; ++q) {
+					// as late as the slabs allow (several slots per slab when there are fewer slabs than slots)
+					constexpr int kPerSlab = (kMaxLoads + NS - 2) / (NS - 1);
+					if (NS - 1 - (kMaxLoads - 1 - q) / kPerSlab == t) {
+						// (fences for the instruction scheduler: left alone it gathers the subtractions of all slots
+						// behind one wait for the last load)
+						__builtin_amdgcn_sched_barrier(0);
+						stage_store_piece_steady(buf ^ 1, ahead, ss, q);
+						__builtin_amdgcn_sched_barrier(0);
+					}
+				}
+				return;
+			}
 			if (!more) return;
 #pragma unroll
 			for (int q = 0; q < kMaxLoads; ++q) {
 				if ((q * NS) / kMaxLoads == t) { // slab behind which slot q is stored
-					if (STEADY) {
-						// (fences for the instruction scheduler: left alone it gathers the subtractions of all slots
-						// at the top of the loop, behind one s_waitcnt vmcnt(0) that then waits for the loads the
-						// previous iteration issued last)
-						__builtin_amdgcn_sched_barrier(0);
-						stage_wait_steady(ahead, q);
-						stage_store_piece_steady(buf ^ 1, ahead, ss, q);
-						stage_load_piece_steady(c + 2, ahead, q);
-						__builtin_amdgcn_sched_barrier(0);
-					} else {
-						stage_store_piece(c + 1, buf ^ 1, ahead, ss, q);
-						if (c + 2 < n_chunks) stage_load_piece(c + 2, ahead, q);
-					}
+					stage_store_piece(c + 1, buf ^ 1, ahead, ss, q);
+					if (c + 2 < n_chunks) stage_load_piece(c + 2, ahead, q);
 				}
 			}
 		});
@@ -589,28 +591,12 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		stage_load(0, sg);
 		stage_store(0, 0, sg);
 	}
+	__syncthreads();
 	{
 		int64_t c = 0;
-		// (one block for the steady loop and the loads it counts on: were the generic loads of chunk 1 on a path that the
-		// compiler cannot tell from this one, it would guard the loop's first use of the staging registers with vmcnt(0))
 		const int64_t n_full = nrows / kChunkRows; // full chunks
-		if (n_full > 2) {
-#pragma unroll
-			for (int q = 0; q < kMaxLoads; ++q) stage_load_piece_steady(1, sg, q); // exactly these loads, in this order
-			__syncthreads();
-			for (; c + 2 < n_full; ++c) iteration(std::true_type(), c, sg);
-			// the last loads of the loop are not known to the compiler: they have landed before the tail uses them
-#pragma unroll
-			for (int q = 0; q < kMaxLoads; ++q) {
-				if (kWideChunk)
-					asm volatile("s_waitcnt vmcnt(0)" : "+v"(sg.a[q]), "+v"(sg.b[q]));
-				else
-					asm volatile("s_waitcnt vmcnt(0)" : "+v"(sg.a[q]));
-			}
-		} else {
-			if (n_chunks > 1) stage_load(1, sg);
-			__syncthreads();
-		}
+		for (; c + 1 < n_full; ++c) iteration(std::true_type(), c, sg); // (nothing of chunk c + 1 is loaded yet)
+		if (c + 1 < n_chunks) stage_load(c + 1, sg);                    // the generic iterations expect the next chunk in registers
 		for (; c < n_chunks; ++c) iteration(std::false_type(), c, sg);
 	}
 
