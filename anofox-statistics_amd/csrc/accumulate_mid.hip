@@ -15,6 +15,10 @@
 //   * row validity: one ballot says whether all 16 rows of a step pass (then the step runs without masks);
 //     otherwise 4 ballots give the row mask (the 16 lanes of a kk group hold the 16 columns of a block) and
 //     invalid rows are removed with bit masks;
+//   * AUX (p <= 16 T - 2): y and a column of ones ride in the two columns behind x_p of the last block, so X'Wy, the
+//     column sums and the y moments come out of the same MFMAs and the per-row side sums (2 T + 3 vector
+//     instructions per K-step, each of which costs matrix-core issue time) disappear, as do the separate y loads;
+//     the record is written with those two columns taken out again;
 //   * four groups per 256-thread workgroup, no LDS, no barrier;
 //   * (measured and removed in round 2: the same kernel with the step buffers in a per-wave LDS ring filled by
 //     global_load_lds_dwordx4, 3-8 steps ahead and no VGPR staging — correct, but slower at p = 9 / 16 / 24-wls
@@ -23,7 +27,14 @@
 //   * a group with more than seg_rows rows (>= 1/2048 of the batch) is cut into segments, one wavefront each
 //     (accumulate_mid_segments_kernel, idle otherwise), all shifted by the group's first valid row, and the wave
 //     that finishes the last segment sums the segment records.
+#include <stdlib.h>
+
 #include "common.h"
+
+// steps per loop trip, by measurement (100 000 x 1000 rows): T = 1: 2 (4 changes nothing; weighted 1 -> 2: 3.19 -> 2.92 ms at
+// p = 14); T = 2: 1 (2 spills: 4.9 -> 8.6 ms at p = 24).  More waves per SIMD do not help either (80 VGPRs, 6 waves:
+// 1.79 against 1.82 ms at p = 9; 64 VGPRs spill).
+#define ANOFOX_MID_S (T == 1 ? 2 : 1)
 
 namespace anofox {
 
@@ -68,9 +79,9 @@ struct MidState {
 };
 
 // One 16-row step of a wave.  ALLVALID: every row of the step passed the row filter (the common case) — no masks.
-template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID>
+template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID, bool AUX>
 __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4], const double (&y)[4], const double (&w)[4],
-                                         unsigned rowmask, int kk, int lj) {
+                                         unsigned rowmask, int kk, int lj, bool is_one) {
 	if (!st.have_first) {
 		const int r = __ffs((int)rowmask) - 1; // first valid row of the group; mid_row(kk, m) == r
 		const int src = 16 * ((r >> 1) & 3) + lj, m = ((r >> 3) << 1) | (r & 1);
@@ -79,8 +90,12 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 			const double mine = m == 0 ? x[I][0] : (m == 1 ? x[I][1] : (m == 2 ? x[I][2] : x[I][3]));
 			st.first[I] = __shfl(mine, src, 64);
 		}
-		const double ym = m == 0 ? y[0] : (m == 1 ? y[1] : (m == 2 ? y[2] : y[3]));
-		st.first_y = __shfl(ym, src, 64);
+		if (AUX) {
+			if (is_one) st.first[T - 1] = 0.0; // the column of ones is not shifted
+		} else {
+			const double ym = m == 0 ? y[0] : (m == 1 ? y[1] : (m == 2 ? y[2] : y[3]));
+			st.first_y = __shfl(ym, src, 64);
+		}
 		st.have_first = true;
 	}
 	st.cnt += ALLVALID ? 16 : __popc(rowmask);
@@ -95,7 +110,7 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 			// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row
 			st.ncmask |= !(fabs(dev) < 1e-10) ? (1u << I) : 0u;
 		}
-		const double dy0 = CENTER ? y[m] - st.first_y : y[m];
+		const double dy0 = AUX ? 0.0 : (CENTER ? y[m] - st.first_y : y[m]);
 		const double dy = ALLVALID ? dy0 : mid_mask(dy0, rm);
 		const double wv = ALLVALID ? w[m] : mid_mask(w[m], rm);
 #pragma unroll
@@ -109,39 +124,42 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 				++tile;
 			}
 		}
+		if (!AUX) {
 #pragma unroll
-		for (int I = 0; I < T; ++I) {
-			st.sx[I] += a[I];
-			st.sxy[I] = fma(a[I], dy, st.sxy[I]);
+			for (int I = 0; I < T; ++I) {
+				st.sx[I] += a[I];
+				st.sxy[I] = fma(a[I], dy, st.sxy[I]);
+			}
+			const double wdy = WEIGHTED ? wv * dy : dy;
+			st.sy += wdy;
+			st.syy = fma(wdy, dy, st.syy);
+			st.sw += wv;
 		}
-		const double wdy = WEIGHTED ? wv * dy : dy;
-		st.sy += wdy;
-		st.syy = fma(wdy, dy, st.syy);
-		st.sw += wv;
 	}
 }
 
 // Row validity of one 16-row step starting at row r0 (ols.rs:59-66, wls.rs:76-86), then the step itself.  Common case
 // first: a full step whose 16 rows all pass.
-template <int T, bool WEIGHTED, bool CENTER>
+template <int T, bool WEIGHTED, bool CENTER, bool AUX>
 __device__ __forceinline__ void mid_process_step(MidState<T> &st, const double (&x)[T][4], const double (&y)[4], const double (&w)[4],
-                                                 int64_t r0, int64_t hi, int kk, int lj) {
+                                                 int64_t r0, int64_t hi, int kk, int lj, bool is_one) {
+	// (AUX: y is one of the x columns here — the lane that holds it tests it)
 	bool ok_all = true;
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
-		ok_all = ok_all && isfinite(y[m]);
+		if (!AUX) ok_all = ok_all && isfinite(y[m]);
 		if (WEIGHTED) ok_all = ok_all && isfinite(w[m]) && (w[m] > 0.0);
 #pragma unroll
 		for (int I = 0; I < T; ++I) ok_all = ok_all && isfinite(x[I][m]);
 	}
 	if (r0 + 16 <= hi && __ballot(ok_all) == ~0ull) {
-		mid_step<T, WEIGHTED, CENTER, true>(st, x, y, w, 0xFFFFu, kk, lj);
+		mid_step<T, WEIGHTED, CENTER, true, AUX>(st, x, y, w, 0xFFFFu, kk, lj, is_one);
 		return;
 	}
 	unsigned rowmask = 0; // bit = row of the step
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
-		bool ok = isfinite(y[m]) && (r0 + mid_row(kk, m) < hi);
+		bool ok = (AUX || isfinite(y[m])) && (r0 + mid_row(kk, m) < hi);
 		if (WEIGHTED) ok = ok && isfinite(w[m]) && (w[m] > 0.0);
 #pragma unroll
 		for (int I = 0; I < T; ++I) ok = ok && isfinite(x[I][m]);
@@ -151,11 +169,11 @@ __device__ __forceinline__ void mid_process_step(MidState<T> &st, const double (
 	}
 	rowmask = __builtin_amdgcn_readfirstlane(rowmask);
 	if (rowmask == 0u) return;
-	mid_step<T, WEIGHTED, CENTER, false>(st, x, y, w, rowmask, kk, lj);
+	mid_step<T, WEIGHTED, CENTER, false, AUX>(st, x, y, w, rowmask, kk, lj, is_one);
 }
 
-template <int T>
-__device__ __forceinline__ void mid_init_state(MidState<T> &st, const bool (&real)[T], const double *forced_first, int lj) {
+template <int T, bool AUX>
+__device__ __forceinline__ void mid_init_state(MidState<T> &st, const bool (&real)[T], const double *forced_first, int lj, bool is_y) {
 	constexpr int P16 = 16 * T, NT = T * (T + 1) / 2;
 #pragma unroll
 	for (int t = 0; t < NT; ++t) st.acc[t] = mid_dbl4{0.0, 0.0, 0.0, 0.0};
@@ -169,22 +187,68 @@ __device__ __forceinline__ void mid_init_state(MidState<T> &st, const bool (&rea
 #pragma unroll
 		for (int I = 0; I < T; ++I) st.first[I] = real[I] ? forced_first[16 * I + lj] : 0.0;
 		st.first_y = forced_first[P16];
+		if (AUX && is_y) st.first[T - 1] = st.first_y; // the lane that carries y in the last block
 		st.have_first = true;
 	}
 }
 
-// the moment record, layout of accumulate_wide.hip
-template <int T>
-__device__ __forceinline__ void mid_write_record(const MidState<T> &st, const bool (&real)[T], double *rec, int lane) {
+// the moment record, layout of accumulate_wide.hip.  AUX: columns p (y) and p + 1 (ones) of the last block are taken
+// out of the tiles again — their entries ARE X'Wy, the column sums and the y moments — and written where the record
+// keeps those.
+template <int T, bool AUX>
+__device__ __forceinline__ void mid_write_record(const MidState<T> &st, const bool (&real)[T], double *rec, int lane, int p) {
 	constexpr int P16 = 16 * T, NT = T * (T + 1) / 2;
 	const int kk = lane >> 4, lj = lane & 15;
+	{
+		int t = 0;
 #pragma unroll
-	for (int t = 0; t < NT; ++t) {
-		double *tp = rec + (int64_t)t * 256; // tile-major, element (row, col) at row * 16 + col
+		for (int I = 0; I < T; ++I) {
 #pragma unroll
-		for (int r = 0; r < 4; ++r) tp[(kk + 4 * r) * 16 + lj] = st.acc[t][r];
+			for (int J = I; J < T; ++J) {
+				double *tp = rec + (int64_t)t * 256; // tile-major, element (row, col) at row * 16 + col
+#pragma unroll
+				for (int r = 0; r < 4; ++r) {
+					const bool keep = !AUX || (16 * J + lj < p && 16 * I + kk + 4 * r < p);
+					tp[(kk + 4 * r) * 16 + lj] = keep ? st.acc[t][r] : 0.0;
+				}
+				++t;
+			}
+		}
 	}
 	double *vec = rec + (int64_t)NT * 256;
+	double *sc = vec + 4 * P16;
+	if (AUX) {
+		const int cy = p - 16 * (T - 1), co = cy + 1; // columns of y and of the ones inside the last block
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			constexpr int dummy = 0;
+			(void)dummy;
+			const int t = I * T - I * (I - 1) / 2 + (T - 1 - I); // tile (I, T - 1)
+#pragma unroll
+			for (int r = 0; r < 4; ++r) {
+				const int j = 16 * I + kk + 4 * r; // the row of the tile this lane's element r belongs to
+				const double v = j < p ? st.acc[t][r] : 0.0;
+				if (lj == co) vec[0 * P16 + j] = v; // sum w d_j
+				if (lj == cy) vec[1 * P16 + j] = v; // sum w d_j dy
+			}
+			unsigned nc = (st.ncmask >> I) & 1u;
+			nc |= (unsigned)__shfl_xor((int)nc, 16, 64);
+			nc |= (unsigned)__shfl_xor((int)nc, 32, 64);
+			if (lane < 16) {
+				vec[2 * P16 + 16 * I + lane] = real[I] ? st.first[I] : 0.0;
+				vec[3 * P16 + 16 * I + lane] = (real[I] && nc) ? 1.0 : 0.0;
+			}
+		}
+		// diagonal tile of the last block: (cy, co) = sum w dy, (cy, cy) = sum w dy^2, (co, co) = sum w
+		constexpr int td = NT - 1;
+		auto elem = [&](int r) { return r == 0 ? st.acc[td][0] : (r == 1 ? st.acc[td][1] : (r == 2 ? st.acc[td][2] : st.acc[td][3])); };
+		if (lj == co && kk == (cy & 3)) sc[0] = elem(cy >> 2);
+		if (lj == cy && kk == (cy & 3)) sc[1] = elem(cy >> 2);
+		if (lj == co && kk == (co & 3)) sc[2] = elem(co >> 2);
+		if (lane == cy) sc[4] = st.first[T - 1]; // y of the first valid row
+		if (lane == 0) sc[3] = (double)st.cnt;
+		return;
+	}
 #pragma unroll
 	for (int I = 0; I < T; ++I) { // reduce over the four kk groups (lanes l, l^16, l^32, l^48)
 		double a = st.sx[I], b = st.sxy[I];
@@ -206,7 +270,6 @@ __device__ __forceinline__ void mid_write_record(const MidState<T> &st, const bo
 	syy += __shfl_xor(syy, 16, 64); syy += __shfl_xor(syy, 32, 64);
 	sw += __shfl_xor(sw, 16, 64); sw += __shfl_xor(sw, 32, 64);
 	if (lane == 0) {
-		double *sc = vec + 4 * P16;
 		sc[0] = sy;
 		sc[1] = syy;
 		sc[2] = sw;
@@ -217,7 +280,7 @@ __device__ __forceinline__ void mid_write_record(const MidState<T> &st, const bo
 
 // The rows [lo, hi) of one group — or of one segment of a very large group, then with the group's first valid
 // row handed in (`forced_first`: x per column, y at index 16 T) — into one wide moment record at `rec`.
-template <int T, bool WEIGHTED, bool CENTER>
+template <int T, bool WEIGHTED, bool CENTER, bool AUX>
 __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
                                                     const double *forced_first, int lane) {
 	const int p = args.p;
@@ -225,21 +288,24 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 
 	mid_gptr_t col[T];
 	bool real[T]; // column 16 I + lj exists (padding columns read column p - 1 and count as zeros)
+	// AUX: the lane of the last block that carries y (column p) / the ones (column p + 1)
+	const bool is_y = AUX && 16 * (T - 1) + lj == p, is_one = AUX && 16 * (T - 1) + lj == p + 1;
 #pragma unroll
 	for (int I = 0; I < T; ++I) {
 		const int j = 16 * I + lj;
 		real[I] = j < p;
 		col[I] = (mid_gptr_t)(uintptr_t)args.x_table[real[I] ? j : p - 1];
 	}
+	if (is_y) col[T - 1] = (mid_gptr_t)(uintptr_t)args.y;
 	const mid_gptr_t ycol = (mid_gptr_t)(uintptr_t)args.y;
 	const mid_gptr_t wcol = (mid_gptr_t)(uintptr_t)args.w;
 
 	MidState<T> st;
-	mid_init_state<T>(st, real, forced_first, lj);
+	mid_init_state<T, AUX>(st, real, forced_first, lj, is_y);
 
 	// S steps (16 S rows) per loop trip, the next trip's loads in flight: per column a wave asks for 128 S
 	// contiguous bytes at a time (DRAM locality: a single 128-byte line per stream and trip ran at ~4 TB/s)
-	constexpr int S = (T == 1 && !WEIGHTED) ? 2 : 1;
+	constexpr int S = ANOFOX_MID_S;
 	double xn[S][T][4], yn[S][4], wn[S][4];
 	// every load of a trip sits in ONE arm of the (wave-uniform) full / tail branch: a join between the x and the
 	// y loads would make the compiler drain the former before issuing the latter
@@ -250,7 +316,7 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 				const int64_t r = r0 + 16 * q;
 #pragma unroll
 				for (int I = 0; I < T; ++I) load4_full(col[I], r, kk, xn[q][I]);
-				load4_full(ycol, r, kk, yn[q]);
+				if (!AUX) load4_full(ycol, r, kk, yn[q]);
 				if (WEIGHTED) load4_full(wcol, r, kk, wn[q]);
 			}
 		} else {
@@ -259,7 +325,7 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 				const int64_t r = r0 + 16 * q;
 #pragma unroll
 				for (int I = 0; I < T; ++I) load4_tail(col[I], r, kk, hi, xn[q][I]);
-				load4_tail(ycol, r, kk, hi, yn[q]);
+				if (!AUX) load4_tail(ycol, r, kk, hi, yn[q]);
 				if (WEIGHTED) load4_tail(wcol, r, kk, hi, wn[q]);
 			}
 		}
@@ -273,7 +339,8 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 			for (int m = 0; m < 4; ++m) {
 #pragma unroll
 				for (int I = 0; I < T; ++I) xs[q][I][m] = real[I] ? xn[q][I][m] : 0.0;
-				ys[q][m] = yn[q][m];
+				if (AUX) xs[q][T - 1][m] = (real[T - 1] || is_y) ? xn[q][T - 1][m] : (is_one ? 1.0 : 0.0);
+				ys[q][m] = AUX ? 0.0 : yn[q][m];
 				ws[q][m] = WEIGHTED ? wn[q][m] : 1.0;
 			}
 		}
@@ -285,14 +352,14 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 			const double (&x)[T][4] = xs[q];
 			const double (&y)[4] = ys[q];
 			const double (&w)[4] = ws[q];
-			mid_process_step<T, WEIGHTED, CENTER>(st, x, y, w, r0, hi, kk, lj);
+			mid_process_step<T, WEIGHTED, CENTER, AUX>(st, x, y, w, r0, hi, kk, lj, is_one);
 		}
 	}
 
-	mid_write_record<T>(st, real, rec, lane);
+	mid_write_record<T, AUX>(st, real, rec, lane, p);
 }
 
-template <int T, bool WEIGHTED, bool CENTER>
+template <int T, bool WEIGHTED, bool CENTER, bool AUX>
 __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const int lane = threadIdx.x & 63;
 	const int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -302,12 +369,12 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	if (args.seg_table && hi - lo > args.seg_rows) {
 		if (wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments)) return;
 	}
-	mid_accumulate_rows<T, WEIGHTED, CENTER>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), nullptr, lane);
+	mid_accumulate_rows<T, WEIGHTED, CENTER, AUX>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), nullptr, lane);
 }
 
 // One wavefront per registered segment; every segment of a group uses the group's first valid row as its shift,
 // so the wave that completes the last one merges by plain (ordered) sums.
-template <int T, bool WEIGHTED, bool CENTER>
+template <int T, bool WEIGHTED, bool CENTER, bool AUX>
 __global__ __launch_bounds__(256) void accumulate_mid_segments_kernel(WideArgs args) {
 	constexpr int P16 = 16 * T;
 	constexpr int NT = T * (T + 1) / 2;
@@ -322,7 +389,7 @@ __global__ __launch_bounds__(256) void accumulate_mid_segments_kernel(WideArgs a
 	SegBigGroup *b = wseg_big(args.seg_table) + e.slot;
 	const double *ff = wseg_first(args.seg_table, kSegMaxBig, kSegMaxSegments) + (size_t)e.slot * (P16 + 2);
 	double *recs = wseg_records(args.seg_table, T, kSegMaxBig, kSegMaxSegments);
-	mid_accumulate_rows<T, WEIGHTED, CENTER>(args, e.lo, e.hi, recs + (int64_t)v * reclen, ff, lane);
+	mid_accumulate_rows<T, WEIGHTED, CENTER, AUX>(args, e.lo, e.hi, recs + (int64_t)v * reclen, ff, lane);
 	__threadfence(); // this segment's record before the counter
 	int old = 0;
 	if (lane == 0) old = atomicAdd(&b->done, 1);
@@ -349,10 +416,17 @@ hipError_t launch_mid_T(const WideArgs &a, hipStream_t stream) {
 	const bool center = a.fit_intercept != 0;
 	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
 	const dim3 seg_grid((unsigned)((kSegMaxSegments + 3) / 4)); // idle unless some group exceeded seg_rows
+	static const bool aux_on = !(getenv("ANOFOX_MID_AUX") && atoi(getenv("ANOFOX_MID_AUX")) == 0); // A/B switch
+	const bool aux = aux_on && a.p + 2 <= 16 * T; // room for y and the ones in the last block
 #define ANOFOX_MID_LAUNCH(W, C)                                                                                  \
 	do {                                                                                                         \
-		hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C>), grid, block, 0, stream, a);                         \
-		if (a.seg_table) hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C>), seg_grid, block, 0, stream, a); \
+		if (aux) {                                                                                               \
+			hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C, true>), grid, block, 0, stream, a);               \
+			if (a.seg_table) hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C, true>), seg_grid, block, 0, stream, a); \
+		} else {                                                                                                 \
+			hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C, false>), grid, block, 0, stream, a);              \
+			if (a.seg_table) hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C, false>), seg_grid, block, 0, stream, a); \
+		}                                                                                                        \
 	} while (0)
 	if (weighted) {
 		if (center) ANOFOX_MID_LAUNCH(true, true);

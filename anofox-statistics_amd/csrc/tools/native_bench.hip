@@ -81,7 +81,7 @@ int main(int argc, char **argv) {
 	AnofoxHipBatchOptions opt;
 	memset(&opt, 0, sizeof opt);
 	opt.model = weighted ? ANOFOX_HIP_MODEL_WLS : (!strcmp(model, "ridge") ? ANOFOX_HIP_MODEL_RIDGE : ANOFOX_HIP_MODEL_OLS);
-	opt.fit_intercept = true;
+	opt.fit_intercept = !(getenv("NB_NO_INTERCEPT") && atoi(getenv("NB_NO_INTERCEPT"))); // NB_NO_INTERCEPT=1: regression through the origin
 	opt.compute_inference = inference;
 	opt.confidence_level = 0.95;
 	opt.alpha = 1.0;
