@@ -43,9 +43,14 @@ def ctx(pkg):
 
 def _case(seed, wide):
     rng = np.random.default_rng(seed)
-    p = int(rng.integers(9, 41)) if wide else int(rng.integers(1, 9))
-    G = int(rng.integers(1, 24 if wide else 60))
-    sizes = SIZES + [p, p + 1, p + 2, 2 * p + 3, 5 * p]
+    if wide == "very":          # every tile count of accumulate_wide (3..8), groups of several 32-row chunks
+        p = int(rng.integers(41, 129))
+        G = int(rng.integers(1, 7))
+        sizes = [0, 1, 2, p, p + 1, p + 2, p + 33, 2 * p + 3, 3 * p + 64, 3 * p + 97]
+    else:
+        p = int(rng.integers(9, 41)) if wide else int(rng.integers(1, 9))
+        G = int(rng.integers(1, 24 if wide else 60))
+        sizes = SIZES + [p, p + 1, p + 2, 2 * p + 3, 5 * p]
     ns = rng.choice(sizes, size=G)
     offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
     N = int(offs[-1])
@@ -111,10 +116,23 @@ def _run(pkg, ctx, seed, wide):
         Xf = np.where(np.isfinite(X), X, 0.0)
         xbar = np.stack([np.abs(Xf[offs[g]:offs[g + 1]]).mean(0) if offs[g + 1] > offs[g] else np.zeros(p)
                          for g in range(len(offs) - 1)])
-    assert_records_match(core, rcore, p, inf, rinf, what=what, skip_diag_groups=skip, xbar=xbar,
-                         # glmnet scaling: lambda_eff = n alpha / sd_y, and without an intercept sd_y comes from uncentred
-                         # moments (digits lost ~ (mean / sd)^2): 2 of 39 000 cases sit between 1e-9 and 1e-8
-                         coef_rtol=1e-9 if model != "ridge" or kw.get("lambda_scaling") == "raw" else 1e-8)
+    # glmnet scaling: lambda_eff = n alpha / sd_y, and without an intercept sd_y comes from uncentred
+    # moments (digits lost ~ (mean / sd)^2): 2 of 39 000 cases sit between 1e-9 and 1e-8
+    rtol = 1e-9 if model != "ridge" or kw.get("lambda_scaling") == "raw" else 1e-8
+    if wide == "very":
+        # Nearly square designs (fewer than p / 4 residual degrees of freedom) of 41..128 random columns are ill
+        # conditioned whatever the column scales (cond of the column-scaled design 1e3..2e4 for n = p + 2, measured with
+        # scripts/diag_fuzz_seed.py): the refined normal equations reach 1e-9..5e-9 there (4e-12 on the well-determined
+        # groups of the same cases).  They are held to 1e-7; everything else to the ordinary tolerances.
+        G = len(n_obs)
+        near = np.array([g for g in range(G) if rcore[g, p + 5] == 0 and n_obs[g] - n_par[g] < max(8, p // 4)], dtype=np.int64)
+        rest = np.setdiff1d(np.arange(G), near)
+        for idx, tol in ((rest, dict(coef_rtol=rtol)), (near, dict(coef_rtol=1e-7, diag_rtol=1e-4))):
+            if idx.size:
+                assert_records_match(core[idx], rcore[idx], p, None if inf is None else inf[idx], None if rinf is None else rinf[idx],
+                                     what=what, xbar=xbar[idx], skip_diag_groups=[k for k, g in enumerate(idx) if int(g) in set(skip)], **tol)
+        return
+    assert_records_match(core, rcore, p, inf, rinf, what=what, skip_diag_groups=skip, xbar=xbar, coef_rtol=rtol)
 
 
 @pytest.mark.parametrize("seed", range(240 * _SCALE))
@@ -125,6 +143,11 @@ def test_fuzz_narrow(pkg, ctx, seed):
 @pytest.mark.parametrize("seed", range(80 * _SCALE))
 def test_fuzz_wide(pkg, ctx, seed):
     _run(pkg, ctx, 20_000 + seed, wide=True)
+
+
+@pytest.mark.parametrize("seed", range(30 * _SCALE))
+def test_fuzz_very_wide(pkg, ctx, seed):
+    _run(pkg, ctx, 30_000 + seed, wide="very")
 
 
 @pytest.mark.parametrize("seed", range(40 * _SCALE))
