@@ -97,6 +97,11 @@ __device__ __forceinline__ int first_row_of_mask(unsigned m) { // lowest row who
 	return best;
 }
 
+// which kernels stage 16 rows per barrier instead of 32: those that spill with the staging registers of 32 rows
+// (p = 128 without intercept 14.2 -> 13.7 ms, p = 112 weighted 12.4 -> 12.0 ms per 8192 x 4096 rows)
+#ifndef ANOFOX_WIDE_SHORT_CHUNK
+#define ANOFOX_WIDE_SHORT_CHUNK(T, weighted, center) (((T) == 8 && ((weighted) || !(center))) || ((T) == 7 && (weighted)))
+#endif
 template <int T>
 struct WideCfg {
 	static constexpr int NT = T * (T + 1) / 2;             // upper-triangular tiles
@@ -104,9 +109,9 @@ struct WideCfg {
 	static constexpr int OWN = (T + kWaves - 1) / kWaves;  // column blocks owned per wave
 	// rows staged per barrier: the per-chunk costs that are latency, not work (row masks through LDS, issuing the next
 	// chunk's loads, the barrier) are as long as the MFMAs of 16 rows at T = 8, so chunks are 32 rows for every width
-	// (the weighted kernel at T = 8 would spill with the staging registers of 32 rows: 16 there)
-	static constexpr int chunk_rows(bool weighted) { return (T == 8 && weighted) ? 16 : 32; }
-	static constexpr int stride(bool weighted) { return chunk_rows(weighted) + 2; } // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
+	// (except where 32 rows of staging registers spill: ANOFOX_WIDE_SHORT_CHUNK)
+	static constexpr int chunk_rows(bool weighted, bool center = true) { return ANOFOX_WIDE_SHORT_CHUNK(T, weighted, center) ? 16 : 32; }
+	static constexpr int stride(bool weighted, bool center = true) { return chunk_rows(weighted, center) + 2; } // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
 };
 
 // One wave's share of a chunk: the slabs of MFMAs + the VALU side sums.  WAVE is a compile-time constant so
@@ -123,7 +128,7 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
                                               dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
                                               double (&sxy)[WideCfg<T>::OWN], double (&dmax)[WideCfg<T>::OWN], unsigned &ncmask,
                                               double &sy, double &syy, double &sw, Between &&between) {
-	constexpr int kChunkRows = WideCfg<T>::chunk_rows(WEIGHTED), kLdsStride = WideCfg<T>::stride(WEIGHTED), OWN = WideCfg<T>::OWN;
+	constexpr int kChunkRows = WideCfg<T>::chunk_rows(WEIGHTED, CENTER), kLdsStride = WideCfg<T>::stride(WEIGHTED, CENTER), OWN = WideCfg<T>::OWN;
 	const int k = lane >> 4;
 	const int i = lane & 15;
 	// without an intercept the image holds raw values; the constant-column test still compares with the first valid row
@@ -216,7 +221,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
                                                           const double *forced_first) {
 	static_assert(!FAST || (!WEIGHTED && CENTER), "the speculative version exists for the unweighted fit with an intercept");
 	using Cfg = WideCfg<T>;
-	constexpr int kChunkRows = Cfg::chunk_rows(WEIGHTED), kLdsStride = Cfg::stride(WEIGHTED);
+	constexpr int kChunkRows = Cfg::chunk_rows(WEIGHTED, CENTER), kLdsStride = Cfg::stride(WEIGHTED, CENTER);
 	constexpr bool kWideChunk = kChunkRows == 32;
 	constexpr unsigned kFullMask = kWideChunk ? 0xffffffffu : 0xffffu;
 	constexpr int P16 = 16 * T;
@@ -815,7 +820,7 @@ hipError_t launch_accumulate_wide_T(const WideArgs &a, hipStream_t stream) {
 	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
 	const bool center = a.fit_intercept != 0;
 	const int ncol_pad = wide_ncol_pad(a.p, weighted);
-	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::stride(weighted) * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
+	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::stride(weighted, center) * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
 	const dim3 grid((unsigned)a.n_groups), block(kThreads);
 	const dim3 seg_grid((unsigned)kWideSegMaxSegments); // idle unless some group exceeded seg_rows
 #define ANOFOX_WIDE_LAUNCH(W, C)                                                                                  \
