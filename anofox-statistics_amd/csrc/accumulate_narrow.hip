@@ -31,6 +31,9 @@ namespace anofox {
 
 typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
 
+#ifndef ANOFOX_NARROW_NT
+#define ANOFOX_NARROW_NT false
+#endif
 // 16-byte streaming load; NT = non-temporal (measured: no gain over the default policy, kept for experiments)
 template <bool NT>
 __device__ __forceinline__ dbl2u load2(const double *p) {
@@ -59,6 +62,13 @@ __device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t l
 	bool have_first = false;
 	int cnt = 0;
 	unsigned mask = 0;
+	// CENTER: the constant-column test (|x - x_first| < 1e-10 on every valid row, ols.rs:76-87) keeps the largest
+	// |d| per column and lane — d is already there, and 0 on rows that do not take part — and is decided once per
+	// group; a ballot per column and tile (the version without intercept below) cost 8 vector + 4 scalar
+	// instructions per column and tile, a fifth of the kernel's instructions
+	double dmax[P];
+#pragma unroll
+	for (int j = 0; j < P; ++j) dmax[j] = 0.0;
 
 	// the loads of tile t + 1 are issued before the arithmetic of tile t (PREFETCH), so that a wave always has
 	// one tile of loads in flight; all loads of a tile sit in one arm of the (wave-uniform) full / ragged branch
@@ -68,17 +78,17 @@ __device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t l
 		if (base + 128 <= hi) { // full tile: one 16-byte load per column
 #pragma unroll
 			for (int j = 0; j < P; ++j) {
-				const dbl2u v = load2<false>(args.x[j] + r0);
+				const dbl2u v = load2<ANOFOX_NARROW_NT>(args.x[j] + r0);
 				n0[j] = v.x;
 				n1[j] = v.y;
 			}
 			{
-				const dbl2u v = load2<false>(args.y + r0);
+				const dbl2u v = load2<ANOFOX_NARROW_NT>(args.y + r0);
 				n0[P] = v.x;
 				n1[P] = v.y;
 			}
 			if (WEIGHTED) {
-				const dbl2u v = load2<false>(args.w + r0);
+				const dbl2u v = load2<ANOFOX_NARROW_NT>(args.w + r0);
 				nw0 = v.x;
 				nw1 = v.y;
 			}
@@ -142,11 +152,13 @@ __device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t l
 		cnt += __popcll(b0) + __popcll(b1);
 
 		// constant-column test against the first valid row: |x - x_first| >= 1e-10 anywhere -> not constant
+		if (!CENTER) {
 #pragma unroll
-		for (int j = 0; j < P; ++j) {
-			const unsigned long long nc = __ballot((v0 && !(fabs(z0[j] - first[j]) < 1e-10)) ||
-			                                       (v1 && !(fabs(z1[j] - first[j]) < 1e-10)));
-			mask |= (nc != 0ull) ? (1u << j) : 0u;
+			for (int j = 0; j < P; ++j) {
+				const unsigned long long nc = __ballot((v0 && !(fabs(z0[j] - first[j]) < 1e-10)) ||
+				                                       (v1 && !(fabs(z1[j] - first[j]) < 1e-10)));
+				mask |= (nc != 0ull) ? (1u << j) : 0u;
+			}
 		}
 
 		double d0[Z], d1[Z];
@@ -155,6 +167,10 @@ __device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t l
 			const double sh = CENTER ? first[a] : 0.0;
 			d0[a] = v0 ? z0[a] - sh : 0.0;
 			d1[a] = v1 ? z1[a] - sh : 0.0;
+		}
+		if (CENTER) {
+#pragma unroll
+			for (int j = 0; j < P; ++j) dmax[j] = fmax(dmax[j], fmax(fabs(d0[j]), fabs(d1[j])));
 		}
 		const double ww0 = v0 ? w0 : 0.0;
 		const double ww1 = v1 ? w1 : 0.0;
@@ -173,6 +189,10 @@ __device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t l
 		}
 	}
 
+	if (CENTER) {
+#pragma unroll
+		for (int j = 0; j < P; ++j) mask |= (__ballot(!(dmax[j] < 1e-10)) != 0ull) ? (1u << j) : 0u;
+	}
 	// ---- cross-lane reduction: transposing butterfly, moment k lands on lane k ----
 	double v[64];
 #pragma unroll
