@@ -9,6 +9,8 @@
 //   upper triangle  : L^-1 transposed (only when inference is requested), one thread per column
 // Queued groups (small pivot ratio or RSS/TSS < 1e-7) get the same iterative-refinement passes as in
 // solve_narrow.hip: MODE 1 = b += (X'WX)^-1 X'Wr from residual_grad_wide_kernel, MODE 2 = final statistics.
+#include <stdlib.h>
+
 #include "common.h"
 #include <mutex>
 #include "device_math.h"
@@ -74,12 +76,22 @@ __device__ __forceinline__ double rl_f64(double v, int src_lane) {
 	                        __builtin_amdgcn_readlane(__double2loint(v), src_lane));
 }
 
-// sum over the 256 threads of a workgroup; every thread gets the result.  `slot` = 4 doubles of LDS scratch.
+// NTHR = threads of the workgroup that solves one group: 256 (four waves share the group), or 64 for the narrower
+// designs (p <= 64), where one wave per group and several groups per CU beat four waves that mostly wait for the
+// single-wave phases of the factorisation.
+// sum over the threads of a workgroup; every thread gets the result.  `slot` = 4 doubles of LDS scratch.
+template <int NTHR>
 __device__ __forceinline__ double block_sum(double v, double *slot, int tid) {
 	for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+	if (NTHR == 64) {
+		__syncthreads(); // (callers count on the barrier between what they wrote to LDS before and read after)
+		return v;
+	}
 	if ((tid & 63) == 0) slot[tid >> 6] = v;
 	__syncthreads();
-	const double tot = slot[0] + slot[1] + slot[2] + slot[3];
+	double tot = slot[0];
+#pragma unroll
+	for (int w = 1; w < NTHR / 64; ++w) tot += slot[w];
 	__syncthreads();
 	return tot;
 }
@@ -105,6 +117,7 @@ __device__ __forceinline__ double getW(const WideLds &l, int kk, int jj) {
 
 // Blocked right-looking Cholesky of the augmented matrix in LDS (block size 16), deactivating constant and
 // aliased columns in place.  Returns (to every thread) the smallest accepted pivot ratio.
+template <int NTHR>
 __device__ double blocked_cholesky(const WideLds &l, int tid) {
 	const int P16 = l.P16, LD = l.LD, T = l.T;
 	double *A = l.A;
@@ -166,8 +179,8 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 #endif
 		// (b) panel: rows below the block (and the y row): X := X L_kk^-T, one thread per row
 		const int n_below = P16 - k0 - 16 + 1;
-		if (tid < n_below) {
-			const int i = k0 + 16 + tid;
+		for (int rb = tid; rb < n_below; rb += NTHR) {
+			const int i = k0 + 16 + rb;
 			double x[16];
 #pragma unroll
 			for (int c = 0; c < 16; ++c) x[c] = A[(size_t)i * LD + k0 + c];
@@ -195,7 +208,7 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 			const int nb = mrem >> 4;
 			const int ntri = nb * (nb + 1) / 2;
 			const int fr = lane & 15, fk = lane >> 4;
-			for (int t = wave; t < ntri; t += 4) {
+			for (int t = wave; t < ntri; t += NTHR / 64) {
 				int a16, b16;
 				tri_decode(t, a16, b16);
 				const int i0 = k0 + 16 + 16 * a16, c0 = k0 + 16 + 16 * b16;
@@ -211,7 +224,7 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 			}
 		}
 		// y row: 1 x 4 tiles
-		for (int b4 = tid; b4 < nt; b4 += 256) {
+		for (int b4 = tid; b4 < nt; b4 += NTHR) {
 			const int c0 = k0 + 16 + 4 * b4;
 			double acc[4] = {0.0, 0.0, 0.0, 0.0};
 			for (int m = 0; m < 16; ++m) {
@@ -234,11 +247,12 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 // W = L^-1, right-looking by 16-row blocks, solving L W = I:  block row kb of W is finished by a triangular
 // solve with L_kk (one thread per column), then the rows below receive the rank-16 update
 // RHS[i][j] -= sum_m L[i][k0+m] W[k0+m][j] in 4x4 register tiles.  W[i][j], i > j, lives at A[j][i].
+template <int NTHR>
 __device__ void blocked_tri_inverse(const WideLds &l, int tid) {
 	const int P16 = l.P16, LD = l.LD, T = l.T;
 	double *A = l.A;
 	// RHS = I: clear the strictly upper triangle (the transposed strictly lower part of the RHS)
-	for (int idx = tid; idx < P16 * P16; idx += 256) {
+	for (int idx = tid; idx < P16 * P16; idx += NTHR) {
 		const int j = idx / P16, i = idx - j * P16;
 		if (i > j) A[(size_t)j * LD + i] = 0.0;
 	}
@@ -246,8 +260,7 @@ __device__ void blocked_tri_inverse(const WideLds &l, int tid) {
 	for (int kb = 0; kb < T; ++kb) {
 		const int k0 = 16 * kb;
 		// (i) block row kb: x = L_kk^-1 rhs, one thread per column j <= k0 + 15
-		if (tid < k0 + 16) {
-			const int j = tid;
+		for (int j = tid; j < k0 + 16; j += NTHR) {
 			double x[16];
 #pragma unroll
 			for (int r = 0; r < 16; ++r) {
@@ -271,7 +284,7 @@ __device__ void blocked_tri_inverse(const WideLds &l, int tid) {
 			const int nrb = (P16 - k0 - 16) >> 4, ncb = (k0 + 16) >> 4;
 			const int lane = tid & 63, wave = tid >> 6;
 			const int fr = lane & 15, fk = lane >> 4;
-			for (int t = wave; t < nrb * ncb; t += 4) {
+			for (int t = wave; t < nrb * ncb; t += NTHR / 64) {
 				const int a16 = t / ncb, b16 = t - a16 * ncb;
 				const int i0 = k0 + 16 + 16 * a16, j0 = 16 * b16;
 				const bool inblock = j0 >= k0; // columns of the current block: W's block is lower triangular
@@ -294,6 +307,7 @@ __device__ void blocked_tri_inverse(const WideLds &l, int tid) {
 
 // beta = L^-T z by 16-column blocks from the bottom: wave 0 finishes the 16 unknowns of a block with readlane
 // broadcasts, then every thread removes their contribution from the rows above.  zv is consumed, bv := beta.
+template <int NTHR>
 __device__ void blocked_back_solve(const WideLds &l, int tid) {
 	const int LD = l.LD, T = l.T;
 	const double *A = l.A;
@@ -317,7 +331,7 @@ __device__ void blocked_back_solve(const WideLds &l, int tid) {
 			if (lane < 16) l.bv[k0 + r] = br;
 		}
 		__syncthreads();
-		for (int i = tid; i < k0; i += 256) {
+		for (int i = tid; i < k0; i += NTHR) {
 			double zi = l.zv[i];
 #pragma unroll
 			for (int m = 0; m < 16; ++m) zi -= A[(size_t)(k0 + m) * LD + i] * l.bv[k0 + m];
@@ -330,37 +344,43 @@ __device__ void blocked_back_solve(const WideLds &l, int tid) {
 // Augmented moment matrix -> LDS, lower triangle; centred when an intercept is fitted; padding rows / columns zero.
 // The record is tile-major (256 contiguous doubles per 16x16 tile): thread t reads element t of each tile.
 // Needs l.sv (column sums) in place.
+template <int NTHR>
 __device__ void load_moment_matrix(const WideLds &l, const double *rec, int p, bool icpt, double lam, double sw, double sy, int tid) {
 	const int T = l.T, P16 = l.P16, LD = l.LD;
 	const int NT = T * (T + 1) / 2;
 	const double *vec = rec + (int64_t)NT * 256;
 	double *A = l.A;
 	const double inv_sw = 1.0 / sw;
-	const int tr = tid >> 4, tc = tid & 15; // element (tr, tc) of an upper-triangular tile = M[16I+tr][16J+tc]
-	// four tiles per trip so that four independent 2 KiB loads are in flight (the record comes from HBM / L2)
+	// four tiles per trip so that four independent 2 KiB loads are in flight (the record comes from HBM / L2); a
+	// 64-thread workgroup takes the four quarters of a tile one after the other
 	for (int t0 = 0; t0 < NT; t0 += 4) {
-		double v4[4];
+#pragma unroll 1
+		for (int e0 = 0; e0 < 256; e0 += NTHR) {
+			const int el = e0 + tid;
+			const int tr = el >> 4, tc = el & 15; // element (tr, tc) of an upper-triangular tile = M[16I+tr][16J+tc]
+			double v4[4];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) v4[u] = rec[(int64_t)((t0 + u < NT) ? t0 + u : NT - 1) * 256 + tid];
+			for (int u = 0; u < 4; ++u) v4[u] = rec[(int64_t)((t0 + u < NT) ? t0 + u : NT - 1) * 256 + el];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const int tile = t0 + u;
-			if (tile >= NT) break;
-			int I = 0;
-			while ((I + 1) * T - (I + 1) * I / 2 <= tile) ++I; // first tile of block row I+1 is past `tile`
-			const int J = I + (tile - (I * T - I * (I - 1) / 2));
-			const int jj = 16 * I + tr, ii = 16 * J + tc; // jj <= ii except inside diagonal tiles
-			if (jj > ii) continue;
-			double v = 0.0;
-			if (ii < p) {
-				v = v4[u];
-				if (icpt) v -= l.sv[ii] * l.sv[jj] * inv_sw;
-				if (ii == jj) v += lam;
+			for (int u = 0; u < 4; ++u) {
+				const int tile = t0 + u;
+				if (tile >= NT) break;
+				int I = 0;
+				while ((I + 1) * T - (I + 1) * I / 2 <= tile) ++I; // first tile of block row I+1 is past `tile`
+				const int J = I + (tile - (I * T - I * (I - 1) / 2));
+				const int jj = 16 * I + tr, ii = 16 * J + tc; // jj <= ii except inside diagonal tiles
+				if (jj > ii) continue;
+				double v = 0.0;
+				if (ii < p) {
+					v = v4[u];
+					if (icpt) v -= l.sv[ii] * l.sv[jj] * inv_sw;
+					if (ii == jj) v += lam;
+				}
+				A[(size_t)ii * LD + jj] = v;
 			}
-			A[(size_t)ii * LD + jj] = v;
 		}
 	}
-	for (int j = tid; j < P16; j += 256) { // y row: centred Sxy
+	for (int j = tid; j < P16; j += NTHR) { // y row: centred Sxy
 		double v = 0.0;
 		if (j < p) {
 			const double q = vec[1 * P16 + j];
@@ -373,8 +393,8 @@ __device__ void load_moment_matrix(const WideLds &l, const double *rec, int p, b
 // OCC = workgroups per CU the register budget is cut for: 2 where the LDS matrix leaves room for two (p <= 88; the
 // spills that costs are cheaper than an idle half of the CU: solve -26 % at p = 64), 1 for the widest designs, whose
 // 134 KB matrix fills the CU's LDS anyway (there the tighter budget only adds spills: +22..47 %).
-template <int MODE, int OCC>
-__global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
+template <int MODE, int OCC, int NTHR>
+__global__ __launch_bounds__(NTHR, OCC) void solve_wide_kernel(WideArgs args) {
 	extern __shared__ double sm[];
 	const int p = args.p;
 	const int tid = threadIdx.x;
@@ -400,9 +420,9 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 		// a record whose fit failed (or has no inference block): everything NaN, status in the last slot
 		auto write_null = [&](int status, bool core_too) {
 			if (core_too)
-				for (int k = tid; k < p + 6; k += 256) core[k] = (k == p + 5) ? (double)status : nan64w();
+				for (int k = tid; k < p + 6; k += NTHR) core[k] = (k == p + 5) ? (double)status : nan64w();
 			if (inf)
-				for (int k = tid; k < 5 * p + 2; k += 256) inf[k] = nan64w();
+				for (int k = tid; k < 5 * p + 2; k += NTHR) inf[k] = nan64w();
 		};
 
 		__syncthreads(); // the previous item's LDS contents are dead
@@ -418,14 +438,14 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 		}
 
 		int mine = 0;
-		for (int j = tid; j < P16; j += 256) {
+		for (int j = tid; j < P16; j += NTHR) {
 			const int a = (j < p && vec[3 * P16 + j] != 0.0) ? 1 : 0;
 			l.active[j] = a;
 			l.sv[j] = j < p ? vec[0 * P16 + j] : 0.0;
 			l.fx[j] = j < p ? vec[2 * P16 + j] : 0.0;
 			mine += a;
 		}
-		const int peff = (int)block_sum((double)mine, l.red + 12, tid);
+		const int peff = (int)block_sum<NTHR>((double)mine, l.red + 12, tid);
 
 		const double cyy_c = syy - sy * sy / sw;
 		const double ymean = (icpt ? first_y : 0.0) + sy / sw;
@@ -434,7 +454,7 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 				write_null(ANOFOX_ERROR_INSUFFICIENT_DATA, true);
 			} else {
 				write_null(0, false); // inference: None
-				for (int k = tid; k < p + 6; k += 256) {
+				for (int k = tid; k < p + 6; k += NTHR) {
 					double v = nan64w();
 					if (k == p) v = ymean;
 					else if (k == p + 1 || k == p + 2 || k == p + 5) v = 0.0;
@@ -457,28 +477,28 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 		}
 		const double tss = icpt ? cyy_c : syy;
 
-		load_moment_matrix(l, rec, p, icpt, lam, sw, sy, tid);
+		load_moment_matrix<NTHR>(l, rec, p, icpt, lam, sw, sy, tid);
 		__syncthreads();
-		for (int j = tid; j < P16; j += 256) l.diag0[j] = j < p ? A[(size_t)j * LD + j] : 1.0;
+		for (int j = tid; j < P16; j += NTHR) l.diag0[j] = j < p ? A[(size_t)j * LD + j] : 1.0;
 		// blocked_cholesky starts with a barrier
 		SOLVE_STAMP(1);
-		const double min_ratio = blocked_cholesky(l, tid);
+		const double min_ratio = blocked_cholesky<NTHR>(l, tid);
 		SOLVE_STAMP(2);
 		// W = L^-1 is needed for the standard errors (diag of the inverse) and for the refinement passes; the
 		// plain primary solve only needs beta = L^-T z
 		const bool need_w = (MODE != MODE_PRIMARY) || (inf != nullptr);
-		for (int j = tid; j < P16; j += 256) l.zv[j] = A[(size_t)P16 * LD + j]; // z = y row
+		for (int j = tid; j < P16; j += NTHR) l.zv[j] = A[(size_t)P16 * LD + j]; // z = y row
 		__syncthreads();
 		if (!need_w) {
-			blocked_back_solve(l, tid);
+			blocked_back_solve<NTHR>(l, tid);
 			SOLVE_STAMP(3);
 		} else {
-			blocked_tri_inverse(l, tid);
+			blocked_tri_inverse<NTHR>(l, tid);
 			SOLVE_STAMP(3);
 			if (MODE == MODE_UPDATE) {
 				// gradient of the (penalised) objective at the record's coefficients, centred: zv := W gc
 				const double gs = rvec[1];
-				for (int j = tid; j < P16; j += 256) {
+				for (int j = tid; j < P16; j += NTHR) {
 					double gj = 0.0;
 					if (j < p && l.live[j]) {
 						gj = rvec[2 + j];
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 					l.bv[j] = gj;
 				}
 				__syncthreads();
-				for (int i = tid; i < P16; i += 256) {
+				for (int i = tid; i < P16; i += NTHR) {
 					double u = 0.0;
 					for (int j = 0; j <= i; ++j) u = fma(getW(l, i, j), l.bv[j], u);
 					l.zv[i] = u;
@@ -496,7 +516,7 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 				__syncthreads();
 			}
 			// bv_j = sum_{i >= j} W[i][j] zv_i  (= beta, or the refinement step delta);  diag_j = sum_i W[i][j]^2
-			for (int j = tid; j < P16; j += 256) {
+			for (int j = tid; j < P16; j += NTHR) {
 				const double wjj = l.linv[j];
 				double bj = wjj * l.zv[j], dj = wjj * wjj;
 				for (int i = j + 1; i < P16; ++i) {
@@ -514,7 +534,7 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 		SOLVE_STAMP(4);
 		// block sums: rank, b'c, b'b, mean correction of the intercept, |z|^2
 		double rk = 0.0, bc = 0.0, bb = 0.0, xb = 0.0, zz = 0.0;
-		for (int j = tid; j < p; j += 256) {
+		for (int j = tid; j < p; j += NTHR) {
 			if (l.live[j]) {
 				rk += 1.0;
 				const double q = vec[1 * P16 + j];
@@ -527,14 +547,14 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 				zz += zj * zj;
 			}
 		}
-		const double rk_t = block_sum(rk, l.red + 12, tid);
-		const double bc_t = block_sum(bc, l.red + 12, tid);
-		const double bb_t = block_sum(bb, l.red + 12, tid);
-		const double xb_t = block_sum(xb, l.red + 12, tid);
-		const double zz_t = block_sum(zz, l.red + 12, tid);
+		const double rk_t = block_sum<NTHR>(rk, l.red + 12, tid);
+		const double bc_t = block_sum<NTHR>(bc, l.red + 12, tid);
+		const double bb_t = block_sum<NTHR>(bb, l.red + 12, tid);
+		const double xb_t = block_sum<NTHR>(xb, l.red + 12, tid);
+		const double zz_t = block_sum<NTHR>(zz, l.red + 12, tid);
 		const int rank = (int)rk_t;
 		if (MODE == MODE_UPDATE) { // only the coefficients change in this pass
-			for (int k = tid; k <= p; k += 256) {
+			for (int k = tid; k <= p; k += NTHR) {
 				if (k < p) core[k] = l.live[k] ? l.bv[k] : nan64w();
 				else core[k] = icpt ? ymean - xb_t : nan64w();
 			}
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 		const double r2 = 1.0 - rss / tss;
 		const double fstat = ((tss - rss) / dfm) / (rss / df);
 
-		for (int k = tid; k < p + 6; k += 256) {
+		for (int k = tid; k < p + 6; k += NTHR) {
 			double v;
 			if (k < p) v = l.live[k] ? l.bv[k] : nan64w();
 			else if (k == p) v = icpt ? ymean - xb_t : nan64w();
@@ -573,7 +593,7 @@ __global__ __launch_bounds__(256, OCC) void solve_wide_kernel(WideArgs args) {
 			// inference_wide_finish_kernel (the special functions' ~240-VGPR call tree stays out of this kernel, which
 			// then fits 2-4 workgroups per CU instead of one).  df travels in the F p-value's slot.
 			const double sigma2 = rss / df;
-			for (int j = tid; j < p; j += 256) inf[j] = l.live[j] ? sqrt(sigma2 * l.diag0[j]) : nan64w();
+			for (int j = tid; j < p; j += NTHR) inf[j] = l.live[j] ? sqrt(sigma2 * l.diag0[j]) : nan64w();
 			if (tid == 0) {
 				inf[5 * p] = fstat;
 				inf[5 * p + 1] = df;
@@ -858,14 +878,14 @@ __global__ __launch_bounds__(256) void hc_wide_kernel(WideArgs args) {
 			l.fx[j] = j < p ? vec[2 * P16 + j] : 0.0;
 			mine += (j < p && !isnan(core[j])) ? 1.0 : 0.0;
 		}
-		const int rank = (int)block_sum(mine, l.red + 12, tid);
+		const int rank = (int)block_sum<256>(mine, l.red + 12, tid);
 		if (rank == 0) continue; // intercept-only fit: inference is None (ols.rs:101-130)
 
-		load_moment_matrix(l, rec, p, icpt, 0.0, sw, sy, tid);
+		load_moment_matrix<256>(l, rec, p, icpt, 0.0, sw, sy, tid);
 		__syncthreads();
 		for (int j = tid; j < P16; j += 256) l.diag0[j] = j < p ? A[(size_t)j * LD + j] : 1.0;
-		(void)blocked_cholesky(l, tid);
-		blocked_tri_inverse(l, tid);
+		(void)blocked_cholesky<256>(l, tid);
+		blocked_tri_inverse<256>(l, tid);
 		// S^-1 = W'W: entry (i, j), i >= j, = sum_{k >= i} W[k][i] W[k][j]; W[k][i] (k > i) sits at A[i][k], so
 		// these are dot products of row tails of the upper triangle; the results go to the (dead) lower triangle
 		for (int idx = tid; idx < P16 * (P16 + 1) / 2; idx += 256) {
@@ -889,7 +909,7 @@ __global__ __launch_bounds__(256) void hc_wide_kernel(WideArgs args) {
 			l.bv[j] = xb;
 			yc = fma(bj, xb, yc);
 		}
-		const double ycen = (icpt ? core[p] : 0.0) + block_sum(yc, l.red + 12, tid); // fitted value at x = xbar
+		const double ycen = (icpt ? core[p] : 0.0) + block_sum<256>(yc, l.red + 12, tid); // fitted value at x = xbar
 		const double df = cnt - (double)(rank + (icpt ? 1 : 0));
 		const double hc1 = cnt / df;
 		const double h0 = icpt ? 1.0 / sw : 0.0;
@@ -961,24 +981,25 @@ hipError_t launch_inference_wide_finish(const WideArgs &a, hipStream_t stream) {
 	return hipGetLastError();
 }
 
-template <int OCC>
+template <int OCC, int NTHR>
 hipError_t launch_solve_wide_occ(const WideArgs &a, int mode, size_t lds, hipStream_t stream) {
 	static std::once_flag attr_once; // contexts of several host threads launch concurrently
 	std::call_once(attr_once, [] {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_PRIMARY, OCC>),
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_PRIMARY, OCC, NTHR>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_UPDATE, OCC>),
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_UPDATE, OCC, NTHR>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_FINAL, OCC>),
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_wide_kernel<MODE_FINAL, OCC, NTHR>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 	});
+	const unsigned few = 256 * (256 / NTHR); // grid of the refinement modes (they loop over the queue)
 	if (mode == MODE_PRIMARY) {
 		const unsigned grid = (unsigned)(a.n_groups < 65535 * 16 ? a.n_groups : 65535 * 16);
-		hipLaunchKernelGGL((solve_wide_kernel<MODE_PRIMARY, OCC>), dim3(grid), dim3(256), lds, stream, a);
+		hipLaunchKernelGGL((solve_wide_kernel<MODE_PRIMARY, OCC, NTHR>), dim3(grid), dim3(NTHR), lds, stream, a);
 	} else if (mode == MODE_UPDATE) {
-		hipLaunchKernelGGL((solve_wide_kernel<MODE_UPDATE, OCC>), dim3(256), dim3(256), lds, stream, a);
+		hipLaunchKernelGGL((solve_wide_kernel<MODE_UPDATE, OCC, NTHR>), dim3(few), dim3(NTHR), lds, stream, a);
 	} else {
-		hipLaunchKernelGGL((solve_wide_kernel<MODE_FINAL, OCC>), dim3(256), dim3(256), lds, stream, a);
+		hipLaunchKernelGGL((solve_wide_kernel<MODE_FINAL, OCC, NTHR>), dim3(few), dim3(NTHR), lds, stream, a);
 	}
 	return hipGetLastError();
 }
@@ -986,7 +1007,17 @@ hipError_t launch_solve_wide_occ(const WideArgs &a, int mode, size_t lds, hipStr
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
 	const size_t lds = solve_wide_lds_bytes(a.p);
-	return 2 * lds <= (size_t)160 * 1024 ? launch_solve_wide_occ<2>(a, mode, lds, stream) : launch_solve_wide_occ<1>(a, mode, lds, stream);
+	// p <= 96 (two or more groups' matrices fit a CU's LDS): one wave per group.  50 000 x 1000 rows, solve without /
+	// with inference: p = 33 5.78 / 9.94 -> 2.18 / 3.30 ms, p = 64 7.20 / 12.4 -> 2.92 / 4.56 ms; 20 000 groups: p = 80
+	// 3.79 / 6.73 -> 3.32 / 5.03 ms, p = 96 4.41 / 7.65 -> 4.14 / 6.27 ms; slower from p = 97 (one group per CU:
+	// p = 112 6.24 / 8.63 -> 9.87 / 15.1 ms; two waves per group there: 7.34 / 10.4 ms).  With the register budget
+	// cut for two waves per SIMD (ANOFOX_SOLVE_WAVE=2) the spills cost more than the occupancy gains (p = 33:
+	// 2.47 / 4.67 ms).  ANOFOX_SOLVE_WAVE=0: four waves per group everywhere.
+	static const int wave_mode = getenv("ANOFOX_SOLVE_WAVE") ? atoi(getenv("ANOFOX_SOLVE_WAVE")) : 1;
+	static const int wave_max_t = getenv("ANOFOX_SOLVE_WAVE_T") ? atoi(getenv("ANOFOX_SOLVE_WAVE_T")) : 6;
+	if (wave_mode && wide_tiles(a.p) <= wave_max_t)
+		return wave_mode == 2 ? launch_solve_wide_occ<2, 64>(a, mode, lds, stream) : launch_solve_wide_occ<1, 64>(a, mode, lds, stream);
+	return 2 * lds <= (size_t)160 * 1024 ? launch_solve_wide_occ<2, 256>(a, mode, lds, stream) : launch_solve_wide_occ<1, 256>(a, mode, lds, stream);
 }
 
 #ifdef ANOFOX_SOLVE_STAMPS
