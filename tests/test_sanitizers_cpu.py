@@ -1,7 +1,10 @@
 """CPU tier: AddressSanitizer + UndefinedBehaviorSanitizer builds of the oracle's C code and of the library's host
 code (GPU ASan is not available on this pool).  tests/tools/Makefile compiles csrc/host_api.hip and
 csrc/agg_state.hip as plain C++ with g++ (kernel launchers stubbed: nothing reaches them without a GPU) and
-oracle/anofox_oracle.c with gcc, each with a driver; a non-zero exit or any sanitizer report fails the test."""
+oracle/anofox_oracle.c with gcc, each with a driver; the DuckDB shim's arena (duckdb_shim/agg_arena.hpp) runs against a
+recording mock of the C ABI (tests/tools/arena_sanitize.cpp: Update vectors of three threads, flushes, Combine, Finalize,
+streaming and host-buffered mode; every accepted row must reach the right slot in the reference's order).  A non-zero
+exit or any sanitizer report fails the test."""
 import os
 import shutil
 import subprocess
@@ -21,7 +24,7 @@ def built():
     return OUT
 
 
-@pytest.mark.parametrize("unit", ["oracle_sanitize", "host_sanitize"])
+@pytest.mark.parametrize("unit", ["oracle_sanitize", "host_sanitize", "arena_sanitize"])
 def test_sanitizer_unit(built, unit):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     env.pop("LD_PRELOAD", None)
