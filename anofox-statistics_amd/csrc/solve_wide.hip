@@ -142,23 +142,41 @@ __device__ double blocked_cholesky(const WideLds &l, int tid) {
 			const double d0 = l.diag0[k0 + r];
 			const double d0inv = 1.0 / d0;
 			const int act = l.active[k0 + r];
-#pragma unroll
-			for (int j = 0; j < 16; ++j) {
-				// The pivot is wave-uniform, but it is deliberately laundered into a vector register: with a scalar
-				// condition the compiler emits ~8 scalar branches per pivot, with a vector one plain selects.
+			// Pivot j: the pivot is wave-uniform, but it is deliberately laundered into a vector register: with a scalar
+			// condition the compiler emits ~8 scalar branches per pivot, with a vector one plain selects.
+			struct Pivot {
+				bool ok;
+				double inv, ljj, ratio;
+			};
+			auto pivot = [&](int j) {
 				double d = rl_f64(arow[j], j);
 				double dj0 = rl_f64(d0, j);
 				int actj = __builtin_amdgcn_readlane(act, j);
 				asm volatile("" : "+v"(d), "+v"(dj0), "+v"(actj));
-				const bool ok = (actj != 0) && (d > kAliasTolW * dj0) && (d > 0.0);
-				const double inv0 = rsqrt(ok ? d : 1.0);
-				const double inv = ok ? inv0 : 0.0;
-				const double ljj = ok ? d * inv0 : 1.0;
-				min_ratio = ok ? fmin(min_ratio, d * rl_f64(d0inv, j)) : min_ratio;
+				Pivot pv;
+				pv.ok = (actj != 0) && (d > kAliasTolW * dj0) && (d > 0.0);
+				const double inv0 = rsqrt(pv.ok ? d : 1.0);
+				pv.inv = pv.ok ? inv0 : 0.0;
+				pv.ljj = pv.ok ? d * inv0 : 1.0;
+				pv.ratio = d * rl_f64(d0inv, j);
+				return pv;
+			};
+			// The chain pivot -> rsqrt -> scale of step j + 1 needs only the FIRST update of step j (column j + 1): it is
+			// started right behind that update, and the other 14 - j updates of step j run while its rsqrt is under way.
+			Pivot pv = pivot(0);
+#pragma unroll
+			for (int j = 0; j < 16; ++j) {
+				const bool ok = pv.ok;
+				const double inv = pv.inv, ljj = pv.ljj;
+				min_ratio = ok ? fmin(min_ratio, pv.ratio) : min_ratio;
 				const double lrj = (r > j) ? arow[j] * inv : 0.0; // aliased / constant: column := 0
 				arow[j] = (r == j) ? ljj : lrj;
+				if (j + 1 < 16) {
+					arow[j + 1] -= lrj * rl_f64(lrj, j + 1); // L[r][j] * L[j + 1][j]
+					pv = pivot(j + 1);
+				}
 #pragma unroll
-				for (int c = j + 1; c < 16; ++c) arow[c] -= lrj * rl_f64(lrj, c); // L[r][j] * L[c][j]
+				for (int c = j + 2; c < 16; ++c) arow[c] -= lrj * rl_f64(lrj, c); // L[r][j] * L[c][j]
 				if (lane == j) {
 					l.ldiag[k0 + j] = ljj;
 					l.linv[k0 + j] = inv;
