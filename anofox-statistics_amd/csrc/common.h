@@ -364,9 +364,9 @@ struct ResidualArgs {
 	int drop_nan_rows;
 };
 hipError_t launch_residuals_narrow(const ResidualArgs &a, hipStream_t stream);
-// residuals_mid.hip: 9 <= p <= 32, one workgroup per group; d_x_table = DEVICE array of the p column pointers
-constexpr int kResidualsMaxP = 32;
-hipError_t launch_residuals_mid(const ResidualArgs &a, const double *const *d_x_table, hipStream_t stream);
+// residuals_wide.hip: 9 <= p <= 128, one workgroup per group; d_x_table = DEVICE array of the p column pointers
+constexpr int kResidualsMaxP = kWideMaxP; // 128
+hipError_t launch_residuals_wide(const ResidualArgs &a, const double *const *d_x_table, hipStream_t stream); // 9 .. 128 features
 
 // ---- streaming ingest (ingest.hip): row chunks in arrival order -> per-slot moment records, p <= kNarrowMaxP ----
 // A "slot" is one aggregate state (one GROUP BY key of one hash table).  The state keeps the narrow path's moment

@@ -1665,11 +1665,11 @@ bool run_residuals(AnofoxHipContext *ctx, int64_t G, size_t p, const int64_t *d_
 	a.include_studentized = include_studentized ? 1 : 0;
 	a.drop_nan_rows = drop_nan_rows ? 1 : 0;
 	if (p > (size_t)kNarrowMaxP) {
-		// 9 .. 32 features: workgroup-per-group kernel; its column pointers travel through a small device table
+		// 9 .. 128 features: workgroup-per-group kernels; their column pointers travel through a small device table
 		if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, (size_t)kResidualsMaxP * sizeof(double *), "residual column table", e)) return false;
 		// (x_cols is pageable host memory: the runtime has read it into its staging buffer when the call returns)
 		if (hip_fail(hipMemcpyAsync(ctx->aux, x_cols, p * sizeof(double *), hipMemcpyHostToDevice, ctx->stream), "H2D column table", e)) return false;
-		return !hip_fail(launch_residuals_mid(a, (const double *const *)ctx->aux, ctx->stream), "residuals kernel launch", e);
+		return !hip_fail(launch_residuals_wide(a, (const double *const *)ctx->aux, ctx->stream), "residuals kernel launch", e);
 	}
 	return !hip_fail(launch_residuals_narrow(a, ctx->stream), "residuals kernel launch", e);
 }

@@ -441,8 +441,8 @@ ANOFOX_HIP_API bool anofox_hip_vif_batch_host(AnofoxHipContext *ctx, int64_t n_g
  * y_hat is NaN are left out, as the aggregate's Update does (:154-163; their records are all NaN); the aggregate
  * itself returns NULL for groups with fewer than 3 used rows (:223) and passes no residual standard error (:232),
  * so d_rse (one value per group, NaN = none) may be NULL.  x_cols / n_features may be NULL / 0 (no leverage);
- * n_features <= anofox_hip_residuals_max_features() = 32 (up to 8: one wavefront per group, residuals_narrow.hip;
- * 9 .. 32: one workgroup per group, residuals_mid.hip).
+ * n_features <= anofox_hip_residuals_max_features() = 128 (up to 8: one wavefront per group, residuals_narrow.hip;
+ * 9 .. 128: one workgroup per group, residuals_wide.hip).
  */
 #define ANOFOX_HIP_RESIDUALS_HAS_STANDARDIZED 1
 #define ANOFOX_HIP_RESIDUALS_HAS_STUDENTIZED 2

@@ -1339,11 +1339,12 @@ def _assert_residuals_match(out, grp, rout, rgrp, what):
     assert np.max(np.abs(out[m] - rout[m]) / scale, initial=0.0) < 1e-9, what
 
 
-@pytest.mark.parametrize("p", [0, 1, 3, 8, 9, 16, 32])
+@pytest.mark.parametrize("p", [0, 1, 3, 8, 9, 16, 32, 33, 64, 128])
 def test_residuals_batch_matches_oracle(pkg, ctx, p):
-    """Tolerance 1e-9 relative on every part (the stated bar is 1e-6 for diagnostics)."""
+    """Tolerance 1e-9 relative on every part (the stated bar is 1e-6 for diagnostics).  p <= 8: residuals_narrow.hip,
+    9 .. 128: residuals_wide.hip."""
     rng = np.random.default_rng(4100 + p)
-    G = 120
+    G = 120 if p <= 32 else 24
     offs, y, x_cols, _ = _random_groups(rng, G, p, 2 * p + 4, 300, offset=25.0)
     ns = np.diff(offs)
     N = len(y)
@@ -1405,12 +1406,14 @@ def test_residuals_rank_deficient_empty_and_poisoned_groups(pkg, ctx):
     assert np.array_equal(out[:, :2], rout[:, :2])
 
 
-def test_residuals_mid_width_rank_deficient_and_poisoned_groups(pkg, ctx):
-    """9 .. 32 features (one workgroup per group, residuals_mid.hip): collinear and constant columns give no leverage,
-    a NaN feature value in a used row poisons the group's leverage, empty and tiny groups, everything else against
-    the oracle."""
+@pytest.mark.parametrize("p", [12, 40, 100])
+def test_residuals_mid_width_rank_deficient_and_poisoned_groups(pkg, ctx, p):
+    """9 .. 128 features (residuals_wide.hip, one workgroup per group): collinear and
+    constant columns give no leverage, a NaN feature value in a used row poisons the group's leverage, empty and tiny
+    groups, everything else against the oracle."""
     rng = np.random.default_rng(12)
-    p, ns = 12, [60, 60, 60, 5, 0, 60, 300]
+    big = max(60, p + 20)
+    ns = [big, big, big, 5, 0, big, 5 * big]
     offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
     N = int(offs[-1])
     X = rng.uniform(-3, 3, (N, p)) + 10.0
@@ -1424,7 +1427,7 @@ def test_residuals_mid_width_rank_deficient_and_poisoned_groups(pkg, ctx):
     rse = np.full(len(ns), 0.1)
     out, grp = pkg.residuals_batch_host(offs, y, y_hat, x_cols, rse, ctx=ctx)
     rout, rgrp = oracle.residuals_groups(y, y_hat, x_cols, offs, rse=rse)
-    assert list(grp[:, 0]) == [60, 60, 60, 5, 0, 60, 299]
+    assert list(grp[:, 0]) == [big, big, big, 5, 0, big, 5 * big - 1]
     assert list(grp[:, 1].astype(int)) == [1, 1, 7, 1, 1, 7, 7]
     for g in (2, 6):
         lo, hi = offs[g], offs[g + 1]
@@ -1433,7 +1436,7 @@ def test_residuals_mid_width_rank_deficient_and_poisoned_groups(pkg, ctx):
     assert np.all(np.isnan(out[lo:hi, 3]))                               # poisoned leverage, flag still set
     assert np.array_equal(np.nan_to_num(out[:, :2], nan=-7.0), np.nan_to_num(rout[:, :2], nan=-7.0))
     with pytest.raises(pkg.AnofoxStatsError):
-        pkg.residuals_batch_host(offs, y, y_hat, [x_cols[0]] * 33, rse, ctx=ctx)
+        pkg.residuals_batch_host(offs, y, y_hat, [x_cols[0]] * 129, rse, ctx=ctx)
 
 
 def test_residuals_reference_structural_tests(pkg, ctx):
@@ -1492,9 +1495,9 @@ def test_compute_residuals_c_symbol_errors(pkg):
     assert [res.raw[i] for i in range(3)] == [0.0, 0.0, 0.0]
     lib.anofox_free_residuals(C.byref(res))
     assert not res.raw and res.len == 0
-    xs = (abi.AnofoxDataArray * 33)(*[a3] * 33)
-    assert not lib.anofox_compute_residuals(a3, a3, xs, 33, 1.0, True, C.byref(res), C.byref(err))
-    assert err.code == 1 and "maximum of 32" in err.text()
+    xs = (abi.AnofoxDataArray * 129)(*[a3] * 129)
+    assert not lib.anofox_compute_residuals(a3, a3, xs, 129, 1.0, True, C.byref(res), C.byref(err))
+    assert err.code == 1 and "maximum of 128" in err.text()
     xs = (abi.AnofoxDataArray * 9)(*[a3] * 9)          # nine identical columns: accepted, rank deficient -> no leverage
     assert lib.anofox_compute_residuals(a3, a3, xs, 9, 1.0, True, C.byref(res), C.byref(err))
     assert res.len == 3 and not res.has_leverage

@@ -39,7 +39,7 @@ STUB(launch_vif_narrow(const double *, const int64_t *, int64_t, int, int64_t, d
 STUB(launch_vif_from_core(const double *, const int64_t *, int64_t, int, int, int, int64_t, double *, hipStream_t))
 STUB(launch_hc_narrow(const BatchArgs &, double *, void *, hipStream_t))
 STUB(launch_information_criteria(const double *, int64_t, int, int, int, double *, hipStream_t))
-STUB(launch_residuals_mid(const ResidualArgs &, const double *const *, hipStream_t))
+STUB(launch_residuals_wide(const ResidualArgs &, const double *const *, hipStream_t))
 STUB(launch_frames_ynn(const double *, int64_t, int64_t *, void *, size_t, hipStream_t))
 STUB(launch_frames_from_rows_spec(const int64_t *, int64_t, int64_t, int64_t, int64_t, int64_t *, int64_t *, hipStream_t, const int32_t *, int64_t))
 STUB(launch_frames_rule(const FrameArgs &, hipStream_t))
