@@ -9,6 +9,9 @@
 //   finalize  the unchanged solve kernel of the batch path (solve_narrow.hip) over the records.
 // Optionally (anofox_hip_agg_state_retain_rows) Update also appends the chunk to a row log in HBM (rowlog.hip), and
 // Finalize refits from it exactly the groups its solve queued for refinement, through the unchanged batch path.
+// Designs wider than 8 features and heteroskedasticity-consistent errors have no moment record to stream into: such a
+// state keeps ONLY the row log ("log-only": the reference's row buffers, in HBM) and Finalize runs the batch path on
+// all of it — same entry points, any p <= 128, any hc_type.
 // Host chunks are staged through two device buffers on a copy stream, so the H2D copy of chunk k + 1 overlaps
 // the kernels of chunk k; update() returns once its inputs have been copied (the caller may reuse them).
 #include <stdlib.h>
@@ -50,6 +53,7 @@ struct AnofoxHipAggState {
 	void *pair_buf = nullptr; // combine: src | dst
 	size_t pair_bytes = 0;
 	// optional row log (anofox_hip_agg_state_retain_rows): slabs in arrival order
+	bool log_only = false;     // p > 8 or HC errors: no moments, the row log IS the state
 	bool retain = false;       // asked for
 	bool log_dropped = false;  // ... and given up because the budget was exceeded
 	size_t log_budget = 0, log_bytes = 0;
@@ -116,6 +120,7 @@ bool attached(AnofoxHipAggState *s, AnofoxError *e) {
 bool state_reserve(AnofoxHipAggState *s, int64_t n_slots, AnofoxError *e) {
 	if (n_slots > (int64_t)0x7fffffff) { set_error(e, ANOFOX_ERROR_INVALID_INPUT, "too many aggregate states (limit 2^31 - 1)"); return false; }
 	if (n_slots > s->n_slots) s->n_slots = n_slots;
+	if (s->log_only) return true; // nothing is kept per slot
 	if (n_slots <= s->capacity) return true;
 	int64_t cap = s->capacity * 2;
 	if (cap < n_slots) cap = n_slots;
@@ -205,6 +210,10 @@ bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const d
 			if ((size_t)cap * rb > left) cap = (int64_t)(left / rb);
 			if (cap < n - done && (size_t)(n - done) * rb <= left) cap = n - done;
 			if (cap <= 0 || cap < n - done) { // the rest of this chunk does not fit: stop retaining
+				if (s->log_only) {
+					set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE, "the aggregate state's row log exceeds its budget (anofox_hip_agg_state_retain_rows)");
+					return false;
+				}
 				log_free(s);
 				s->log_dropped = true;
 				return true;
@@ -222,6 +231,10 @@ bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const d
 				void *parts[] = {sl.x, sl.y, sl.w, sl.slot, sl.valid};
 				for (void *q : parts)
 					if (q) (void)hipFree(q);
+				if (s->log_only) {
+					set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE, "hipMalloc failed for the aggregate state's row log");
+					return false;
+				}
 				log_free(s);
 				s->log_dropped = true;
 				return true;
@@ -251,6 +264,7 @@ bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const d
 // one pass (<= kIngestChunkRows rows) on device-resident inputs
 bool run_pass(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const double *d_y, const double *d_x, const double *d_w,
               const uint8_t *d_valid, AnofoxError *e) {
+	if (s->log_only) return log_append(s, n, d_slot, d_y, d_x, d_w, d_valid, e);
 	if (!state_scratch(s, e)) return false;
 	const size_t b_n = align_up((size_t)kIngestChunkRows * sizeof(uint32_t), 256);
 	const size_t b_pt = align_up(ingest_piece_table_bytes((int)s->p), 256);
@@ -319,16 +333,15 @@ bool anofox_hip_agg_state_create(AnofoxHipContext *ctx, size_t n_features, Anofo
 	if (n_features == 0 || n_features > anofox_hip_agg_state_max_features()) {
 		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT,
 		          "streaming aggregate states support 1.." + std::to_string(anofox_hip_agg_state_max_features()) +
-		              " features (got " + std::to_string(n_features) + "); wider designs go through the batch entry points");
+		              " features (got " + std::to_string(n_features) + ")");
 		return false;
 	}
 	if (options.model != ANOFOX_HIP_MODEL_OLS && options.model != ANOFOX_HIP_MODEL_RIDGE && options.model != ANOFOX_HIP_MODEL_WLS) {
 		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "unknown model");
 		return false;
 	}
-	if (options.compute_inference && options.hc_type != ANOFOX_HC_NONE && options.model != ANOFOX_HIP_MODEL_RIDGE) {
-		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT,
-		          "hc_type needs a second pass over the rows, which a streaming aggregate state does not keep; use the batch entry points");
+	if ((int)options.hc_type < ANOFOX_HC_NONE || (int)options.hc_type > ANOFOX_HC_HC3) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "unknown hc_type");
 		return false;
 	}
 	if (initial_slots < 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "negative initial_slots"); return false; }
@@ -339,6 +352,13 @@ bool anofox_hip_agg_state_create(AnofoxHipContext *ctx, size_t n_features, Anofo
 	s->ctx = ctx;
 	s->p = n_features;
 	s->opt = options;
+	// no moment record for these: the rows themselves are the state (HC errors need a second pass over them)
+	s->log_only = n_features > (size_t)kNarrowMaxP ||
+	              (options.compute_inference && options.hc_type != ANOFOX_HC_NONE && options.model != ANOFOX_HIP_MODEL_RIDGE);
+	if (s->log_only) {
+		s->retain = true;
+		s->log_budget = ~(size_t)0; // until anofox_hip_agg_state_retain_rows caps it
+	}
 	bool ok = !hip_fail(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking), "hipStreamCreate", out_error);
 	for (int k = 0; ok && k < 2; ++k) {
 		ok = !hip_fail(hipEventCreateWithFlags(&s->stage[k].copied, hipEventDisableTiming), "hipEventCreate", out_error) &&
@@ -379,7 +399,7 @@ void anofox_hip_agg_state_destroy(AnofoxHipAggState *s) {
 	delete s;
 }
 
-size_t anofox_hip_agg_state_max_features(void) { return (size_t)kNarrowMaxP; }
+size_t anofox_hip_agg_state_max_features(void) { return (size_t)kWideMaxP; }
 
 int64_t anofox_hip_agg_state_slots(const AnofoxHipAggState *s) { return s ? s->n_slots : 0; }
 int64_t anofox_hip_agg_state_rows(const AnofoxHipAggState *s) { return s ? s->rows : 0; }
@@ -402,6 +422,10 @@ bool anofox_hip_agg_state_retain_rows(AnofoxHipAggState *s, size_t max_bytes, An
 	if (s->rows > 0) {
 		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "retain_rows has to be called before the first update");
 		return false;
+	}
+	if (s->log_only) { // the log is the state: max_bytes only caps it (0 = no cap); exceeding it fails the update
+		s->log_budget = max_bytes ? max_bytes : ~(size_t)0;
+		return true;
 	}
 	s->retain = max_bytes > 0;
 	s->log_budget = max_bytes;
@@ -515,7 +539,8 @@ bool anofox_hip_agg_state_combine(AnofoxHipAggState *s, int64_t n_pairs, const u
 	uint32_t *d_src = (uint32_t *)s->pair_buf, *d_dst = (uint32_t *)((char *)s->pair_buf + b);
 	if (hip_fail(hipMemcpyAsync(d_src, source_slots, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
 	if (hip_fail(hipMemcpyAsync(d_dst, target_slots, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
-	if (hip_fail(launch_ingest_combine(s->moments, s->n_accum, s->n_slots, d_src, d_dst, n_pairs, (int)s->p, s->opt.fit_intercept ? 1 : 0, st),
+	if (!s->log_only &&
+	    hip_fail(launch_ingest_combine(s->moments, s->n_accum, s->n_slots, d_src, d_dst, n_pairs, (int)s->p, s->opt.fit_intercept ? 1 : 0, st),
 	             "combine kernel launch", out_error))
 		return false;
 	if (s->retain && !s->log_dropped && s->log_rows > 0) { // the sources' rows in the log now belong to the targets
@@ -578,10 +603,88 @@ bool run_finalize(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf
 	return true;
 }
 
+// The batch path (accumulate -> solve -> refine [-> HC]) on the logged rows of K slots — d_list[0 .. K) (device), or
+// every slot 0 .. n - 1 when d_list is nullptr (K == n) — rowlog.hip's header has the steps.  Records go to rows
+// d_list[k] of d_core / d_inf (scatter) or, for all slots, straight to rows 0 .. n - 1.  Synchronises the stream once
+// (the number of selected rows has to reach the host).
+bool refit_from_log(AnofoxHipAggState *s, int64_t n, int64_t K, const int32_t *d_list, bool keep_hc, double *d_core, double *d_inf,
+                    AnofoxError *e) {
+	AnofoxHipContext *ctx = s->ctx;
+	hipStream_t st = ctx->stream;
+	const size_t p = s->p;
+	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
+	const bool all = d_list == nullptr;
+	// index scratch: sorted slots | dense map | counters | slab table | sort temp for K keys
+	const size_t n_tab = s->slabs.size() ? s->slabs.size() : 1;
+	const size_t b_sorted = align_up((size_t)K * sizeof(int32_t), 256), b_dense = align_up((size_t)n * sizeof(int32_t), 256);
+	const size_t b_tab = align_up(n_tab * sizeof(RowLogSlab), 256), b_t1 = align_up(rowlog_sort_temp_bytes(K), 256);
+	if (!ensure_buffer(&s->refit_idx, &s->refit_idx_bytes, b_sorted + b_dense + 256 + b_tab + b_t1, "refit scratch", e)) return false;
+	char *ib = (char *)s->refit_idx;
+	int32_t *d_sorted = (int32_t *)ib, *d_dense = (int32_t *)(ib + b_sorted);
+	unsigned long long *d_counter = (unsigned long long *)(ib + b_sorted + b_dense); // [0] selected rows, [1] rows of slots >= n
+	RowLogSlab *d_tab = (RowLogSlab *)(ib + b_sorted + b_dense + 256);
+	void *d_t1 = ib + b_sorted + b_dense + 256 + b_tab;
+	bool bad = all ? hip_fail(launch_rowlog_iota(d_sorted, K, st), "refit iota", e)
+	               : hip_fail(launch_rowlog_sort_slots(d_list, d_sorted, K, d_t1, b_t1, st), "refit sort", e);
+	bad = bad || hip_fail(launch_rowlog_dense(d_sorted, K, d_dense, n, st), "refit mark", e);
+	bad = bad || hip_fail(hipMemsetAsync(d_counter, 0, 256, st), "hipMemsetAsync", e);
+	if (!s->slabs.empty())
+		bad = bad || hip_fail(hipMemcpyAsync(d_tab, s->slabs.data(), s->slabs.size() * sizeof(RowLogSlab), hipMemcpyHostToDevice, st), "H2D", e);
+	for (size_t k = 0; !bad && k < s->slabs.size(); ++k) {
+		const RowLogSlab &sl = s->slabs[k];
+		bad = hip_fail(launch_rowlog_select(false, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, nullptr, st), "refit count", e);
+	}
+	unsigned long long counts[2] = {0, 0};
+	bad = bad || hip_fail(hipMemcpyAsync(counts, d_counter, sizeof counts, hipMemcpyDeviceToHost, st), "D2H", e);
+	bad = bad || hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e); // (also: the slab table copy has left the vector)
+	if (bad) return false;
+	if (all && counts[1] != 0) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "update: a row named a slot index >= n_slots (the row was dropped)");
+		return false;
+	}
+	if (!all && counts[0] == 0) return true; // nothing logged for them (cannot happen for a fitted group): leave them as they are
+	const size_t M = (size_t)counts[0];
+	const size_t Mb = M ? M : 1;
+	// row scratch: keys a | keys b | y | w | x columns | offsets | core | inference | sort temp for M keys
+	const size_t b_k = align_up(Mb * sizeof(uint64_t), 256), b_c = align_up(Mb * sizeof(double), 256);
+	const size_t b_off = align_up((size_t)(K + 1) * sizeof(int64_t), 256);
+	const size_t b_core = all ? 0 : align_up((size_t)K * (p + 6) * sizeof(double), 256);
+	const size_t b_inf = (!all && s->opt.compute_inference) ? align_up((size_t)K * (5 * p + 2) * sizeof(double), 256) : 0;
+	const size_t b_t2 = align_up(rowlog_sort_temp_bytes((int64_t)Mb), 256);
+	if (!ensure_buffer(&s->refit_rows, &s->refit_rows_bytes, 2 * b_k + (2 + p) * b_c + b_off + b_core + b_inf + b_t2, "refit scratch", e)) return false;
+	char *rb = (char *)s->refit_rows;
+	uint64_t *d_ka = (uint64_t *)rb, *d_kb = (uint64_t *)(rb + b_k);
+	double *d_y = (double *)(rb + 2 * b_k), *d_w = (double *)(rb + 2 * b_k + b_c), *d_x = (double *)(rb + 2 * b_k + 2 * b_c);
+	int64_t *d_off = (int64_t *)(rb + 2 * b_k + (2 + p) * b_c);
+	double *d_core2 = all ? d_core : (double *)((char *)d_off + b_off);
+	double *d_inf2 = all ? d_inf : (b_inf ? (double *)((char *)d_off + b_off + b_core) : nullptr);
+	void *d_t2 = (char *)d_off + b_off + b_core + b_inf;
+	bad = hip_fail(hipMemsetAsync(d_counter, 0, 256, st), "hipMemsetAsync", e);
+	for (size_t k = 0; !bad && k < s->slabs.size(); ++k) {
+		const RowLogSlab &sl = s->slabs[k];
+		bad = hip_fail(launch_rowlog_select(true, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, d_ka, st), "refit fill", e);
+	}
+	if (M) bad = bad || hip_fail(launch_rowlog_sort_keys(d_ka, d_kb, (int64_t)M, K, d_t2, b_t2, st), "refit sort", e);
+	// (columns are b_c bytes apart, not M doubles: every column starts 256-byte aligned)
+	const size_t col_stride = b_c / sizeof(double);
+	bad = bad || hip_fail(launch_rowlog_gather(d_kb, (int64_t)M, K, d_tab, (int)s->slabs.size(), (int)p, weighted ? 1 : 0, d_y, d_x, col_stride, d_w,
+	                                           d_off, st),
+	                      "refit gather", e);
+	if (bad) return false;
+	const double *x_cols[kWideMaxP];
+	for (size_t j = 0; j < p; ++j) x_cols[j] = d_x + j * col_stride;
+	AnofoxHipBatchOptions opt = s->opt;
+	if (!keep_hc) opt.hc_type = ANOFOX_HC_NONE;
+	if (!refit_groups_device(ctx, K, p, (int64_t)M, d_off, d_y, x_cols, weighted ? d_w : nullptr, opt, d_core2, d_inf2, e)) return false;
+	if (all) return true;
+	bad = hip_fail(launch_rowlog_scatter(d_core2, d_sorted, K, (int)(p + 6), d_core, st), "refit scatter", e);
+	if (d_inf2) bad = bad || hip_fail(launch_rowlog_scatter(d_inf2, d_sorted, K, (int)(5 * p + 2), d_inf, st), "refit scatter", e);
+	return !bad;
+}
+
 // After run_finalize: how many groups its solve queued for refinement, and — with a row log — their refit through
-// the batch path (rowlog.hip's header has the steps).  *remaining = the groups still unrefined afterwards; when it
-// is not 0 their slot numbers are still the first *remaining words of the context's workspace.
-// Synchronises the stream (the two counts have to reach the host).
+// the batch path.  *remaining = the groups still unrefined afterwards; when it is not 0 their slot numbers are still
+// the first *remaining words of the context's workspace.  Synchronises the stream (the counts have to reach the host).
 bool refit_queued(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf, int64_t *remaining, AnofoxError *e) {
 	AnofoxHipContext *ctx = s->ctx;
 	hipStream_t st = ctx->stream;
@@ -591,65 +694,9 @@ bool refit_queued(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf
 	if (queued > n) queued = (int32_t)n;
 	*remaining = queued;
 	if (queued == 0 || !s->retain || s->log_dropped || s->log_rows == 0) return true;
-	const int64_t K = queued;
-	const size_t p = s->p;
-	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
-	// index scratch: sorted slots | dense map | counter | slab table | sort temp for K keys
-	const size_t b_sorted = align_up((size_t)K * sizeof(int32_t), 256), b_dense = align_up((size_t)n * sizeof(int32_t), 256);
-	const size_t b_tab = align_up(s->slabs.size() * sizeof(RowLogSlab), 256), b_t1 = align_up(rowlog_sort_temp_bytes(K), 256);
-	if (!ensure_buffer(&s->refit_idx, &s->refit_idx_bytes, b_sorted + b_dense + 256 + b_tab + b_t1, "refit scratch", e)) return false;
-	char *ib = (char *)s->refit_idx;
-	int32_t *d_sorted = (int32_t *)ib, *d_dense = (int32_t *)(ib + b_sorted);
-	unsigned long long *d_counter = (unsigned long long *)(ib + b_sorted + b_dense);
-	RowLogSlab *d_tab = (RowLogSlab *)(ib + b_sorted + b_dense + 256);
-	void *d_t1 = ib + b_sorted + b_dense + 256 + b_tab;
-	bool bad = hip_fail(launch_rowlog_sort_slots((const int32_t *)ctx->ws, d_sorted, K, d_t1, b_t1, st), "refit sort", e);
-	bad = bad || hip_fail(launch_rowlog_dense(d_sorted, K, d_dense, n, st), "refit mark", e);
-	bad = bad || hip_fail(hipMemsetAsync(d_counter, 0, 256, st), "hipMemsetAsync", e);
-	bad = bad || hip_fail(hipMemcpyAsync(d_tab, s->slabs.data(), s->slabs.size() * sizeof(RowLogSlab), hipMemcpyHostToDevice, st), "H2D", e);
-	for (size_t k = 0; !bad && k < s->slabs.size(); ++k) {
-		const RowLogSlab &sl = s->slabs[k];
-		bad = hip_fail(launch_rowlog_select(false, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, nullptr, st), "refit count", e);
-	}
-	unsigned long long m_rows = 0;
-	bad = bad || hip_fail(hipMemcpyAsync(&m_rows, d_counter, sizeof m_rows, hipMemcpyDeviceToHost, st), "D2H", e);
-	bad = bad || hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e); // (also: the slab table copy has left the vector)
-	if (bad) return false;
-	if (m_rows == 0) return true; // nothing logged for them (cannot happen for a fitted group): leave them reported
-	const size_t M = (size_t)m_rows;
-	// row scratch: keys a | keys b | y | w | x columns | offsets | core | inference | sort temp for M keys
-	const size_t b_k = align_up(M * sizeof(uint64_t), 256), b_c = align_up(M * sizeof(double), 256);
-	const size_t b_off = align_up((size_t)(K + 1) * sizeof(int64_t), 256), b_core = align_up((size_t)K * (p + 6) * sizeof(double), 256);
-	const size_t b_inf = s->opt.compute_inference ? align_up((size_t)K * (5 * p + 2) * sizeof(double), 256) : 0;
-	const size_t b_t2 = align_up(rowlog_sort_temp_bytes((int64_t)M), 256);
-	if (!ensure_buffer(&s->refit_rows, &s->refit_rows_bytes, 2 * b_k + (2 + p) * b_c + b_off + b_core + b_inf + b_t2, "refit scratch", e)) return false;
-	char *rb = (char *)s->refit_rows;
-	uint64_t *d_ka = (uint64_t *)rb, *d_kb = (uint64_t *)(rb + b_k);
-	double *d_y = (double *)(rb + 2 * b_k), *d_w = (double *)(rb + 2 * b_k + b_c), *d_x = (double *)(rb + 2 * b_k + 2 * b_c);
-	int64_t *d_off = (int64_t *)(rb + 2 * b_k + (2 + p) * b_c);
-	double *d_core2 = (double *)((char *)d_off + b_off);
-	double *d_inf2 = b_inf ? (double *)((char *)d_core2 + b_core) : nullptr;
-	void *d_t2 = (char *)d_core2 + b_core + b_inf;
-	bad = hip_fail(hipMemsetAsync(d_counter, 0, 256, st), "hipMemsetAsync", e);
-	for (size_t k = 0; !bad && k < s->slabs.size(); ++k) {
-		const RowLogSlab &sl = s->slabs[k];
-		bad = hip_fail(launch_rowlog_select(true, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, d_ka, st), "refit fill", e);
-	}
-	bad = bad || hip_fail(launch_rowlog_sort_keys(d_ka, d_kb, (int64_t)M, K, d_t2, b_t2, st), "refit sort", e);
-	// (columns are b_c bytes apart, not M doubles: every column starts 256-byte aligned)
-	const size_t col_stride = b_c / sizeof(double);
-	bad = bad || hip_fail(launch_rowlog_gather(d_kb, (int64_t)M, K, d_tab, (int)s->slabs.size(), (int)p, weighted ? 1 : 0, d_y, d_x, col_stride, d_w,
-	                                           d_off, st),
-	                      "refit gather", e);
-	if (bad) return false;
-	const double *x_cols[kNarrowMaxP];
-	for (size_t j = 0; j < p; ++j) x_cols[j] = d_x + j * col_stride;
-	AnofoxHipBatchOptions opt = s->opt;
-	opt.hc_type = ANOFOX_HC_NONE;
-	if (!refit_groups_device(ctx, K, p, (int64_t)M, d_off, d_y, x_cols, weighted ? d_w : nullptr, opt, d_core2, d_inf2, e)) return false;
-	bad = hip_fail(launch_rowlog_scatter(d_core2, d_sorted, K, (int)(p + 6), d_core, st), "refit scatter", e);
-	if (d_inf2) bad = bad || hip_fail(launch_rowlog_scatter(d_inf2, d_sorted, K, (int)(5 * p + 2), d_inf, st), "refit scatter", e);
-	if (bad) return false;
+	// (the queue is the first words of the context's workspace, which the refit's own batch call reuses: refit_from_log
+	// sorts it into the state's scratch before that)
+	if (!refit_from_log(s, n, queued, (const int32_t *)ctx->ws, false, d_core, d_inf, e)) return false;
 	*remaining = 0;
 	return true;
 }
@@ -686,6 +733,7 @@ bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *s, int64_t n_slots,
 	if (!attached(s, out_error)) return false;
 	std::lock_guard<std::mutex> lk(s->ctx->mu);
 	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
+	if (s->log_only) return refit_from_log(s, n_slots, n_slots, nullptr, true, d_core, d_inference, out_error);
 	if (!run_finalize(s, n_slots, d_core, d_inference, out_error)) return false;
 	if (!s->retain) return true; // (no log: nothing to refit, and no reason to synchronise)
 	int64_t remaining = 0;
@@ -709,9 +757,13 @@ bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, d
 	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_core + b_inf, "staging", out_error)) return false;
 	double *d_core = (double *)ctx->stage;
 	double *d_inf = b_inf ? (double *)((char *)ctx->stage + b_core) : nullptr;
-	if (!run_finalize(s, n_slots, d_core, d_inf, out_error)) return false;
 	int64_t queued = 0;
-	if (!refit_queued(s, n_slots, d_core, d_inf, &queued, out_error)) return false;
+	if (s->log_only) {
+		if (!refit_from_log(s, n_slots, n_slots, nullptr, true, d_core, d_inf, out_error)) return false;
+	} else {
+		if (!run_finalize(s, n_slots, d_core, d_inf, out_error)) return false;
+		if (!refit_queued(s, n_slots, d_core, d_inf, &queued, out_error)) return false;
+	}
 	hipStream_t st = ctx->stream;
 	if (hip_fail(hipMemcpyAsync(core, d_core, G * (p + 6) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;
 	if (d_inf && hip_fail(hipMemcpyAsync(inference, d_inf, G * (5 * p + 2) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H inference", out_error)) return false;

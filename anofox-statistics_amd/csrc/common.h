@@ -420,6 +420,7 @@ struct RowLogSlab {
 };
 size_t rowlog_sort_temp_bytes(int64_t n);
 hipError_t launch_rowlog_sort_slots(const int32_t *in, int32_t *out, int64_t n, void *temp, size_t temp_bytes, hipStream_t st);
+hipError_t launch_rowlog_iota(int32_t *v, int64_t n, hipStream_t st); // v[i] = i
 hipError_t launch_rowlog_dense(const int32_t *sorted_slots, int64_t k_n, int32_t *dense, int64_t n_slots, hipStream_t st);
 hipError_t launch_rowlog_select(bool fill, const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row, const int32_t *dense,
                                 int64_t n_slots, unsigned long long *counter, uint64_t *keys, hipStream_t st);

@@ -41,6 +41,11 @@ __global__ void rowlog_remap_kernel(uint32_t *slot, int64_t n, const uint32_t *r
 	}
 }
 
+__global__ void rowlog_iota_kernel(int32_t *v, int64_t n) {
+	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) v[i] = (int32_t)i;
+}
+
 __global__ void rowlog_remap_init_kernel(uint32_t *remap, int64_t n_slots) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < n_slots) remap[i] = (uint32_t)i;
@@ -58,11 +63,12 @@ __global__ void rowlog_remap_pairs_kernel(uint32_t *remap, const uint32_t *src, 
 constexpr int kSelectItems = 16;
 constexpr int kSelectTile = kLogBlock * kSelectItems;
 
+// -1: the row is not selected; -2: it names a slot >= n_slots (Update's mistake, reported by the log-only Finalize)
 __device__ __forceinline__ int32_t rowlog_group_of(const uint32_t *slot, const uint8_t *valid, int64_t i, int64_t n, const int32_t *dense,
                                                    int64_t n_slots) {
 	if (i >= n || !valid[i]) return -1;
 	const uint32_t s = slot[i];
-	return (int64_t)s < n_slots ? dense[s] : -1;
+	return (int64_t)s < n_slots ? dense[s] : -2;
 }
 
 template <bool FILL>
@@ -75,11 +81,15 @@ __global__ void __launch_bounds__(kLogBlock) rowlog_select_kernel(const uint32_t
 	// wave w of the block reads rows tile0 + (it * 4 + w) * 64 + lane
 	const int64_t tile0 = (int64_t)blockIdx.x * kSelectTile;
 	int mine = 0; // selected rows of this wave (uniform)
+	bool oob = false;
 #pragma unroll 4
 	for (int it = 0; it < kSelectItems; ++it) {
 		const int64_t i = tile0 + (int64_t)((it * (kLogBlock / 64) + wave) * 64 + lane);
-		mine += __popcll(__ballot(rowlog_group_of(slot, valid, i, n, dense, n_slots) >= 0));
+		const int32_t k = rowlog_group_of(slot, valid, i, n, dense, n_slots);
+		mine += __popcll(__ballot(k >= 0));
+		oob = oob || k == -2;
 	}
+	if (!FILL && __ballot(oob) != 0ull && lane == 0) atomicAdd(counter + 1, 1ull); // counter[1]: rows of slots >= n_slots
 	if (lane == 0) s_wave[wave] = mine;
 	__syncthreads();
 	if (threadIdx.x == 0) {
@@ -164,6 +174,12 @@ size_t rowlog_sort_temp_bytes(int64_t n) {
 
 hipError_t launch_rowlog_sort_slots(const int32_t *in, int32_t *out, int64_t n, void *temp, size_t temp_bytes, hipStream_t st) {
 	return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0u, 31u, st); // slot numbers are < 2^31
+}
+
+hipError_t launch_rowlog_iota(int32_t *v, int64_t n, hipStream_t st) {
+	if (n <= 0) return hipSuccess;
+	rowlog_iota_kernel<<<grid_for(n, 1 << 30), kLogBlock, 0, st>>>(v, n);
+	return hipGetLastError();
 }
 
 hipError_t launch_rowlog_dense(const int32_t *sorted_slots, int64_t k_n, int32_t *dense, int64_t n_slots, hipStream_t st) {

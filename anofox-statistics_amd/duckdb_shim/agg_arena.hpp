@@ -13,10 +13,9 @@
 //   Solve()     flushes, then ONE finalize for every slot of the query; Core(slot) / Inference(slot) serve the
 //               Finalize vectors from that result (ols_aggregate.cpp:249-338 loops one FFI call per group).
 //
-// Wider designs (9 .. 128 features): the GPU-resident state holds at most 8 features, so the arena keeps such rows in
-// host chunk buffers (the reference's own O(n p) footprint, but columnar chunks instead of per-group vectors: no
-// per-row scatter), groups them by slot with a counting sort at Solve() and makes ONE anofox_hip_fit_batch_host call;
-// Combine redirects the source's slot to the target's (rows of a redirected slot sort behind the target's own).
+// Wider designs (9 .. 128 features) and HC standard errors go through the same calls: the library then keeps the rows
+// themselves in HBM instead of moments (a "log-only" state, include/anofox_stats_hip.h) and fits them at Finalize.
+// (Round 2's first version buffered such rows in host chunks here and made one batched call at Solve; removed.)
 //
 // Plain C++17 over the C ABI of include/anofox_stats_hip.h; no DuckDB types, so it is compiled and tested in this
 // repository (duckdb_shim/arena_capi.cpp + tests/test_gpu_arena.py).  fit_agg_hip.cpp is the thin DuckDB glue on top.
@@ -83,11 +82,6 @@ public:
 
 	void Combine(const uint32_t *source_slots, const uint32_t *target_slots, size_t n) {
 		std::lock_guard<std::mutex> lk(mu_);
-		if (buffered_) { // wide designs: remember the redirections, resolved when the rows are grouped
-			for (size_t i = 0; i < n; ++i) redirect_.emplace_back(source_slots[i], target_slots[i]);
-			solved_ = false;
-			return;
-		}
 		if (n == 0 || !state_) return; // no accepted row anywhere: every slot is empty already
 		FlushLocked();
 		Reserve();
@@ -102,8 +96,7 @@ public:
 		if (solved_) return;
 		core_.clear();
 		inf_.clear();
-		if (buffered_) SolveBuffered();
-		else if (state_) {
+		if (state_) {
 			FlushLocked();
 			Reserve();
 			core_.resize((size_t)n_slots_ * (p_ + 6));
@@ -138,93 +131,20 @@ private:
 			p_ = n_features;
 			AnofoxError err;
 			if (!anofox_hip_context_create(-1, &ctx_, &err)) Throw(err);
-			// streaming needs the rows only once; HC errors and designs wider than the GPU-resident state are buffered
-			buffered_ = p_ > anofox_hip_agg_state_max_features() ||
-			            (opt_.compute_inference && opt_.hc_type != ANOFOX_HC_NONE && opt_.model != ANOFOX_HIP_MODEL_RIDGE);
-			if (!buffered_) {
-				if (!anofox_hip_agg_state_create(ctx_, p_, opt_, 0, &state_, &err)) Throw(err);
-				if (retain_bytes_ && !anofox_hip_agg_state_retain_rows(state_, retain_bytes_, &err)) Throw(err);
-				AllocBuffers();
-			}
+			// up to 8 features without HC errors: O(p^2) moments per slot (+ the row log for the groups they cannot
+			// resolve); wider designs and HC errors: the library keeps the rows themselves in HBM (log-only state)
+			if (!anofox_hip_agg_state_create(ctx_, p_, opt_, 0, &state_, &err)) Throw(err);
+			if (retain_bytes_ && !anofox_hip_agg_state_retain_rows(state_, retain_bytes_, &err)) Throw(err);
+			AllocBuffers();
 		}
 		if (n_features != p_)
 			throw std::invalid_argument("Inconsistent feature count: expected " + std::to_string(p_) + ", got " + std::to_string(n_features));
-		if (buffered_) {
-			bslot_.push_back(slot);
-			by_.push_back(y);
-			bx_.insert(bx_.end(), x, x + p_);
-			if (opt_.model == ANOFOX_HIP_MODEL_WLS) bw_.push_back(w);
-			++rows_;
-			return;
-		}
 		slot_[fill_] = slot;
 		y_[fill_] = y;
 		memcpy(x_ + fill_ * p_, x, p_ * sizeof(double));
 		if (w_) w_[fill_] = w;
 		++rows_;
 		if (++fill_ == cap_) FlushLocked();
-	}
-
-	// Buffered designs: group the rows by (redirected) slot, arrival order kept inside a slot — a target's own rows
-	// first, then each merged source's in Combine order — and fit all slots in one batched call.
-	void SolveBuffered() {
-		const size_t G = n_slots_, N = bslot_.size(), p = p_;
-		// Combine tree: parent[src] = the slot it was merged into; a slot's buffer at Finalize is its own rows followed
-		// by its children's buffers in Combine order (ols_aggregate.cpp:224-233 appends) = a pre-order walk
-		const uint32_t kNone = 0xffffffffu;
-		std::vector<uint32_t> parent(G, kNone);
-		std::vector<std::vector<uint32_t>> children(G);
-		for (auto &pr : redirect_) {
-			if (pr.first >= G || pr.second >= G || pr.first == pr.second || parent[pr.first] != kNone) continue;
-			parent[pr.first] = pr.second;
-			children[pr.second].push_back(pr.first); // redirect_ is in Combine order
-		}
-		std::vector<uint32_t> root(G), pos(G);
-		{
-			uint32_t next = 0;
-			std::vector<std::pair<uint32_t, size_t>> stack;
-			for (size_t r = 0; r < G; ++r) {
-				if (parent[r] != kNone) continue;
-				stack.emplace_back((uint32_t)r, 0);
-				root[r] = (uint32_t)r;
-				pos[r] = next++;
-				while (!stack.empty()) {
-					auto &top = stack.back();
-					if (top.second < children[top.first].size()) {
-						const uint32_t c = children[top.first][top.second++];
-						root[c] = (uint32_t)r;
-						pos[c] = next++;
-						stack.emplace_back(c, 0);
-					} else {
-						stack.pop_back();
-					}
-				}
-			}
-		}
-		std::vector<int64_t> offs(G + 1, 0);
-		for (size_t i = 0; i < N; ++i) offs[root[bslot_[i]] + 1]++;
-		for (size_t g = 0; g < G; ++g) offs[g + 1] += offs[g];
-		// roots are visited in slot order, so walk position orders the rows by (final slot, buffer order); arrival
-		// order inside one slot is kept by the stable sort
-		std::vector<size_t> order(N);
-		for (size_t i = 0; i < N; ++i) order[i] = i;
-		std::stable_sort(order.begin(), order.end(), [&](size_t u, size_t v) { return pos[bslot_[u]] < pos[bslot_[v]]; });
-		std::vector<double> y(N), w(opt_.model == ANOFOX_HIP_MODEL_WLS ? N : 0);
-		std::vector<std::vector<double>> cols(p, std::vector<double>(N));
-		for (size_t k = 0; k < N; ++k) {
-			const size_t i = order[k];
-			y[k] = by_[i];
-			if (!w.empty()) w[k] = bw_[i];
-			for (size_t j = 0; j < p; ++j) cols[j][k] = bx_[i * p + j];
-		}
-		std::vector<const double *> xc(p);
-		for (size_t j = 0; j < p; ++j) xc[j] = cols[j].data();
-		core_.assign(G * (p + 6), 0.0);
-		if (opt_.compute_inference) inf_.assign(G * (5 * p + 2), 0.0);
-		AnofoxError err;
-		if (G > 0 && !anofox_hip_fit_batch_host(ctx_, (int64_t)G, p, (int64_t)N, offs.data(), y.data(), xc.data(), w.empty() ? nullptr : w.data(),
-		                                        opt_, core_.data(), inf_.empty() ? nullptr : inf_.data(), &err))
-			Throw(err);
 	}
 
 	void Reserve() {
@@ -270,11 +190,6 @@ private:
 	uint32_t *slot_ = nullptr;
 	double *y_ = nullptr, *x_ = nullptr, *w_ = nullptr;
 	size_t fill_ = 0;
-	// buffered mode (more than 8 features, or HC errors): rows in arrival order + Combine redirections
-	bool buffered_ = false;
-	std::vector<uint32_t> bslot_;
-	std::vector<double> by_, bx_, bw_;
-	std::vector<std::pair<uint32_t, uint32_t>> redirect_;
 	// solved records
 	bool solved_ = false;
 	int64_t unrefined_ = 0;

@@ -94,7 +94,7 @@ static void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, i
 	auto states = (HipAggState **)sdata.data;
 
 	anofox_shim::AggArena::Writer writer(arena); // one lock per vector
-	double row[128]; // anofox_hip_max_features(); up to 8 features stream into the GPU state, wider designs are buffered
+	double row[128]; // anofox_hip_max_features(); everything goes to the GPU state (moments up to 8 features, the rows themselves beyond)
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
 		if (state.slot < 0) state.slot = writer.NewSlot(); // the group exists even if every row of it is skipped

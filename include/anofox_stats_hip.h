@@ -482,8 +482,7 @@ ANOFOX_HIP_API bool anofox_hip_residuals_batch_host(AnofoxHipContext *ctx, int64
  *             *out_unrefined (optional) is the number of groups that would have taken them — smallest Cholesky
  *             pivot ratio below 1e-3 or rss / tss below 1e-7: their coefficients carry cond^2 eps and their sigma / r^2
  *             the cancellation of rss = tss - |z|^2 — and out_unrefined_slots (optional, room for n_slots entries)
- *             receives their slot numbers, in no particular order.  hc_type other than none needs the rows as well and
- *             is rejected at creation.
+ *             receives their slot numbers, in no particular order.
  *   retain_rows(max_bytes)  (optional, before the first update) keeps every chunk in a row log in HBM as well — p + 2 (+ 1
  *             with weights) doubles and 5 bytes per row, up to max_bytes — and Finalize then refits exactly the groups
  *             its solve queued, through the batch path (accumulate, solve, refinement passes) on their logged rows:
@@ -491,9 +490,14 @@ ANOFOX_HIP_API bool anofox_hip_residuals_batch_host(AnofoxHipContext *ctx, int64
  *             slots' logged rows.  Exceeding max_bytes (or device memory) is not an error: the log is dropped,
  *             anofox_hip_agg_state_retaining() turns 0 and Finalize reports the queued groups as without a log.
  *             finalize_device synchronises the stream once when a log is kept (it does not otherwise).
+ *   log-only  Designs of more than 8 features have no moment record to stream into, and HC standard errors (hc_type
+ *             other than none, with inference, OLS / WLS) need a second pass over the rows: such a state keeps ONLY the
+ *             row log — the reference's row buffers, in HBM — and Finalize runs the batch path over all of it.  Same
+ *             entry points and results as above (*out_unrefined is 0); retain_rows(max_bytes) caps the log (0 = no
+ *             cap) and an Update that exceeds the cap or device memory FAILS with ANOFOX_ERROR_ALLOCATION_FAILURE.
  *
  * A state belongs to one context (device + stream); calls on one state are serialised.  n_features <=
- * anofox_hip_agg_state_max_features() = 8.
+ * anofox_hip_agg_state_max_features() = 128.
  */
 typedef struct AnofoxHipAggState AnofoxHipAggState;
 ANOFOX_HIP_API size_t anofox_hip_agg_state_max_features(void);

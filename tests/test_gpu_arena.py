@@ -46,8 +46,8 @@ def _lib():
 @pytest.mark.parametrize("model,flush_rows,p,hc", [("ols", 5000, 6, None), ("wls", 1 << 20, 6, None), ("ridge", 777, 6, None),
                                                    ("ols", 5000, 12, None), ("wls", 5000, 20, None), ("ols", 5000, 4, "hc1")])
 def test_threads_update_combine_finalize(model, flush_rows, p, hc):
-    """p <= 8 without HC errors: rows stream into the GPU-resident state; wider designs and HC errors: the arena buffers
-    the rows in host chunks and makes one batched call at Solve — same calls, same results."""
+    """p <= 8 without HC errors: rows stream into O(p^2) moments on the GPU; wider designs and HC errors: the library keeps
+    the rows themselves in HBM (log-only state) and fits them at Finalize — same calls from the arena, same results."""
     pkg, lib = _lib()
     rng = np.random.default_rng(len(model) + p)
     G, T = 400, 3

@@ -189,13 +189,10 @@ def test_combine_merges_partial_states(pkg, ctx, model, icpt):
 def test_creation_and_argument_errors(pkg, ctx):
     o = pkg.RegressionOptions().batch_options("ols")
     with pytest.raises(pkg.AnofoxStatsError) as ei:
-        pkg.AggState(ctx, 9, o)
+        pkg.AggState(ctx, 129, o)
     assert ei.value.code == 1 and "features" in str(ei.value)
     with pytest.raises(pkg.AnofoxStatsError):
         pkg.AggState(ctx, 0, o)
-    with pytest.raises(pkg.AnofoxStatsError) as ei:
-        pkg.AggState(ctx, 3, pkg.RegressionOptions(compute_inference=True, hc_type="hc3").batch_options("ols"))
-    assert "hc_type" in str(ei.value)
     st = pkg.AggState(ctx, 2, pkg.RegressionOptions().batch_options("wls"))
     with pytest.raises(pkg.AnofoxStatsError):
         st.update([0], [1.0], [[1.0, 2.0]], None, n_slots=1)     # WLS without weights
@@ -474,4 +471,80 @@ def test_row_log_budget_and_call_order(pkg, ctx):
     err = pkg._abi.AnofoxError()
     import ctypes
     assert not lib.anofox_hip_agg_state_retain_rows(st._h, 1 << 20, ctypes.byref(err)) and "before the first update" in err.text()
+    st.close()
+
+
+# ---- log-only states: designs wider than 8 features and HC errors keep the rows, not moments ----
+
+@pytest.mark.parametrize("model,p,hc", [("ols", 12, None), ("wls", 20, None), ("ridge", 40, None), ("ols", 128, None),
+                                        ("ols", 5, "hc1"), ("wls", 8, "hc3"), ("ols", 17, "hc2")])
+def test_log_only_states_wide_designs_and_hc_errors(pkg, ctx, model, p, hc):
+    """No O(p^2) record to stream into for p > 8, and HC errors need a second pass over the rows: the state then IS the
+    row log in HBM (the reference's per-group row buffers, ols_aggregate.cpp:19-42), Update appends, Combine re-labels,
+    Finalize runs the batch path over all of it.  Same entry points; against the oracle's fit of each key's rows in
+    the reference's order (thread 0's, then thread 1's)."""
+    rng = np.random.default_rng(5000 + 7 * p + len(model))
+    G = 60 if p <= 40 else 12
+    kw = _kw(model, True)
+    if hc:
+        kw["hc_type"] = hc
+    opts = pkg.RegressionOptions(**kw).batch_options(model)
+    parts = [_rows(rng, G, p, 0 if t else 2, 3 * p + 40, offset=3.0 * t) for t in range(2)]
+    valid = [(rng.random(len(q[0])) > 0.07).astype(np.uint8) for q in parts]
+    for q in parts:                                              # NaN / inf values are accumulated rows the fit drops
+        q[2][rng.random(q[2].shape[0]) < 0.01, 0] = np.nan
+    st = pkg.AggState(ctx, p, opts)
+    assert st.retaining
+    for t, (slot, y, X, w) in enumerate(parts):
+        _feed(st, slot + np.uint32(t * G), y, X, w if model == "wls" else None, 2 * G, [2048, 1, 333], valid=valid[t])
+    ar = np.arange(G, dtype=np.uint32)
+    st.combine(ar + G, ar)
+    core, inf, unref = st.finalize()
+    assert unref == 0 and st.retained_bytes > 0
+    slot = np.concatenate([q[0] for q in parts])
+    y = np.concatenate([q[1] for q in parts])
+    X = np.concatenate([q[2] for q in parts])
+    w = np.concatenate([q[3] for q in parts])
+    keep = np.concatenate(valid)
+    offs, yg, xg, wg = _grouped(slot, y, X, w, G, keep=keep)
+    rcore, rinf = oracle.fit_groups(yg, xg, offs, w=(wg if model == "wls" else None), model=model, n_threads=8, **kw)
+    slack = 3 if hc in ("hc2", "hc3") else 0
+    n_par = np.sum(~np.isnan(rcore[:, :p]), axis=1) + 1
+    skip = [g for g in range(G) if rcore[g, p + 5] == 0 and rcore[g, p + 4] - n_par[g] <= slack]
+    assert_records_match(core[:G], rcore, p, inf[:G], rinf, what=f"log-only {model} p={p} hc={hc}", skip_diag_groups=skip)
+    assert np.all(core[G:, p + 5] == 100)                        # the sources were emptied
+    assert (rcore[:, p + 5] == 0).sum() >= G // 2
+    # the batch entry point on the same grouped rows gives the same records (it is the same path): bit for bit for the
+    # wide kernels; for p <= 8 the batch of 2 G slots (the emptied sources included) may pick another accumulate kernel
+    # than the batch of G groups (packed small groups / a wave per group), and the HC sums of a group are completed by
+    # whichever wave finishes last — equal to rounding there
+    bcore, binf = ctx.fit_batch_host(offs, yg, xg, wg if model == "wls" else None, opts)
+    if p > 8 and hc is None:
+        assert np.array_equal(core[:G], bcore, equal_nan=True) and np.array_equal(inf[:G], binf, equal_nan=True)
+    else:
+        assert np.allclose(core[:G], bcore, rtol=1e-10, atol=1e-12, equal_nan=True)
+        assert np.allclose(inf[:G], binf, rtol=1e-8, atol=1e-12, equal_nan=True)
+    st.close()
+
+
+def test_log_only_state_budget_and_bad_slots(pkg, ctx):
+    o = pkg.RegressionOptions().batch_options("ols")
+    p = 12
+    rng = np.random.default_rng(1)
+    st = pkg.AggState(ctx, p, o, retain_bytes=50 * (8 * (p + 1) + 5))        # room for 50 rows: the log IS the state
+    X = rng.standard_normal((200, p))
+    with pytest.raises(pkg.AnofoxStatsError) as ei:
+        st.update(np.zeros(200, dtype=np.uint32), X[:, 0], X, n_slots=1)
+    assert ei.value.code == 7 and "budget" in str(ei.value)
+    st.close()
+    st = pkg.AggState(ctx, p, o)
+    st.update(np.array([0] * 30 + [5], dtype=np.uint32), rng.standard_normal(31), rng.standard_normal((31, p)), n_slots=2)
+    with pytest.raises(pkg.AnofoxStatsError) as ei:
+        st.finalize()
+    assert "slot index" in str(ei.value)
+    st.close()
+    st = pkg.AggState(ctx, p, o)                                 # slots announced, no row ever
+    st.reserve(3)
+    core, inf, _ = st.finalize(3)
+    assert np.all(core[:, p + 5] == 100)
     st.close()

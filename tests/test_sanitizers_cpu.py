@@ -3,7 +3,7 @@ code (GPU ASan is not available on this pool).  tests/tools/Makef
 csrc/agg_state.hip as plain C++ with g++ (kernel launchers stubbed: nothing reaches them without a GPU) and
 oracle/anofox_oracle.c with gcc, each with a driver; the DuckDB shim's arena (duckdb_shim/agg_arena.hpp) runs against a
 recording mock of the C ABI (tests/tools/arena_sanitize.cpp: Update vectors of three threads, flushes, Combine, Finalize,
-streaming and host-buffered mode; every accepted row must reach the right slot in the reference's order).  A non-zero
+narrow and wide designs; every accepted row must reach the right slot in the reference's order).  A non-zero
 exit or any sanitizer report fails the test."""
 import os
 import shutil

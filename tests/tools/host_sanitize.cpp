@@ -46,6 +46,7 @@ STUB(launch_frames_rule(const FrameArgs &, hipStream_t))
 STUB(launch_frames_predict(const FrameArgs &, hipStream_t))
 size_t frames_scan_temp_bytes(int64_t) { return 4096; }
 STUB(launch_rowlog_sort_slots(const int32_t *, int32_t *, int64_t, void *, size_t, hipStream_t))
+STUB(launch_rowlog_iota(int32_t *, int64_t, hipStream_t))
 STUB(launch_rowlog_dense(const int32_t *, int64_t, int32_t *, int64_t, hipStream_t))
 STUB(launch_rowlog_select(bool, const uint32_t *, const uint8_t *, int64_t, int64_t, const int32_t *, int64_t, unsigned long long *, uint64_t *, hipStream_t))
 STUB(launch_rowlog_sort_keys(const uint64_t *, uint64_t *, int64_t, int64_t, void *, size_t, hipStream_t))
@@ -187,7 +188,7 @@ int main() {
 		CHECK(!anofox_hip_agg_state_finalize_host(nullptr, 0, nullptr, nullptr, nullptr, nullptr, &err));
 		CHECK(!anofox_hip_agg_state_combine(nullptr, 1, nullptr, nullptr, &err));
 		CHECK(anofox_hip_core_record_len(8) == 14 && anofox_hip_inference_record_len(8) == 42 && anofox_hip_max_features() == 128);
-		CHECK(anofox_hip_agg_state_max_features() == 8 && anofox_hip_vif_record_len(5) == 6);
+		CHECK(anofox_hip_agg_state_max_features() == 128 && anofox_hip_vif_record_len(5) == 6);
 		if (have) anofox_hip_context_destroy(ctx);
 		anofox_hip_context_destroy(nullptr);
 		anofox_hip_host_free(nullptr);
