@@ -134,7 +134,10 @@ private:
 			// up to 8 features without HC errors: O(p^2) moments per slot (+ the row log for the groups they cannot
 			// resolve); wider designs and HC errors: the library keeps the rows themselves in HBM (log-only state)
 			if (!anofox_hip_agg_state_create(ctx_, p_, opt_, 0, &state_, &err)) Throw(err);
-			if (retain_bytes_ && !anofox_hip_agg_state_retain_rows(state_, retain_bytes_, &err)) Throw(err);
+			// the budget is for the OPTIONAL log of a moment state; a log-only state needs every row it is given (its
+			// log grows until the device is full, and an Update beyond that fails like any allocation)
+			const bool log_only = p_ > 8 || (opt_.compute_inference && opt_.hc_type != ANOFOX_HC_NONE && opt_.model != ANOFOX_HIP_MODEL_RIDGE);
+			if (!log_only && retain_bytes_ && !anofox_hip_agg_state_retain_rows(state_, retain_bytes_, &err)) Throw(err);
 			AllocBuffers();
 		}
 		if (n_features != p_)
