@@ -203,9 +203,13 @@ bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const d
 	int64_t done = 0;
 	while (done < n) {
 		if (s->slabs.empty() || s->slabs.back().rows == s->slabs.back().cap) {
-			// slabs grow geometrically from 64 Ki rows to 16 Mi rows, never beyond what the budget still allows
+			// slabs grow geometrically from 64 Ki rows to 16 Mi rows or 2 GiB, never beyond what the budget still allows
 			int64_t cap = s->slabs.empty() ? 65536 : s->slabs.back().cap * 2;
 			if (cap > (int64_t)1 << 24) cap = (int64_t)1 << 24;
+			if ((size_t)cap * rb > ((size_t)2 << 30) && cap > 65536) { // and never more than 2 GiB per slab (1 KB rows at p = 128)
+				cap = (int64_t)(((size_t)2 << 30) / rb);
+				if (cap < 65536) cap = 65536;
+			}
 			const size_t left = s->log_budget > s->log_bytes ? s->log_budget - s->log_bytes : 0;
 			if ((size_t)cap * rb > left) cap = (int64_t)(left / rb);
 			if (cap < n - done && (size_t)(n - done) * rb <= left) cap = n - done;
