@@ -461,6 +461,9 @@ hipError_t launch_frames_predict(const FrameArgs &a, hipStream_t stream);
 hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream);
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream);
 hipError_t launch_inference_wide_finish(const WideArgs &a, hipStream_t stream); // after the last solve_wide mode
+// solve_tiles.hip: the primary solve (mode 0) with one wavefront per group and the matrix in registers, 32 < p <= 128
+bool solve_tiles_supports(int p);
+hipError_t launch_solve_tiles(const WideArgs &a, hipStream_t stream);
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);
 // accumulate_mid.hip: wave-per-group accumulation into the same records for 8 < p <= 32
 bool accumulate_mid_supports(int p);

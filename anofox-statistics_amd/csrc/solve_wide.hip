@@ -1024,6 +1024,10 @@ hipError_t launch_solve_wide_occ(const WideArgs &a, int mode, size_t lds, hipStr
 
 hipError_t launch_solve_wide(const WideArgs &a, int mode, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
+	// the primary solve of 32 < p <= 128 runs with one wavefront per group and the matrix in registers (solve_tiles.hip);
+	// the refinement modes — a handful of queued groups — stay here.  ANOFOX_SOLVE_TILES=0: this file's kernels only.
+	static const bool tiles_on = !(getenv("ANOFOX_SOLVE_TILES") && atoi(getenv("ANOFOX_SOLVE_TILES")) == 0);
+	if (tiles_on && mode == MODE_PRIMARY && solve_tiles_supports(a.p)) return launch_solve_tiles(a, stream);
 	const size_t lds = solve_wide_lds_bytes(a.p);
 	// p <= 96 (two or more groups' matrices fit a CU's LDS): one wave per group.  50 000 x 1000 rows, solve without /
 	// with inference: p = 33 5.78 / 9.94 -> 2.18 / 3.30 ms, p = 64 7.20 / 12.4 -> 2.92 / 4.56 ms; 20 000 groups: p = 80
