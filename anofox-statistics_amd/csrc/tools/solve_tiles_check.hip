@@ -14,8 +14,12 @@ using namespace anofox;
 
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
 
+#ifndef STC_WPE
+#define STC_WPE 1
+#endif
 template <int T>
 int run(int G, double corr) {
+	constexpr int WPE_ = STC_WPE;
 	const int P16 = 16 * T, p = P16 - (T == 8 ? 0 : 3), NT = T * (T + 1) / 2;
 	const int reclen = wide_record_len(T);
 	const int n = 400;
@@ -79,7 +83,7 @@ int run(int G, double corr) {
 	CHECK(hipMalloc(&d_list, G * 4)); CHECK(hipMalloc(&d_cnt, 64)); CHECK(hipMemset(d_cnt, 0, 64));
 	a.row_offsets = d_off; a.group_base = 0; a.n_groups = G; a.p = p; a.model = ANOFOX_HIP_MODEL_OLS; a.fit_intercept = 1; a.compute_inference = 1;
 	a.confidence_level = 0.95; a.alpha = 0; a.moments = d_rec; a.core = d_core; a.inference = d_inf; a.refine_list = d_list; a.refine_count = d_cnt;
-	hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, 1>), dim3(G), dim3(64), 0, 0, a);
+	hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, WPE_>), dim3(G), dim3(64), 0, 0, a);
 	CHECK(hipDeviceSynchronize());
 	std::vector<double> core((size_t)G * (p + 6));
 	CHECK(hipMemcpy(core.data(), d_core, core.size() * 8, hipMemcpyDeviceToHost));
@@ -90,6 +94,23 @@ int run(int G, double corr) {
 		for (int j = 0; j < p; ++j) worst_b = fmax(worst_b, (double)(fabsl(core[(size_t)g * (p + 6) + j] - refb[(size_t)g * p + j]) / sc));
 		const double sig = sqrt((double)refrss[g] / (n - p - 1));
 		worst_s = fmax(worst_s, fabs(core[(size_t)g * (p + 6) + p + 3] / sig - 1.0));
+	}
+	if (getenv("STC_BENCH")) { // timing: the same records replicated to STC_BENCH groups
+		const int GB = atoi(getenv("STC_BENCH"));
+		double *d_big, *d_core2, *d_inf2; int64_t *d_off2;
+		CHECK(hipMalloc(&d_big, (size_t)GB * reclen * 8)); CHECK(hipMalloc(&d_core2, (size_t)GB * (p + 6) * 8)); CHECK(hipMalloc(&d_inf2, (size_t)GB * (5 * p + 2) * 8));
+		CHECK(hipMalloc(&d_off2, ((size_t)GB + 1) * 8));
+		std::vector<int64_t> o2(GB + 1); for (int g = 0; g <= GB; ++g) o2[g] = (int64_t)g * n;
+		CHECK(hipMemcpy(d_off2, o2.data(), o2.size() * 8, hipMemcpyHostToDevice));
+		for (int g = 0; g < GB; ++g) CHECK(hipMemcpyAsync(d_big + (size_t)g * reclen, d_rec + (size_t)(g % G) * reclen, (size_t)reclen * 8, hipMemcpyDeviceToDevice, 0));
+		WideArgs b = a; b.moments = d_big; b.core = d_core2; b.inference = d_inf2; b.row_offsets = d_off2; b.n_groups = GB;
+		hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+		for (int it = 0; it < 2; ++it) hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, WPE_>), dim3(GB), dim3(64), 0, 0, b);
+		CHECK(hipEventRecord(e0, 0));
+		for (int it = 0; it < 5; ++it) hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, WPE_>), dim3(GB), dim3(64), 0, 0, b);
+		CHECK(hipEventRecord(e1, 0)); CHECK(hipDeviceSynchronize());
+		float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+		printf("T=%d WPE=%d: %d groups in %.3f ms per launch\n", T, WPE_, GB, ms / 5);
 	}
 	printf("T=%d p=%d G=%d corr=%.2f: max coef err (rel to max|b|) %.3e, sigma rel err %.3e, status0 %.0f, queued %d\n", T, p, G, corr, worst_b, worst_s, core[p + 5], cnt);
 	return 0;
