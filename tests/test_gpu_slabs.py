@@ -101,6 +101,43 @@ def test_cfg5_record_slabs_at_full_group_count():
     ctx.close()
 
 
+def test_cfg5_at_its_baseline_size():
+    """BASELINE cfg5 as it is quoted: 50 000 groups x n = 4096 x p = 128 with full diagnostics — 211 GB of inputs
+    resident in HBM, four record slabs.  Head, both sides of every slab boundary and the tail against the oracle,
+    and two size-independent properties over ALL groups: linearity of least squares (y' = 2 y + 3 x_1 - 1 gives
+    slopes 2 b + 3 e_1 and sigma' = 2 sigma) and the row count / status of every record."""
+    import torch
+    pkg = import_pkg()
+    synth = import_pkg("synth")
+    G, n, p = 50_000, 4096, 128
+    need = G * n * (p + 2) * 8
+    free, _ = torch.cuda.mem_get_info()
+    if need > 0.92 * free:
+        pytest.skip(f"needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} GB free")
+    slab = _slab_groups(p)
+    assert (G + slab - 1) // slab == 4
+    offs, y, x_cols, _ = synth.make_grouped(G, n, p, device="cuda:0", chunk_groups=max(1, (1 << 25) // n))
+    ctx = pkg.Context(0)
+    kw = dict(compute_inference=True)
+    opts = pkg.RegressionOptions(**kw).batch_options("ols")
+    core, inf = ctx.fit_batch_device(offs, y, x_cols, None, opts)
+    torch.cuda.synchronize()
+    assert bool((core[:, p + 5] == 0).all()) and bool((core[:, p + 4] == n).all())
+    assert bool(torch.isfinite(inf).all())
+    _check_windows(core, inf, offs, y, x_cols, None, p, "ols", kw, _windows(G, slab, 4), "cfg5 full size")
+    y2 = 2.0 * y + 3.0 * x_cols[0] - 1.0
+    core2, inf2 = ctx.fit_batch_device(offs, y2, x_cols, None, opts)
+    torch.cuda.synchronize()
+    want = 2.0 * core[:, :p].clone()
+    want[:, 0] += 3.0
+    scale = want.abs().max(dim=1, keepdim=True).values
+    assert float(((core2[:, :p] - want).abs() / torch.maximum(want.abs(), 1e-3 * scale)).max()) < COEF_RTOL
+    assert float((core2[:, p + 3] / (2.0 * core[:, p + 3]) - 1.0).abs().max()) < DIAG_RTOL
+    # standard errors scale with sigma: se' = 2 se for every coefficient of every group
+    assert float((inf2[:, :p] / (2.0 * inf[:, :p]) - 1.0).abs().max()) < DIAG_RTOL
+    ctx.close()
+
+
 @pytest.mark.parametrize("p,model", [(1, "ols"), (3, "wls")])
 def test_host_entry_point_beyond_one_row_slab(p, model):
     """anofox_hip_fit_batch_host streams more than 32M rows in several row slabs: groups of the first and of the
