@@ -181,6 +181,7 @@ SYMBOLS = {
     "anofox_hip_comm_destroy": (None, [C.c_void_p]),
     "anofox_hip_comm_world_size": (C.c_int, [C.c_void_p]),
     "anofox_hip_comm_rank": (C.c_int, [C.c_void_p]),
+    "anofox_hip_comm_ranks_seen": (C.c_int, [C.c_void_p]),
     "anofox_hip_gather_records_device": (C.c_bool, [C.c_void_p, C.c_void_p, C.c_int64, C.c_size_t, C.c_void_p, _ERRP]),
     "anofox_hip_context_last_window_refit_count": (C.c_bool, [_CTX, C.POINTER(C.c_int64), _ERRP]),
     "anofox_hip_fit_predict_frames_device": (C.c_bool, [_CTX, C.c_int64, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p,
@@ -195,7 +196,9 @@ SYMBOLS = {
     "anofox_hip_agg_state_destroy": (None, [C.c_void_p]),
     "anofox_hip_agg_state_reserve": (C.c_bool, [C.c_void_p, C.c_int64, _ERRP]),
     "anofox_hip_agg_state_retain_rows": (C.c_bool, [C.c_void_p, C.c_size_t, _ERRP]),
+    "anofox_hip_agg_state_retain_rows_host": (C.c_bool, [C.c_void_p, C.c_size_t, _ERRP]),
     "anofox_hip_agg_state_retaining": (C.c_int, [C.c_void_p]),
+    "anofox_hip_agg_state_retained_host_bytes": (C.c_size_t, [C.c_void_p]),
     "anofox_hip_agg_state_retained_bytes": (C.c_size_t, [C.c_void_p]),
     "anofox_hip_agg_state_slots": (C.c_int64, [C.c_void_p]),
     "anofox_hip_agg_state_rows": (C.c_int64, [C.c_void_p]),

@@ -56,7 +56,8 @@ struct AnofoxHipAggState {
 	bool log_only = false;     // p > 8 or HC errors: no moments, the row log IS the state
 	bool retain = false;       // asked for
 	bool log_dropped = false;  // ... and given up because the budget was exceeded
-	size_t log_budget = 0, log_bytes = 0;
+	size_t log_budget = 0, log_bytes = 0;            // HBM part of the log
+	size_t log_host_budget = 0, log_host_bytes = 0;  // page-locked host part (the spill beyond the HBM budget)
 	int64_t log_rows = 0;
 	std::vector<RowLogSlab> slabs;
 	void *refit_idx = nullptr, *refit_rows = nullptr; // Finalize's refit scratch
@@ -64,6 +65,15 @@ struct AnofoxHipAggState {
 	void *remap_buf = nullptr;
 	size_t remap_bytes = 0;
 };
+
+namespace {
+void slab_release(RowLogSlab &sl) {
+	void *parts[] = {sl.x, sl.y, sl.w, sl.slot, sl.valid};
+	for (void *q : parts)
+		if (q) (void)(sl.on_host ? hipHostFree(q) : hipFree(q));
+	sl = RowLogSlab{};
+}
+} // namespace
 
 namespace anofox {
 namespace host {
@@ -85,13 +95,10 @@ void agg_state_detach(AnofoxHipAggState *s) {
 		if (st.done) (void)hipEventDestroy(st.done);
 		st = AnofoxHipAggState::Stage();
 	}
-	for (auto &sl : s->slabs) {
-		void *parts[] = {sl.x, sl.y, sl.w, sl.slot, sl.valid};
-		for (void *q : parts)
-			if (q) (void)hipFree(q);
-	}
+	for (auto &sl : s->slabs) slab_release(sl);
 	s->slabs.clear();
 	s->log_bytes = 0;
+	s->log_host_bytes = 0;
 	s->log_rows = 0;
 	void **bufs[] = {(void **)&s->moments, (void **)&s->n_accum, (void **)&s->run_start, (void **)&s->run_end, &s->scratch,
 	                 (void **)&s->counters, &s->pair_buf, &s->refit_idx, &s->refit_rows, &s->remap_buf};
@@ -182,13 +189,10 @@ size_t log_row_bytes(const AnofoxHipAggState *s) {
 
 void log_free(AnofoxHipAggState *s) {
 	(void)hipStreamSynchronize(s->ctx->stream);
-	for (auto &sl : s->slabs) {
-		void *parts[] = {sl.x, sl.y, sl.w, sl.slot, sl.valid};
-		for (void *q : parts)
-			if (q) (void)hipFree(q);
-	}
+	for (auto &sl : s->slabs) slab_release(sl);
 	s->slabs.clear();
 	s->log_bytes = 0;
+	s->log_host_bytes = 0;
 	s->log_rows = 0;
 }
 
@@ -210,33 +214,49 @@ bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const d
 				cap = (int64_t)(((size_t)2 << 30) / rb);
 				if (cap < 65536) cap = 65536;
 			}
-			const size_t left = s->log_budget > s->log_bytes ? s->log_budget - s->log_bytes : 0;
-			if ((size_t)cap * rb > left) cap = (int64_t)(left / rb);
-			if (cap < n - done && (size_t)(n - done) * rb <= left) cap = n - done;
-			if (cap <= 0 || cap < n - done) { // the rest of this chunk does not fit: stop retaining
-				if (s->log_only) {
-					set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE, "the aggregate state's row log exceeds its budget (anofox_hip_agg_state_retain_rows)");
+			// HBM while its budget lasts, then page-locked host memory (the same kernels read it over PCIe), then nothing
+			auto fit_cap = [&](size_t left) { // rows of the next slab within `left` bytes; 0 = the rest of the chunk does not fit
+				int64_t c = cap;
+				if ((size_t)c * rb > left) c = (int64_t)(left / rb);
+				if (c < n - done && (size_t)(n - done) * rb <= left) c = n - done;
+				return (c <= 0 || c < n - done) ? (int64_t)0 : c;
+			};
+			auto alloc_slab = [&](int64_t c, bool on_host, RowLogSlab *out) {
+				RowLogSlab nsl{};
+				nsl.cap = c;
+				nsl.first_row = s->log_rows;
+				nsl.on_host = on_host ? 1 : 0;
+				auto get = [&](void **q, size_t bytes) {
+					return (on_host ? hipHostMalloc(q, bytes, hipHostMallocDefault) : hipMalloc(q, bytes)) == hipSuccess;
+				};
+				const bool ok = get((void **)&nsl.x, (size_t)c * p * sizeof(double)) && get((void **)&nsl.y, (size_t)c * sizeof(double)) &&
+				                (!weighted || get((void **)&nsl.w, (size_t)c * sizeof(double))) &&
+				                get((void **)&nsl.slot, (size_t)c * sizeof(uint32_t)) && get((void **)&nsl.valid, (size_t)c);
+				if (!ok) {
+					(void)hipGetLastError();
+					slab_release(nsl);
 					return false;
 				}
-				log_free(s);
-				s->log_dropped = true;
+				*out = nsl;
 				return true;
-			}
+			};
 			RowLogSlab sl{};
-			sl.cap = cap;
-			sl.first_row = s->log_rows;
-			bool ok = hipMalloc((void **)&sl.x, (size_t)cap * p * sizeof(double)) == hipSuccess &&
-			          hipMalloc((void **)&sl.y, (size_t)cap * sizeof(double)) == hipSuccess &&
-			          (!weighted || hipMalloc((void **)&sl.w, (size_t)cap * sizeof(double)) == hipSuccess) &&
-			          hipMalloc((void **)&sl.slot, (size_t)cap * sizeof(uint32_t)) == hipSuccess &&
-			          hipMalloc((void **)&sl.valid, (size_t)cap) == hipSuccess;
-			if (!ok) { // out of device memory: same outcome as an exceeded budget
-				(void)hipGetLastError();
-				void *parts[] = {sl.x, sl.y, sl.w, sl.slot, sl.valid};
-				for (void *q : parts)
-					if (q) (void)hipFree(q);
+			bool have = false;
+			const int64_t cap_dev = fit_cap(s->log_budget > s->log_bytes ? s->log_budget - s->log_bytes : 0);
+			if (cap_dev > 0 && alloc_slab(cap_dev, false, &sl)) {
+				have = true;
+				s->log_bytes += (size_t)cap_dev * rb;
+			} else {
+				const int64_t cap_host = fit_cap(s->log_host_budget > s->log_host_bytes ? s->log_host_budget - s->log_host_bytes : 0);
+				if (cap_host > 0 && alloc_slab(cap_host, true, &sl)) {
+					have = true;
+					s->log_host_bytes += (size_t)cap_host * rb;
+				}
+			}
+			if (!have) { // both budgets (or the memory itself) are exhausted: stop retaining
 				if (s->log_only) {
-					set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE, "hipMalloc failed for the aggregate state's row log");
+					set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE,
+					          "the aggregate state's row log exceeds its budgets (anofox_hip_agg_state_retain_rows / _retain_rows_host)");
 					return false;
 				}
 				log_free(s);
@@ -244,17 +264,16 @@ bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const d
 				return true;
 			}
 			s->slabs.push_back(sl);
-			s->log_bytes += (size_t)cap * rb;
 		}
 		RowLogSlab &sl = s->slabs.back();
 		const int64_t m = (n - done) < (sl.cap - sl.rows) ? (n - done) : (sl.cap - sl.rows);
 		const size_t at = (size_t)sl.rows;
-		bool bad = hip_fail(hipMemcpyAsync(sl.x + at * p, d_x + (size_t)done * p, (size_t)m * p * sizeof(double), hipMemcpyDeviceToDevice, st), "row log", e);
-		bad = bad || hip_fail(hipMemcpyAsync(sl.y + at, d_y + done, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st), "row log", e);
-		if (weighted) bad = bad || hip_fail(hipMemcpyAsync(sl.w + at, d_w + done, (size_t)m * sizeof(double), hipMemcpyDeviceToDevice, st), "row log", e);
-		bad = bad || hip_fail(hipMemcpyAsync(sl.slot + at, d_slot + done, (size_t)m * sizeof(uint32_t), hipMemcpyDeviceToDevice, st), "row log", e);
+		bool bad = hip_fail(hipMemcpyAsync(sl.x + at * p, d_x + (size_t)done * p, (size_t)m * p * sizeof(double), hipMemcpyDefault, st), "row log", e);
+		bad = bad || hip_fail(hipMemcpyAsync(sl.y + at, d_y + done, (size_t)m * sizeof(double), hipMemcpyDefault, st), "row log", e);
+		if (weighted) bad = bad || hip_fail(hipMemcpyAsync(sl.w + at, d_w + done, (size_t)m * sizeof(double), hipMemcpyDefault, st), "row log", e);
+		bad = bad || hip_fail(hipMemcpyAsync(sl.slot + at, d_slot + done, (size_t)m * sizeof(uint32_t), hipMemcpyDefault, st), "row log", e);
 		if (d_valid)
-			bad = bad || hip_fail(hipMemcpyAsync(sl.valid + at, d_valid + done, (size_t)m, hipMemcpyDeviceToDevice, st), "row log", e);
+			bad = bad || hip_fail(hipMemcpyAsync(sl.valid + at, d_valid + done, (size_t)m, hipMemcpyDefault, st), "row log", e);
 		else
 			bad = bad || hip_fail(hipMemsetAsync(sl.valid + at, 1, (size_t)m, st), "row log", e);
 		if (bad) return false;
@@ -431,14 +450,29 @@ bool anofox_hip_agg_state_retain_rows(AnofoxHipAggState *s, size_t max_bytes, An
 		s->log_budget = max_bytes ? max_bytes : ~(size_t)0;
 		return true;
 	}
-	s->retain = max_bytes > 0;
 	s->log_budget = max_bytes;
+	s->retain = s->log_budget > 0 || s->log_host_budget > 0;
 	s->log_dropped = false;
+	return true;
+}
+
+bool anofox_hip_agg_state_retain_rows_host(AnofoxHipAggState *s, size_t max_host_bytes, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!s) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL"); return false; }
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	if (s->rows > 0) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "retain_rows_host has to be called before the first update");
+		return false;
+	}
+	s->log_host_budget = max_host_bytes;
+	if (!s->log_only) s->retain = s->log_budget > 0 || s->log_host_budget > 0; // (a log-only state always keeps its rows)
 	return true;
 }
 
 int anofox_hip_agg_state_retaining(const AnofoxHipAggState *s) { return s && s->retain && !s->log_dropped ? 1 : 0; }
 size_t anofox_hip_agg_state_retained_bytes(const AnofoxHipAggState *s) { return s ? s->log_bytes : 0; }
+size_t anofox_hip_agg_state_retained_host_bytes(const AnofoxHipAggState *s) { return s ? s->log_host_bytes : 0; }
 
 bool anofox_hip_agg_state_update_device(AnofoxHipAggState *s, int64_t n_rows, int64_t n_slots, const uint32_t *d_slot, const double *d_y,
                                         const double *d_x_rowmajor, const double *d_w, const uint8_t *d_valid, AnofoxError *out_error) {
@@ -618,6 +652,12 @@ bool refit_from_log(AnofoxHipAggState *s, int64_t n, int64_t K, const int32_t *d
 	const size_t p = s->p;
 	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
 	const bool all = d_list == nullptr;
+	unsigned row_bits = 0, end_bit = 0;
+	if (!rowlog_key_bits(s->log_rows, K, &row_bits, &end_bit)) {
+		set_error(e, ANOFOX_ERROR_INVALID_INPUT, "finalize: " + std::to_string(K) + " groups x " + std::to_string(s->log_rows) +
+		                                             " logged rows do not fit one 64-bit refit key");
+		return false;
+	}
 	// index scratch: sorted slots | dense map | counters | slab table | sort temp for K keys
 	const size_t n_tab = s->slabs.size() ? s->slabs.size() : 1;
 	const size_t b_sorted = align_up((size_t)K * sizeof(int32_t), 256), b_dense = align_up((size_t)n * sizeof(int32_t), 256);
@@ -636,7 +676,7 @@ bool refit_from_log(AnofoxHipAggState *s, int64_t n, int64_t K, const int32_t *d
 		bad = bad || hip_fail(hipMemcpyAsync(d_tab, s->slabs.data(), s->slabs.size() * sizeof(RowLogSlab), hipMemcpyHostToDevice, st), "H2D", e);
 	for (size_t k = 0; !bad && k < s->slabs.size(); ++k) {
 		const RowLogSlab &sl = s->slabs[k];
-		bad = hip_fail(launch_rowlog_select(false, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, nullptr, st), "refit count", e);
+		bad = hip_fail(launch_rowlog_select(false, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, nullptr, row_bits, st), "refit count", e);
 	}
 	unsigned long long counts[2] = {0, 0};
 	bad = bad || hip_fail(hipMemcpyAsync(counts, d_counter, sizeof counts, hipMemcpyDeviceToHost, st), "D2H", e);
@@ -666,13 +706,13 @@ bool refit_from_log(AnofoxHipAggState *s, int64_t n, int64_t K, const int32_t *d
 	bad = hip_fail(hipMemsetAsync(d_counter, 0, 256, st), "hipMemsetAsync", e);
 	for (size_t k = 0; !bad && k < s->slabs.size(); ++k) {
 		const RowLogSlab &sl = s->slabs[k];
-		bad = hip_fail(launch_rowlog_select(true, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, d_ka, st), "refit fill", e);
+		bad = hip_fail(launch_rowlog_select(true, sl.slot, sl.valid, sl.rows, sl.first_row, d_dense, n, d_counter, d_ka, row_bits, st), "refit fill", e);
 	}
-	if (M) bad = bad || hip_fail(launch_rowlog_sort_keys(d_ka, d_kb, (int64_t)M, K, d_t2, b_t2, st), "refit sort", e);
+	if (M) bad = bad || hip_fail(launch_rowlog_sort_keys(d_ka, d_kb, (int64_t)M, end_bit, d_t2, b_t2, st), "refit sort", e);
 	// (columns are b_c bytes apart, not M doubles: every column starts 256-byte aligned)
 	const size_t col_stride = b_c / sizeof(double);
 	bad = bad || hip_fail(launch_rowlog_gather(d_kb, (int64_t)M, K, d_tab, (int)s->slabs.size(), (int)p, weighted ? 1 : 0, d_y, d_x, col_stride, d_w,
-	                                           d_off, st),
+	                                           d_off, row_bits, st),
 	                      "refit gather", e);
 	if (bad) return false;
 	const double *x_cols[kWideMaxP];
@@ -703,6 +743,15 @@ bool refit_queued(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf
 	if (!refit_from_log(s, n, queued, (const int32_t *)ctx->ws, false, d_core, d_inf, e)) return false;
 	*remaining = 0;
 	return true;
+}
+
+// The groups run_finalize queued and nothing refitted are not handed out as numbers: NaN records with status
+// ANOFOX_HIP_STATUS_UNREFINED.  The queue and its length are read on the device (no synchronisation).
+bool flag_unrefined(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf, AnofoxError *e) {
+	AnofoxHipContext *ctx = s->ctx;
+	return !hip_fail(launch_rowlog_flag_unrefined((const int32_t *)ctx->ws, ctx->last_refine_count, n, (int)s->p, d_core,
+	                                              s->opt.compute_inference ? d_inf : nullptr, ctx->stream),
+	                 "flag kernel launch", e);
 }
 
 bool check_finalize(AnofoxHipAggState *s, int64_t n, const void *core, const void *inf, AnofoxError *e) {
@@ -739,9 +788,14 @@ bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *s, int64_t n_slots,
 	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
 	if (s->log_only) return refit_from_log(s, n_slots, n_slots, nullptr, true, d_core, d_inference, out_error);
 	if (!run_finalize(s, n_slots, d_core, d_inference, out_error)) return false;
-	if (!s->retain) return true; // (no log: nothing to refit, and no reason to synchronise)
+	if (!s->retain || s->log_dropped) // no log: nothing to refit and no reason to synchronise — the queued groups are flagged
+		return flag_unrefined(s, n_slots, d_core, d_inference, out_error);
 	int64_t remaining = 0;
-	return refit_queued(s, n_slots, d_core, d_inference, &remaining, out_error);
+	if (!refit_queued(s, n_slots, d_core, d_inference, &remaining, out_error)) return false;
+	if (remaining != 0 && !flag_unrefined(s, n_slots, d_core, d_inference, out_error)) return false;
+	// (this path has synchronised already: report rows that named a slot >= n_slots, as finalize_host does; without a
+	// log the device entry point stays asynchronous and leaves that check to the caller's own validation)
+	return check_slot_flag(s, out_error);
 }
 
 bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, double *core, double *inference, int64_t *out_unrefined,
@@ -767,6 +821,7 @@ bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, d
 	} else {
 		if (!run_finalize(s, n_slots, d_core, d_inf, out_error)) return false;
 		if (!refit_queued(s, n_slots, d_core, d_inf, &queued, out_error)) return false;
+		if (queued > 0 && !flag_unrefined(s, n_slots, d_core, d_inf, out_error)) return false;
 	}
 	hipStream_t st = ctx->stream;
 	if (hip_fail(hipMemcpyAsync(core, d_core, G * (p + 6) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;

@@ -10,6 +10,7 @@
 // build container) do not need RCCL at all, and a process that already has an RCCL loaded (PyTorch ships one) keeps
 // using that copy.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 #include "context.h"
@@ -32,6 +33,7 @@ struct Rccl {
 	ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+	ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
 	std::string error;
 };
 
@@ -39,13 +41,20 @@ Rccl &rccl() {
 	static Rccl r;
 	static std::once_flag once;
 	std::call_once(once, [] {
+		// ANOFOX_RCCL_LIB: the one library to load (deployments with RCCL elsewhere; the test of the error path below)
+		const char *only = getenv("ANOFOX_RCCL_LIB");
 		const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-		for (const char *n : names) {
-			r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-			if (r.handle) break;
+		if (only && *only) {
+			r.handle = dlopen(only, RTLD_NOW | RTLD_LOCAL);
+		} else {
+			for (const char *n : names) {
+				r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+				if (r.handle) break;
+			}
 		}
 		if (!r.handle) {
-			r.error = std::string("RCCL is not available: ") + (dlerror() ? dlerror() : "dlopen failed");
+			const char *msg = dlerror(); // (reading it clears it: once)
+			r.error = std::string("RCCL is not available: ") + (msg ? msg : "dlopen failed");
 			return;
 		}
 		r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
@@ -53,6 +62,7 @@ Rccl &rccl() {
 		r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
 		r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
 		r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
+		r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
 		if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.error = "RCCL symbols missing in librccl";
 	});
 	return r;
@@ -122,6 +132,14 @@ void anofox_hip_comm_destroy(AnofoxHipComm *comm) {
 }
 
 int anofox_hip_comm_world_size(const AnofoxHipComm *comm) { return comm ? comm->world : 0; }
+// ranks RCCL itself counts in the communicator (ncclCommCount) — what an N-GPU run can be audited with; 0 if unknown
+int anofox_hip_comm_ranks_seen(const AnofoxHipComm *comm) {
+	if (!comm || !comm->comm) return 0;
+	Rccl &r = rccl();
+	int n = 0;
+	if (!r.CommCount || r.CommCount(comm->comm, &n) != ncclSuccess) return 0;
+	return n;
+}
 int anofox_hip_comm_rank(const AnofoxHipComm *comm) { return comm ? comm->rank : -1; }
 
 bool anofox_hip_gather_records_device(AnofoxHipComm *comm, const double *d_local, int64_t records_per_rank, size_t record_len,

@@ -409,7 +409,6 @@ hipError_t launch_ingest_combine(double *moments, int64_t *n_accum, int64_t n_sl
                                  int64_t n_pairs, int p, int center, hipStream_t stream);
 
 // ---- row log of a streaming aggregate state (rowlog.hip): the rows kept for the refit of queued groups ----
-constexpr unsigned kRowLogRowBits = 40; // global row number inside a sort key (group index above it)
 struct RowLogSlab {
 	double *x;       // [cap * p] row-major
 	double *y;       // [cap]
@@ -417,17 +416,23 @@ struct RowLogSlab {
 	uint32_t *slot;  // [cap]
 	uint8_t *valid;  // [cap]
 	int64_t first_row, rows, cap;
+	int32_t on_host; // 1: page-locked host memory (the spill beyond the HBM budget), read by the kernels over PCIe
+	int32_t pad;
 };
 size_t rowlog_sort_temp_bytes(int64_t n);
 hipError_t launch_rowlog_sort_slots(const int32_t *in, int32_t *out, int64_t n, void *temp, size_t temp_bytes, hipStream_t st);
 hipError_t launch_rowlog_iota(int32_t *v, int64_t n, hipStream_t st); // v[i] = i
 hipError_t launch_rowlog_dense(const int32_t *sorted_slots, int64_t k_n, int32_t *dense, int64_t n_slots, hipStream_t st);
+bool rowlog_key_bits(int64_t log_rows, int64_t k_n, unsigned *row_bits, unsigned *end_bit); // false: they do not fit one key
 hipError_t launch_rowlog_select(bool fill, const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row, const int32_t *dense,
-                                int64_t n_slots, unsigned long long *counter, uint64_t *keys, hipStream_t st);
-hipError_t launch_rowlog_sort_keys(const uint64_t *in, uint64_t *out, int64_t m, int64_t k_n, void *temp, size_t temp_bytes, hipStream_t st);
+                                int64_t n_slots, unsigned long long *counter, uint64_t *keys, unsigned row_bits, hipStream_t st);
+hipError_t launch_rowlog_sort_keys(const uint64_t *in, uint64_t *out, int64_t m, unsigned end_bit, void *temp, size_t temp_bytes, hipStream_t st);
 hipError_t launch_rowlog_gather(const uint64_t *keys, int64_t m, int64_t k_n, const RowLogSlab *d_slabs, int n_slabs, int p, int weighted,
-                                double *y, double *x_cols, size_t col_stride, double *w, int64_t *offs, hipStream_t st);
+                                double *y, double *x_cols, size_t col_stride, double *w, int64_t *offs, unsigned row_bits, hipStream_t st);
 hipError_t launch_rowlog_scatter(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, hipStream_t st);
+// records of the slots list[0 .. *count) (both on the device): every field NaN, status ANOFOX_HIP_STATUS_UNREFINED
+hipError_t launch_rowlog_flag_unrefined(const int32_t *list, const int32_t *count, int64_t n_slots, int p, double *core, double *inf,
+                                        hipStream_t st);
 hipError_t launch_rowlog_remap(uint32_t *remap, int64_t n_slots, const uint32_t *src, const uint32_t *dst, int64_t n_pairs,
                                const RowLogSlab *h_slabs, int n_slabs, hipStream_t st);
 

@@ -7,7 +7,8 @@
 // kernel), and Finalize pulls out the rows of exactly the groups its solve queued for refinement:
 //   mark      dense[slot] = k for the k-th queued slot (ascending), -1 elsewhere
 //   count     rows of the log that belong to a queued slot (one pass over the 4-byte slot column)
-//   fill      key = k << 40 | global row number, appended through a wave-aggregated counter
+//   fill      key = k << row_bits | global row number (row_bits = the bits the log's row count needs, so that
+//             2^31 slots and 2^33 rows both fit a 64-bit key), appended through a wave-aggregated counter
 //   sort      rocPRIM radix sort of the keys: groups contiguous, arrival order inside a group, whatever order the
 //             appends happened in
 //   gather    key -> slab row -> y / w / x columns of an ordinary batch (column-major), row_offsets by binary search
@@ -24,7 +25,6 @@ namespace anofox {
 namespace {
 
 constexpr int kLogBlock = 256;
-constexpr uint64_t kRowMask = (1ull << kRowLogRowBits) - 1;
 
 __global__ void rowlog_dense_kernel(const int32_t *sorted_slots, int64_t k_n, int32_t *dense) {
 	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,7 +74,7 @@ __device__ __forceinline__ int32_t rowlog_group_of(const uint32_t *slot, const u
 template <bool FILL>
 __global__ void __launch_bounds__(kLogBlock) rowlog_select_kernel(const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row,
                                                                   const int32_t *dense, int64_t n_slots, unsigned long long *counter,
-                                                                  uint64_t *keys) {
+                                                                  uint64_t *keys, unsigned row_bits) {
 	__shared__ unsigned long long s_base;
 	__shared__ int s_wave[kLogBlock / 64];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(kLogBlock) rowlog_select_kernel(const uint32_t
 		const int64_t i = tile0 + (int64_t)((it * (kLogBlock / 64) + wave) * 64 + lane);
 		const int32_t k = rowlog_group_of(slot, valid, i, n, dense, n_slots);
 		const uint64_t m = __ballot(k >= 0);
-		if (k >= 0) keys[at + (unsigned long long)__popcll(m & ((1ull << lane) - 1))] = ((uint64_t)k << kRowLogRowBits) | (uint64_t)(base_row + i);
+		if (k >= 0) keys[at + (unsigned long long)__popcll(m & ((1ull << lane) - 1))] = ((uint64_t)k << row_bits) | (uint64_t)(base_row + i);
 		at += (unsigned long long)__popcll(m);
 	}
 }
@@ -121,10 +121,10 @@ __device__ __forceinline__ int slab_of_row(const RowLogSlab *slabs, int n_slabs,
 }
 
 __global__ void rowlog_gather_kernel(const uint64_t *keys, int64_t m, const RowLogSlab *slabs, int n_slabs, int p, int weighted, double *y,
-                                     double *x_cols, size_t col_stride, double *w) {
+                                     double *x_cols, size_t col_stride, double *w, unsigned row_bits) {
 	const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= m) return;
-	const int64_t row = (int64_t)(keys[i] & kRowMask);
+	const int64_t row = (int64_t)(keys[i] & ((1ull << row_bits) - 1));
 	const RowLogSlab sl = slabs[slab_of_row(slabs, n_slabs, row)];
 	const int64_t r = row - sl.first_row;
 	y[i] = sl.y[r];
@@ -134,10 +134,10 @@ __global__ void rowlog_gather_kernel(const uint64_t *keys, int64_t m, const RowL
 }
 
 // offs[k] = first position whose key belongs to group >= k (k = 0 .. k_n)
-__global__ void rowlog_offsets_kernel(const uint64_t *keys, int64_t m, int64_t k_n, int64_t *offs) {
+__global__ void rowlog_offsets_kernel(const uint64_t *keys, int64_t m, int64_t k_n, int64_t *offs, unsigned row_bits) {
 	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (k > k_n) return;
-	const uint64_t want = (uint64_t)k << kRowLogRowBits;
+	const uint64_t want = (uint64_t)k << row_bits; // (k == k_n may need bit 64: row_bits + bits(k_n) <= 63, rowlog_key_bits)
 	int64_t lo = 0, hi = m;
 	while (lo < hi) {
 		const int64_t mid = (lo + hi) >> 1;
@@ -152,6 +152,21 @@ __global__ void rowlog_scatter_kernel(const double *src, const int32_t *sorted_s
 	const int64_t k = t / len;
 	const int j = (int)(t - k * len);
 	dst[(size_t)sorted_slots[k] * (size_t)len + (size_t)j] = src[t];
+}
+
+// one workgroup per list entry (grid-stride): a group the state could not refine is not handed out as a number
+__global__ void rowlog_flag_unrefined_kernel(const int32_t *list, const int32_t *count, int64_t n_slots, int p, double *core, double *inf) {
+	const int n = *count;
+	for (int k = blockIdx.x; k < n; k += gridDim.x) {
+		const int64_t g = list[k];
+		if (g < 0 || g >= n_slots) continue;
+		double *c = core + g * (int64_t)(p + 6);
+		for (int j = threadIdx.x; j < p + 6; j += blockDim.x) c[j] = (j == p + 5) ? (double)ANOFOX_HIP_STATUS_UNREFINED : __builtin_nan("");
+		if (inf) {
+			double *f = inf + g * (int64_t)(5 * p + 2);
+			for (int j = threadIdx.x; j < 5 * p + 2; j += blockDim.x) f[j] = __builtin_nan("");
+		}
+	}
 }
 
 inline unsigned grid_for(int64_t n, int64_t cap = 1 << 16) {
@@ -190,32 +205,48 @@ hipError_t launch_rowlog_dense(const int32_t *sorted_slots, int64_t k_n, int32_t
 }
 
 hipError_t launch_rowlog_select(bool fill, const uint32_t *slot, const uint8_t *valid, int64_t n, int64_t base_row, const int32_t *dense,
-                                int64_t n_slots, unsigned long long *counter, uint64_t *keys, hipStream_t st) {
+                                int64_t n_slots, unsigned long long *counter, uint64_t *keys, unsigned row_bits, hipStream_t st) {
 	if (n <= 0) return hipSuccess;
 	const unsigned tiles = (unsigned)((n + kSelectTile - 1) / kSelectTile); // n <= 2^24 rows per slab
 	if (fill)
-		rowlog_select_kernel<true><<<tiles, kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys);
+		rowlog_select_kernel<true><<<tiles, kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys, row_bits);
 	else
-		rowlog_select_kernel<false><<<tiles, kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys);
+		rowlog_select_kernel<false><<<tiles, kLogBlock, 0, st>>>(slot, valid, n, base_row, dense, n_slots, counter, keys, row_bits);
 	return hipGetLastError();
 }
 
-hipError_t launch_rowlog_sort_keys(const uint64_t *in, uint64_t *out, int64_t m, int64_t k_n, void *temp, size_t temp_bytes, hipStream_t st) {
-	unsigned end_bit = kRowLogRowBits;
-	while (end_bit < 64 && ((uint64_t)k_n >> (end_bit - kRowLogRowBits)) != 0) ++end_bit;
+// bits of a refit key: row_bits for the global row number, then the dense group index.  false when log_rows rows and
+// k_n groups do not fit 63 bits together (2^31 slots x 2^33 rows do not; the caller reports it instead of wrapping).
+bool rowlog_key_bits(int64_t log_rows, int64_t k_n, unsigned *row_bits, unsigned *end_bit) {
+	unsigned rb = 1;
+	while (rb < 62 && ((uint64_t)log_rows >> rb) != 0) ++rb;
+	unsigned kb = 1;
+	while (kb < 62 && ((uint64_t)k_n >> kb) != 0) ++kb; // k_n itself must be representable (rowlog_offsets_kernel)
+	*row_bits = rb;
+	*end_bit = rb + kb;
+	return rb + kb <= 63;
+}
+
+hipError_t launch_rowlog_sort_keys(const uint64_t *in, uint64_t *out, int64_t m, unsigned end_bit, void *temp, size_t temp_bytes, hipStream_t st) {
 	return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)m, 0u, end_bit, st);
 }
 
 hipError_t launch_rowlog_gather(const uint64_t *keys, int64_t m, int64_t k_n, const RowLogSlab *d_slabs, int n_slabs, int p, int weighted,
-                                double *y, double *x_cols, size_t col_stride, double *w, int64_t *offs, hipStream_t st) {
-	if (m > 0) rowlog_gather_kernel<<<grid_for(m, 1 << 30), kLogBlock, 0, st>>>(keys, m, d_slabs, n_slabs, p, weighted, y, x_cols, col_stride, w);
-	rowlog_offsets_kernel<<<grid_for(k_n + 1, 1 << 30), kLogBlock, 0, st>>>(keys, m, k_n, offs);
+                                double *y, double *x_cols, size_t col_stride, double *w, int64_t *offs, unsigned row_bits, hipStream_t st) {
+	if (m > 0) rowlog_gather_kernel<<<grid_for(m, 1 << 30), kLogBlock, 0, st>>>(keys, m, d_slabs, n_slabs, p, weighted, y, x_cols, col_stride, w, row_bits);
+	rowlog_offsets_kernel<<<grid_for(k_n + 1, 1 << 30), kLogBlock, 0, st>>>(keys, m, k_n, offs, row_bits);
 	return hipGetLastError();
 }
 
 hipError_t launch_rowlog_scatter(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, hipStream_t st) {
 	if (k_n <= 0) return hipSuccess;
 	rowlog_scatter_kernel<<<grid_for(k_n * len, 1 << 30), kLogBlock, 0, st>>>(src, sorted_slots, k_n, len, dst);
+	return hipGetLastError();
+}
+
+hipError_t launch_rowlog_flag_unrefined(const int32_t *list, const int32_t *count, int64_t n_slots, int p, double *core, double *inf,
+                                        hipStream_t st) {
+	rowlog_flag_unrefined_kernel<<<1024, 64, 0, st>>>(list, count, n_slots, p, core, inf);
 	return hipGetLastError();
 }
 

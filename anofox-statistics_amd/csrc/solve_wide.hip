@@ -659,12 +659,35 @@ __global__ __launch_bounds__(128) void inference_wide_finish_kernel(WideArgs arg
 	if (tid == 0) inf[5 * p + 1] = dm_f_sf(fstat, dfm, df); // every thread read df before the barrier above
 }
 
+// Error-free transformations for the residual pass below (round-to-nearest, no fast-math: -fno-fast-math in the Makefile).
+__device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
+	s = a + b;
+	const double bb = s - a;
+	e = (a - (s - bb)) + (b - bb);
+}
+__device__ __forceinline__ void two_prod(double a, double b, double &p, double &e) {
+	p = a * b;
+	e = fma(a, b, -p);
+}
+// (hi, lo) += (ahi, alo), kept as an unevaluated sum with |lo| <= ulp(hi)
+__device__ __forceinline__ void dd_add(double &hi, double &lo, double ahi, double alo) {
+	double s, e;
+	two_sum(hi, ahi, s, e);
+	e += lo + alo;
+	hi = s + e;
+	lo = e - (hi - s);
+}
+
 // One workgroup per queued group, straight from the data with the record's current coefficients:
 //   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ... },  r = y - b0 - x'b  over the valid rows.
+// The residual and the two gradient sums are formed in double-double arithmetic (compensated dot products): with the
+// residual in working precision the refinement stalls at cond(X) * 1e-13 — 1e-9 .. 5e-9 on nearly square designs of
+// 40 .. 128 columns (cond 1e3 .. 2e4), measured in round 2 — while an extended-precision residual takes the same
+// update to cond * eps in one step (the oracle refines the same way, in long double).  Only queued groups pay for it.
 __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) {
 	__shared__ double bsh[kWideMaxP];
-	__shared__ double we[256];
-	__shared__ double part[8];
+	__shared__ double weh[256], wel[256];
+	__shared__ double part[16];
 	const int p = args.p;
 	const int T = wide_tiles(p);
 	const int P16 = 16 * T;
@@ -687,18 +710,22 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 		const double shift = (tid < p && args.fit_intercept) ? vec[2 * P16 + tid] : 0.0; // x at the first valid row
 		const double *mycol = tid < p ? args.x_table[tid] : nullptr;
 		const int64_t lo = args.row_offsets[g], hi = group_row_end(args, g);
-		double rss = 0.0, gs = 0.0, gj = 0.0;
+		double rss = 0.0, gs_h = 0.0, gs_l = 0.0, gj_h = 0.0, gj_l = 0.0;
 		for (int64_t r0 = lo; r0 < hi; r0 += 256) {
 			const int64_t r = r0 + tid;
-			double wev = 0.0;
+			double wh = 0.0, wl = 0.0;
 			if (r < hi) {
 				const double yv = args.y[r];
 				bool ok = isfinite(yv);
-				double fit = b0;
+				double fh = b0, fl = 0.0; // fit = fh + fl
 				for (int j = 0; j < p; ++j) {
 					const double xv = args.x_table[j][r];
 					ok = ok && isfinite(xv);
-					fit = fma(bsh[j], xv, fit);
+					double ph, pl, sh, sl;
+					two_prod(bsh[j], xv, ph, pl);
+					two_sum(fh, ph, sh, sl);
+					fh = sh;
+					fl += pl + sl;
 				}
 				double wv = 1.0;
 				if (weighted) {
@@ -706,38 +733,56 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 					ok = ok && (wv > 0.0) && isfinite(wv);
 				}
 				if (ok) {
-					const double e = yv - fit;
-					wev = wv * e;
-					rss = fma(wev, e, rss);
-					gs += wev;
+					double eh, el;
+					two_sum(yv, -fh, eh, el);
+					el -= fl;
+					const double e = eh + el;
+					const double e_l = el - (e - eh); // e + e_l = y - fit to twice the working precision
+					double ph, pl;
+					two_prod(wv, e, ph, pl);
+					pl = fma(wv, e_l, pl);
+					wh = ph + pl;
+					wl = pl - (wh - ph);
+					rss = fma(wh, e, rss);
+					dd_add(gs_h, gs_l, wh, wl);
 				}
 			}
-			we[tid] = wev;
+			weh[tid] = wh;
+			wel[tid] = wl;
 			__syncthreads();
 			if (mycol) {
 				const int64_t m = (hi - r0 < 256) ? hi - r0 : 256;
 				for (int64_t t = 0; t < m; ++t) {
-					const double wt = we[t];
-					if (wt != 0.0) gj = fma(wt, mycol[r0 + t] - shift, gj); // invalid rows carry 0 and are skipped
+					const double wt = weh[t];
+					if (wt != 0.0) { // invalid rows carry 0 and are skipped
+						const double dx = mycol[r0 + t] - shift;
+						double ph, pl;
+						two_prod(wt, dx, ph, pl);
+						pl = fma(wel[t], dx, pl);
+						dd_add(gj_h, gj_l, ph, pl);
+					}
 				}
 			}
 			__syncthreads();
 		}
 		for (int m = 32; m >= 1; m >>= 1) {
 			rss += __shfl_xor(rss, m, 64);
-			gs += __shfl_xor(gs, m, 64);
+			dd_add(gs_h, gs_l, __shfl_xor(gs_h, m, 64), __shfl_xor(gs_l, m, 64));
 		}
 		if ((tid & 63) == 0) {
 			part[tid >> 6] = rss;
-			part[4 + (tid >> 6)] = gs;
+			part[4 + (tid >> 6)] = gs_h;
+			part[8 + (tid >> 6)] = gs_l;
 		}
 		__syncthreads();
 		double *out = args.refine_vec + g * (int64_t)(p + 2);
 		if (tid == 0) {
 			out[0] = part[0] + part[1] + part[2] + part[3];
-			out[1] = part[4] + part[5] + part[6] + part[7];
+			double h = part[4], l = part[8];
+			for (int w2 = 1; w2 < 4; ++w2) dd_add(h, l, part[4 + w2], part[8 + w2]);
+			out[1] = h + l;
 		}
-		if (tid < p) out[2 + tid] = gj;
+		if (tid < p) out[2 + tid] = gj_h + gj_l;
 	}
 }
 

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -239,9 +240,17 @@ class AggState:
     moment record per slot; `update` folds row chunks in, `combine` merges slots, `finalize` solves them."""
 
     def __init__(self, ctx: Context, n_features: int, options: _abi.AnofoxHipBatchOptions, initial_slots: int = 0,
-                 retain_bytes: int = 0):
-        """retain_bytes > 0: also keep the rows in HBM (up to that many bytes) so that finalize can refit the groups
-        the moments alone cannot resolve accurately (anofox_hip_agg_state_retain_rows)."""
+                 retain_bytes: Optional[int] = None, retain_host_bytes: Optional[int] = None):
+        """retain_bytes: HBM for a row log next to the moments (anofox_hip_agg_state_retain_rows), so that finalize can
+        refit the groups the moments alone cannot resolve; retain_host_bytes: page-locked host memory the log continues
+        in once that is spent (anofox_hip_agg_state_retain_rows_host).  None = the shim's defaults (64 GiB / 32 GiB,
+        ANOFOX_HIP_RETAIN_BYTES / ANOFOX_HIP_RETAIN_HOST_BYTES; slabs are allocated as rows arrive), 0 = moments only.
+        Groups that finalize can neither resolve nor refit come back as NaN records with status 101."""
+        log_only = int(n_features) > 8 or (bool(options.compute_inference) and int(options.hc_type) != 0 and int(options.model) != 1)
+        if retain_bytes is None:      # (a log-only state IS its log: uncapped unless the caller caps it)
+            retain_bytes = 0 if log_only else int(os.environ.get("ANOFOX_HIP_RETAIN_BYTES", 64 << 30))
+        if retain_host_bytes is None:
+            retain_host_bytes = int(os.environ.get("ANOFOX_HIP_RETAIN_HOST_BYTES", 32 << 30))
         self._lib = _abi.load()
         self._ctx = ctx          # keeps the context alive
         self.p = int(n_features)
@@ -255,6 +264,9 @@ class AggState:
         if retain_bytes:
             if not self._lib.anofox_hip_agg_state_retain_rows(self._h, int(retain_bytes), C.byref(err)):
                 raise AnofoxStatsError(err.code, err.text())
+        if retain_host_bytes:
+            if not self._lib.anofox_hip_agg_state_retain_rows_host(self._h, int(retain_host_bytes), C.byref(err)):
+                raise AnofoxStatsError(err.code, err.text())
 
     @property
     def retaining(self) -> bool:
@@ -263,6 +275,10 @@ class AggState:
     @property
     def retained_bytes(self) -> int:
         return int(self._lib.anofox_hip_agg_state_retained_bytes(self._h))
+
+    @property
+    def retained_host_bytes(self) -> int:
+        return int(self._lib.anofox_hip_agg_state_retained_host_bytes(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -334,7 +350,8 @@ class AggState:
             raise AnofoxStatsError(err.code, err.text())
 
     def finalize(self, n_slots: Optional[int] = None):
-        """-> (core[G, p+6], inference[G, 5p+2] or None, groups that would have taken the refinement passes)."""
+        """-> (core[G, p+6], inference[G, 5p+2] or None, number of groups flagged as unrefined: status 101, NaN record —
+        they asked for the refinement passes and their rows were not kept)."""
         G = self.n_slots if n_slots is None else int(n_slots)
         p = self.p
         core = np.empty((G, p + 6), dtype=np.float64)

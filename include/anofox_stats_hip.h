@@ -266,6 +266,10 @@ typedef struct {
 /* Per-group status word stored in the core record: an AnofoxErrorCode, or this value for groups the
  * aggregate maps to SQL NULL before calling the fit (fewer than 2 rows, ols_aggregate.cpp:263-267). */
 #define ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS 100
+/* A streaming aggregate state could not bring this group to the contract's accuracy: its solve asked for the
+ * refinement passes (ill-conditioned, or fitting almost exactly) and the group's rows are no longer there — no row log,
+ * or one that outgrew its budgets.  The record is NaN; the SQL layer returns NULL and counts it. */
+#define ANOFOX_HIP_STATUS_UNREFINED 101
 
 /* Result records, row-major f64, one per group:
  *   core[g]      = { coefficients[0..p), intercept, r_squared, adj_r_squared, residual_std_error,
@@ -478,23 +482,28 @@ ANOFOX_HIP_API bool anofox_hip_residuals_batch_host(AnofoxHipContext *ctx, int64
  *             per call.
  *   finalize  fit records of slots [0, n_slots) exactly as anofox_hip_fit_batch_* lays them out (status 100 for
  *             fewer than 2 accumulated rows, ols_aggregate.cpp:263-267).  The rows are gone, so the batch path's
- *             refinement passes (re-reading the rows of ill-conditioned or exactly fitting groups) cannot run:
- *             *out_unrefined (optional) is the number of groups that would have taken them — smallest Cholesky
- *             pivot ratio below 1e-3 or rss / tss below 1e-7: their coefficients carry cond^2 eps and their sigma / r^2
- *             the cancellation of rss = tss - |z|^2 — and out_unrefined_slots (optional, room for n_slots entries)
- *             receives their slot numbers, in no particular order.
+ *             refinement passes (re-reading the rows of ill-conditioned or exactly fitting groups) cannot run
+ *             unless a row log is kept (below).  A group that would have taken them — smallest Cholesky pivot ratio
+ *             below 1e-3 or rss / tss below 1e-7: its coefficients would carry cond^2 eps and its sigma / r^2 the
+ *             cancellation of rss = tss - |z|^2 — is NOT handed out as a number: its record is NaN with status
+ *             ANOFOX_HIP_STATUS_UNREFINED (101 -> SQL NULL).  *out_unrefined (optional) is the number of such groups
+ *             and out_unrefined_slots (optional, room for n_slots entries) receives their slot numbers, in no
+ *             particular order.  Every other record meets the batch entry points' tolerances.
  *   retain_rows(max_bytes)  (optional, before the first update) keeps every chunk in a row log in HBM as well — p + 2 (+ 1
  *             with weights) doubles and 5 bytes per row, up to max_bytes — and Finalize then refits exactly the groups
  *             its solve queued, through the batch path (accumulate, solve, refinement passes) on their logged rows:
  *             *out_unrefined is 0 and every group has the batch entry points' accuracy.  Combine re-labels the source
- *             slots' logged rows.  Exceeding max_bytes (or device memory) is not an error: the log is dropped,
- *             anofox_hip_agg_state_retaining() turns 0 and Finalize reports the queued groups as without a log.
- *             finalize_device synchronises the stream once when a log is kept (it does not otherwise).
+ *             slots' logged rows.  Exceeding max_bytes (or device memory) is not an error: the log continues in
+ *             page-locked host memory up to retain_rows_host's max_host_bytes (the kernels of Finalize read those
+ *             slabs over PCIe: 5 bytes per row for the selection, the queued groups' rows for the refit); beyond
+ *             both budgets the log is dropped, anofox_hip_agg_state_retaining() turns 0 and Finalize flags the queued
+ *             groups as without a log.  finalize_device synchronises the stream once when a log is kept.
  *   log-only  Designs of more than 8 features have no moment record to stream into, and HC standard errors (hc_type
  *             other than none, with inference, OLS / WLS) need a second pass over the rows: such a state keeps ONLY the
  *             row log — the reference's row buffers, in HBM — and Finalize runs the batch path over all of it.  Same
- *             entry points and results as above (*out_unrefined is 0); retain_rows(max_bytes) caps the log (0 = no
- *             cap) and an Update that exceeds the cap or device memory FAILS with ANOFOX_ERROR_ALLOCATION_FAILURE.
+ *             entry points and results as above (*out_unrefined is 0); retain_rows(max_bytes) caps the HBM part of the
+ *             log (0 = no cap), retain_rows_host its host part, and an Update that exceeds both (or the memory itself)
+ *             FAILS with ANOFOX_ERROR_ALLOCATION_FAILURE.
  *
  * A state belongs to one context (device + stream); calls on one state are serialised.  n_features <=
  * anofox_hip_agg_state_max_features() = 128.
@@ -506,8 +515,10 @@ ANOFOX_HIP_API bool anofox_hip_agg_state_create(AnofoxHipContext *ctx, size_t n_
 ANOFOX_HIP_API void anofox_hip_agg_state_destroy(AnofoxHipAggState *state);
 ANOFOX_HIP_API bool anofox_hip_agg_state_reserve(AnofoxHipAggState *state, int64_t n_slots, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_agg_state_retain_rows(AnofoxHipAggState *state, size_t max_bytes, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_agg_state_retain_rows_host(AnofoxHipAggState *state, size_t max_host_bytes, AnofoxError *out_error);
 ANOFOX_HIP_API int anofox_hip_agg_state_retaining(const AnofoxHipAggState *state);          /* 1 while a row log is kept */
 ANOFOX_HIP_API size_t anofox_hip_agg_state_retained_bytes(const AnofoxHipAggState *state);  /* HBM held by the log */
+ANOFOX_HIP_API size_t anofox_hip_agg_state_retained_host_bytes(const AnofoxHipAggState *state); /* page-locked host memory held by it */
 ANOFOX_HIP_API int64_t anofox_hip_agg_state_slots(const AnofoxHipAggState *state);
 ANOFOX_HIP_API int64_t anofox_hip_agg_state_rows(const AnofoxHipAggState *state);
 ANOFOX_HIP_API bool anofox_hip_agg_state_update_host(AnofoxHipAggState *state, int64_t n_rows, int64_t n_slots, const uint32_t *slot,
@@ -551,6 +562,8 @@ ANOFOX_HIP_API bool anofox_hip_comm_create(AnofoxHipContext *ctx, int world_size
 ANOFOX_HIP_API void anofox_hip_comm_destroy(AnofoxHipComm *comm);
 ANOFOX_HIP_API int anofox_hip_comm_world_size(const AnofoxHipComm *comm);
 ANOFOX_HIP_API int anofox_hip_comm_rank(const AnofoxHipComm *comm);
+/* ranks RCCL itself counts in the communicator (ncclCommCount): the audit figure of an N-GPU run; 0 = unknown */
+ANOFOX_HIP_API int anofox_hip_comm_ranks_seen(const AnofoxHipComm *comm);
 ANOFOX_HIP_API bool anofox_hip_gather_records_device(AnofoxHipComm *comm, const double *d_local, int64_t records_per_rank,
                                       size_t record_len, double *d_all, AnofoxError *out_error);
 

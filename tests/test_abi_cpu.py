@@ -144,3 +144,27 @@ def test_host_prediction_helpers_need_no_gpu():
     abi = import_pkg("_abi")
     assert not abi.load().anofox_predict_with_interval(None, 0, 0.0, None, 0, 1.0, 10, 0.95,
                                                         C.byref(abi.AnofoxPredictionResult()))
+
+
+def test_missing_rccl_is_a_clean_error_not_a_crash():
+    """The library loads RCCL at run time (dlopen).  When it cannot — a host without RCCL — the first comm call must
+    fail with ANOFOX_ERROR_INTERNAL and a message, not crash (round 2's error path read dlerror() twice: the second
+    read is NULL).  Run in a child process: the loader result is cached per process."""
+    import subprocess
+    import sys
+    code = (
+        "import importlib, ctypes as C\n"
+        "abi = importlib.import_module('anofox-statistics_amd._abi')\n"
+        "lib = abi.load()\n"
+        "err = abi.AnofoxError()\n"
+        "buf = (C.c_uint8 * 128)()\n"
+        "ok = lib.anofox_hip_comm_unique_id(buf, C.byref(err))\n"
+        "assert not ok and err.code == 99, (ok, err.code)\n"
+        "assert 'RCCL is not available' in err.text(), err.text()\n"
+        "ok = lib.anofox_hip_comm_unique_id(buf, C.byref(err))   # and again: the cached failure\n"
+        "assert not ok and 'RCCL is not available' in err.text()\n"
+        "assert lib.anofox_hip_comm_ranks_seen(None) == 0\n"
+        "print('clean')\n")
+    env = dict(os.environ, ANOFOX_RCCL_LIB="/nonexistent/librccl.so.1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "clean" in out.stdout, out.stderr[-2000:]

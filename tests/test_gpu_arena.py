@@ -194,7 +194,6 @@ def test_arena_keeps_rows_for_the_groups_moments_cannot_resolve(retain, monkeypa
         assert lib.arena_unrefined(arena) >= int(exact.sum())
         easy = ~exact
         assert_records_match(core[easy], rcore[easy], p, inf[easy], rinf[easy], what="arena, moments only, easy keys")
-        with np.errstate(all="ignore"):
-            d = np.abs(core[exact, p + 3] - rcore[exact, p + 3]) / rcore[exact, p + 3]
-        assert np.nanmax(np.where(np.isnan(d), np.inf, d)) > 1e-3          # sigma of the nearly exact keys is not usable
+        # sigma of the nearly exact keys cannot be had from the moments: those keys come back as SQL NULL, not as numbers
+        assert np.all(nn[exact] == 1) and np.all(nn[easy] == 0)
     lib.arena_destroy(arena)

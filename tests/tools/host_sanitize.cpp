@@ -48,12 +48,14 @@ size_t frames_scan_temp_bytes(int64_t) { return 4096; }
 STUB(launch_rowlog_sort_slots(const int32_t *, int32_t *, int64_t, void *, size_t, hipStream_t))
 STUB(launch_rowlog_iota(int32_t *, int64_t, hipStream_t))
 STUB(launch_rowlog_dense(const int32_t *, int64_t, int32_t *, int64_t, hipStream_t))
-STUB(launch_rowlog_select(bool, const uint32_t *, const uint8_t *, int64_t, int64_t, const int32_t *, int64_t, unsigned long long *, uint64_t *, hipStream_t))
-STUB(launch_rowlog_sort_keys(const uint64_t *, uint64_t *, int64_t, int64_t, void *, size_t, hipStream_t))
-STUB(launch_rowlog_gather(const uint64_t *, int64_t, int64_t, const RowLogSlab *, int, int, int, double *, double *, size_t, double *, int64_t *, hipStream_t))
+STUB(launch_rowlog_select(bool, const uint32_t *, const uint8_t *, int64_t, int64_t, const int32_t *, int64_t, unsigned long long *, uint64_t *, unsigned, hipStream_t))
+STUB(launch_rowlog_sort_keys(const uint64_t *, uint64_t *, int64_t, unsigned, void *, size_t, hipStream_t))
+STUB(launch_rowlog_gather(const uint64_t *, int64_t, int64_t, const RowLogSlab *, int, int, int, double *, double *, size_t, double *, int64_t *, unsigned, hipStream_t))
 STUB(launch_rowlog_scatter(const double *, const int32_t *, int64_t, int, double *, hipStream_t))
 STUB(launch_rowlog_remap(uint32_t *, int64_t, const uint32_t *, const uint32_t *, int64_t, const RowLogSlab *, int, hipStream_t))
 size_t rowlog_sort_temp_bytes(int64_t) { return 4096; }
+STUB(launch_rowlog_flag_unrefined(const int32_t *, const int32_t *, int64_t, int, double *, double *, hipStream_t))
+bool rowlog_key_bits(int64_t, int64_t, unsigned *rb, unsigned *eb) { *rb = 40; *eb = 64; return true; }
 size_t ingest_piece_table_bytes(int) { return 4096; }
 size_t ingest_sort_temp_bytes(int64_t) { return 4096; }
 bool accumulate_mid_supports(int p) { return p > 8 && p <= 32; }
