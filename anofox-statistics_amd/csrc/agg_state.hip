@@ -543,6 +543,11 @@ bool anofox_hip_agg_state_update_host(AnofoxHipAggState *s, int64_t n_rows, int6
 
 bool anofox_hip_agg_state_combine(AnofoxHipAggState *s, int64_t n_pairs, const uint32_t *source_slots, const uint32_t *target_slots,
                                   AnofoxError *out_error) {
+	return anofox_hip_agg_state_combine_ex(s, n_pairs, source_slots, target_slots, false, out_error);
+}
+
+bool anofox_hip_agg_state_combine_ex(AnofoxHipAggState *s, int64_t n_pairs, const uint32_t *source_slots, const uint32_t *target_slots,
+                                     bool preserve_sources, AnofoxError *out_error) {
 	reset_error(out_error);
 	if (!s || n_pairs < 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL or n_pairs negative"); return false; }
 	if (n_pairs == 0) return true;
@@ -560,11 +565,26 @@ bool anofox_hip_agg_state_combine(AnofoxHipAggState *s, int64_t n_pairs, const u
 				return false;
 			}
 			if (a == b) continue;
-			if (!seen.insert(a).second || !seen.insert(b).second) {
+			// (sources that are preserved are only read: the same one may feed several targets of a call)
+			const bool dup = preserve_sources ? (!seen.insert(b).second) : (!seen.insert(a).second || !seen.insert(b).second);
+			if (dup) {
 				set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "combine: a slot may take part in one pair per call");
 				return false;
 			}
 		}
+		if (preserve_sources)
+			for (int64_t i = 0; i < n_pairs; ++i)
+				if (source_slots[i] != target_slots[i] && seen.count(source_slots[i])) {
+					set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "combine: a slot is source and target in one call");
+					return false;
+				}
+	}
+	if (preserve_sources && s->log_only) {
+		// a row belongs to one slot of the log: sources that live on cannot also count for their targets
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT,
+		          "combine with preserved sources (window segment trees) is not available for designs of more than 8 features or HC "
+		          "standard errors: use the fit_predict window functions");
+		return false;
 	}
 	std::lock_guard<std::mutex> lk(s->ctx->mu);
 	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
@@ -577,10 +597,15 @@ bool anofox_hip_agg_state_combine(AnofoxHipAggState *s, int64_t n_pairs, const u
 	uint32_t *d_src = (uint32_t *)s->pair_buf, *d_dst = (uint32_t *)((char *)s->pair_buf + b);
 	if (hip_fail(hipMemcpyAsync(d_src, source_slots, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
 	if (hip_fail(hipMemcpyAsync(d_dst, target_slots, (size_t)n_pairs * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
-	if (!s->log_only &&
-	    hip_fail(launch_ingest_combine(s->moments, s->n_accum, s->n_slots, d_src, d_dst, n_pairs, (int)s->p, s->opt.fit_intercept ? 1 : 0, st),
-	             "combine kernel launch", out_error))
+	if (!s->log_only && hip_fail(launch_ingest_combine(s->moments, s->n_accum, s->n_slots, d_src, d_dst, n_pairs, (int)s->p,
+	                                                   s->opt.fit_intercept ? 1 : 0, preserve_sources ? 1 : 0, st),
+	                             "combine kernel launch", out_error))
 		return false;
+	if (preserve_sources && s->retain && !s->log_dropped) {
+		// the log cannot say "these rows count twice": it is given up, and Finalize flags what the moments cannot resolve
+		log_free(s);
+		s->log_dropped = true;
+	}
 	if (s->retain && !s->log_dropped && s->log_rows > 0) { // the sources' rows in the log now belong to the targets
 		if (!ensure_buffer(&s->remap_buf, &s->remap_bytes, (size_t)s->n_slots * sizeof(uint32_t), "row log remap", out_error)) return false;
 		if (hip_fail(launch_rowlog_remap((uint32_t *)s->remap_buf, s->n_slots, d_src, d_dst, n_pairs, s->slabs.data(), (int)s->slabs.size(), st),
@@ -595,8 +620,12 @@ bool anofox_hip_agg_state_combine(AnofoxHipAggState *s, int64_t n_pairs, const u
 
 namespace {
 
-// solve every slot [0, n) on the state's records; d_core / d_inf are device buffers
+// solve n records (the state's own: every slot [0, n); or a gathered subset); d_core / d_inf are device buffers
+bool run_solve(AnofoxHipAggState *s, int64_t n, double *d_moments, const int64_t *d_rule_counts, double *d_core, double *d_inf, AnofoxError *e);
 bool run_finalize(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf, AnofoxError *e) {
+	return run_solve(s, n, s->moments, s->n_accum, d_core, d_inf, e);
+}
+bool run_solve(AnofoxHipAggState *s, int64_t n, double *d_moments, const int64_t *d_rule_counts, double *d_core, double *d_inf, AnofoxError *e) {
 	AnofoxHipContext *ctx = s->ctx;
 	const size_t p = s->p;
 	// workspace: refine list | refine vec | counters | t memo  (the refinement passes need the rows and do not run here;
@@ -616,14 +645,14 @@ bool run_finalize(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf
 	a.hc_type = ANOFOX_HC_NONE;
 	a.confidence_level = s->opt.confidence_level;
 	a.alpha = s->opt.alpha;
-	a.moments = s->moments;
+	a.moments = d_moments;
 	a.core = d_core;
 	a.inference = s->opt.compute_inference ? d_inf : nullptr;
 	a.refine_list = (int32_t *)base;
 	a.refine_vec = (double *)(base + b_lst);
 	a.refine_count = (int32_t *)(base + b_lst + b_vec);
 	a.tcrit_table = base + b_lst + b_vec + 256;
-	a.rule_counts = s->n_accum; // the aggregate's "< 2 accumulated rows -> NULL" (ols_aggregate.cpp:263-267)
+	a.rule_counts = d_rule_counts; // the aggregate's "< 2 accumulated rows -> NULL" (ols_aggregate.cpp:263-267)
 	ctx->last_refine_count = a.refine_count;
 	hipStream_t st = ctx->stream;
 	if (hip_fail(hipMemsetAsync(a.refine_count, 0, 256 + kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
@@ -646,7 +675,7 @@ bool run_finalize(AnofoxHipAggState *s, int64_t n, double *d_core, double *d_inf
 // d_list[k] of d_core / d_inf (scatter) or, for all slots, straight to rows 0 .. n - 1.  Synchronises the stream once
 // (the number of selected rows has to reach the host).
 bool refit_from_log(AnofoxHipAggState *s, int64_t n, int64_t K, const int32_t *d_list, bool keep_hc, double *d_core, double *d_inf,
-                    AnofoxError *e) {
+                    AnofoxError *e, const int32_t *d_pos = nullptr) {
 	AnofoxHipContext *ctx = s->ctx;
 	hipStream_t st = ctx->stream;
 	const size_t p = s->p;
@@ -721,8 +750,8 @@ bool refit_from_log(AnofoxHipAggState *s, int64_t n, int64_t K, const int32_t *d
 	if (!keep_hc) opt.hc_type = ANOFOX_HC_NONE;
 	if (!refit_groups_device(ctx, K, p, (int64_t)M, d_off, d_y, x_cols, weighted ? d_w : nullptr, opt, d_core2, d_inf2, e)) return false;
 	if (all) return true;
-	bad = hip_fail(launch_rowlog_scatter(d_core2, d_sorted, K, (int)(p + 6), d_core, st), "refit scatter", e);
-	if (d_inf2) bad = bad || hip_fail(launch_rowlog_scatter(d_inf2, d_sorted, K, (int)(5 * p + 2), d_inf, st), "refit scatter", e);
+	bad = hip_fail(launch_rowlog_scatter(d_core2, d_sorted, K, (int)(p + 6), d_core, d_pos, st), "refit scatter", e);
+	if (d_inf2) bad = bad || hip_fail(launch_rowlog_scatter(d_inf2, d_sorted, K, (int)(5 * p + 2), d_inf, d_pos, st), "refit scatter", e);
 	return !bad;
 }
 
@@ -832,6 +861,112 @@ bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *s, int64_t n_slots, d
 		if (hip_fail(hipMemcpy(out_unrefined_slots, ctx->ws, (size_t)queued * sizeof(int32_t), hipMemcpyDeviceToHost), "D2H", out_error)) return false;
 	}
 	return true;
+}
+
+// Finalize of a SUBSET of the slots (DuckDB finalizes vectors of states; under the windowed-aggregate protocol states
+// are created, finalized and destroyed per frame, so fitting every slot at every Finalize would cost frames x slots):
+// record k of core / inference belongs to slots[k].  The listed slots must be distinct.
+bool anofox_hip_agg_state_finalize_slots_host(AnofoxHipAggState *s, int64_t n_list, const uint32_t *slots, double *core, double *inference,
+                                              int64_t *out_unrefined, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (out_unrefined) *out_unrefined = 0;
+	if (!s || n_list < 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL or n_list negative"); return false; }
+	if (n_list == 0) return true;
+	if (!slots || !core) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "slots or core is NULL"); return false; }
+	if (s->opt.compute_inference && !inference) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "inference buffer is NULL"); return false; }
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	for (int64_t k = 0; k < n_list; ++k)
+		if ((int64_t)slots[k] >= s->n_slots) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "finalize: slot index out of range"); return false; }
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	AnofoxHipContext *ctx = s->ctx;
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	if (!s->log_only && !state_reserve(s, s->n_slots, out_error)) return false; // slots handed out but never updated
+	hipStream_t st = ctx->stream;
+	const size_t p = s->p, K = (size_t)n_list, rec = (size_t)moment_record_len((int)p);
+	// staging: core | inference | list | positions | gathered records | gathered counts | mapped queue
+	const size_t b_core = align_up(K * (p + 6) * sizeof(double), 256);
+	const size_t b_inf = s->opt.compute_inference ? align_up(K * (5 * p + 2) * sizeof(double), 256) : 0;
+	const size_t b_list = align_up(K * sizeof(uint32_t), 256), b_pos = align_up((size_t)s->n_slots * sizeof(int32_t), 256);
+	const size_t b_mom = s->log_only ? 0 : align_up(K * rec * sizeof(double), 256), b_cnt = s->log_only ? 0 : align_up(K * sizeof(int64_t), 256);
+	const size_t b_q = align_up(K * sizeof(int32_t), 256);
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_core + b_inf + b_list + b_pos + b_mom + b_cnt + b_q, "staging", out_error)) return false;
+	char *sb = (char *)ctx->stage;
+	double *d_core = (double *)sb;
+	double *d_inf = b_inf ? (double *)(sb + b_core) : nullptr;
+	uint32_t *d_sel = (uint32_t *)(sb + b_core + b_inf);
+	int32_t *d_pos = (int32_t *)(sb + b_core + b_inf + b_list);
+	double *d_mom = (double *)(sb + b_core + b_inf + b_list + b_pos);
+	int64_t *d_cnt = (int64_t *)((char *)d_mom + b_mom);
+	int32_t *d_q = (int32_t *)((char *)d_cnt + b_cnt);
+	bool bad = hip_fail(hipMemcpyAsync(d_sel, slots, K * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error);
+	bad = bad || hip_fail(launch_rowlog_positions(d_sel, n_list, d_pos, s->n_slots, st), "positions kernel launch", out_error);
+	if (bad) return false;
+	int64_t queued = 0;
+	if (s->log_only) {
+		if (!refit_from_log(s, s->n_slots, n_list, (const int32_t *)d_sel, true, d_core, d_inf, out_error, d_pos)) return false;
+	} else {
+		if (hip_fail(launch_ingest_gather_slots(s->moments, s->n_accum, d_sel, n_list, (int)p, d_mom, d_cnt, st), "gather kernel launch", out_error))
+			return false;
+		if (!run_solve(s, n_list, d_mom, d_cnt, d_core, d_inf, out_error)) return false;
+		int32_t q32 = 0;
+		if (hip_fail(hipMemcpyAsync(&q32, ctx->last_refine_count, sizeof q32, hipMemcpyDeviceToHost, st), "D2H", out_error)) return false;
+		if (hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error)) return false;
+		queued = q32 > n_list ? n_list : q32;
+		if (queued > 0) {
+			if (s->retain && !s->log_dropped && s->log_rows > 0) {
+				// the queue holds positions in the list: the refit wants slot numbers, its scatter goes back to positions
+				if (hip_fail(launch_rowlog_map_queue((const int32_t *)ctx->ws, ctx->last_refine_count, d_sel, d_q, st), "queue kernel launch", out_error))
+					return false;
+				if (!refit_from_log(s, s->n_slots, queued, d_q, false, d_core, d_inf, out_error, d_pos)) return false;
+				queued = 0;
+			} else if (hip_fail(launch_rowlog_flag_unrefined((const int32_t *)ctx->ws, ctx->last_refine_count, n_list, (int)p, d_core, d_inf, st),
+			                    "flag kernel launch", out_error)) {
+				return false;
+			}
+		}
+	}
+	if (hip_fail(hipMemcpyAsync(core, d_core, K * (p + 6) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H core", out_error)) return false;
+	if (d_inf && hip_fail(hipMemcpyAsync(inference, d_inf, K * (5 * p + 2) * sizeof(double), hipMemcpyDeviceToHost, st), "D2H inference", out_error)) return false;
+	if (!check_slot_flag(s, out_error)) return false; // (synchronises the stream)
+	if (out_unrefined) *out_unrefined = queued;
+	return true;
+}
+
+// Destroy of aggregate states (ols_aggregate.cpp:108-118): the listed slots are emptied — all-zero record, no accepted
+// rows, their logged rows invalidated — and may be handed out again by the caller.
+bool anofox_hip_agg_state_release_slots(AnofoxHipAggState *s, int64_t n_list, const uint32_t *slots, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!s || n_list < 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL or n_list negative"); return false; }
+	if (n_list == 0) return true;
+	if (!slots) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "slots is NULL"); return false; }
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	for (int64_t k = 0; k < n_list; ++k)
+		if ((int64_t)slots[k] >= s->n_slots) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "release: slot index out of range"); return false; }
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
+	hipStream_t st = s->ctx->stream;
+	const size_t b = align_up((size_t)n_list * sizeof(uint32_t), 256);
+	if (b > s->pair_bytes) {
+		if (hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error)) return false;
+		if (!ensure_buffer(&s->pair_buf, &s->pair_bytes, b, "release list", out_error)) return false;
+	}
+	uint32_t *d_list = (uint32_t *)s->pair_buf;
+	if (hip_fail(hipMemcpyAsync(d_list, slots, (size_t)n_list * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
+	if (!s->log_only && s->moments) {
+		// (slots beyond the capacity were never written: nothing to clear)
+		for (int64_t k = 0; k < n_list; ++k)
+			if ((int64_t)slots[k] >= s->capacity) { if (!state_reserve(s, s->n_slots, out_error)) return false; break; }
+		if (hip_fail(launch_ingest_clear_slots(s->moments, s->n_accum, d_list, n_list, (int)s->p, st), "clear kernel launch", out_error)) return false;
+	}
+	if ((s->retain || s->log_only) && !s->log_dropped && s->log_rows > 0) {
+		if (!ensure_buffer(&s->remap_buf, &s->remap_bytes, (size_t)s->n_slots * sizeof(uint32_t), "row log marks", out_error)) return false;
+		if (hip_fail(launch_rowlog_invalidate((uint8_t *)s->remap_buf, s->n_slots, d_list, n_list, s->slabs.data(), (int)s->slabs.size(), st),
+		             "row log invalidate launch", out_error))
+			return false;
+	}
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error); // the list is pageable host memory
 }
 
 void *anofox_hip_host_alloc(size_t bytes) {

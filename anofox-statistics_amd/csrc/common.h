@@ -405,8 +405,12 @@ size_t ingest_sort_temp_bytes(int64_t n);
 hipError_t launch_ingest_chunk(const IngestArgs &a, hipStream_t stream);
 // merge slot src[i] into slot dst[i] (dst's rows come first, as in OlsAggCombine: ols_aggregate.cpp:189-234) and
 // empty src[i]; the dst indices of one call must be distinct
+// preserve != 0: the sources keep their records (DuckDB's AggregateCombineType::PRESERVE_INPUT: window segment trees)
 hipError_t launch_ingest_combine(double *moments, int64_t *n_accum, int64_t n_slots, const uint32_t *src, const uint32_t *dst,
-                                 int64_t n_pairs, int p, int center, hipStream_t stream);
+                                 int64_t n_pairs, int p, int center, int preserve, hipStream_t stream);
+hipError_t launch_ingest_gather_slots(const double *moments, const int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, double *out_m,
+                                      int64_t *out_n, hipStream_t st);
+hipError_t launch_ingest_clear_slots(double *moments, int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, hipStream_t st);
 
 // ---- row log of a streaming aggregate state (rowlog.hip): the rows kept for the refit of queued groups ----
 struct RowLogSlab {
@@ -429,7 +433,16 @@ hipError_t launch_rowlog_select(bool fill, const uint32_t *slot, const uint8_t *
 hipError_t launch_rowlog_sort_keys(const uint64_t *in, uint64_t *out, int64_t m, unsigned end_bit, void *temp, size_t temp_bytes, hipStream_t st);
 hipError_t launch_rowlog_gather(const uint64_t *keys, int64_t m, int64_t k_n, const RowLogSlab *d_slabs, int n_slabs, int p, int weighted,
                                 double *y, double *x_cols, size_t col_stride, double *w, int64_t *offs, unsigned row_bits, hipStream_t st);
-hipError_t launch_rowlog_scatter(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, hipStream_t st);
+// dst row of sorted_slots[k]: the slot itself, or pos[slot] when pos is given (subset Finalize: rows of the caller's list)
+hipError_t launch_rowlog_scatter(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, const int32_t *pos,
+                                 hipStream_t st);
+// pos[list[k]] = k, -1 elsewhere
+hipError_t launch_rowlog_positions(const uint32_t *list, int64_t n_list, int32_t *pos, int64_t n_slots, hipStream_t st);
+// out[i] = sel[queue[i]] for i < *count (the slots behind the subset indices a solve queued); grid-stride, count on the device
+hipError_t launch_rowlog_map_queue(const int32_t *queue, const int32_t *count, const uint32_t *sel, int32_t *out, hipStream_t st);
+// logged rows of the slots marked in mark[] (one byte per slot) are invalidated (Destroy of their aggregate states)
+hipError_t launch_rowlog_invalidate(uint8_t *mark, int64_t n_slots, const uint32_t *list, int64_t n_list, const RowLogSlab *h_slabs, int n_slabs,
+                                    hipStream_t st);
 // records of the slots list[0 .. *count) (both on the device): every field NaN, status ANOFOX_HIP_STATUS_UNREFINED
 hipError_t launch_rowlog_flag_unrefined(const int32_t *list, const int32_t *count, int64_t n_slots, int p, double *core, double *inf,
                                         hipStream_t st);

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void ingest_pieces_kernel(IngestArgs a) {
 
 template <int P, bool CENTER>
 __global__ __launch_bounds__(256) void ingest_combine_kernel(double *moments, int64_t *n_accum, int64_t n_slots, const uint32_t *src,
-                                                             const uint32_t *dst, int64_t n_pairs) {
+                                                             const uint32_t *dst, int64_t n_pairs, int preserve) {
 	using L = MomentLayout<P>;
 	const int lane = threadIdx.x & 63;
 	const int64_t v = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + (int64_t)blockIdx.x * 4;
@@ -311,10 +311,11 @@ __global__ __launch_bounds__(256) void ingest_combine_kernel(double *moments, in
 	if ((int64_t)s >= n_slots || (int64_t)d >= n_slots || s == d) return;
 	double *srec = moments + (int64_t)s * L::REC;
 	merge_into_state<P, CENTER>(moments + (int64_t)d * L::REC, srec, 1, lane);
-	for (int k = lane; k < L::REC; k += 64) srec[k] = 0.0; // the source state is reset (Combine moves its rows)
+	if (!preserve)
+		for (int k = lane; k < L::REC; k += 64) srec[k] = 0.0; // the source state is reset (Combine moves its rows)
 	if (lane == 0) {
 		n_accum[d] += n_accum[s];
-		n_accum[s] = 0;
+		if (!preserve) n_accum[s] = 0;
 	}
 }
 
@@ -351,10 +352,10 @@ hipError_t launch_chunk_p(const IngestArgs &a, hipStream_t st) {
 
 template <int P>
 hipError_t launch_combine_p(double *moments, int64_t *n_accum, int64_t n_slots, const uint32_t *src, const uint32_t *dst,
-                            int64_t n_pairs, int center, hipStream_t st) {
+                            int64_t n_pairs, int center, int preserve, hipStream_t st) {
 	const dim3 grid((unsigned)((n_pairs + 3) / 4)), block(256);
-	if (center) hipLaunchKernelGGL((ingest_combine_kernel<P, true>), grid, block, 0, st, moments, n_accum, n_slots, src, dst, n_pairs);
-	else hipLaunchKernelGGL((ingest_combine_kernel<P, false>), grid, block, 0, st, moments, n_accum, n_slots, src, dst, n_pairs);
+	if (center) hipLaunchKernelGGL((ingest_combine_kernel<P, true>), grid, block, 0, st, moments, n_accum, n_slots, src, dst, n_pairs, preserve);
+	else hipLaunchKernelGGL((ingest_combine_kernel<P, false>), grid, block, 0, st, moments, n_accum, n_slots, src, dst, n_pairs, preserve);
 	return hipGetLastError();
 }
 
@@ -388,18 +389,53 @@ hipError_t launch_ingest_chunk(const IngestArgs &a, hipStream_t stream) {
 	}
 }
 
+namespace {
+// records and accepted-row counts of the listed slots -> contiguous rows k = 0 .. n_list - 1 (subset Finalize)
+__global__ void ingest_gather_slots_kernel(const double *moments, const int64_t *n_accum, const uint32_t *list, int64_t n_list, int rec,
+                                           double *out_m, int64_t *out_n) {
+	for (int64_t k = blockIdx.x; k < n_list; k += gridDim.x) {
+		const int64_t s = list[k];
+		for (int j = threadIdx.x; j < rec; j += blockDim.x) out_m[k * rec + j] = moments[s * rec + j];
+		if (threadIdx.x == 0) out_n[k] = n_accum[s];
+	}
+}
+// Destroy of aggregate states: the listed slots become empty again (all-zero record, no accepted rows)
+__global__ void ingest_clear_slots_kernel(double *moments, int64_t *n_accum, const uint32_t *list, int64_t n_list, int rec) {
+	for (int64_t k = blockIdx.x; k < n_list; k += gridDim.x) {
+		const int64_t s = list[k];
+		for (int j = threadIdx.x; j < rec; j += blockDim.x) moments[s * rec + j] = 0.0;
+		if (threadIdx.x == 0) n_accum[s] = 0;
+	}
+}
+} // namespace
+
+hipError_t launch_ingest_gather_slots(const double *moments, const int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, double *out_m,
+                                      int64_t *out_n, hipStream_t st) {
+	if (n_list <= 0) return hipSuccess;
+	const unsigned grid = (unsigned)(n_list < 65535 ? n_list : 65535);
+	hipLaunchKernelGGL(ingest_gather_slots_kernel, dim3(grid), dim3(64), 0, st, moments, n_accum, list, n_list, moment_record_len(p), out_m, out_n);
+	return hipGetLastError();
+}
+
+hipError_t launch_ingest_clear_slots(double *moments, int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, hipStream_t st) {
+	if (n_list <= 0) return hipSuccess;
+	const unsigned grid = (unsigned)(n_list < 65535 ? n_list : 65535);
+	hipLaunchKernelGGL(ingest_clear_slots_kernel, dim3(grid), dim3(64), 0, st, moments, n_accum, list, n_list, moment_record_len(p));
+	return hipGetLastError();
+}
+
 hipError_t launch_ingest_combine(double *moments, int64_t *n_accum, int64_t n_slots, const uint32_t *src, const uint32_t *dst,
-                                 int64_t n_pairs, int p, int center, hipStream_t stream) {
+                                 int64_t n_pairs, int p, int center, int preserve, hipStream_t stream) {
 	if (n_pairs <= 0) return hipSuccess;
 	switch (p) {
-	case 1: return launch_combine_p<1>(moments, n_accum, n_slots, src, dst, n_pairs, center, stream);
-	case 2: return launch_combine_p<2>(moments, n_accum, n_slots, src, dst, n_pairs, center, stream);
-	case 3: return launch_combine_p<3>(moments, n_accum, n_slots, src, dst, n_pairs, center, stream);
-	case 4: return launch_combine_p<4>(moments, n_accum, n_slots, src, dst, n_pairs, center, stream);
-	case 5: return launch_combine_p<5>(moments, n_accum, n_slots, src, dst, n_pairs, center, stream);
-	case 6: return launch_combine_p<6>(moments, n_accum, n_slots, src, dst, n_pairs, center, stream);
-	case 7: return launch_combine_p<7>(moments, n_accum, n_slots, src, dst, n_pairs, center, stream);
-	case 8: return launch_combine_p<8>(moments, n_accum, n_slots, src, dst, n_pairs, center, stream);
+	case 1: return launch_combine_p<1>(moments, n_accum, n_slots, src, dst, n_pairs, center, preserve, stream);
+	case 2: return launch_combine_p<2>(moments, n_accum, n_slots, src, dst, n_pairs, center, preserve, stream);
+	case 3: return launch_combine_p<3>(moments, n_accum, n_slots, src, dst, n_pairs, center, preserve, stream);
+	case 4: return launch_combine_p<4>(moments, n_accum, n_slots, src, dst, n_pairs, center, preserve, stream);
+	case 5: return launch_combine_p<5>(moments, n_accum, n_slots, src, dst, n_pairs, center, preserve, stream);
+	case 6: return launch_combine_p<6>(moments, n_accum, n_slots, src, dst, n_pairs, center, preserve, stream);
+	case 7: return launch_combine_p<7>(moments, n_accum, n_slots, src, dst, n_pairs, center, preserve, stream);
+	case 8: return launch_combine_p<8>(moments, n_accum, n_slots, src, dst, n_pairs, center, preserve, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -146,12 +146,35 @@ __global__ void rowlog_offsets_kernel(const uint64_t *keys, int64_t m, int64_t k
 	offs[k] = lo;
 }
 
-__global__ void rowlog_scatter_kernel(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst) {
+__global__ void rowlog_scatter_kernel(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, const int32_t *pos) {
 	const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (t >= k_n * len) return;
 	const int64_t k = t / len;
 	const int j = (int)(t - k * len);
-	dst[(size_t)sorted_slots[k] * (size_t)len + (size_t)j] = src[t];
+	const int64_t row = pos ? pos[sorted_slots[k]] : sorted_slots[k];
+	if (row >= 0) dst[(size_t)row * (size_t)len + (size_t)j] = src[t];
+}
+
+__global__ void rowlog_positions_kernel(const uint32_t *list, int64_t n_list, int32_t *pos) {
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n_list) pos[list[k]] = (int32_t)k;
+}
+
+__global__ void rowlog_map_queue_kernel(const int32_t *queue, const int32_t *count, const uint32_t *sel, int32_t *out) {
+	const int n = *count;
+	for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (int32_t)sel[queue[i]];
+}
+
+__global__ void rowlog_mark_kernel(const uint32_t *list, int64_t n_list, uint8_t *mark) {
+	const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (k < n_list) mark[list[k]] = 1;
+}
+
+__global__ void rowlog_invalidate_kernel(const uint32_t *slot, uint8_t *valid, int64_t n, const uint8_t *mark, int64_t n_slots) {
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+		const uint32_t s = slot[i];
+		if ((int64_t)s < n_slots && mark[s]) valid[i] = 0;
+	}
 }
 
 // one workgroup per list entry (grid-stride): a group the state could not refine is not handed out as a number
@@ -238,9 +261,34 @@ hipError_t launch_rowlog_gather(const uint64_t *keys, int64_t m, int64_t k_n, co
 	return hipGetLastError();
 }
 
-hipError_t launch_rowlog_scatter(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, hipStream_t st) {
+hipError_t launch_rowlog_scatter(const double *src, const int32_t *sorted_slots, int64_t k_n, int len, double *dst, const int32_t *pos,
+                                 hipStream_t st) {
 	if (k_n <= 0) return hipSuccess;
-	rowlog_scatter_kernel<<<grid_for(k_n * len, 1 << 30), kLogBlock, 0, st>>>(src, sorted_slots, k_n, len, dst);
+	rowlog_scatter_kernel<<<grid_for(k_n * len, 1 << 30), kLogBlock, 0, st>>>(src, sorted_slots, k_n, len, dst, pos);
+	return hipGetLastError();
+}
+
+hipError_t launch_rowlog_positions(const uint32_t *list, int64_t n_list, int32_t *pos, int64_t n_slots, hipStream_t st) {
+	hipError_t rc = hipMemsetAsync(pos, 0xff, (size_t)n_slots * sizeof(int32_t), st);
+	if (rc != hipSuccess) return rc;
+	if (n_list > 0) rowlog_positions_kernel<<<grid_for(n_list, 1 << 30), kLogBlock, 0, st>>>(list, n_list, pos);
+	return hipGetLastError();
+}
+
+hipError_t launch_rowlog_map_queue(const int32_t *queue, const int32_t *count, const uint32_t *sel, int32_t *out, hipStream_t st) {
+	rowlog_map_queue_kernel<<<256, kLogBlock, 0, st>>>(queue, count, sel, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_rowlog_invalidate(uint8_t *mark, int64_t n_slots, const uint32_t *list, int64_t n_list, const RowLogSlab *h_slabs, int n_slabs,
+                                    hipStream_t st) {
+	if (n_list <= 0) return hipSuccess;
+	hipError_t rc = hipMemsetAsync(mark, 0, (size_t)n_slots, st);
+	if (rc != hipSuccess) return rc;
+	rowlog_mark_kernel<<<grid_for(n_list, 1 << 30), kLogBlock, 0, st>>>(list, n_list, mark);
+	for (int k = 0; k < n_slabs; ++k)
+		if (h_slabs[k].rows > 0)
+			rowlog_invalidate_kernel<<<grid_for(h_slabs[k].rows, 4096), kLogBlock, 0, st>>>(h_slabs[k].slot, h_slabs[k].valid, h_slabs[k].rows, mark, n_slots);
 	return hipGetLastError();
 }
 

@@ -1,34 +1,46 @@
-// agg_arena.hpp — the DuckDB-independent half of the aggregate shim: what Update / Combine /
-// Finalize of {ols,ridge,wls}_fit_agg do with their rows once the per-group row buffers of the reference
+// agg_arena.hpp — the DuckDB-independent half of the aggregate shim: what Initialize / Update /
+// Combine / Finalize / Destroy of {ols,ridge,wls}_fit_agg do once the per-group row buffers of the reference
 // (src/aggregate_functions/ols_aggregate.cpp:19-42) are replaced by ONE GPU-resident state per query.
 //
-//   NewSlot()   Initialize of one DuckDB aggregate state: hands out the next slot number.
-//   Writer      one Update call (a vector of <= 2048 rows): locks the arena once, appends the accepted rows
-//               {slot, y, x[p], w} to page-locked chunk buffers ("columnar arenas": y and w arrays, row-major x as
-//               the LIST child delivers it), and ships a full buffer with anofox_hip_agg_state_update_host — the
-//               rows then live on as O(p^2) moments on the GPU and the buffer is reused.  The first accepted row
-//               fixes the feature count; a different LIST length throws the reference's message
-//               (ols_aggregate.cpp:165-175).
-//   Combine()   pairs of (source slot, target slot) -> anofox_hip_agg_state_combine (ols_aggregate.cpp:189-234).
-//   Solve()     flushes, then ONE finalize for every slot of the query; Core(slot) / Inference(slot) serve the
-//               Finalize vectors from that result (ols_aggregate.cpp:249-338 loops one FFI call per group).
+//   NewSlot() / ReleaseSlot()   Initialize / Destroy of one DuckDB aggregate state (ols_aggregate.cpp:103-118): a slot
+//               number of the query's GPU state.  Released slots are emptied on the device and handed out again, so
+//               the windowed-aggregate protocol (states created, finalized and destroyed frame by frame) does not grow
+//               the state without bound.
+//   Writer      one Update call (a vector of <= 2048 rows, ols_aggregate.cpp:120-186).  Appends go WITHOUT a lock into
+//               the calling thread's own page-locked chunk buffer ({slot, y, x[p] row-major as the LIST child delivers
+//               it, w}); only a full chunk is handed — under the shipping lock — to anofox_hip_agg_state_update_host,
+//               after which the rows live on as O(p^2) moments (or as logged rows) on the GPU and the buffer is reused.
+//               (Round 2 held ONE mutex for the whole Update and copied to the GPU inside it: every worker thread of
+//               the query serialised on it.)  The first accepted row fixes the feature count; a different LIST length
+//               throws the reference's message (ols_aggregate.cpp:165-175).
+//   Combine()   pairs of (source slot, target slot) -> anofox_hip_agg_state_combine_ex (ols_aggregate.cpp:189-234);
+//               a target that occurs several times in a call is served in rounds, in order; preserve = the sources live
+//               on (DuckDB's AggregateCombineType::PRESERVE_INPUT: window segment trees).
+//   Fetch()     Finalize of one vector of states (ols_aggregate.cpp:249-338 loops one FFI call per group): fits the
+//               slots that changed since they were last fitted — ALL of a GROUP BY's groups in one batched call at the
+//               first Finalize, only a window frame's new states later — and copies the asked records out.
 //
 // Wider designs (9 .. 128 features) and HC standard errors go through the same calls: the library then keeps the rows
 // themselves in HBM instead of moments (a "log-only" state, include/anofox_stats_hip.h) and fits them at Finalize.
-// (Round 2's first version buffered such rows in host chunks here and made one batched call at Solve; removed.)
 //
 // Plain C++17 over the C ABI of include/anofox_stats_hip.h; no DuckDB types, so it is compiled and tested in this
-// repository (duckdb_shim/arena_capi.cpp + tests/test_gpu_arena.py).  fit_agg_hip.cpp is the thin DuckDB glue on top.
+// repository (duckdb_shim/arena_capi.cpp + tests/test_gpu_arena.py, tests/tools/arena_sanitize.cpp under ASan / UBSan).
+// fit_agg_hip.cpp is the DuckDB glue on top.
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
-#include <utility>
 #include <string>
+#include <thread>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "anofox_stats_hip.h"
@@ -37,167 +49,395 @@ namespace anofox_shim {
 
 class AggArena {
 public:
-	// flush_rows: rows per page-locked chunk buffer (1M rows = 76 MB at p = 8: one ingest pass of the library)
-	// retain_bytes: HBM the device state may spend on keeping the rows (anofox_hip_agg_state_retain_rows), so that
-	//   Finalize refits ill-conditioned and nearly exactly fitting groups as the batch path does; the reference keeps
-	//   every row on the host anyway (ols_aggregate.cpp:19-42).  0 = moments only.  Default 64 GiB of the 288;
-	//   ANOFOX_HIP_RETAIN_BYTES overrides it.  A query that outgrows it continues without the log (Unrefined() > 0).
-	explicit AggArena(AnofoxHipBatchOptions options, size_t flush_rows = (size_t)1 << 20, size_t retain_bytes = (size_t)64 << 30)
-	    : opt_(options), cap_(flush_rows), retain_bytes_(retain_bytes) {
-		if (cap_ == 0) cap_ = 1;
+	// chunk_rows: rows per page-locked chunk buffer, one buffer per thread that calls Update (256 Ki rows = 19 MB at
+	//   p = 8; capped at 32 MiB of x per buffer for wide designs)
+	// retain_bytes / retain_host_bytes: HBM, then page-locked host memory, that the device state may spend on keeping
+	//   the rows (anofox_hip_agg_state_retain_rows / _retain_rows_host) so that Finalize refits ill-conditioned and
+	//   nearly exactly fitting groups as the batch path does; the reference keeps every row on the host anyway
+	//   (ols_aggregate.cpp:19-42).  Defaults 64 GiB of the 288 and 32 GiB; ANOFOX_HIP_RETAIN_BYTES /
+	//   ANOFOX_HIP_RETAIN_HOST_BYTES override them.  Groups of a query that outgrows both come back as SQL NULL with
+	//   status ANOFOX_HIP_STATUS_UNREFINED when (and only when) the moments cannot resolve them; Unrefined() counts them.
+	explicit AggArena(AnofoxHipBatchOptions options, size_t chunk_rows = (size_t)1 << 18, size_t retain_bytes = (size_t)64 << 30,
+	                  size_t retain_host_bytes = (size_t)32 << 30)
+	    : opt_(options), chunk_rows_(chunk_rows ? chunk_rows : 1), retain_bytes_(retain_bytes), retain_host_bytes_(retain_host_bytes) {
 		if (const char *v = getenv("ANOFOX_HIP_RETAIN_BYTES")) retain_bytes_ = (size_t)strtoull(v, nullptr, 10);
+		if (const char *v = getenv("ANOFOX_HIP_RETAIN_HOST_BYTES")) retain_host_bytes_ = (size_t)strtoull(v, nullptr, 10);
 	}
 	AggArena(const AggArena &) = delete;
 	AggArena &operator=(const AggArena &) = delete;
 	~AggArena() {
 		if (state_) anofox_hip_agg_state_destroy(state_);
 		if (ctx_) anofox_hip_context_destroy(ctx_);
-		FreeBuffers();
+		for (auto &c : chunks_) FreeChunk(*c);
 	}
 
 	uint32_t NewSlot() {
 		std::lock_guard<std::mutex> lk(mu_);
-		solved_ = false;
-		return n_slots_++;
+		uint32_t s;
+		if (!free_.empty()) {
+			s = free_.back();
+			free_.pop_back();
+		} else {
+			s = n_slots_.fetch_add(1, std::memory_order_relaxed);
+		}
+		++live_slots_;
+		return s;
 	}
-	uint32_t SlotCount() const { return n_slots_; }
-	size_t FeatureCount() const { return p_; } // 0 until the first accepted row
-	uint64_t RowsAccepted() const { return rows_; }
-	int64_t Unrefined() const { return unrefined_; }
+	// Destroy of a state: the slot is emptied on the device before it is handed out again (at the next Combine / Fetch)
+	void ReleaseSlot(uint32_t slot) {
+		std::lock_guard<std::mutex> lk(mu_);
+		pending_release_.push_back(slot);
+		if (live_slots_) --live_slots_;
+	}
+	uint32_t SlotCount() const { return n_slots_.load(std::memory_order_relaxed); } // high-water mark
+	uint32_t LiveSlots() const {
+		std::lock_guard<std::mutex> lk(mu_);
+		return live_slots_;
+	}
+	size_t FeatureCount() const { return p_.load(std::memory_order_acquire); } // 0 until the first accepted row
+	uint64_t RowsAccepted() const { return rows_.load(std::memory_order_relaxed); }
+	int64_t Unrefined() const { return unrefined_.load(std::memory_order_relaxed); } // groups flagged so far (status 101)
+	uint64_t FitCalls() const { return fit_calls_.load(std::memory_order_relaxed); }
+	uint64_t SlotsFitted() const { return slots_fitted_.load(std::memory_order_relaxed); }
 	bool RetainingRows() const { return state_ && anofox_hip_agg_state_retaining(state_) != 0; }
+	const AnofoxHipBatchOptions &Options() const { return opt_; }
 
-	// One Update call: holds the arena's lock for the lifetime of the object.
-	class Writer {
-	public:
-		explicit Writer(AggArena &a) : a_(a), lk_(a.mu_) { a_.solved_ = false; }
-		// Initialize of a state that this Update call is the first to touch (the lock is already held)
-		uint32_t NewSlot() { return a_.n_slots_++; }
-		// x: the row's LIST(DOUBLE) entries, NULL entries already replaced by NaN; w ignored unless the model is WLS
-		void Append(uint32_t slot, double y, const double *x, size_t n_features, double w = 1.0) { a_.AppendLocked(slot, y, x, n_features, w); }
-
-	private:
-		AggArena &a_;
-		std::lock_guard<std::mutex> lk_;
+private:
+	// page-locked rows of ONE thread that calls Update, waiting for their trip to the GPU
+	struct Chunk {
+		uint32_t *slot = nullptr;
+		double *y = nullptr, *x = nullptr, *w = nullptr;
+		size_t fill = 0, cap = 0;
+		std::thread::id owner;
+		bool busy = false; // an Update call (or a flush) is using it
 	};
 
-	void Combine(const uint32_t *source_slots, const uint32_t *target_slots, size_t n) {
-		std::lock_guard<std::mutex> lk(mu_);
-		if (n == 0 || !state_) return; // no accepted row anywhere: every slot is empty already
-		FlushLocked();
+public:
+	// One Update call.  Not shared between threads; appends take no lock.
+	class Writer {
+	public:
+		explicit Writer(AggArena &a) : a_(a) {}
+		Writer(const Writer &) = delete;
+		Writer &operator=(const Writer &) = delete;
+		~Writer() { a_.EndWriter(chunk_, touched_, n_rows_); }
+		// Initialize of a state that this Update call is the first to touch
+		uint32_t NewSlot() { return a_.NewSlot(); }
+		// Starts a row and returns where its n_features values go (NULL list entries as NaN: the fit's row filter drops
+		// such rows, ols.rs:59-66); w is ignored unless the model is WLS.
+		double *Begin(uint32_t slot, double y, size_t n_features, double w = 1.0) {
+			size_t p = a_.p_.load(std::memory_order_acquire);
+			if (p == 0) p = a_.Init(n_features);
+			if (n_features != p)
+				throw std::invalid_argument("Inconsistent feature count: expected " + std::to_string(p) + ", got " + std::to_string(n_features));
+			if (!chunk_) chunk_ = a_.AcquireChunk();
+			if (chunk_->fill == chunk_->cap) a_.Ship(*chunk_);
+			const size_t i = chunk_->fill++;
+			chunk_->slot[i] = slot;
+			chunk_->y[i] = y;
+			if (chunk_->w) chunk_->w[i] = w;
+			if (touched_.empty() || touched_.back() != slot) touched_.push_back(slot);
+			++n_rows_;
+			return chunk_->x + i * p;
+		}
+		void Append(uint32_t slot, double y, const double *x, size_t n_features, double w = 1.0) {
+			double *dst = Begin(slot, y, n_features, w);
+			memcpy(dst, x, n_features * sizeof(double));
+		}
+
+	private:
+		friend class AggArena;
+		AggArena &a_;
+		Chunk *chunk_ = nullptr;
+		std::vector<uint32_t> touched_;
+		uint64_t n_rows_ = 0;
+	};
+
+	// preserve: the sources keep their rows (AggregateCombineType::PRESERVE_INPUT); otherwise they are emptied, as the
+	// reference's Combine moves or appends them (ols_aggregate.cpp:189-234).
+	void Combine(const uint32_t *source_slots, const uint32_t *target_slots, size_t n, bool preserve = false) {
+		if (n == 0) return;
+		std::lock_guard<std::mutex> ship(ship_mu_);
+		if (!state_) return; // no accepted row anywhere: every slot is empty already
+		FlushAllShipLocked();
+		DrainReleasesShipLocked();
 		Reserve();
+		// Rounds: within one library call every pair is merged by its own wavefront, so a slot may be written by one
+		// pair only, and the sequential meaning of the pair list (ols_aggregate.cpp:196-233 loops it in order) has to
+		// survive: pair (a -> b) runs after every earlier pair that wrote a or b, and after every earlier pair that read b.
+		std::unordered_map<uint32_t, uint32_t> after_write, after_read; // slot -> first round that may touch it again
+		std::vector<std::vector<uint32_t>> src, dst;
+		for (size_t i = 0; i < n; ++i) {
+			const uint32_t a = source_slots[i], b = target_slots[i];
+			if (a == b) continue;
+			uint32_t r = std::max(after_write[a], after_write[b]);
+			r = std::max(r, after_read[b]);
+			if (!preserve) r = std::max(r, after_read[a]); // (a destructive combine writes its source as well)
+			if (r >= src.size()) {
+				src.resize(r + 1);
+				dst.resize(r + 1);
+			}
+			src[r].push_back(a);
+			dst[r].push_back(b);
+			after_write[b] = r + 1;
+			if (preserve) after_read[a] = std::max(after_read[a], r + 1);
+			else after_write[a] = r + 1;
+		}
 		AnofoxError err;
-		if (!anofox_hip_agg_state_combine(state_, (int64_t)n, source_slots, target_slots, &err)) Throw(err);
-		solved_ = false;
+		for (size_t r = 0; r < src.size(); ++r)
+			if (!src[r].empty() && !anofox_hip_agg_state_combine_ex(state_, (int64_t)src[r].size(), src[r].data(), dst[r].data(), preserve, &err)) Throw(err);
+		std::lock_guard<std::mutex> lk(mu_);
+		for (size_t i = 0; i < n; ++i) {
+			MarkDirtyLocked(target_slots[i]);
+			if (!preserve) MarkDirtyLocked(source_slots[i]);
+		}
 	}
 
-	// Flush the pending rows and fit every slot (once; later calls are free until the state changes again).
-	void Solve() {
-		std::lock_guard<std::mutex> lk(mu_);
-		if (solved_) return;
-		core_.clear();
-		inf_.clear();
-		if (state_) {
-			FlushLocked();
-			Reserve();
-			core_.resize((size_t)n_slots_ * (p_ + 6));
-			if (opt_.compute_inference) inf_.resize((size_t)n_slots_ * (5 * p_ + 2));
-			AnofoxError err;
-			if (!anofox_hip_agg_state_finalize_host(state_, n_slots_, core_.data(), inf_.empty() ? nullptr : inf_.data(), &unrefined_, nullptr, &err))
-				Throw(err);
+	// Finalize of n states: out_core [n x (p + 6)], out_inf [n x (5 p + 2)] (nullptr unless inference was asked for),
+	// out_status[n] = the record's status word (0 = a fit; 100 = fewer than 2 accumulated rows; an AnofoxErrorCode; 101 =
+	// unrefined).  A query without any accepted row: every status 100.
+	void Fetch(const uint32_t *slots, size_t n, double *out_core, double *out_inf, int *out_status) {
+		std::lock_guard<std::mutex> ship(ship_mu_);
+		SolveShipLocked();
+		const size_t p = p_.load(std::memory_order_acquire);
+		const size_t lc = p + 6, li = 5 * p + 2;
+		for (size_t i = 0; i < n; ++i) {
+			const size_t s = slots[i];
+			if (!state_ || (s + 1) * lc > core_.size()) {
+				out_status[i] = ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS;
+				continue;
+			}
+			const double *rec = &core_[s * lc];
+			out_status[i] = (int)rec[p + 5];
+			if (out_core) memcpy(out_core + i * lc, rec, lc * sizeof(double));
+			if (out_inf && !inf_.empty()) memcpy(out_inf + i * li, &inf_[s * li], li * sizeof(double));
 		}
-		solved_ = true;
-	}
-	// Records of one slot after Solve(): nullptr = SQL NULL (no accepted row in the whole query, or a status != 0).
-	const double *Core(uint32_t slot) const {
-		if (core_.empty() || slot >= n_slots_) return nullptr;
-		const double *rec = &core_[(size_t)slot * (p_ + 6)];
-		return rec[p_ + 5] != 0.0 ? nullptr : rec;
-	}
-	const double *Inference(uint32_t slot) const { return inf_.empty() || slot >= n_slots_ ? nullptr : &inf_[(size_t)slot * (5 * p_ + 2)]; }
-	int Status(uint32_t slot) const {
-		if (core_.empty() || slot >= n_slots_) return ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS;
-		return (int)core_[(size_t)slot * (p_ + 6) + p_ + 5];
 	}
 
 private:
+	friend class Writer;
+
 	[[noreturn]] static void Throw(const AnofoxError &e) { throw std::runtime_error(std::string("anofox_stats fit_agg (HIP): ") + e.message); }
 
-	void AppendLocked(uint32_t slot, double y, const double *x, size_t n_features, double w) {
-		if (p_ == 0) { // first accepted row of the query fixes the feature count (per state in the reference; the
-			// aggregate's x argument is one column, so every state sees the same LIST length or the query fails)
-			if (n_features == 0 || n_features > anofox_hip_max_features())
-				throw std::invalid_argument("anofox_stats fit_agg (HIP): 1.." + std::to_string(anofox_hip_max_features()) +
-				                            " features are supported, got " + std::to_string(n_features));
-			p_ = n_features;
-			AnofoxError err;
-			if (!anofox_hip_context_create(-1, &ctx_, &err)) Throw(err);
-			// up to 8 features without HC errors: O(p^2) moments per slot (+ the row log for the groups they cannot
-			// resolve); wider designs and HC errors: the library keeps the rows themselves in HBM (log-only state)
-			if (!anofox_hip_agg_state_create(ctx_, p_, opt_, 0, &state_, &err)) Throw(err);
-			// the budget is for the OPTIONAL log of a moment state; a log-only state needs every row it is given (its
-			// log grows until the device is full, and an Update beyond that fails like any allocation)
-			const bool log_only = p_ > 8 || (opt_.compute_inference && opt_.hc_type != ANOFOX_HC_NONE && opt_.model != ANOFOX_HIP_MODEL_RIDGE);
-			if (!log_only && retain_bytes_ && !anofox_hip_agg_state_retain_rows(state_, retain_bytes_, &err)) Throw(err);
-			AllocBuffers();
+	// First accepted row of the query: fixes the feature count (per state in the reference; the aggregate's x argument is
+	// one column, so every state sees the same LIST length or the query fails) and creates the device state.  Context
+	// and state are built into locals and committed only when all of it succeeded.
+	size_t Init(size_t n_features) {
+		std::lock_guard<std::mutex> ship(ship_mu_);
+		size_t p = p_.load(std::memory_order_acquire);
+		if (p) return p;
+		if (n_features == 0 || n_features > anofox_hip_max_features())
+			throw std::invalid_argument("anofox_stats fit_agg (HIP): 1.." + std::to_string(anofox_hip_max_features()) +
+			                            " features are supported, got " + std::to_string(n_features));
+		AnofoxError err;
+		AnofoxHipContext *ctx = nullptr;
+		AnofoxHipAggState *state = nullptr;
+		if (!anofox_hip_context_create(-1, &ctx, &err)) Throw(err);
+		// up to 8 features without HC errors: O(p^2) moments per slot (+ the row log for the groups they cannot resolve);
+		// wider designs and HC errors: the library keeps the rows themselves (log-only state)
+		bool ok = anofox_hip_agg_state_create(ctx, n_features, opt_, 0, &state, &err);
+		const bool log_only = n_features > 8 || (opt_.compute_inference && opt_.hc_type != ANOFOX_HC_NONE && opt_.model != ANOFOX_HIP_MODEL_RIDGE);
+		// the HBM budget is for the OPTIONAL log of a moment state; a log-only state needs every row it is given (HBM until
+		// the device is full, then the host budget; an Update beyond both fails like any allocation)
+		if (ok && !log_only && retain_bytes_) ok = anofox_hip_agg_state_retain_rows(state, retain_bytes_, &err);
+		if (ok && retain_host_bytes_ && (log_only || retain_bytes_)) ok = anofox_hip_agg_state_retain_rows_host(state, retain_host_bytes_, &err);
+		if (!ok) {
+			if (state) anofox_hip_agg_state_destroy(state);
+			anofox_hip_context_destroy(ctx);
+			Throw(err);
 		}
-		if (n_features != p_)
-			throw std::invalid_argument("Inconsistent feature count: expected " + std::to_string(p_) + ", got " + std::to_string(n_features));
-		slot_[fill_] = slot;
-		y_[fill_] = y;
-		memcpy(x_ + fill_ * p_, x, p_ * sizeof(double));
-		if (w_) w_[fill_] = w;
-		++rows_;
-		if (++fill_ == cap_) FlushLocked();
+		ctx_ = ctx;
+		state_ = state;
+		p_.store(n_features, std::memory_order_release);
+		return n_features;
 	}
 
-	void Reserve() {
-		AnofoxError err;
-		if (!anofox_hip_agg_state_reserve(state_, n_slots_, &err)) Throw(err);
-	}
-	void FlushLocked() {
-		if (!state_ || fill_ == 0) return;
-		AnofoxError err;
-		// returns once the rows have been copied to the GPU; the kernels run on while the buffer refills
-		if (!anofox_hip_agg_state_update_host(state_, (int64_t)fill_, n_slots_, slot_, y_, x_, w_, nullptr, &err)) Throw(err);
-		fill_ = 0;
-	}
-	void AllocBuffers() {
+	// the calling thread's chunk buffer (created on its first Update)
+	Chunk *AcquireChunk() {
+		const std::thread::id me = std::this_thread::get_id();
+		{
+			std::unique_lock<std::mutex> lk(mu_);
+			for (auto &c : chunks_)
+				if (c->owner == me) {
+					cv_.wait(lk, [&] { return !c->busy; }); // (a flush from another thread may hold it for a moment)
+					c->busy = true;
+					return c.get();
+				}
+		}
+		const size_t p = p_.load(std::memory_order_acquire);
+		auto c = std::make_unique<Chunk>();
+		size_t cap = chunk_rows_;
+		const size_t max_rows = ((size_t)32 << 20) / (p * sizeof(double));
+		if (cap > max_rows) cap = max_rows < 2048 ? 2048 : max_rows;
+		c->cap = cap;
+		c->owner = me;
+		c->busy = true;
 		const bool weighted = opt_.model == ANOFOX_HIP_MODEL_WLS;
-		slot_ = (uint32_t *)anofox_hip_host_alloc(cap_ * sizeof(uint32_t));
-		y_ = (double *)anofox_hip_host_alloc(cap_ * sizeof(double));
-		x_ = (double *)anofox_hip_host_alloc(cap_ * p_ * sizeof(double));
-		w_ = weighted ? (double *)anofox_hip_host_alloc(cap_ * sizeof(double)) : nullptr;
-		if (!slot_ || !y_ || !x_ || (weighted && !w_)) {
-			FreeBuffers();
+		c->slot = (uint32_t *)anofox_hip_host_alloc(cap * sizeof(uint32_t));
+		c->y = (double *)anofox_hip_host_alloc(cap * sizeof(double));
+		c->x = (double *)anofox_hip_host_alloc(cap * p * sizeof(double));
+		c->w = weighted ? (double *)anofox_hip_host_alloc(cap * sizeof(double)) : nullptr;
+		if (!c->slot || !c->y || !c->x || (weighted && !c->w)) {
+			FreeChunk(*c);
 			throw std::bad_alloc();
 		}
+		std::lock_guard<std::mutex> lk(mu_);
+		chunks_.push_back(std::move(c));
+		return chunks_.back().get();
 	}
-	void FreeBuffers() {
-		anofox_hip_host_free(slot_);
-		anofox_hip_host_free(y_);
-		anofox_hip_host_free(x_);
-		anofox_hip_host_free(w_);
-		slot_ = nullptr;
-		y_ = x_ = w_ = nullptr;
+	static void FreeChunk(Chunk &c) {
+		anofox_hip_host_free(c.slot);
+		anofox_hip_host_free(c.y);
+		anofox_hip_host_free(c.x);
+		anofox_hip_host_free(c.w);
+		c.slot = nullptr;
+		c.y = c.x = c.w = nullptr;
+	}
+	void EndWriter(Chunk *c, const std::vector<uint32_t> &touched, uint64_t n_rows) noexcept {
+		rows_.fetch_add(n_rows, std::memory_order_relaxed);
+		std::lock_guard<std::mutex> lk(mu_);
+		for (uint32_t s : touched) MarkDirtyLocked(s);
+		if (c) {
+			c->busy = false;
+			cv_.notify_all();
+		}
+	}
+	void MarkDirtyLocked(uint32_t slot) {
+		if (slot >= dirty_.size()) dirty_.resize((size_t)slot + 1 + dirty_.size() / 2, 0);
+		if (dirty_[slot] == 0) dirty_list_.push_back(slot);
+		dirty_[slot] = 1; // (2 = released while dirty: already listed)
+	}
+
+	// a full chunk of the calling Writer goes to the GPU; returns once the rows have been copied (the kernels run on
+	// while the buffer refills)
+	void Ship(Chunk &c) {
+		std::lock_guard<std::mutex> ship(ship_mu_);
+		ShipLocked(c);
+	}
+	void ShipLocked(Chunk &c) {
+		if (c.fill == 0) return;
+		AnofoxError err;
+		if (!anofox_hip_agg_state_update_host(state_, (int64_t)c.fill, (int64_t)n_slots_.load(std::memory_order_relaxed), c.slot, c.y, c.x, c.w, nullptr, &err))
+			Throw(err);
+		c.fill = 0;
+	}
+	// Every thread's pending rows, except those of a thread that is inside an Update call right now: DuckDB never
+	// finalizes or combines a state while another thread is still feeding it (hash aggregates sink completely before they
+	// combine; a window task creates, feeds, finalizes and destroys its states on its own thread), so such a chunk holds
+	// no row of the states this call is about.  (Waiting for it instead would deadlock: its thread may be waiting for the
+	// shipping lock this thread holds.)
+	void FlushAllShipLocked() {
+		for (size_t k = 0;; ++k) {
+			Chunk *c = nullptr;
+			{
+				std::lock_guard<std::mutex> lk(mu_);
+				if (k >= chunks_.size()) break;
+				c = chunks_[k].get();
+				if (c->busy || c->fill == 0) continue;
+				c->busy = true;
+			}
+			try {
+				ShipLocked(*c);
+			} catch (...) {
+				std::lock_guard<std::mutex> lk(mu_);
+				c->busy = false;
+				cv_.notify_all();
+				throw;
+			}
+			std::lock_guard<std::mutex> lk(mu_);
+			c->busy = false;
+			cv_.notify_all();
+		}
+	}
+	// the slots Destroy gave back: emptied on the device (their pending rows have been flushed before), then reusable
+	void DrainReleasesShipLocked() {
+		std::vector<uint32_t> rel;
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			rel.swap(pending_release_);
+		}
+		if (rel.empty()) return;
+		std::sort(rel.begin(), rel.end());
+		rel.erase(std::unique(rel.begin(), rel.end()), rel.end());
+		if (state_) {
+			Reserve();
+			AnofoxError err;
+			if (!anofox_hip_agg_state_release_slots(state_, (int64_t)rel.size(), rel.data(), &err)) Throw(err);
+		}
+		const size_t p = p_.load(std::memory_order_acquire);
+		std::lock_guard<std::mutex> lk(mu_);
+		for (uint32_t s : rel) {
+			if (s < dirty_.size() && dirty_[s]) dirty_[s] = 2; // (stays in dirty_list_, skipped there)
+			if (p && ((size_t)s + 1) * (p + 6) <= core_.size()) core_[(size_t)s * (p + 6) + p + 5] = (double)ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS;
+			free_.push_back(s);
+		}
+	}
+	void Reserve() {
+		AnofoxError err;
+		if (!anofox_hip_agg_state_reserve(state_, (int64_t)n_slots_.load(std::memory_order_relaxed), &err)) Throw(err);
+	}
+
+	// fit the slots that changed since they were last fitted
+	void SolveShipLocked() {
+		if (!state_) return;
+		FlushAllShipLocked();
+		DrainReleasesShipLocked();
+		std::vector<uint32_t> todo;
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			for (uint32_t s : dirty_list_) {
+				if (dirty_[s] == 1) todo.push_back(s);
+				dirty_[s] = 0;
+			}
+			dirty_list_.clear();
+		}
+		if (todo.empty()) return;
+		Reserve();
+		const size_t p = p_.load(std::memory_order_acquire), lc = p + 6, li = 5 * p + 2;
+		const size_t n_all = n_slots_.load(std::memory_order_relaxed);
+		const bool inference = opt_.compute_inference;
+		if (core_.size() < n_all * lc) {
+			const size_t old = core_.size() / lc;
+			core_.resize(n_all * lc);
+			for (size_t s = old; s < n_all; ++s) core_[s * lc + p + 5] = (double)ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS;
+			if (inference) inf_.resize(n_all * li);
+		}
+		AnofoxError err;
+		int64_t unref = 0;
+		if (todo.size() == n_all) { // a GROUP BY's first Finalize: one batched call for every group
+			if (!anofox_hip_agg_state_finalize_host(state_, (int64_t)n_all, core_.data(), inference ? inf_.data() : nullptr, &unref, nullptr, &err)) Throw(err);
+		} else {
+			std::sort(todo.begin(), todo.end());
+			std::vector<double> c(todo.size() * lc), f(inference ? todo.size() * li : 0);
+			if (!anofox_hip_agg_state_finalize_slots_host(state_, (int64_t)todo.size(), todo.data(), c.data(), inference ? f.data() : nullptr, &unref, &err))
+				Throw(err);
+			for (size_t k = 0; k < todo.size(); ++k) {
+				memcpy(&core_[(size_t)todo[k] * lc], &c[k * lc], lc * sizeof(double));
+				if (inference) memcpy(&inf_[(size_t)todo[k] * li], &f[k * li], li * sizeof(double));
+			}
+		}
+		unrefined_.fetch_add(unref, std::memory_order_relaxed);
+		fit_calls_.fetch_add(1, std::memory_order_relaxed);
+		slots_fitted_.fetch_add(todo.size(), std::memory_order_relaxed);
 	}
 
 	AnofoxHipBatchOptions opt_;
-	size_t cap_;
-	std::mutex mu_;
+	size_t chunk_rows_;
+	size_t retain_bytes_, retain_host_bytes_;
+	mutable std::mutex mu_; // slots, dirty marks, the chunk table
+	std::mutex ship_mu_;    // every call into the library (taken before mu_, never while holding it)
+	std::condition_variable cv_;
 	AnofoxHipContext *ctx_ = nullptr;
 	AnofoxHipAggState *state_ = nullptr;
-	size_t p_ = 0;
-	uint32_t n_slots_ = 0;
-	uint64_t rows_ = 0;
-	// page-locked chunk buffers
-	uint32_t *slot_ = nullptr;
-	double *y_ = nullptr, *x_ = nullptr, *w_ = nullptr;
-	size_t fill_ = 0;
-	// solved records
-	bool solved_ = false;
-	int64_t unrefined_ = 0;
-	size_t retain_bytes_ = 0;
-	std::vector<double> core_, inf_;
+	std::atomic<size_t> p_ {0};
+	std::atomic<uint32_t> n_slots_ {0};
+	uint32_t live_slots_ = 0;
+	std::vector<uint32_t> free_, pending_release_;
+	std::vector<std::unique_ptr<Chunk>> chunks_;
+	std::vector<uint8_t> dirty_; // 1 = changed since its last fit, 2 = released while dirty
+	std::vector<uint32_t> dirty_list_;
+	std::atomic<uint64_t> rows_ {0}, fit_calls_ {0}, slots_fitted_ {0};
+	std::atomic<int64_t> unrefined_ {0};
+	std::vector<double> core_, inf_; // last fitted record of every slot
 };
 
 } // namespace anofox_shim

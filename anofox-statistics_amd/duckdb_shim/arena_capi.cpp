@@ -55,19 +55,30 @@ ARENA_API int arena_combine(void *a, const uint32_t *src, const uint32_t *dst, s
 		return -1;
 	}
 }
-// Finalize of one vector of states: out_core [n x (p+6)], out_inf [n x (5p+2)] or NULL, is_null [n].
+// Combine with the sources left intact (AggregateCombineType::PRESERVE_INPUT)
+ARENA_API int arena_combine_preserve(void *a, const uint32_t *src, const uint32_t *dst, size_t n, char *msg) {
+	try {
+		static_cast<AggArena *>(a)->Combine(src, dst, n, true);
+		return 0;
+	} catch (const std::exception &e) {
+		if (msg) {
+			strncpy(msg, e.what(), 255);
+			msg[255] = 0;
+		}
+		return -1;
+	}
+}
+// Destroy of n states
+ARENA_API void arena_release(void *a, const uint32_t *slot, size_t n) {
+	for (size_t i = 0; i < n; ++i) static_cast<AggArena *>(a)->ReleaseSlot(slot[i]);
+}
+// Finalize of one vector of states: out_core [n x (p+6)], out_inf [n x (5p+2)] or NULL, is_null [n] (status != 0).
 ARENA_API int arena_finalize(void *a, size_t n, const uint32_t *slot, double *out_core, double *out_inf, uint8_t *is_null, char *msg) {
 	try {
 		AggArena &ar = *static_cast<AggArena *>(a);
-		ar.Solve();
-		const size_t p = ar.FeatureCount();
-		for (size_t i = 0; i < n; ++i) {
-			const double *c = ar.Core(slot[i]);
-			is_null[i] = c ? 0 : 1;
-			if (!c) continue;
-			memcpy(out_core + i * (p + 6), c, (p + 6) * sizeof(double));
-			if (out_inf) memcpy(out_inf + i * (5 * p + 2), ar.Inference(slot[i]), (5 * p + 2) * sizeof(double));
-		}
+		std::vector<int> status(n);
+		ar.Fetch(slot, n, out_core, out_inf, status.data());
+		for (size_t i = 0; i < n; ++i) is_null[i] = status[i] != 0 ? 1 : 0;
 		return 0;
 	} catch (const std::exception &e) {
 		if (msg) {
@@ -79,8 +90,13 @@ ARENA_API int arena_finalize(void *a, size_t n, const uint32_t *slot, double *ou
 }
 ARENA_API size_t arena_feature_count(void *a) { return static_cast<AggArena *>(a)->FeatureCount(); }
 ARENA_API uint64_t arena_rows(void *a) { return static_cast<AggArena *>(a)->RowsAccepted(); }
-// after a Finalize: groups the device state could not refit (0 while it keeps the rows), and whether it still does
+// groups flagged as unrefined by the Finalize calls so far (0 while the device state keeps the rows), and whether it does
 ARENA_API int64_t arena_unrefined(void *a) { return static_cast<AggArena *>(a)->Unrefined(); }
 ARENA_API int arena_retaining(void *a) { return static_cast<AggArena *>(a)->RetainingRows() ? 1 : 0; }
+// bookkeeping the tests look at: slot numbers handed out (high-water mark), live states, library fit calls, slots fitted
+ARENA_API uint32_t arena_slot_count(void *a) { return static_cast<AggArena *>(a)->SlotCount(); }
+ARENA_API uint32_t arena_live_slots(void *a) { return static_cast<AggArena *>(a)->LiveSlots(); }
+ARENA_API uint64_t arena_fit_calls(void *a) { return static_cast<AggArena *>(a)->FitCalls(); }
+ARENA_API uint64_t arena_slots_fitted(void *a) { return static_cast<AggArena *>(a)->SlotsFitted(); }
 
 } // extern "C"

@@ -1,34 +1,45 @@
-// fit_agg_hip.cpp — DuckDB glue of the three aggregates over the GPU-resident state.
+// fit_agg_hip.cpp — DuckDB glue of {ols,ridge,wls}_fit_agg over the GPU-resident aggregate state.
 //
 // Replaces, in the reference's
-//   src/aggregate_functions/ols_aggregate.cpp    (state :19-42, Initialize :103, Destroy :108, Update :120-186,
-//                                                 Combine :189-234, Finalize :249-338)
-//   src/aggregate_functions/ridge_aggregate.cpp  (:19-43, :124-191, :194-240, :255-345)
-//   src/aggregate_functions/wls_aggregate.cpp    (:19-44, :122-201, :204-253, :268-362)
-// the per-group std::vector row buffers and the one-FFI-call-per-group Finalize.  The DuckDB state shrinks to a
-// slot number; the rows go through anofox_shim::AggArena (agg_arena.hpp: page-locked chunk buffers ->
-// anofox_hip_agg_state_update_host) into one O(p^2) moment record per slot on the GPU; Finalize reads the records of
-// one batched solve.  Bind, the result type, the options parser and the registration (names, aliases, overloads:
-// ols_aggregate.cpp:74-96,343-426) stay exactly as they are — only the five callbacks and the state size change:
+//   src/aggregate_functions/ols_aggregate.cpp    (state :19-42, bind data :47-69, result type :74-96, Initialize :103,
+//                                                 Destroy :108-118, Update :120-186, Combine :189-234, Finalize :249-338,
+//                                                 Bind :343-372, registration :377-426)
+//   src/aggregate_functions/ridge_aggregate.cpp  (:19-43, :49-76, :78-104, :124-191, :194-240, :255-345, :350-385, :388-440)
+//   src/aggregate_functions/wls_aggregate.cpp    (:19-44, :49-74, :76-102, :122-201, :204-253, :268-362, :367-398, :401-452)
+// the per-group std::vector row buffers and the one-FFI-call-per-group Finalize: the extension's entry point calls
+// RegisterHip{Ols,Ridge,Wls}AggregateFunction(loader) instead of Register{Ols,Ridge,Wls}AggregateFunction(loader) and
+// the SQL surface stays what it was — names anofox_stats_*_fit_agg with the aliases *_fit_agg, the overloads with and
+// without the constant options argument, the 7 / 14-field STRUCT result, NULL for groups that cannot be fitted.
 //
-//   AggregateFunction(name, args, LogicalType::ANY, AggregateFunction::StateSize<HipAggState>, HipAggInitialize,
-//                     HipAggUpdate<OlsTraits>, HipAggCombine, HipAggFinalize<OlsTraits>, nullptr, OlsAggBind, HipAggDestroy)
+// The DuckDB state shrinks to a slot number.  Rows go through anofox_shim::AggArena (agg_arena.hpp: lock-free appends
+// into the calling thread's page-locked chunk -> anofox_hip_agg_state_update_host) into one O(p^2) moment record per
+// slot on the GPU (or the logged rows, for designs wider than 8 features and HC errors); Finalize asks the arena for
+// the records of its vector of states, which fits whatever changed since it was last fitted in ONE batched call.
+// The bind data owns the arena and Copy() shares it: every thread of the query reaches the same device state.
 //
-// and the bind data gains one member, `shared_ptr<anofox_shim::AggArena> arena`, created in Bind from the parsed
-// options and shared by Copy() (every thread of the query must reach the same state).
-//
-// NOT COMPILED IN THIS REPOSITORY: the reference's `duckdb` submodule (headers) is empty here; written against the
-// DuckDB v1.4.5 / v1.5.5 API exactly as the reference uses it.  All logic that does not need
-// DuckDB types lives in agg_arena.hpp, which IS compiled and tested here (arena_capi.cpp, tests/test_gpu_arena.py).
-#include "duckdb.hpp"
-#include "duckdb/function/aggregate_function.hpp"
+// Compiled and driven in this repository against a stand-in of DuckDB's headers (tests/tools/duckdb_stub, -Wall -Wextra
+// under ASan / UBSan with a mock of the C ABI; on the GPU with the real library: tests/test_gpu_glue.py).  Written
+// against the DuckDB v1.4.5 / v1.5.5 API exactly as the reference uses it.
+#include <math.h>
+#include <stdlib.h>
 
-#include "../include/anofox_stats_ffi.h" // the reference's header: structs and enums
-#include "../include/ffi_enum_converters.hpp"
-#include "anofox_stats_hip.h"            // after the reference's header: adds only the batch / state API
+#include <algorithm>
+#include <cctype>
+
+#include "duckdb.hpp"
+#include "duckdb/common/types/data_chunk.hpp"
+#include "duckdb/execution/expression_executor.hpp"
+#include "duckdb/function/aggregate_function.hpp"
+#include "duckdb/main/extension/extension_loader.hpp"
+#include "duckdb/parser/parsed_data/create_aggregate_function_info.hpp"
+
+#include "anofox_stats_hip.h" // coexists with the reference's anofox_stats_ffi.h (same structs and enums, guarded)
 #include "agg_arena.hpp"
+#include "fit_agg_hip.hpp"
 
 namespace duckdb {
+
+namespace {
 
 // The whole DuckDB-side aggregate state: which slot of the query's GPU state this group (of this thread's hash
 // table) owns.  -1 until the first Update touches it (Initialize has no access to the bind data).
@@ -36,118 +47,260 @@ struct HipAggState {
 	int64_t slot;
 };
 
-// What the three bind-data classes add (OlsAggregateBindData etc. keep their option fields):
-struct HipAggBindMixin {
-	shared_ptr<anofox_shim::AggArena> arena;
+enum class HipModel : uint8_t { OLS, RIDGE, WLS };
+
+// ---- options: the keys, aliases, defaults and error texts of the reference's parser ----
+// (RegressionMapOptions::ParseFromValue src/include/map_options_parser.cpp:637-750, ExtractBool :21-45,
+//  ExtractSolverType / ExtractHcType / ExtractLambdaScaling :222-266, VisitOptionEntries :343-373 — STRUCT and MAP
+//  literals, lower-cased keys, unknown keys ignored :798 — GetRegularizationStrength map_options_parser.hpp:265-270;
+//  defaults ols_aggregate.cpp:48-52, ridge_aggregate.cpp:49-54, wls_aggregate.cpp:49-54)
+struct HipFitOptions {
+	bool fit_intercept = true;
+	bool compute_inference = false;
+	double confidence_level = 0.95;
+	AnofoxSolverType solver = ANOFOX_SOLVER_SVD; // accepted; the GPU path has one solver (results agree within 1e-10)
+	AnofoxHcType hc_type = ANOFOX_HC_NONE;
+	double alpha = 1.0;
+	AnofoxLambdaScaling lambda_scaling = ANOFOX_LAMBDA_SCALING_RAW;
+	bool operator==(const HipFitOptions &o) const {
+		return fit_intercept == o.fit_intercept && compute_inference == o.compute_inference && confidence_level == o.confidence_level &&
+		       solver == o.solver && hc_type == o.hc_type && alpha == o.alpha && lambda_scaling == o.lambda_scaling;
+	}
 };
 
-struct OlsTraits {
-	static constexpr bool kWeighted = false;
-	using BindData = OlsAggregateBindData; // + HipAggBindMixin
-};
-struct RidgeTraits {
-	static constexpr bool kWeighted = false;
-	using BindData = RidgeAggregateBindData;
-};
-struct WlsTraits {
-	static constexpr bool kWeighted = true;
-	using BindData = WlsAggregateBindData;
-};
-
-// Bind-time helper: the batch options of the query from the parsed bind data (called at the end of *AggBind).
-template <class BIND>
-AnofoxHipBatchOptions MakeHipOptions(const BIND &b, AnofoxHipModel model) {
-	AnofoxHipBatchOptions o {};
-	o.model = model;
-	o.fit_intercept = b.fit_intercept;
-	o.compute_inference = b.compute_inference;
-	o.confidence_level = b.confidence_level;
-	o.solver = ConvertSolverType(b.solver);
-	o.alpha = 1.0;
-	return o; // ridge: o.alpha = b.alpha, o.lambda_scaling = ConvertLambdaScaling(b.lambda_scaling); ols/wls: o.hc_type
+string Lower(string s) {
+	std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+	return s;
 }
 
-static void HipAggInitialize(const AggregateFunction &, data_ptr_t state_p) {
+bool ExtractBool(const Value &v) {
+	switch (v.type().id()) {
+	case LogicalTypeId::BOOLEAN: return BooleanValue::Get(v);
+	case LogicalTypeId::INTEGER:
+	case LogicalTypeId::BIGINT: return v.GetValue<int64_t>() != 0;
+	case LogicalTypeId::DOUBLE: return v.GetValue<double>() != 0.0;
+	default: throw InvalidInputException("Cannot convert value of type %s to boolean", v.type().ToString().c_str());
+	}
+}
+
+template <class ENUM>
+ENUM ExtractEnum(const Value &v, const char *what, const char *valid, std::initializer_list<std::pair<const char *, ENUM>> table) {
+	const string s = Lower(v.type().id() == LogicalTypeId::VARCHAR ? StringValue::Get(v) : v.ToString());
+	for (auto &e : table)
+		if (s == e.first) return e.second;
+	throw InvalidInputException("Invalid %s: '%s'. Valid values are %s", what, s.c_str(), valid);
+}
+
+void ApplyOption(const string &raw_key, const Value &v, HipFitOptions &o, bool &has_alpha, double &alpha, bool &has_lambda, double &lambda) {
+	if (v.IsNull()) return;
+	const string key = Lower(raw_key);
+	if (key == "fit_intercept" || key == "intercept") o.fit_intercept = ExtractBool(v);
+	else if (key == "compute_inference" || key == "inference") o.compute_inference = ExtractBool(v);
+	else if (key == "confidence_level" || key == "confidence") o.confidence_level = v.GetValue<double>(); // no range check upstream
+	else if (key == "alpha") { has_alpha = true; alpha = v.GetValue<double>(); }
+	else if (key == "lambda") { has_lambda = true; lambda = v.GetValue<double>(); }
+	else if (key == "solver")
+		o.solver = ExtractEnum<AnofoxSolverType>(v, "solver", "'qr', 'svd', 'cholesky'",
+		                                         {{"qr", ANOFOX_SOLVER_QR}, {"svd", ANOFOX_SOLVER_SVD}, {"cholesky", ANOFOX_SOLVER_CHOLESKY}});
+	else if (key == "hc_type")
+		o.hc_type = ExtractEnum<AnofoxHcType>(v, "hc_type", "'none', 'hc0', 'hc1', 'hc2', 'hc3'",
+		                                      {{"none", ANOFOX_HC_NONE}, {"hc0", ANOFOX_HC_HC0}, {"hc1", ANOFOX_HC_HC1}, {"hc2", ANOFOX_HC_HC2}, {"hc3", ANOFOX_HC_HC3}});
+	else if (key == "lambda_scaling")
+		o.lambda_scaling = ExtractEnum<AnofoxLambdaScaling>(v, "lambda_scaling", "'raw', 'glmnet'",
+		                                                    {{"raw", ANOFOX_LAMBDA_SCALING_RAW}, {"glmnet", ANOFOX_LAMBDA_SCALING_GLMNET}});
+	// every other key: ignored, as upstream (the legacy {'full_output': true} of the reference's examples must bind)
+}
+
+void ParseHipFitOptions(const Value &v, HipFitOptions &o) {
+	if (v.IsNull()) return;
+	bool has_alpha = false, has_lambda = false;
+	double alpha = 0.0, lambda = 0.0;
+	if (v.type().id() == LogicalTypeId::STRUCT) {
+		auto &kids = StructValue::GetChildren(v);
+		for (idx_t i = 0; i < kids.size(); i++) ApplyOption(StructType::GetChildName(v.type(), i), kids[i], o, has_alpha, alpha, has_lambda, lambda);
+	} else if (v.type().id() == LogicalTypeId::MAP) {
+		for (auto &entry : MapValue::GetChildren(v)) { // a list of {key, value} structs
+			auto &kv = StructValue::GetChildren(entry);
+			if (kv.size() != 2 || kv[0].IsNull()) continue;
+			ApplyOption(kv[0].type().id() == LogicalTypeId::VARCHAR ? StringValue::Get(kv[0]) : kv[0].ToString(), kv[1], o, has_alpha, alpha,
+			            has_lambda, lambda);
+		}
+	} else {
+		throw InvalidInputException("Options must be a MAP or STRUCT, got %s", v.type().ToString().c_str());
+	}
+	if (has_alpha) o.alpha = alpha; // alpha wins over lambda
+	else if (has_lambda) o.alpha = lambda;
+}
+
+AnofoxHipBatchOptions MakeHipOptions(HipModel model, const HipFitOptions &o) {
+	AnofoxHipBatchOptions b;
+	memset(&b, 0, sizeof b);
+	b.model = model == HipModel::OLS ? ANOFOX_HIP_MODEL_OLS : (model == HipModel::RIDGE ? ANOFOX_HIP_MODEL_RIDGE : ANOFOX_HIP_MODEL_WLS);
+	b.fit_intercept = o.fit_intercept;
+	b.compute_inference = o.compute_inference;
+	b.confidence_level = o.confidence_level;
+	b.solver = o.solver;
+	// ridge: alpha and its scaling, no HC branch (ridge.rs:36-229); ols / wls: HC standard errors (ols.rs:209-245)
+	b.alpha = model == HipModel::RIDGE ? o.alpha : 0.0;
+	b.lambda_scaling = model == HipModel::RIDGE ? o.lambda_scaling : ANOFOX_LAMBDA_SCALING_RAW;
+	b.hc_type = model == HipModel::RIDGE ? ANOFOX_HC_NONE : o.hc_type;
+	return b;
+}
+
+// ---- bind data: the parsed options and the query's arena; Copy() shares the arena ----
+struct HipAggBindData : public FunctionData {
+	HipAggBindData(HipModel model_p, const HipFitOptions &opts_p)
+	    : model(model_p), opts(opts_p), arena(make_shared_ptr<anofox_shim::AggArena>(MakeHipOptions(model_p, opts_p))) {}
+	HipAggBindData(HipModel model_p, const HipFitOptions &opts_p, shared_ptr<anofox_shim::AggArena> arena_p)
+	    : model(model_p), opts(opts_p), arena(std::move(arena_p)) {}
+	HipModel model;
+	HipFitOptions opts;
+	shared_ptr<anofox_shim::AggArena> arena;
+
+	unique_ptr<FunctionData> Copy() const override { return make_uniq<HipAggBindData>(model, opts, arena); }
+	bool Equals(const FunctionData &other_p) const override {
+		auto &other = other_p.Cast<HipAggBindData>();
+		return model == other.model && opts == other.opts && arena == other.arena;
+	}
+};
+
+// result type: GetOlsAggResultType (ols_aggregate.cpp:74-96) and its ridge / wls twins
+LogicalType GetHipAggResultType(bool compute_inference) {
+	child_list_t<LogicalType> children;
+	children.push_back(make_pair("coefficients", LogicalType::LIST(LogicalType::DOUBLE)));
+	children.push_back(make_pair("intercept", LogicalType::DOUBLE));
+	children.push_back(make_pair("r_squared", LogicalType::DOUBLE));
+	children.push_back(make_pair("adj_r_squared", LogicalType::DOUBLE));
+	children.push_back(make_pair("residual_std_error", LogicalType::DOUBLE));
+	children.push_back(make_pair("n_observations", LogicalType::BIGINT));
+	children.push_back(make_pair("n_features", LogicalType::BIGINT));
+	if (compute_inference) {
+		children.push_back(make_pair("std_errors", LogicalType::LIST(LogicalType::DOUBLE)));
+		children.push_back(make_pair("t_values", LogicalType::LIST(LogicalType::DOUBLE)));
+		children.push_back(make_pair("p_values", LogicalType::LIST(LogicalType::DOUBLE)));
+		children.push_back(make_pair("ci_lower", LogicalType::LIST(LogicalType::DOUBLE)));
+		children.push_back(make_pair("ci_upper", LogicalType::LIST(LogicalType::DOUBLE)));
+		children.push_back(make_pair("f_statistic", LogicalType::DOUBLE));
+		children.push_back(make_pair("f_pvalue", LogicalType::DOUBLE));
+	}
+	return LogicalType::STRUCT(std::move(children));
+}
+
+template <HipModel MODEL>
+unique_ptr<FunctionData> HipAggBind(ClientContext &context, AggregateFunction &function, vector<unique_ptr<Expression>> &arguments) {
+	HipFitOptions opts;
+	// the optional last argument: y, x[, weight][, options] — parsed only when it folds to a constant, as upstream
+	// (ols_aggregate.cpp:348, ridge_aggregate.cpp:355, wls_aggregate.cpp:372)
+	const idx_t opt_idx = MODEL == HipModel::WLS ? 3 : 2;
+	if (arguments.size() > opt_idx && arguments[opt_idx]->IsFoldable()) ParseHipFitOptions(ExpressionExecutor::EvaluateScalar(context, *arguments[opt_idx]), opts);
+	function.return_type = GetHipAggResultType(opts.compute_inference);
+	return make_uniq<HipAggBindData>(MODEL, opts);
+}
+
+void HipAggInitialize(const AggregateFunction &, data_ptr_t state_p) {
 	reinterpret_cast<HipAggState *>(state_p)->slot = -1;
 }
 
-static void HipAggDestroy(Vector &, AggregateInputData &, idx_t) {
-	// nothing per state: the slots belong to the arena, which the bind data's shared_ptr releases with the query
+// Destroy: the state's slot goes back to the arena, which empties it on the device before handing it out again
+// (ols_aggregate.cpp:108-118 runs the row buffers' destructors)
+void HipAggDestroy(Vector &state_vector, AggregateInputData &aggr_input_data, idx_t count) {
+	UnifiedVectorFormat sdata;
+	state_vector.ToUnifiedFormat(count, sdata);
+	auto states = (HipAggState **)sdata.data;
+	auto &arena = *aggr_input_data.bind_data->Cast<HipAggBindData>().arena;
+	for (idx_t i = 0; i < count; i++) {
+		auto &state = *states[sdata.sel->get_index(i)];
+		if (state.slot >= 0) arena.ReleaseSlot((uint32_t)state.slot);
+		state.slot = -1;
+	}
 }
 
-// Update: ols_aggregate.cpp:120-186 / wls_aggregate.cpp:122-201 with the push_backs replaced by one arena append.
-template <class TRAITS>
-static void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, idx_t input_count, Vector &state_vector, idx_t count) {
-	auto &bind = aggr_input_data.bind_data->Cast<typename TRAITS::BindData>();
-	auto &arena = *bind.arena;
+// Update: ols_aggregate.cpp:120-186 / ridge_aggregate.cpp:124-191 / wls_aggregate.cpp:122-201 with the push_backs replaced
+// by one append into the calling thread's chunk; the row's LIST entries are copied straight into page-locked memory.
+template <HipModel MODEL>
+void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, idx_t input_count, Vector &state_vector, idx_t count) {
+	constexpr bool kWeighted = MODEL == HipModel::WLS;
+	if (input_count < (kWeighted ? 3u : 2u)) throw InvalidInputException("anofox_stats fit_agg (HIP): too few arguments");
+	auto &arena = *aggr_input_data.bind_data->Cast<HipAggBindData>().arena;
 	UnifiedVectorFormat y_data, x_data, w_data, sdata;
 	inputs[0].ToUnifiedFormat(count, y_data);
 	inputs[1].ToUnifiedFormat(count, x_data);
-	if (TRAITS::kWeighted) inputs[2].ToUnifiedFormat(count, w_data);
+	if (kWeighted) inputs[2].ToUnifiedFormat(count, w_data);
 	auto y_values = UnifiedVectorFormat::GetData<double>(y_data);
-	auto w_values = TRAITS::kWeighted ? UnifiedVectorFormat::GetData<double>(w_data) : nullptr;
-	auto x_list = ListVector::GetData(inputs[1]);
+	auto w_values = kWeighted ? UnifiedVectorFormat::GetData<double>(w_data) : nullptr;
+	auto x_list = UnifiedVectorFormat::GetData<list_entry_t>(x_data);
 	auto &x_child = ListVector::GetEntry(inputs[1]);
 	auto x_child_data = FlatVector::GetData<double>(x_child);
 	auto &x_child_validity = FlatVector::Validity(x_child);
 	state_vector.ToUnifiedFormat(count, sdata);
 	auto states = (HipAggState **)sdata.data;
+	const idx_t max_features = anofox_hip_max_features();
 
-	anofox_shim::AggArena::Writer writer(arena); // one lock per vector
-	double row[128]; // anofox_hip_max_features(); everything goes to the GPU state (moments up to 8 features, the rows themselves beyond)
+	anofox_shim::AggArena::Writer writer(arena);
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
 		if (state.slot < 0) state.slot = writer.NewSlot(); // the group exists even if every row of it is skipped
 		auto y_idx = y_data.sel->get_index(i);
-		if (!y_data.validity.RowIsValid(y_idx)) continue;                       // ols_aggregate.cpp:150-153
+		if (!y_data.validity.RowIsValid(y_idx)) continue; // ols_aggregate.cpp:150-153
 		auto x_idx = x_data.sel->get_index(i);
-		if (!x_data.validity.RowIsValid(x_idx)) continue;                       // :157-159
+		if (!x_data.validity.RowIsValid(x_idx)) continue; // :157-159
 		double w = 1.0;
-		if (TRAITS::kWeighted) {
+		if (kWeighted) {
 			auto w_idx = w_data.sel->get_index(i);
-			if (!w_data.validity.RowIsValid(w_idx)) continue;                   // wls_aggregate.cpp:160-166
+			if (!w_data.validity.RowIsValid(w_idx)) continue; // wls_aggregate.cpp:160-166
 			w = w_values[w_idx];
 		}
-		auto entry = x_list[x_idx];
-		if (entry.length > 128) throw InvalidInputException("anofox_stats fit_agg (HIP): at most 128 features are supported");
-		const idx_t n = entry.length;
-		for (idx_t j = 0; j < n; j++) // a NULL list element becomes NaN: the fit's row filter drops the row (ols.rs:59-66)
-			row[j] = x_child_validity.RowIsValid(entry.offset + j) ? x_child_data[entry.offset + j] : NAN;
+		const auto entry = x_list[x_idx];
+		if (entry.length > max_features)
+			throw InvalidInputException("anofox_stats fit_agg (HIP): at most %llu features are supported, got %llu", (unsigned long long)max_features,
+			                            (unsigned long long)entry.length);
+		double *row;
 		try {
-			writer.Append((uint32_t)state.slot, y_values[y_idx], row, entry.length, w);
+			row = writer.Begin((uint32_t)state.slot, y_values[y_idx], entry.length, w);
 		} catch (const std::invalid_argument &e) {
-			throw InvalidInputException(e.what());                              // "Inconsistent feature count: ..." (:172-175)
+			throw InvalidInputException(string(e.what())); // "Inconsistent feature count: expected N, got M" (:172-175)
 		}
+		for (idx_t j = 0; j < entry.length; j++) // a NULL list element becomes NaN: the fit's row filter drops the row (ols.rs:59-66)
+			row[j] = x_child_validity.RowIsValid(entry.offset + j) ? x_child_data[entry.offset + j] : NAN;
 	}
 }
 
-// Combine: ols_aggregate.cpp:189-234.  A source without a slot has seen no Update; a target without one adopts the
-// source's slot (the reference moves the buffers); otherwise the pair is merged on the GPU.
-static void HipAggCombine(Vector &source_vector, Vector &target_vector, AggregateInputData &aggr_input_data, idx_t count) {
+// Combine: ols_aggregate.cpp:189-234.  A source without a slot has seen no Update.  A target without one adopts the
+// source's slot when the source may be consumed (the reference moves the buffers), and otherwise gets a slot of its
+// own that the source is merged into; pairs with slots on both sides are merged on the GPU, in the order given.
+void HipAggCombine(Vector &source_vector, Vector &target_vector, AggregateInputData &aggr_input_data, idx_t count) {
 	UnifiedVectorFormat source_data, target_data;
 	source_vector.ToUnifiedFormat(count, source_data);
 	target_vector.ToUnifiedFormat(count, target_data);
 	auto sources = (HipAggState **)source_data.data;
 	auto targets = (HipAggState **)target_data.data;
+	auto &arena = *aggr_input_data.bind_data->Cast<HipAggBindData>().arena;
+	const bool preserve = aggr_input_data.combine_type == AggregateCombineType::PRESERVE_INPUT;
 	vector<uint32_t> src, dst;
 	for (idx_t i = 0; i < count; i++) {
 		auto &source = *sources[source_data.sel->get_index(i)];
 		auto &target = *targets[target_data.sel->get_index(i)];
-		if (source.slot < 0) continue;
+		if (source.slot < 0 || &source == &target) continue;
 		if (target.slot < 0) {
-			target.slot = source.slot;
-			source.slot = -1;
-			continue;
+			if (!preserve) {
+				target.slot = source.slot;
+				source.slot = -1;
+				continue;
+			}
+			target.slot = arena.NewSlot();
 		}
 		src.push_back((uint32_t)source.slot);
 		dst.push_back((uint32_t)target.slot);
 	}
 	if (src.empty()) return;
-	auto &arena = *aggr_input_data.bind_data->Cast<HipAggBindMixin>().arena;
-	arena.Combine(src.data(), dst.data(), src.size());
+	try {
+		arena.Combine(src.data(), dst.data(), src.size(), preserve);
+	} catch (const std::runtime_error &e) {
+		throw InvalidInputException(string(e.what()));
+	}
 }
 
-static void AppendList(Vector &list_vec, idx_t row, const double *src, idx_t n) {
+void AppendList(Vector &list_vec, idx_t row, const double *src, idx_t n) {
 	auto entries = ListVector::GetData(list_vec);
 	auto offset = ListVector::GetListSize(list_vec);
 	ListVector::Reserve(list_vec, offset + n); // the reference's SetListInResult omits this (ols_aggregate.cpp:237-246)
@@ -158,26 +311,50 @@ static void AppendList(Vector &list_vec, idx_t row, const double *src, idx_t n) 
 	ListVector::SetListSize(list_vec, offset + n);
 }
 
-// Finalize: ols_aggregate.cpp:249-338.  The first call of the query solves every slot at once; each call then only
-// copies its <= 2048 records into the STRUCT vector (field order of GetOlsAggResultType, :74-96).
-template <class TRAITS>
-static void HipAggFinalize(Vector &state_vector, AggregateInputData &aggr_input_data, Vector &result, idx_t count, idx_t offset) {
-	auto &bind = aggr_input_data.bind_data->Cast<typename TRAITS::BindData>();
+// Finalize: ols_aggregate.cpp:249-338.  One arena call for the vector: it fits what changed since it was last fitted (a
+// GROUP BY: every group of the query, once) and returns this vector's records; they go into the STRUCT vector in the
+// field order of the result type.  NULL where the reference returns NULL: fewer than 2 accumulated rows (:263-267), a
+// fit that failed (:298-301) — and a group the device state could not bring to the contract's accuracy (status 101).
+void HipAggFinalize(Vector &state_vector, AggregateInputData &aggr_input_data, Vector &result, idx_t count, idx_t offset) {
+	auto &bind = aggr_input_data.bind_data->Cast<HipAggBindData>();
 	auto &arena = *bind.arena;
-	arena.Solve();
-	const idx_t p = arena.FeatureCount();
 	UnifiedVectorFormat sdata;
 	state_vector.ToUnifiedFormat(count, sdata);
 	auto states = (HipAggState **)sdata.data;
-	auto &entries = StructVector::GetEntries(result);
+	vector<uint32_t> slots;
+	vector<idx_t> rows;
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
-		const idx_t r = i + offset;
-		const double *rec = state.slot < 0 ? nullptr : arena.Core((uint32_t)state.slot);
-		if (!rec) { // fewer than 2 accumulated rows or a failed fit -> NULL, the query continues (:263-267,298-301)
+		if (state.slot < 0) {
+			FlatVector::SetNull(result, i + offset, true); // never updated
+			continue;
+		}
+		slots.push_back((uint32_t)state.slot);
+		rows.push_back(i + offset);
+	}
+	if (slots.empty()) return;
+	const bool inference = bind.opts.compute_inference;
+	vector<int> status(slots.size());
+	vector<double> core, inf;
+	try {
+		// (the feature count is known once any row of the query was accepted; 0 = every state of the query is empty)
+		core.resize(slots.size() * (arena.FeatureCount() + 6));
+		if (inference) inf.resize(slots.size() * (5 * arena.FeatureCount() + 2));
+		arena.Fetch(slots.data(), slots.size(), core.data(), inference ? inf.data() : nullptr, status.data());
+	} catch (const std::runtime_error &e) {
+		throw InvalidInputException(string(e.what()));
+	}
+	const idx_t p = arena.FeatureCount();
+	auto &entries = StructVector::GetEntries(result);
+	idx_t unrefined = 0;
+	for (idx_t k = 0; k < slots.size(); k++) {
+		const idx_t r = rows[k];
+		if (status[k] != 0) {
+			if (status[k] == ANOFOX_HIP_STATUS_UNREFINED) unrefined++;
 			FlatVector::SetNull(result, r, true);
 			continue;
 		}
+		const double *rec = &core[k * (p + 6)];
 		AppendList(*entries[0], r, rec, p);
 		FlatVector::GetData<double>(*entries[1])[r] = rec[p];
 		FlatVector::GetData<double>(*entries[2])[r] = rec[p + 1];
@@ -185,13 +362,90 @@ static void HipAggFinalize(Vector &state_vector, AggregateInputData &aggr_input_
 		FlatVector::GetData<double>(*entries[4])[r] = rec[p + 3];
 		FlatVector::GetData<int64_t>(*entries[5])[r] = (int64_t)rec[p + 4];
 		FlatVector::GetData<int64_t>(*entries[6])[r] = (int64_t)p;
-		if (bind.compute_inference) {
-			const double *ir = arena.Inference((uint32_t)state.slot);
-			for (idx_t k = 0; k < 5; k++) AppendList(*entries[7 + k], r, ir + k * p, p); // se, t, p, ci_lower, ci_upper
+		if (inference) {
+			const double *ir = &inf[k * (5 * p + 2)];
+			for (idx_t f = 0; f < 5; f++) AppendList(*entries[7 + f], r, ir + f * p, p); // se, t, p, ci_lower, ci_upper
 			FlatVector::GetData<double>(*entries[12])[r] = ir[5 * p];
 			FlatVector::GetData<double>(*entries[13])[r] = ir[5 * p + 1];
 		}
 	}
+	// Groups the device state could neither resolve nor refit are NULL, never a number outside the contract; a site
+	// that prefers a failing query sets ANOFOX_HIP_UNREFINED=error.  (AggArena::Unrefined() keeps the query's total.)
+	if (unrefined) {
+		const char *mode = getenv("ANOFOX_HIP_UNREFINED");
+		if (mode && string(mode) == "error")
+			throw InvalidInputException("anofox_stats fit_agg (HIP): %llu group(s) are ill-conditioned or fit (almost) exactly and their rows "
+			                            "outgrew the row-log budgets (ANOFOX_HIP_RETAIN_BYTES / ANOFOX_HIP_RETAIN_HOST_BYTES)",
+			                            (unsigned long long)unrefined);
+	}
+}
+
+template <HipModel MODEL>
+void RegisterHipAggregate(ExtensionLoader &loader, const char *name, const char *alias, const char *what, const char *example_opts) {
+	constexpr bool kWeighted = MODEL == HipModel::WLS;
+	vector<LogicalType> basic_args = {LogicalType::DOUBLE, LogicalType::LIST(LogicalType::DOUBLE)};
+	vector<string> basic_names = {"y", "x"};
+	if (kWeighted) {
+		basic_args.push_back(LogicalType::DOUBLE);
+		basic_names.push_back("weight");
+	}
+	vector<LogicalType> map_args = basic_args;
+	map_args.push_back(LogicalType::ANY); // MAP or STRUCT of options, constant
+	vector<string> map_names = basic_names;
+	map_names.push_back("options");
+
+	auto make = [&](const string &fname, const vector<LogicalType> &args) {
+		return AggregateFunction(fname, args, LogicalType::ANY /* set in bind */, AggregateFunction::StateSize<HipAggState>, HipAggInitialize,
+		                         HipAggUpdate<MODEL>, HipAggCombine, HipAggFinalize, nullptr /* simple_update */, HipAggBind<MODEL>, HipAggDestroy);
+	};
+	AggregateFunctionSet func_set(name);
+	func_set.AddFunction(make(name, basic_args)); // (y, x[, weight]) — defaults
+	func_set.AddFunction(make(name, map_args));   // (y, x[, weight], {'intercept': true, ...})
+	CreateAggregateFunctionInfo info(std::move(func_set));
+	info.on_conflict = OnCreateConflict::ALTER_ON_CONFLICT;
+	FunctionDescription d1;
+	d1.description = what;
+	d1.examples = {string(name) + "(y, x" + (kWeighted ? ", w" : "") + ", " + example_opts + ")"};
+	d1.categories = {"regression"};
+	d1.parameter_names = map_names;
+	d1.parameter_types = map_args;
+	info.descriptions.push_back(std::move(d1));
+	FunctionDescription d2;
+	d2.description = what;
+	d2.examples = {string(name) + "(y, x" + (kWeighted ? ", w" : "") + ")"};
+	d2.categories = {"regression"};
+	d2.parameter_names = basic_names;
+	d2.parameter_types = basic_args;
+	info.descriptions.push_back(std::move(d2));
+	loader.RegisterFunction(std::move(info));
+
+	AggregateFunctionSet alias_set(alias); // the short alias (ols_aggregate.cpp:415-425)
+	alias_set.AddFunction(make(alias, basic_args));
+	alias_set.AddFunction(make(alias, map_args));
+	CreateAggregateFunctionInfo alias_info(std::move(alias_set));
+	alias_info.on_conflict = OnCreateConflict::ALTER_ON_CONFLICT;
+	alias_info.alias_of = name;
+	loader.RegisterFunction(std::move(alias_info));
+}
+
+} // namespace
+
+anofox_shim::AggArena *HipAggArenaOf(FunctionData &bind_data) {
+	auto *b = dynamic_cast<HipAggBindData *>(&bind_data);
+	return b ? b->arena.get() : nullptr;
+}
+
+void RegisterHipOlsAggregateFunction(ExtensionLoader &loader) {
+	RegisterHipAggregate<HipModel::OLS>(loader, "anofox_stats_ols_fit_agg", "ols_fit_agg",
+	                                    "Fits an OLS regression model and returns coefficients and fit statistics as a struct.", "{'fit_intercept': true}");
+}
+void RegisterHipRidgeAggregateFunction(ExtensionLoader &loader) {
+	RegisterHipAggregate<HipModel::RIDGE>(loader, "anofox_stats_ridge_fit_agg", "ridge_fit_agg",
+	                                      "Fits a Ridge regression model and returns coefficients and fit statistics as a struct.", "{'alpha': 1.0}");
+}
+void RegisterHipWlsAggregateFunction(ExtensionLoader &loader) {
+	RegisterHipAggregate<HipModel::WLS>(loader, "anofox_stats_wls_fit_agg", "wls_fit_agg",
+	                                    "Fits a weighted least squares model and returns coefficients and fit statistics as a struct.", "{'fit_intercept': true}");
 }
 
 } // namespace duckdb

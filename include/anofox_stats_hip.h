@@ -529,6 +529,17 @@ ANOFOX_HIP_API bool anofox_hip_agg_state_update_device(AnofoxHipAggState *state,
                                         AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_agg_state_combine(AnofoxHipAggState *state, int64_t n_pairs, const uint32_t *source_slots,
                                   const uint32_t *target_slots, AnofoxError *out_error);
+/* combine with preserve_sources = true leaves the sources as they are (DuckDB's AggregateCombineType::PRESERVE_INPUT: a
+ * window segment tree combines one node into many frames); the same source may then feed several targets of a call.
+ * A row log cannot count a row for two slots: it is given up on the first such call (unresolved groups are flagged by
+ * Finalize), and log-only states refuse it. */
+ANOFOX_HIP_API bool anofox_hip_agg_state_combine_ex(AnofoxHipAggState *state, int64_t n_pairs, const uint32_t *source_slots,
+                                     const uint32_t *target_slots, bool preserve_sources, AnofoxError *out_error);
+/* Finalize of the listed (distinct) slots only: record k belongs to slots[k].  Same records as finalize_host. */
+ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_slots_host(AnofoxHipAggState *state, int64_t n_list, const uint32_t *slots, double *core,
+                                              double *inference, int64_t *out_unrefined, AnofoxError *out_error);
+/* Destroy of aggregate states (ols_aggregate.cpp:108-118): the listed slots become empty and may be handed out again. */
+ANOFOX_HIP_API bool anofox_hip_agg_state_release_slots(AnofoxHipAggState *state, int64_t n_list, const uint32_t *slots, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *state, int64_t n_slots, double *core, double *inference,
                                         int64_t *out_unrefined, int32_t *out_unrefined_slots, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *state, int64_t n_slots, double *d_core, double *d_inference,

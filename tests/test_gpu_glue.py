@@ -1,0 +1,180 @@
+"""The DuckDB glue (duckdb_shim/fit_agg_hip.cpp) on a GPU: compiled against the stand-in of DuckDB's headers, linked with
+the real library and driven as DuckDB drives an aggregate (tests/tools/glue_driver.hpp) — a parallel hash aggregate with
+thread-local states and Combine, the naive window aggregator, and a segment tree's Combine — against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import ROOT, assert_records_match
+
+pytestmark = pytest.mark.gpu
+LIB = os.path.join(ROOT, "anofox-statistics_amd", "duckdb_shim", "libanofox_glue_capi.so")
+_DP = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = C.CDLL(LIB)
+    lib.glue_open.restype = C.c_void_p
+    lib.glue_open.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p]
+    lib.glue_close.argtypes = [C.c_void_p]
+    lib.glue_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.glue_group_by.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_char_p]
+    lib.glue_window.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+    lib.glue_tree_window.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                     C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+    return lib
+
+
+def _stats(lib, q):
+    s = (C.c_int64 * 6)()
+    lib.glue_stats(q, s)
+    return dict(rows=s[0], unrefined=s[1], slots=s[2], live=s[3], fit_calls=s[4], slots_fitted=s[5])
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _fix_last_column(core, p):
+    """The SQL struct carries n_features where the library's record carries the status: a row that is not NULL has status 0."""
+    out = core.copy()
+    out[:, p + 5] = 0.0
+    return out
+
+
+@pytest.mark.parametrize("fn,model,p,spec,kw", [
+    ("anofox_stats_ols_fit_agg", "ols", 3, None, {}),
+    ("ols_fit_agg", "ols", 8, b"compute_inference=true;confidence_level=0.9", dict(compute_inference=True, confidence_level=0.9)),
+    ("anofox_stats_ridge_fit_agg", "ridge", 5, b"alpha=0.5;inference=true", dict(alpha=0.5, compute_inference=True)),
+    ("wls_fit_agg", "wls", 4, b"intercept=false;compute_inference=true", dict(fit_intercept=False, compute_inference=True)),
+    ("ols_fit_agg", "ols", 20, b"compute_inference=true", dict(compute_inference=True)),            # log-only state
+    ("anofox_stats_ols_fit_agg", "ols", 3, b"compute_inference=true;hc_type=hc1", dict(compute_inference=True, hc_type="hc1")),
+])
+def test_group_by_through_the_glue_matches_oracle(lib, fn, model, p, spec, kw):
+    rng = np.random.default_rng(len(fn) * 31 + p)
+    K, n = 400, 60_000
+    key = rng.integers(0, K, n).astype(np.uint32)
+    X = rng.uniform(-5, 5, (n, p)) + 1.0
+    beta = rng.uniform(-3, 3, (K, p))
+    y = np.einsum("ij,ij->i", beta[key], X) + 4.0 + rng.standard_normal(n)
+    w = rng.uniform(0.5, 1.5, n)
+    y_null = (rng.random(n) < 0.03).astype(np.uint8)        # NULL y / NULL x list / NULL weight: the row is skipped
+    x_null = (rng.random(n) < 0.02).astype(np.uint8)
+    w_null = (rng.random(n) < 0.02).astype(np.uint8)
+    xe_null = (rng.random((n, p)) < 0.002).astype(np.uint8)  # NULL list elements: NaN, the fit drops the row
+    key[:7] = K - 1                                          # a key with few rows
+    msg = C.create_string_buffer(512)
+    q = lib.glue_open(fn.encode(), spec, 0, msg)
+    assert q, msg.value
+    inference = kw.get("compute_inference", False)
+    core = np.full((K, p + 6), np.nan)
+    inf = np.full((K, 5 * p + 2), np.nan) if inference else None
+    nn = np.zeros(K, dtype=np.uint8)
+    rc = lib.glue_group_by(q, n, p, _ptr(key), K, _ptr(y), _ptr(X), _ptr(w), _ptr(y_null), _ptr(x_null), _ptr(xe_null), _ptr(w_null),
+                           6, 2048, 1, _ptr(core), _ptr(inf), _ptr(nn), msg)
+    assert rc == 0, msg.value
+    st = _stats(lib, q)
+    lib.glue_close(q)
+    keep = ~(y_null.astype(bool) | x_null.astype(bool) | ((model == "wls") & w_null.astype(bool)))
+    Xn = np.where(xe_null.astype(bool), np.nan, X)
+    idx = np.nonzero(keep)[0]
+    order = idx[np.argsort(key[idx], kind="stable")]
+    offs = np.concatenate([[0], np.cumsum(np.bincount(key[idx], minlength=K))]).astype(np.int64)
+    rcore, rinf = oracle.fit_groups(y[order], [np.ascontiguousarray(Xn[order, j]) for j in range(p)], offs,
+                                    w=(w[order] if model == "wls" else None), model=model, **kw)
+    assert st["rows"] == int(keep.sum()) and st["live"] == 0 and st["unrefined"] == 0
+    assert st["fit_calls"] == 1                                   # ONE batched fit for the whole GROUP BY
+    fitted = rcore[:, p + 5] == 0
+    assert np.array_equal(nn == 0, fitted)                        # NULL exactly where the reference returns NULL
+    assert np.all(core[fitted, p + 5] == p)                       # n_features
+    assert_records_match(_fix_last_column(core[fitted], p), rcore[fitted], p, None if inf is None else inf[fitted],
+                         None if rinf is None else rinf[fitted], what=f"glue GROUP BY {fn} p={p}")
+
+
+def test_reference_window_test_through_the_glue(lib):
+    """test/sql/comprehensive_tests.test:425-444: anofox_stats_ols_fit_agg(y, [x]) OVER (ORDER BY idx ROWS BETWEEN 4 PRECEDING
+    AND CURRENT ROW) over y = 2 i + 1, i = 1..20 — 16 rows have n_observations = 5.  The frames fit exactly (rss = 0): the
+    device state queues every one of them for refinement and refits them from its row log."""
+    i = np.arange(1, 21, dtype=np.float64)
+    y, X = 2 * i + 1, i.reshape(-1, 1).copy()
+    for vsize in (2048, 4):
+        msg = C.create_string_buffer(512)
+        q = lib.glue_open(b"anofox_stats_ols_fit_agg", None, 0, msg)
+        core = np.full((20, 7), np.nan)
+        nn = np.zeros(20, dtype=np.uint8)
+        assert lib.glue_window(q, 20, 1, _ptr(y), _ptr(X), None, 4, vsize, _ptr(core), None, _ptr(nn), msg) == 0, msg.value
+        st = _stats(lib, q)
+        lib.glue_close(q)
+        assert int(np.sum((nn == 0) & (core[:, 5] == 5))) == 16
+        assert nn[0] == 1 and np.all(nn[1:] == 0)                 # a single row -> NULL (ols_aggregate.cpp:263-267)
+        assert np.allclose(core[1:, 0], 2.0, rtol=1e-9) and np.allclose(core[1:, 1], 1.0, rtol=0, atol=1e-8) and np.allclose(core[1:, 2], 1.0)
+        assert st["live"] == 0 and st["slots_fitted"] == 20 and st["unrefined"] == 0
+        if vsize == 4:
+            assert st["slots"] <= 8                               # destroyed states' slots are handed out again
+
+
+@pytest.mark.parametrize("p,model", [(2, "ols"), (6, "wls")])
+def test_rolling_window_through_the_glue_matches_oracle(lib, p, model):
+    rng = np.random.default_rng(7 + p)
+    n, back = 3000, 39
+    X = rng.uniform(-5, 5, (n, p)) + np.linspace(0, 3, n)[:, None]
+    y = X @ rng.uniform(-2, 2, p) + 1.5 + rng.standard_normal(n)
+    w = rng.uniform(0.5, 1.5, n)
+    msg = C.create_string_buffer(512)
+    fn = b"anofox_stats_wls_fit_agg" if model == "wls" else b"ols_fit_agg"
+    q = lib.glue_open(fn, b"compute_inference=true", 0, msg)
+    core = np.full((n, p + 6), np.nan)
+    inf = np.full((n, 5 * p + 2), np.nan)
+    nn = np.zeros(n, dtype=np.uint8)
+    assert lib.glue_window(q, n, p, _ptr(y), _ptr(X), _ptr(w), back, 512, _ptr(core), _ptr(inf), _ptr(nn), msg) == 0, msg.value
+    st = _stats(lib, q)
+    lib.glue_close(q)
+    # the oracle: every frame as a group of its own
+    lo = np.maximum(0, np.arange(n) - back)
+    lens = np.arange(n) + 1 - lo
+    rows = np.concatenate([np.arange(a, b + 1) for a, b in zip(lo, np.arange(n))])
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    rcore, rinf = oracle.fit_groups(y[rows], [np.ascontiguousarray(X[rows, j]) for j in range(p)], offs,
+                                    w=(w[rows] if model == "wls" else None), model=model, compute_inference=True)
+    fitted = rcore[:, p + 5] == 0
+    assert np.array_equal(nn == 0, fitted)
+    zero_df = [k for k, g in enumerate(np.nonzero(fitted)[0]) if lens[g] <= p + 1]
+    assert_records_match(_fix_last_column(core[fitted], p), rcore[fitted], p, inf[fitted], rinf[fitted],
+                         what=f"glue window {model} p={p}", skip_diag_groups=zero_df)
+    assert st["live"] == 0 and st["slots"] <= 2 * 512 and st["slots_fitted"] == n     # bounded state, each frame fitted once
+
+
+def test_segment_tree_combine_through_the_glue(lib):
+    """PRESERVE_INPUT Combine: every leaf state is the source of up to three frames of one Combine call and lives on."""
+    rng = np.random.default_rng(11)
+    p, leaf, back, n = 3, 50, 2, 50 * 40
+    X = rng.uniform(-5, 5, (n, p))
+    y = X @ np.array([1.0, -2.0, 0.5]) + 3.0 + rng.standard_normal(n)
+    msg = C.create_string_buffer(512)
+    q = lib.glue_open(b"ols_fit_agg", None, 0, msg)
+    L = n // leaf
+    core = np.full((L, p + 6), np.nan)
+    nn = np.zeros(L, dtype=np.uint8)
+    assert lib.glue_tree_window(q, n, p, _ptr(y), _ptr(X), None, leaf, back, 2048, _ptr(core), None, _ptr(nn), msg) == 0, msg.value
+    lib.glue_close(q)
+    los = np.maximum(0, np.arange(L) - back) * leaf
+    his = (np.arange(L) + 1) * leaf
+    rows = np.concatenate([np.arange(a, b) for a, b in zip(los, his)])
+    offs = np.concatenate([[0], np.cumsum(his - los)]).astype(np.int64)
+    rcore, _ = oracle.fit_groups(y[rows], [np.ascontiguousarray(X[rows, j]) for j in range(p)], offs, model="ols")
+    assert np.all(nn == 0)
+    assert_records_match(_fix_last_column(core, p), rcore, p, None, None, what="glue segment tree")
+    # wide designs keep rows, not moments: a row cannot count for two states, and the glue says so
+    q = lib.glue_open(b"ols_fit_agg", None, 0, msg)
+    Xw = rng.uniform(-1, 1, (200, 12))
+    core = np.full((4, 18), np.nan)
+    rc = lib.glue_tree_window(q, 200, 12, _ptr(Xw[:, 0].copy()), _ptr(Xw), None, 50, 1, 2048, _ptr(core), None, _ptr(np.zeros(4, dtype=np.uint8)), msg)
+    lib.glue_close(q)
+    assert rc == -1 and "fit_predict window functions" in msg.value.decode()

@@ -3,8 +3,12 @@ code (GPU ASan is not available on this pool).  tests/tools/Makef
 csrc/agg_state.hip as plain C++ with g++ (kernel launchers stubbed: nothing reaches them without a GPU) and
 oracle/anofox_oracle.c with gcc, each with a driver; the DuckDB shim's arena (duckdb_shim/agg_arena.hpp) runs against a
 recording mock of the C ABI (tests/tools/arena_sanitize.cpp: Update vectors of three threads, flushes, Combine, Finalize,
-narrow and wide designs; every accepted row must reach the right slot in the reference's order).  A non-zero
-exit or any sanitizer report fails the test."""
+narrow and wide designs, concurrent writers, the windowed-aggregate protocol, a failing device; every accepted row must
+reach the right slot in the reference's order), and the DuckDB glue itself (duckdb_shim/fit_agg_hip.cpp) is compiled
+against a stand-in of DuckDB's headers (tests/tools/duckdb_stub) with -Wall -Wextra -Werror and driven through
+registration, bind and the Update / Combine / Finalize / Destroy protocol as a parallel hash aggregate, as the naive
+window aggregator (the reference's test/sql/comprehensive_tests.test:425-444) and as a segment tree
+(tests/tools/glue_sanitize.cpp).  A non-zero exit or any sanitizer report fails the test."""
 import os
 import shutil
 import subprocess
@@ -24,7 +28,7 @@ def built():
     return OUT
 
 
-@pytest.mark.parametrize("unit", ["oracle_sanitize", "host_sanitize", "arena_sanitize"])
+@pytest.mark.parametrize("unit", ["oracle_sanitize", "host_sanitize", "arena_sanitize", "glue_sanitize"])
 def test_sanitizer_unit(built, unit):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
     env.pop("LD_PRELOAD", None)

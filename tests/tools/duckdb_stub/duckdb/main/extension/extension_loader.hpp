@@ -1,0 +1,3 @@
+// stand-in: see ../duckdb.hpp
+#pragma once
+#include "duckdb.hpp"

@@ -1,0 +1,93 @@
+// glue_capi.cpp — C entry points around glue_driver.hpp for tests/test_gpu_glue.py: the DuckDB glue
+// (duckdb_shim/fit_agg_hip.cpp, compiled against the stand-in of DuckDB's headers) on top of the REAL library on a GPU,
+// driven as a parallel hash aggregate and as a window aggregate.  Test infrastructure; builds into
+// anofox-statistics_amd/duckdb_shim/libanofox_glue_capi.so (duckdb_shim/Makefile).
+#include "glue_driver.hpp"
+
+using namespace glue_driver;
+
+extern "C" {
+#define GLUE_API __attribute__((visibility("default")))
+
+static int fail(char *msg, const std::exception &e) {
+	if (msg) {
+		strncpy(msg, e.what(), 511);
+		msg[511] = 0;
+	}
+	return -1;
+}
+
+GLUE_API void *glue_open(const char *fn_name, const char *options_spec /* NULL = no options argument */, int as_map, char *msg) {
+	try {
+		return new Query(fn_name, options_spec, as_map != 0);
+	} catch (const std::exception &e) {
+		fail(msg, e);
+		return nullptr;
+	}
+}
+GLUE_API void glue_close(void *q) { delete static_cast<Query *>(q); }
+GLUE_API int glue_result_fields(void *q) { return (int)static_cast<Query *>(q)->ReturnType().children().size(); }
+// arena statistics: [0] rows accepted [1] unrefined groups [2] slot high-water mark [3] live slots [4] fit calls [5] slots fitted
+GLUE_API void glue_stats(void *q, int64_t *out6) {
+	auto &a = static_cast<Query *>(q)->Arena();
+	out6[0] = (int64_t)a.RowsAccepted();
+	out6[1] = a.Unrefined();
+	out6[2] = a.SlotCount();
+	out6[3] = a.LiveSlots();
+	out6[4] = (int64_t)a.FitCalls();
+	out6[5] = (int64_t)a.SlotsFitted();
+}
+
+static Inputs make_inputs(size_t n, size_t p, const double *y, const double *x, const double *w, const uint8_t *y_null, const uint8_t *x_null,
+                          const uint8_t *xe_null, const uint8_t *w_null) {
+	Inputs in;
+	in.n = n; in.p = p; in.y = y; in.x = x; in.w = w;
+	in.y_null = y_null; in.x_null = x_null; in.xe_null = xe_null; in.w_null = w_null;
+	return in;
+}
+static void copy_out(const Records &r, size_t rows, size_t p, double *core, double *inf, uint8_t *is_null) {
+	for (size_t k = 0; k < rows; ++k) {
+		is_null[k] = r.is_null[k];
+		if (r.is_null[k] || r.p != p) continue;
+		memcpy(core + k * (p + 6), &r.core[k * (p + 6)], (p + 6) * sizeof(double));
+		if (inf && r.inference) memcpy(inf + k * (5 * p + 2), &r.inf[k * (5 * p + 2)], (5 * p + 2) * sizeof(double));
+	}
+}
+
+// GROUP BY key: out_core [n_keys x (p + 6)] (last column = n_features), out_inf [n_keys x (5 p + 2)] or NULL, is_null [n_keys]
+GLUE_API int glue_group_by(void *q, size_t n, size_t p, const uint32_t *key, size_t n_keys, const double *y, const double *x, const double *w,
+                           const uint8_t *y_null, const uint8_t *x_null, const uint8_t *xe_null, const uint8_t *w_null, int n_threads,
+                           size_t vector_size, int dictionary, double *out_core, double *out_inf, uint8_t *is_null, char *msg) {
+	try {
+		Records r = static_cast<Query *>(q)->GroupBy(make_inputs(n, p, y, x, w, y_null, x_null, xe_null, w_null), key, n_keys, n_threads, vector_size,
+		                                             dictionary != 0);
+		copy_out(r, n_keys, p, out_core, out_inf, is_null);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(msg, e);
+	}
+}
+// the aggregate OVER (ROWS BETWEEN preceding PRECEDING AND CURRENT ROW), one output row per input row
+GLUE_API int glue_window(void *q, size_t n, size_t p, const double *y, const double *x, const double *w, size_t preceding, size_t vector_size,
+                         double *out_core, double *out_inf, uint8_t *is_null, char *msg) {
+	try {
+		Records r = static_cast<Query *>(q)->Window(make_inputs(n, p, y, x, w, nullptr, nullptr, nullptr, nullptr), preceding, vector_size);
+		copy_out(r, n, p, out_core, out_inf, is_null);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(msg, e);
+	}
+}
+// a segment tree over leaves of `leaf` rows, frames of the `back` + 1 latest leaves: one output row per leaf
+GLUE_API int glue_tree_window(void *q, size_t n, size_t p, const double *y, const double *x, const double *w, size_t leaf, size_t back,
+                              size_t vector_size, double *out_core, double *out_inf, uint8_t *is_null, char *msg) {
+	try {
+		Records r = static_cast<Query *>(q)->TreeWindow(make_inputs(n, p, y, x, w, nullptr, nullptr, nullptr, nullptr), leaf, back, vector_size);
+		copy_out(r, (n + leaf - 1) / leaf, p, out_core, out_inf, is_null);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(msg, e);
+	}
+}
+
+} // extern "C"

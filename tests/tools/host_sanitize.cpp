@@ -22,7 +22,7 @@ STUB(launch_tcrit_table(double *, int, double, hipStream_t))
 STUB(launch_window_predict(const WindowArgs &, hipStream_t))
 STUB(launch_residuals_narrow(const ResidualArgs &, hipStream_t))
 STUB(launch_ingest_chunk(const IngestArgs &, hipStream_t))
-STUB(launch_ingest_combine(double *, int64_t *, int64_t, const uint32_t *, const uint32_t *, int64_t, int, int, hipStream_t))
+STUB(launch_ingest_combine(double *, int64_t *, int64_t, const uint32_t *, const uint32_t *, int64_t, int, int, int, hipStream_t))
 STUB(launch_accumulate_wide(const WideArgs &, hipStream_t))
 STUB(launch_solve_wide(const WideArgs &, int, hipStream_t))
 STUB(launch_inference_wide_finish(const WideArgs &, hipStream_t))
@@ -51,7 +51,12 @@ STUB(launch_rowlog_dense(const int32_t *, int64_t, int32_t *, int64_t, hipStream
 STUB(launch_rowlog_select(bool, const uint32_t *, const uint8_t *, int64_t, int64_t, const int32_t *, int64_t, unsigned long long *, uint64_t *, unsigned, hipStream_t))
 STUB(launch_rowlog_sort_keys(const uint64_t *, uint64_t *, int64_t, unsigned, void *, size_t, hipStream_t))
 STUB(launch_rowlog_gather(const uint64_t *, int64_t, int64_t, const RowLogSlab *, int, int, int, double *, double *, size_t, double *, int64_t *, unsigned, hipStream_t))
-STUB(launch_rowlog_scatter(const double *, const int32_t *, int64_t, int, double *, hipStream_t))
+STUB(launch_rowlog_scatter(const double *, const int32_t *, int64_t, int, double *, const int32_t *, hipStream_t))
+STUB(launch_rowlog_positions(const uint32_t *, int64_t, int32_t *, int64_t, hipStream_t))
+STUB(launch_rowlog_map_queue(const int32_t *, const int32_t *, const uint32_t *, int32_t *, hipStream_t))
+STUB(launch_rowlog_invalidate(uint8_t *, int64_t, const uint32_t *, int64_t, const RowLogSlab *, int, hipStream_t))
+STUB(launch_ingest_gather_slots(const double *, const int64_t *, const uint32_t *, int64_t, int, double *, int64_t *, hipStream_t))
+STUB(launch_ingest_clear_slots(double *, int64_t *, const uint32_t *, int64_t, int, hipStream_t))
 STUB(launch_rowlog_remap(uint32_t *, int64_t, const uint32_t *, const uint32_t *, int64_t, const RowLogSlab *, int, hipStream_t))
 size_t rowlog_sort_temp_bytes(int64_t) { return 4096; }
 STUB(launch_rowlog_flag_unrefined(const int32_t *, const int32_t *, int64_t, int, double *, double *, hipStream_t))
