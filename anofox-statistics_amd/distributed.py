@@ -3,10 +3,10 @@ groups with no data-path communication, and one all-gather of the fixed-size per
 the full result on every rank.  `torch.distributed` backend "nccl" is RCCL over xGMI on
 ROCm; "gloo" is used by the CPU tests of the partition / gather plumbing.
 
-Partitioning: rank r owns the contiguous range [r*ceil(G/W), (r+1)*ceil(G/W)) of the *sorted distinct
-keys*; a DuckDB shim would route rows with `hash(key) % W` instead — any assignment that keeps all rows of
-a key on one rank works, because no arithmetic crosses groups (ols_aggregate.cpp:257-337 loops groups
-independently).
+Partitioning: the synthetic bench gives rank r the contiguous range [r*ceil(G/W), (r+1)*ceil(G/W)) of the *sorted
+distinct keys*; arriving rows are routed with `hash64(key) % W` (`hash_partition`, mirrored by the C++ ingest of
+duckdb_shim/sharded_arena.hpp: W device states, per-shard page-locked buffers).  Any assignment that keeps all rows of a
+key on one shard works, because no arithmetic crosses groups (ols_aggregate.cpp:257-337 loops groups independently).
 """
 from __future__ import annotations
 
@@ -14,6 +14,25 @@ from typing import Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def hash64(keys):
+    """splitmix64 finaliser over uint64 keys (numpy array or int) — the routing hash of the hash-partitioned ingest,
+    bit-identical to anofox_shim::hash64 (duckdb_shim/sharded_arena.hpp)."""
+    import numpy as np
+    z = np.asarray(keys).astype(np.uint64, copy=True)
+    with np.errstate(over="ignore"):
+        z += np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def hash_partition(keys, world: int):
+    """shard[i] = hash64(keys[i]) % world: which rank / device owns the group of row i.  All rows of a key land on one
+    shard, so no arithmetic crosses shards (BASELINE north_star: groups hash-partitioned across the GPUs)."""
+    import numpy as np
+    return (hash64(keys) % np.uint64(world)).astype(np.int64)
 
 
 def shard_range(n_groups: int, rank: int, world: int) -> Tuple[int, int]:

@@ -57,9 +57,10 @@ public:
 	//   (ols_aggregate.cpp:19-42).  Defaults 64 GiB of the 288 and 32 GiB; ANOFOX_HIP_RETAIN_BYTES /
 	//   ANOFOX_HIP_RETAIN_HOST_BYTES override them.  Groups of a query that outgrows both come back as SQL NULL with
 	//   status ANOFOX_HIP_STATUS_UNREFINED when (and only when) the moments cannot resolve them; Unrefined() counts them.
+	// device: the GPU of this arena's state (-1 = the calling thread's current device); ShardedAggArena gives every shard its own
 	explicit AggArena(AnofoxHipBatchOptions options, size_t chunk_rows = (size_t)1 << 18, size_t retain_bytes = (size_t)64 << 30,
-	                  size_t retain_host_bytes = (size_t)32 << 30)
-	    : opt_(options), chunk_rows_(chunk_rows ? chunk_rows : 1), retain_bytes_(retain_bytes), retain_host_bytes_(retain_host_bytes) {
+	                  size_t retain_host_bytes = (size_t)32 << 30, int device = -1)
+	    : opt_(options), chunk_rows_(chunk_rows ? chunk_rows : 1), retain_bytes_(retain_bytes), retain_host_bytes_(retain_host_bytes), device_(device) {
 		if (const char *v = getenv("ANOFOX_HIP_RETAIN_BYTES")) retain_bytes_ = (size_t)strtoull(v, nullptr, 10);
 		if (const char *v = getenv("ANOFOX_HIP_RETAIN_HOST_BYTES")) retain_host_bytes_ = (size_t)strtoull(v, nullptr, 10);
 	}
@@ -231,7 +232,7 @@ private:
 		AnofoxError err;
 		AnofoxHipContext *ctx = nullptr;
 		AnofoxHipAggState *state = nullptr;
-		if (!anofox_hip_context_create(-1, &ctx, &err)) Throw(err);
+		if (!anofox_hip_context_create(device_, &ctx, &err)) Throw(err);
 		// up to 8 features without HC errors: O(p^2) moments per slot (+ the row log for the groups they cannot resolve);
 		// wider designs and HC errors: the library keeps the rows themselves (log-only state)
 		bool ok = anofox_hip_agg_state_create(ctx, n_features, opt_, 0, &state, &err);
@@ -423,6 +424,7 @@ private:
 	AnofoxHipBatchOptions opt_;
 	size_t chunk_rows_;
 	size_t retain_bytes_, retain_host_bytes_;
+	int device_;
 	mutable std::mutex mu_; // slots, dirty marks, the chunk table
 	std::mutex ship_mu_;    // every call into the library (taken before mu_, never while holding it)
 	std::condition_variable cv_;

@@ -4,8 +4,10 @@
 // threads, lazily initialised states, Combine of thread-local states, Finalize vector by vector).
 // Test infrastructure for the shim: builds into libanofox_arena_capi.so next to this file.
 #include "agg_arena.hpp"
+#include "sharded_arena.hpp"
 
 using anofox_shim::AggArena;
+using anofox_shim::ShardedAggArena;
 
 extern "C" {
 
@@ -98,5 +100,65 @@ ARENA_API uint32_t arena_slot_count(void *a) { return static_cast<AggArena *>(a)
 ARENA_API uint32_t arena_live_slots(void *a) { return static_cast<AggArena *>(a)->LiveSlots(); }
 ARENA_API uint64_t arena_fit_calls(void *a) { return static_cast<AggArena *>(a)->FitCalls(); }
 ARENA_API uint64_t arena_slots_fitted(void *a) { return static_cast<AggArena *>(a)->SlotsFitted(); }
+
+// ---- hash-partitioned ingest over W device states (sharded_arena.hpp) ----
+ARENA_API uint32_t sharded_shard_of(uint64_t key, uint32_t n_shards) { return anofox_shim::shard_of_key(key, n_shards); }
+ARENA_API void *sharded_create(AnofoxHipBatchOptions options, uint32_t n_shards, const int *devices, size_t chunk_rows) {
+	try {
+		return new ShardedAggArena(options, n_shards, devices, chunk_rows);
+	} catch (...) {
+		return nullptr;
+	}
+}
+ARENA_API void sharded_destroy(void *a) { delete static_cast<ShardedAggArena *>(a); }
+// one Update call: row i has group key keys[i]; rows with accept[i] == 0 register their key but are skipped
+ARENA_API int sharded_update(void *a, size_t n, const uint64_t *keys, const double *y, const double *x, size_t n_features, const double *w,
+                             const uint8_t *accept, char *msg) {
+	try {
+		ShardedAggArena::Writer wr(*static_cast<ShardedAggArena *>(a));
+		for (size_t i = 0; i < n; ++i) {
+			if (accept && !accept[i]) { wr.Touch(keys[i]); continue; }
+			wr.Append(keys[i], y[i], x + i * n_features, n_features, w ? w[i] : 1.0);
+		}
+		return 0;
+	} catch (const std::exception &e) {
+		if (msg) {
+			strncpy(msg, e.what(), 255);
+			msg[255] = 0;
+		}
+		return -1;
+	}
+}
+ARENA_API uint64_t sharded_rows_of_shard(void *a, uint32_t s) { return static_cast<ShardedAggArena *>(a)->RowsOfShard(s); }
+ARENA_API size_t sharded_keys_of_shard(void *a, uint32_t s) { return static_cast<ShardedAggArena *>(a)->KeysOfShard(s); }
+ARENA_API size_t sharded_key_count(void *a) {
+	auto &ar = *static_cast<ShardedAggArena *>(a);
+	size_t n = 0;
+	for (uint32_t s = 0; s < ar.ShardCount(); ++s) n += ar.KeysOfShard(s);
+	return n;
+}
+// Finalize: out_keys [K], out_core [K x (p + 6)], out_inf [K x (5 p + 2)] or NULL, out_status [K]; K = sharded_key_count
+ARENA_API int sharded_finalize(void *a, size_t capacity, uint64_t *out_keys, double *out_core, double *out_inf, int32_t *out_status, char *msg) {
+	try {
+		auto &ar = *static_cast<ShardedAggArena *>(a);
+		std::vector<uint64_t> keys;
+		std::vector<double> core, inf;
+		std::vector<int> status;
+		ar.Fetch(keys, core, out_inf ? &inf : nullptr, status);
+		if (keys.size() > capacity) throw std::runtime_error("sharded_finalize: output capacity too small");
+		const size_t p = ar.FeatureCount();
+		memcpy(out_keys, keys.data(), keys.size() * sizeof(uint64_t));
+		memcpy(out_core, core.data(), keys.size() * (p + 6) * sizeof(double));
+		if (out_inf && !inf.empty()) memcpy(out_inf, inf.data(), keys.size() * (5 * p + 2) * sizeof(double));
+		for (size_t k = 0; k < keys.size(); ++k) out_status[k] = status[k];
+		return 0;
+	} catch (const std::exception &e) {
+		if (msg) {
+			strncpy(msg, e.what(), 255);
+			msg[255] = 0;
+		}
+		return -1;
+	}
+}
 
 } // extern "C"

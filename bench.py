@@ -119,6 +119,66 @@ def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=12.0):
                       f"(dense Householder QR per group, {cores} threads), {t:.1f} s"}
 
 
+def multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, steps, rehearsal, dev):
+    """Per-rank figures of an N-rank run, gathered to rank 0: each rank's accumulate-kernel time per step, the time of one
+    all-gather of the records alone, and the number of ranks RCCL itself counts in a communicator created through the
+    library's C ABI (anofox_hip_comm_create -> ncclCommCount) — over which the same records are gathered once more
+    (anofox_hip_gather_records_device) and compared with torch.distributed's result."""
+    import ctypes as C
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = {"rank": rank, "groups": hi - lo, "kernel_ms_per_step": kt["accumulate_ms"] / steps, "solve_span_ms_per_step": kt["solve_ms"] / steps}
+    # one gather alone, timed with events on this rank's stream (5 repetitions after a warm-up)
+    gather_ms = None
+    if not rehearsal:
+        per = dmod.padded_shard_len(G, world)
+        local = torch.full((per, p + 6), float("nan"), dtype=torch.float64, device=dev)
+        local[: hi - lo] = core_all[lo:hi]
+        outb = torch.empty((per * world, p + 6), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(outb, local)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_gather_into_tensor(outb, local)
+        e1.record()
+        torch.cuda.synchronize()
+        gather_ms = e0.elapsed_time(e1) / 5
+        mine["gather_ms"] = gather_ms
+        # the exchange step behind the C ABI: RCCL's own count of the ranks, and the same gather through it
+        try:
+            abi = importlib.import_module(PKG + "._abi")
+            lib = abi.load()
+            err = abi.AnofoxError()
+            uid = (C.c_uint8 * 128)()
+            if rank == 0 and not lib.anofox_hip_comm_unique_id(uid, C.byref(err)):
+                raise RuntimeError(err.text())
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, 0)
+            uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+            comm = C.c_void_p()
+            ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            if not lib.anofox_hip_comm_create(ctx._h, world, rank, uid, C.byref(comm), C.byref(err)):
+                raise RuntimeError(err.text())
+            mine["n_ranks_seen"] = int(lib.anofox_hip_comm_ranks_seen(comm))
+            out2 = torch.empty_like(outb)
+            if not lib.anofox_hip_gather_records_device(comm, C.c_void_p(local.data_ptr()), per, p + 6, C.c_void_p(out2.data_ptr()), C.byref(err)):
+                raise RuntimeError(err.text())
+            torch.cuda.synchronize()
+            mine["c_abi_gather_matches_torch"] = bool(torch.equal(torch.nan_to_num(out2, nan=-1.0), torch.nan_to_num(outb, nan=-1.0)))
+            lib.anofox_hip_comm_destroy(comm)
+        except Exception as exc:      # the audit must not cost the run its number
+            mine["c_abi_comm_error"] = str(exc)[:200]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    if rank != 0:
+        return None
+    return {"backend": dist.get_backend(), "world_size": world, "per_rank": everyone,
+            "n_ranks_seen": everyone[0].get("n_ranks_seen"),
+            "kernel_ms_per_step_max": max(r["kernel_ms_per_step"] for r in everyone),
+            "kernel_ms_per_step_min": min(r["kernel_ms_per_step"] for r in everyone),
+            "gather_ms": gather_ms}
+
+
 def launch_ranks(n: int) -> int:
     """Start `n` ranks of this script (one process per GPU) through torch.distributed.run on 127.0.0.1 and wait."""
     import socket
@@ -309,6 +369,11 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item() > 0.5)
 
+    # ---- N > 1: what the SCALE record can be audited with (outside the timed region; the N = 1 path takes none of it) ----
+    multi = None
+    if world > 1:
+        multi = multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, args.steps, rehearsal, dev)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         fits_per_s = G * args.steps / elapsed
@@ -393,6 +458,8 @@ def main():
                          "solve_overlap_ms_per_step": overlap_ms,
                          "solve_overlaps_next_accumulate": bool(solve_step_ms > 0 and overlap_ms > 0.5 * solve_step_ms)},
         }
+        if multi is not None:
+            out["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(offs, y, x_cols, w, args.model, kw, n, p)
         print(json.dumps(out), flush=True)

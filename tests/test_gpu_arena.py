@@ -197,3 +197,111 @@ def test_arena_keeps_rows_for_the_groups_moments_cannot_resolve(retain, monkeypa
         # sigma of the nearly exact keys cannot be had from the moments: those keys come back as SQL NULL, not as numbers
         assert np.all(nn[exact] == 1) and np.all(nn[easy] == 0)
     lib.arena_destroy(arena)
+
+
+# ---- hash-partitioned ingest: W device states, rows routed by hash64(key) % W (duckdb_shim/sharded_arena.hpp) ----
+
+def _sharded_lib():
+    pkg, lib = _lib()
+    abi = import_pkg("_abi")
+    lib.sharded_create.restype = C.c_void_p
+    lib.sharded_create.argtypes = [abi.AnofoxHipBatchOptions, C.c_uint32, C.c_void_p, C.c_size_t]
+    lib.sharded_destroy.argtypes = [C.c_void_p]
+    lib.sharded_update.restype = C.c_int
+    lib.sharded_update.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_char_p]
+    lib.sharded_finalize.restype = C.c_int
+    lib.sharded_finalize.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
+    lib.sharded_key_count.restype = C.c_size_t
+    lib.sharded_key_count.argtypes = [C.c_void_p]
+    lib.sharded_rows_of_shard.restype = C.c_uint64
+    lib.sharded_rows_of_shard.argtypes = [C.c_void_p, C.c_uint32]
+    lib.sharded_keys_of_shard.restype = C.c_size_t
+    lib.sharded_keys_of_shard.argtypes = [C.c_void_p, C.c_uint32]
+    lib.sharded_shard_of.restype = C.c_uint32
+    lib.sharded_shard_of.argtypes = [C.c_uint64, C.c_uint32]
+    return pkg, lib
+
+
+def _run_sharded(pkg, lib, W, model, kw, keys, y, X, w, accept, n_threads=4):
+    p = X.shape[1]
+    h = lib.sharded_create(pkg.RegressionOptions(**kw).batch_options(model), W, None, 1 << 18)
+    assert h
+    errs = []
+
+    def feed(t):          # thread t owns the rows of every n_threads-th Update vector (keys shared between threads)
+        msg = C.create_string_buffer(256)
+        for v, c0 in enumerate(range(0, len(keys), 2048)):
+            if v % n_threads != t:
+                continue
+            sl = slice(c0, c0 + 2048)
+            k, yy, xx, ww, aa = (np.ascontiguousarray(a[sl]) for a in (keys, y, X, w, accept))
+            if lib.sharded_update(h, len(k), k.ctypes.data, yy.ctypes.data, xx.ctypes.data, p, ww.ctypes.data, aa.ctypes.data, msg) != 0:
+                errs.append(msg.value)
+    if n_threads == 1:
+        feed(0)
+    else:
+        th = [threading.Thread(target=feed, args=(t,)) for t in range(n_threads)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    assert not errs, errs
+    K = lib.sharded_key_count(h)
+    okeys = np.empty(K, dtype=np.uint64)
+    core = np.empty((K, p + 6))
+    inf = np.empty((K, 5 * p + 2))
+    status = np.empty(K, dtype=np.int32)
+    msg = C.create_string_buffer(256)
+    assert lib.sharded_finalize(h, K, okeys.ctypes.data, core.ctypes.data, inf.ctypes.data, status.ctypes.data, msg) == 0, msg.value
+    rows = [lib.sharded_rows_of_shard(h, s) for s in range(W)]
+    nkeys = [lib.sharded_keys_of_shard(h, s) for s in range(W)]
+    lib.sharded_destroy(h)
+    order = np.argsort(okeys, kind="stable")
+    return okeys[order], core[order], inf[order], status[order], rows, nkeys
+
+
+@pytest.mark.parametrize("model,p", [("ols", 8), ("wls", 5), ("ols", 12)])
+def test_hash_partitioned_ingest_matches_oracle_and_one_shard(model, p):
+    """W = 2 and 4 device states on this box's one GPU (a node has one per GPU): every key's rows meet in one shard, the
+    shards' fits are the oracle's, and — the rows of a key arriving in the same order whatever W is — bit-identical to W = 1
+    for moment states (p <= 8), identical to rounding for log-only ones."""
+    pkg, lib = _sharded_lib()
+    dmod = import_pkg("distributed")
+    rng = np.random.default_rng(900 + p)
+    K, n = 5000, 150_000
+    key_values = rng.integers(1, 1 << 63, K, dtype=np.uint64)
+    kidx = rng.integers(0, K, n)
+    keys = key_values[kidx]
+    X = rng.uniform(-5, 5, (n, p)) + 1.0
+    y = np.einsum("ij,ij->i", rng.uniform(-3, 3, (K, p))[kidx], X) + 2.0 + rng.standard_normal(n)
+    w = rng.uniform(0.5, 1.5, n)
+    accept = (rng.random(n) > 0.05).astype(np.uint8)
+    kw = dict(compute_inference=True)
+    # single-threaded feeding: arrival order of a key's rows is then the same for every W (bit-for-bit comparison)
+    base = _run_sharded(pkg, lib, 1, model, kw, keys, y, X, w, accept, n_threads=1)
+    keep = accept.astype(bool)
+    ukeys, inv = np.unique(keys, return_inverse=True)
+    order = np.nonzero(keep)[0][np.argsort(inv[keep], kind="stable")]
+    offs = np.concatenate([[0], np.cumsum(np.bincount(inv[keep], minlength=len(ukeys)))]).astype(np.int64)
+    rcore, rinf = oracle.fit_groups(y[order], [np.ascontiguousarray(X[order, j]) for j in range(p)], offs,
+                                    w=(w[order] if model == "wls" else None), model=model, **kw)
+    assert np.array_equal(base[0], ukeys) and np.array_equal(base[3], rcore[:, p + 5].astype(np.int32))
+    fitted = rcore[:, p + 5] == 0
+    assert_records_match(base[1][fitted], rcore[fitted], p, base[2][fitted], rinf[fitted], what=f"sharded W=1 {model} p={p}")
+    for W in (2, 4):
+        got = _run_sharded(pkg, lib, W, model, kw, keys, y, X, w, accept, n_threads=1)
+        assert np.array_equal(got[0], ukeys) and np.array_equal(got[3], base[3])
+        if p <= 8:      # moment states sum a key's rows in arrival order whatever the shard holds besides: bit for bit
+            assert np.array_equal(got[1][fitted], base[1][fitted]) and np.array_equal(got[2][fitted], base[2][fitted])
+        else:           # log-only states run the batch kernels, whose summation order follows the group's row offset in
+            # the gathered batch (16-byte load alignment): the same fit to rounding
+            assert_records_match(got[1][fitted], base[1][fitted], p, got[2][fitted], base[2][fitted],
+                                 what=f"sharded W={W} vs W=1 {model} p={p}", coef_rtol=1e-12, diag_rtol=1e-10)
+        # the routing is the documented hash: shard sizes are what hash64(key) % W says, and balanced
+        owner = dmod.hash_partition(keys, W)
+        assert got[4] == [int(np.sum(keep & (owner == s))) for s in range(W)]
+        assert got[5] == [int(len(np.unique(keys[owner == s]))) for s in range(W)]
+        assert all(lib.sharded_shard_of(int(k), W) == int(o) for k, o in zip(keys[:200], owner[:200]))
+        assert max(got[5]) < 1.15 * K / W
+    # several feeding threads per shard: same groups, rounding-level differences at most (arrival order across threads varies)
+    mt = _run_sharded(pkg, lib, 4, model, kw, keys, y, X, w, accept, n_threads=4)
+    assert np.array_equal(mt[0], ukeys) and np.array_equal(mt[3], base[3])
+    assert_records_match(mt[1][fitted], rcore[fitted], p, mt[2][fitted], rinf[fitted], what=f"sharded W=4 threads {model} p={p}")
