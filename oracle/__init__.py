@@ -28,6 +28,7 @@ class OracleOptions(C.Structure):
         ("alpha", C.c_double),
         ("hc_type", C.c_int32),
         ("plain_qr", C.c_int32),
+        ("plain_svd", C.c_int32),
     ]
 
 
@@ -114,12 +115,15 @@ def lib():
 
 
 def _opts(model="ols", fit_intercept=True, compute_inference=False, confidence_level=0.95, alpha=1.0,
-          lambda_scaling="raw", hc_type="none", plain_qr=False) -> OracleOptions:
-    """plain_qr=True stops after the QR solve (the reference's algorithm class as it is — the CPU baseline that
-    bench.py times); the default adds the extended-precision refinement that makes the oracle the checker."""
+          lambda_scaling="raw", hc_type="none", plain_qr=False, plain_svd=False) -> OracleOptions:
+    """plain_qr=True stops after the QR solve, plain_svd=True solves through an SVD (QR, then one-sided Jacobi on the
+    triangular factor) — the reference's algorithm classes as they are: `solver` qr and svd, the latter the aggregates'
+    default (ols_aggregate.cpp:51); bench.py times both as CPU baselines.  The default adds the extended-precision
+    refinement that makes the oracle the checker."""
     return OracleOptions(MODEL[model], int(bool(fit_intercept)), int(bool(compute_inference)),
                          {"raw": 0, "glmnet": 1}[lambda_scaling], float(confidence_level), float(alpha),
-                         {"none": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}[hc_type], int(bool(plain_qr)))
+                         {"none": 0, "hc0": 1, "hc1": 2, "hc2": 3, "hc3": 4}[hc_type], int(bool(plain_qr)),
+                         int(bool(plain_svd)))
 
 
 def _col_ptrs(cols):

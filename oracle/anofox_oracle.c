@@ -71,6 +71,11 @@ typedef struct {
 	double alpha; /* ridge penalty */
 	int32_t hc_type; /* AnofoxHcType: 0 none, 1..4 = HC0..HC3 (anofox_stats_ffi.h:119-125); OLS and WLS only */
 	int32_t plain_qr; /* 1 = stop after the QR solve (the reference's algorithm class as it is: what bench.py times as the CPU baseline); 0 = refine (the checker) */
+	int32_t plain_svd; /* 1 = solve through a singular value decomposition, no refinement: the reference AGGREGATES' default
+	                      solver (ols_aggregate.cpp:51, ridge_aggregate.cpp:53, wls_aggregate.cpp:53 bind `solver = SVD`) —
+	                      the second CPU baseline of bench.py.  QR of the design first, then a one-sided Jacobi SVD of the
+	                      triangular factor (the tall-matrix route of LAPACK's dgejsv; faer's thin SVD also reduces a tall
+	                      matrix by QR first), beta = V S^-1 U' (Q'b). */
 } OracleOptions;
 
 typedef struct {
@@ -407,6 +412,59 @@ ORACLE_EXPORT int oracle_fit(const double *y, const double *const *x, const doub
 		for (int l = k + 1; l < rank; l++) s -= A[(size_t)piv[l] * m + k] * beta[piv[l]];
 		beta[piv[k]] = s / A[(size_t)piv[k] * m + k];
 	}
+	if (opt->plain_svd && rank > 0) {
+		/* R (rank x rank, upper triangular, on the accepted pivots) = U S V'.  One-sided Jacobi (Hestenes): rotate pairs
+		 * of columns of G = R until they are mutually orthogonal; then S_j = |g_j|, U = G S^-1, and V accumulates the
+		 * rotations.  beta = V S^-1 U' c with c = (Q'b)[0 .. rank). */
+		const size_t k = (size_t)rank;
+		double *G = (double *)calloc(k * k, sizeof(double));
+		double *V = (double *)calloc(k * k, sizeof(double));
+		if (!G || !V) { free(G); free(V); rc = ORC_ALLOC; goto done; }
+		for (size_t c = 0; c < k; c++) {
+			for (size_t r = 0; r <= c; r++) G[c * k + r] = A[(size_t)piv[c] * m + r];
+			V[c * k + c] = 1.0;
+		}
+		for (int sweep = 0; sweep < 60; sweep++) {
+			int rotated = 0;
+			for (size_t i = 0; i + 1 < k; i++)
+				for (size_t j = i + 1; j < k; j++) {
+					double a = 0.0, bb = 0.0, g = 0.0;
+					const double *gi = G + i * k, *gj = G + j * k;
+					for (size_t r = 0; r < k; r++) { a += gi[r] * gi[r]; bb += gj[r] * gj[r]; g += gi[r] * gj[r]; }
+					if (!(fabs(g) > 1e-15 * sqrt(a * bb))) continue;
+					rotated = 1;
+					const double zeta = (bb - a) / (2.0 * g);
+					const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+					const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+					for (size_t r = 0; r < k; r++) {
+						const double x0 = G[i * k + r], x1 = G[j * k + r];
+						G[i * k + r] = cs * x0 - sn * x1;
+						G[j * k + r] = sn * x0 + cs * x1;
+						const double v0 = V[i * k + r], v1 = V[j * k + r];
+						V[i * k + r] = cs * v0 - sn * v1;
+						V[j * k + r] = sn * v0 + cs * v1;
+					}
+				}
+			if (!rotated) break;
+		}
+		double smax = 0.0;
+		for (size_t c = 0; c < k; c++) {
+			double s2 = 0.0;
+			for (size_t r = 0; r < k; r++) s2 += G[c * k + r] * G[c * k + r];
+			if (s2 > smax) smax = s2;
+		}
+		smax = sqrt(smax);
+		for (size_t l = 0; l < k; l++) beta[piv[l]] = 0.0;
+		for (size_t c = 0; c < k; c++) {
+			double s2 = 0.0, uc = 0.0;
+			for (size_t r = 0; r < k; r++) { s2 += G[c * k + r] * G[c * k + r]; uc += G[c * k + r] * b[r]; }
+			const double sv = sqrt(s2);
+			if (!(sv > 1e-14 * smax)) continue; /* (the aliased columns were already taken out by the pivoted QR) */
+			const double coef = uc / s2;        /* (u_c' c) / s_c with u_c = g_c / s_c */
+			for (size_t l = 0; l < k; l++) beta[piv[l]] += V[c * k + l] * coef;
+		}
+		free(G); free(V);
+	}
 	/* Two steps of iterative refinement with the residual in extended precision (corrected semi-normal equations:
 	 * R'R delta = A'(b - A beta)).  A plain QR solve of a least-squares problem with a sizeable residual carries a
 	 * forward error ~ eps cond(A)^2 tan(theta) — 1e-8 for the uncentred, weakly penalised ridge problems of the
@@ -416,7 +474,7 @@ ORACLE_EXPORT int oracle_fit(const double *y, const double *const *x, const doub
 		long double *res_l = (long double *)malloc(m * sizeof(long double));
 		double *gvec = (double *)malloc((qd ? qd : 1) * sizeof(double));
 		if (res_l && gvec) {
-			for (int it = 0; it < 2 && rank > 0 && !opt->plain_qr; it++) {
+			for (int it = 0; it < 2 && rank > 0 && !opt->plain_qr && !opt->plain_svd; it++) {
 				for (size_t i = 0; i < m; i++) {
 					long double acc = (long double)b0v[i];
 					for (int l = 0; l < rank; l++) acc -= (long double)A0[(size_t)piv[l] * m + i] * (long double)beta[piv[l]];
