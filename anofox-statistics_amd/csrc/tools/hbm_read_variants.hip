@@ -151,6 +151,59 @@ __global__ __launch_bounds__(256) void read_nine_like(Cols cols, const long long
 	if (s == 123.456) out[0] = s;
 }
 
+// Several consecutive groups per wavefront (wave w of a workgroup: groups base + w NG .. base + w NG + NG - 1, i.e. NG x 8 KB
+// contiguous per column), records either written per group (WRITE 1) or staged in LDS and flushed by the workgroup as one
+// contiguous 4 NG x 77-double block at its end (WRITE 5): fewer, larger writes between the read streams.
+template <bool NT, int NG, int WRITE>
+__global__ __launch_bounds__(256) void read_nine_multi(Cols cols, const long long *offs, size_t n_groups, double *recs, double *out) {
+	extern __shared__ double stage[]; // [4 NG][77] when WRITE == 5 (the launch passes at least 70 KB to fix the occupancy)
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const size_t base = (size_t)blockIdx.x * 4 * NG;
+	double s = 0.0;
+	for (int i = 0; i < NG; ++i) {
+		const size_t g = base + (size_t)wave * NG + i;
+		if (g >= n_groups) break;
+		const size_t lo = (size_t)offs[g] >> 1, hi = (size_t)offs[g + 1] >> 1;
+		dbl2 nx[9];
+#pragma unroll
+		for (int j = 0; j < 9; ++j) nx[j] = NT ? __builtin_nontemporal_load(cols.c[j] + lo + lane) : cols.c[j][lo + lane];
+		double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+		for (size_t t = lo; t < hi; t += 64) {
+			dbl2 v[9];
+#pragma unroll
+			for (int j = 0; j < 9; ++j) v[j] = nx[j];
+			if (t + 64 < hi) {
+#pragma unroll
+				for (int j = 0; j < 9; ++j) nx[j] = NT ? __builtin_nontemporal_load(cols.c[j] + t + 64 + lane) : cols.c[j][t + 64 + lane];
+			}
+#pragma unroll
+			for (int j = 0; j < 9; ++j) {
+#pragma unroll
+				for (int c = 0; c < 6; ++c) acc[(j + c) % 9] = fma(v[j].x, v[j].y, acc[(j + c) % 9]);
+			}
+		}
+		double r = 0.0;
+#pragma unroll
+		for (int j = 0; j < 9; ++j) r += acc[j];
+		s += r;
+		if (WRITE == 1) {
+			recs[g * 77 + lane] = r;
+			if (lane < 13) recs[g * 77 + 64 + lane] = r;
+		} else if (WRITE == 5) {
+			double *d = stage + (size_t)(wave * NG + i) * 77;
+			d[lane] = r;
+			if (lane < 13) d[64 + lane] = r;
+		}
+	}
+	if (WRITE == 5) {
+		__syncthreads();
+		const size_t n_rec = (base + 4 * NG <= n_groups) ? 4 * NG : (n_groups > base ? n_groups - base : 0);
+		double *dst = recs + base * 77;
+		for (size_t k = threadIdx.x; k < n_rec * 77; k += 256) __builtin_nontemporal_store(stage[k], dst + k);
+	}
+	if (s == 123.456) out[0] = s;
+}
+
 int main(int argc, char **argv) {
 	const size_t gib = argc > 1 ? (size_t)atoll(argv[1]) : 36;
 	const size_t bytes = gib << 30;
@@ -241,6 +294,24 @@ int main(int argc, char **argv) {
 		LIKE(true, 4, 6, 70 * 1024, "group-shaped, NT + aligned NT writes + 108 FMA per row pair");
 		LIKE(false, 1, 6, 70 * 1024, "group-shaped, plain + 77-double writes + 108 FMA");
 		LIKE(false, 4, 6, 70 * 1024, "group-shaped, plain loads + aligned NT writes + 108 FMA");
+#define MULTI(NTv, NGv, Wv, text)                                                                                        \
+	do {                                                                                                                 \
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&read_nine_multi<NTv, NGv, Wv>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024); \
+		const unsigned wg = (unsigned)((n_groups + 4 * NGv - 1) / (4 * NGv));                                            \
+		time(text, [&] { hipLaunchKernelGGL((read_nine_multi<NTv, NGv, Wv>), dim3(wg), dim3(256), 70 * 1024, 0, cols, offs, n_groups, recs, out); }); \
+	} while (0)
+		MULTI(false, 1, 1, "multi: 1 group/wave, plain, write per group + FMA");
+		MULTI(false, 1, 5, "multi: 1 group/wave, plain, staged flush + FMA");
+		MULTI(false, 4, 1, "multi: 4 groups/wave, plain, write per group + FMA");
+		MULTI(false, 4, 5, "multi: 4 groups/wave, plain, staged flush + FMA");
+		MULTI(false, 8, 5, "multi: 8 groups/wave, plain, staged flush + FMA");
+		MULTI(false, 16, 5, "multi: 16 groups/wave, plain, staged flush + FMA");
+		MULTI(false, 8, 0, "multi: 8 groups/wave, plain, no record + FMA");
+		MULTI(true, 1, 1, "multi: 1 group/wave, NT, write per group + FMA");
+		MULTI(true, 4, 5, "multi: 4 groups/wave, NT, staged flush + FMA");
+		MULTI(true, 8, 5, "multi: 8 groups/wave, NT, staged flush + FMA");
+		MULTI(true, 16, 5, "multi: 16 groups/wave, NT, staged flush + FMA");
+		MULTI(true, 8, 0, "multi: 8 groups/wave, NT, no record + FMA");
 	}
 	for (int blocks : {8192, 65536}) {
 		char label[96];
