@@ -137,7 +137,16 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		}
 		// moderately wide designs: one lane per group (solve_mid.hip); beyond that one workgroup per group
 		auto solve = [&](int mode) { return mid ? launch_solve_mid(a, mode, st) : launch_solve_wide(a, mode, st); };
-		if (hip_fail(solve(0), "wide solve kernel launch", e)) return false;
+		// the primary solve of every width runs with one wavefront per group and the matrix in registers (solve_tiles.hip);
+		// the lane-per-group / workgroup-per-group kernels keep the refinement modes.  ANOFOX_SOLVE_TILES=0: without it.
+		static const bool tiles_on = !(getenv("ANOFOX_SOLVE_TILES") && atoi(getenv("ANOFOX_SOLVE_TILES")) == 0);
+		// (p <= 10: a 16 x 16 tile is mostly padding and the lane-per-group solve is as fast — 200 000 x 1000 x 9: 0.58 vs 0.70 ms;
+		// from there on the tiles win: p = 16 1.74 -> 0.69 ms, 100 000 x 1000 x 32 4.24 -> 0.76 ms, x 24 with inference 3.40 -> 1.77 ms)
+		const bool tiles_mid = mid && tiles_on && p >= 11 && solve_tiles_supports((int)p);
+		if (hip_fail(tiles_mid ? launch_solve_tiles(a, st) : solve(0), "wide solve kernel launch", e)) return false;
+		// (solve_mid writes complete inference records itself; after the tiles kernel t, p and the interval come from the
+		// finish kernel — before the refinement modes, whose final pass rewrites the queued groups' records in full)
+		if (tiles_mid && hip_fail(launch_inference_wide_finish(a, st), "wide inference finish kernel launch", e)) return false;
 		for (int it = 0; it < kRefineSteps; ++it) { // queued groups only: b += (X'WX)^-1 X'Wr
 			if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
 			if (hip_fail(solve(1), "wide refine kernel launch", e)) return false;

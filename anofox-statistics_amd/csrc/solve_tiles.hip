@@ -5,14 +5,16 @@ namespace anofox {
 
 bool solve_tiles_supports(int p) {
 	const int T = wide_tiles(p);
-	return T >= 3 && T <= 8;
+	return T >= 1 && T <= 8;
 }
 
 // the second template argument is the occupancy (waves per SIMD) the register budget is cut for: 36 tiles are 288
-// vector registers per lane at T = 8, so one wave per SIMD there; the narrow ones fit two
+// vector registers per lane at T = 8, so one wave per SIMD there; the narrow ones fit two to four
 hipError_t launch_solve_tiles(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
 	switch (wide_tiles(a.p)) {
+	case 1: return launch_solve_tiles_T<1, 4>(a, stream);
+	case 2: return launch_solve_tiles_T<2, 3>(a, stream);
 	case 3: return launch_solve_tiles_T<3, 2>(a, stream);
 	case 4: return launch_solve_tiles_T<4, 2>(a, stream);
 	case 5: return launch_solve_tiles_T<5, 1>(a, stream);
