@@ -147,7 +147,11 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		// (solve_mid writes complete inference records itself; after the tiles kernel t, p and the interval come from the
 		// finish kernel — before the refinement modes, whose final pass rewrites the queued groups' records in full)
 		if (tiles_mid && hip_fail(launch_inference_wide_finish(a, st), "wide inference finish kernel launch", e)) return false;
-		for (int it = 0; it < kRefineSteps; ++it) { // queued groups only: b += (X'WX)^-1 X'Wr
+		// four updates on the wide path: with the residual in double-double every update gains about two digits even at
+		// cond(X) = 2e7 (an exactly determined 67 x 67 system of the deep fuzz sweep: 5.4e-7 after two, 4.3e-9 after three,
+		// 2.3e-11 after four); the launches are idle unless groups are queued.  ANOFOX_WIDE_REFINE_STEPS overrides (measurements).
+		static const int wide_steps = getenv("ANOFOX_WIDE_REFINE_STEPS") ? atoi(getenv("ANOFOX_WIDE_REFINE_STEPS")) : 2 * kRefineSteps;
+		for (int it = 0; it < wide_steps; ++it) { // queued groups only: b += (X'WX)^-1 X'Wr
 			if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
 			if (hip_fail(solve(1), "wide refine kernel launch", e)) return false;
 		}

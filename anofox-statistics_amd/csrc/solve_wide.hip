@@ -582,9 +582,10 @@ __global__ __launch_bounds__(NTHR, OCC) void solve_wide_kernel(WideArgs args) {
 		if (MODE == MODE_FINAL) rss = rvec[0];
 		else if (model == ANOFOX_HIP_MODEL_RIDGE) rss = tss - bc_t - lam * bb_t;
 		else rss = tss - zz_t; // Syy - |L^-1 Sxy|^2
-		const bool refine = (MODE == MODE_PRIMARY) && (!(rss > kRefineTolW * tss) || min_ratio < kPivotWarnW);
 		const int n_par = rank + (icpt ? 1 : 0);
 		const double df = cnt - (double)n_par;
+		// (nearly square designs as well: see solve_tiles_impl.h)
+		const bool refine = (MODE == MODE_PRIMARY) && (!(rss > kRefineTolW * tss) || min_ratio < kPivotWarnW || df < 0.25 * (double)rank);
 		const double dfm = (double)rank;
 		const double r2 = 1.0 - rss / tss;
 		const double fstat = ((tss - rss) / dfm) / (rss / df);

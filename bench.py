@@ -411,6 +411,8 @@ def main():
         # streams alternate): spans add up to more than the step exactly by the overlapped part
         solve_step_ms = kt["solve_ms"] / args.steps
         overlap_ms = max(0.0, acc_step_ms + solve_step_ms - ms_per_step)
+        # the part of a step that no accumulate kernel covers: solve / refinement / launch gaps that are NOT hidden
+        exposed_ms = max(0.0, ms_per_step - acc_step_ms)
         traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (profiles/hbm_traffic.json), if recorded
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath) and not args.vif:
@@ -466,7 +468,9 @@ def main():
                          "frac_of_measured_ceiling": kernel_achieved / (MEASURED_STREAM_READ_GBS if bound == "hbm" else MEASURED_MFMA_F64_TFLOPS),
                          "solve_span_ms_per_step": solve_step_ms,
                          "solve_overlap_ms_per_step": overlap_ms,
-                         "solve_overlaps_next_accumulate": bool(solve_step_ms > 0 and overlap_ms > 0.5 * solve_step_ms)},
+                         "exposed_non_accumulate_ms_per_step": exposed_ms,
+                         # true only when (nearly) nothing of the solve is left outside the accumulate kernels' time
+                         "solve_overlaps_next_accumulate": bool(exposed_ms <= 0.02 * ms_per_step)},
         }
         if multi is not None:
             out["multi_gpu"] = multi
