@@ -115,18 +115,17 @@ __device__ __forceinline__ constexpr int slot(int i, int j) { // i <= j
 
 constexpr int kDsLd = 18; // row stride of the diagonal-block image (doubles): 16-byte aligned rows
 constexpr int kXsLd = 17;
-constexpr int kLdsDoubles = 17 * kDsLd + 16 * kXsLd + 16 + 2 * kWideMaxP;
 
 template <int T, int WPE>
 __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 	constexpr int P16 = 16 * T;
 	constexpr int NT = T * (T + 1) / 2;
-	__shared__ __attribute__((aligned(16))) double lds[kLdsDoubles];
+	__shared__ __attribute__((aligned(16))) double lds[17 * kDsLd + 16 * kXsLd + 16 + 2 * P16];
 	double *Ds = lds;                 // [17][18]: the diagonal block (rows 0..15) and the y column (row 16)
 	double *Xs = Ds + 17 * kDsLd;     // [16][17]: X = L_kk^-1
 	double *zs = Xs + 16 * kXsLd;     // [16]: z_k
 	double *d0s = zs + 16;            // [P16]: the diagonal before the factorisation
-	double *acts = d0s + kWideMaxP;   // [P16]: 1.0 = column takes part
+	double *acts = d0s + P16;         // [P16]: 1.0 = column takes part
 
 	const int p = args.p;
 	const int lane = threadIdx.x;
@@ -134,7 +133,11 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 	const bool icpt = args.fit_intercept != 0;
 	const int model = args.model;
 
-	for (int64_t gl = blockIdx.x; gl < args.n_groups; gl += gridDim.x) {
+	// one group per workgroup (the launcher's grid is the group count): as a grid-stride loop the compiler hoisted every
+	// group-invariant mask and address out of it and kept them in (spilled) registers
+	const int64_t gl = blockIdx.x;
+	if (gl >= args.n_groups) return;
+	{
 		const int64_t g = args.group_base + gl;
 		const double *rec = args.moments + gl * (int64_t)wide_record_len(T);
 		const double *vec = rec + (int64_t)NT * 256;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		else if (!(cnt > 0.0)) status = ANOFOX_ERROR_NO_VALID_DATA;                                         // ols.rs:68-70
 		if (status != ANOFOX_ERROR_SUCCESS) {
 			write_null(status, true);
-			continue;
+			return;
 		}
 
 		// per column block J: this lane's column 16 J + n
@@ -188,11 +191,11 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 					core[k] = v;
 				}
 			}
-			continue;
+			return;
 		}
 		if (cnt < (double)(peff + (icpt ? 1 : 0))) { // ols.rs:132-139
 			write_null(ANOFOX_ERROR_INSUFFICIENT_DATA, true);
-			continue;
+			return;
 		}
 
 		double lam = 0.0;
@@ -207,14 +210,22 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		// (every index into tile[] is a constant expression — sfor, not a loop — so that the array is split into
 		// registers before any unrolling; as an unrolled loop nest the 36 tiles of T = 8 stayed in scratch memory)
 		d4 tile[NT];
-		sfor<0, NT>([&](auto t_) __attribute__((always_inline)) {
-			constexpr int t = decltype(t_)::value;
-#pragma unroll
-			for (int r = 0; r < 4; ++r) tile[t][r] = rec[(int64_t)t * 256 + 64 * r + lane];
-		});
 		wave_lds_sync(); // the previous group's reads of d0s / acts are done
+		// (loaded and centred one tile row at a time, the next row's loads issued before this row's arithmetic: all 144
+		// loads of T = 8 at once need more than the 256 architectural registers a load can target and spilled)
+		auto load_row = [&](auto I_) __attribute__((always_inline)) {
+			constexpr int I = decltype(I_)::value;
+			sfor<I, T>([&](auto J_) __attribute__((always_inline)) {
+				constexpr int t = slot<T>(I, decltype(J_)::value);
+#pragma unroll
+				for (int r = 0; r < 4; ++r) tile[t][r] = rec[(int64_t)t * 256 + 64 * r + lane];
+			});
+		};
+		load_row(std::integral_constant<int, 0>{});
 		sfor<0, T>([&](auto I_) __attribute__((always_inline)) {
 			constexpr int I = decltype(I_)::value;
+			if constexpr (I + 1 < T) load_row(std::integral_constant<int, I + 1>{});
+			__builtin_amdgcn_sched_barrier(0);
 			double srow[4];
 #pragma unroll
 			for (int r = 0; r < 4; ++r) {
@@ -270,6 +281,13 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 
 		sfor<0, T>([&](auto k_) __attribute__((always_inline)) {
 			constexpr int k = decltype(k_)::value;
+			// (the lane's coordinates are re-derived from an opaque copy in every step: otherwise the compiler hoists the
+			// step-invariant masks, identity columns and LDS addresses of all T steps out of the loops and keeps ~200
+			// registers of them alive — spilled to scratch memory at T = 8)
+			int lane_k = lane;
+			asm volatile("" : "+v"(lane_k));
+			const int q = lane_k >> 4, n = lane_k & 15, lane = lane_k;
+			(void)lane;
 			// ---- (1) diagonal block and y column -> row layout ----
 			{
 				const d4 &dk = tile[slot<T>(k, k)];
@@ -453,8 +471,8 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 
 template <int T, int WPE>
 hipError_t launch_solve_tiles_T(const WideArgs &a, hipStream_t stream) {
-	const unsigned grid = (unsigned)(a.n_groups < 65535 * 16 ? a.n_groups : 65535 * 16);
-	hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, WPE>), dim3(grid), dim3(64), 0, stream, a);
+	if (a.n_groups > (int64_t)0x7fffffff) return hipErrorInvalidValue; // (a slab of run_wide_batch holds at most 2^30 / 2.6 KB groups)
+	hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, WPE>), dim3((unsigned)a.n_groups), dim3(64), 0, stream, a);
 	return hipGetLastError();
 }
 

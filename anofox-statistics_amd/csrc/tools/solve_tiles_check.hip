@@ -121,6 +121,8 @@ int main(int argc, char **argv) {
 	const int G = argc > 2 ? atoi(argv[2]) : 8;
 	const double corr = argc > 3 ? atof(argv[3]) : 0.0;
 	switch (T) {
+	case 1: return run<1>(G, corr);
+	case 2: return run<2>(G, corr);
 	case 3: return run<3>(G, corr);
 	case 4: return run<4>(G, corr);
 	case 5: return run<5>(G, corr);
