@@ -11,8 +11,9 @@
 //               it, w}); only a full chunk is handed — under the shipping lock — to anofox_hip_agg_state_update_host,
 //               after which the rows live on as O(p^2) moments (or as logged rows) on the GPU and the buffer is reused.
 //               (Round 2 held ONE mutex for the whole Update and copied to the GPU inside it: every worker thread of
-//               the query serialised on it.)  The first accepted row fixes the feature count; a different LIST length
-//               throws the reference's message (ols_aggregate.cpp:165-175).
+//               the query serialised on it.)  The arena's first accepted row fixes its feature count; a different LIST
+//               length throws (the glue keeps one arena per feature count and applies the reference's per-state rule,
+//               ols_aggregate.cpp:165-175, before rows get here).
 //   Combine()   pairs of (source slot, target slot) -> anofox_hip_agg_state_combine_ex (ols_aggregate.cpp:189-234);
 //               a target that occurs several times in a call is served in rounds, in order; preserve = the sources live
 //               on (DuckDB's AggregateCombineType::PRESERVE_INPUT: window segment trees).
@@ -219,9 +220,10 @@ private:
 
 	[[noreturn]] static void Throw(const AnofoxError &e) { throw std::runtime_error(std::string("anofox_stats fit_agg (HIP): ") + e.message); }
 
-	// First accepted row of the query: fixes the feature count (per state in the reference; the aggregate's x argument is
-	// one column, so every state sees the same LIST length or the query fails) and creates the device state.  Context
-	// and state are built into locals and committed only when all of it succeeded.
+	// First accepted row of this arena: fixes ITS feature count and creates the device state.  (The reference fixes the
+	// count per state, ols_aggregate.cpp:164-175; the glue keeps one arena per count that occurs and checks every row
+	// against its own state's count, so this arena only ever sees one width.)  Context and state are built into locals and
+	// committed only when all of it succeeded.
 	size_t Init(size_t n_features) {
 		std::lock_guard<std::mutex> ship(ship_mu_);
 		size_t p = p_.load(std::memory_order_acquire);

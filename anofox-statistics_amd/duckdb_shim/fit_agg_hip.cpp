@@ -25,6 +25,9 @@
 
 #include <algorithm>
 #include <cctype>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include "duckdb.hpp"
 #include "duckdb/common/types/data_chunk.hpp"
@@ -41,10 +44,12 @@ namespace duckdb {
 
 namespace {
 
-// The whole DuckDB-side aggregate state: which slot of the query's GPU state this group (of this thread's hash
-// table) owns.  -1 until the first Update touches it (Initialize has no access to the bind data).
+// The whole DuckDB-side aggregate state: the group's feature count, fixed by its first accepted row exactly as in the
+// reference (ols_aggregate.cpp:164-175: per STATE, so groups of one query may differ in width), and which slot of the
+// query's GPU state of that width the group (of this thread's hash table) owns.
 struct HipAggState {
-	int64_t slot;
+	int64_t slot;       // -1 until the first accepted row (Initialize has no access to the bind data)
+	int64_t n_features; // -1 = no accepted row yet
 };
 
 enum class HipModel : uint8_t { OLS, RIDGE, WLS };
@@ -147,20 +152,39 @@ AnofoxHipBatchOptions MakeHipOptions(HipModel model, const HipFitOptions &o) {
 	return b;
 }
 
-// ---- bind data: the parsed options and the query's arena; Copy() shares the arena ----
+// ---- the query's device states: one AggArena per feature count that occurs (normally one) ----
+struct HipArenaSet {
+	explicit HipArenaSet(const AnofoxHipBatchOptions &o) : options(o) {}
+	anofox_shim::AggArena &ForWidth(size_t p) {
+		std::lock_guard<std::mutex> lk(mu);
+		auto &slot = arenas[p];
+		if (!slot) slot.reset(new anofox_shim::AggArena(options));
+		return *slot;
+	}
+	template <class F>
+	void ForEach(F &&f) {
+		std::lock_guard<std::mutex> lk(mu);
+		for (auto &kv : arenas) f(kv.first, *kv.second);
+	}
+	AnofoxHipBatchOptions options;
+	std::mutex mu;
+	std::map<size_t, std::unique_ptr<anofox_shim::AggArena>> arenas;
+};
+
+// ---- bind data: the parsed options and the query's arenas; Copy() shares them ----
 struct HipAggBindData : public FunctionData {
 	HipAggBindData(HipModel model_p, const HipFitOptions &opts_p)
-	    : model(model_p), opts(opts_p), arena(make_shared_ptr<anofox_shim::AggArena>(MakeHipOptions(model_p, opts_p))) {}
-	HipAggBindData(HipModel model_p, const HipFitOptions &opts_p, shared_ptr<anofox_shim::AggArena> arena_p)
-	    : model(model_p), opts(opts_p), arena(std::move(arena_p)) {}
+	    : model(model_p), opts(opts_p), arenas(make_shared_ptr<HipArenaSet>(MakeHipOptions(model_p, opts_p))) {}
+	HipAggBindData(HipModel model_p, const HipFitOptions &opts_p, shared_ptr<HipArenaSet> arenas_p)
+	    : model(model_p), opts(opts_p), arenas(std::move(arenas_p)) {}
 	HipModel model;
 	HipFitOptions opts;
-	shared_ptr<anofox_shim::AggArena> arena;
+	shared_ptr<HipArenaSet> arenas;
 
-	unique_ptr<FunctionData> Copy() const override { return make_uniq<HipAggBindData>(model, opts, arena); }
+	unique_ptr<FunctionData> Copy() const override { return make_uniq<HipAggBindData>(model, opts, arenas); }
 	bool Equals(const FunctionData &other_p) const override {
 		auto &other = other_p.Cast<HipAggBindData>();
-		return model == other.model && opts == other.opts && arena == other.arena;
+		return model == other.model && opts == other.opts && arenas == other.arenas;
 	}
 };
 
@@ -198,20 +222,23 @@ unique_ptr<FunctionData> HipAggBind(ClientContext &context, AggregateFunction &f
 }
 
 void HipAggInitialize(const AggregateFunction &, data_ptr_t state_p) {
-	reinterpret_cast<HipAggState *>(state_p)->slot = -1;
+	auto &st = *reinterpret_cast<HipAggState *>(state_p);
+	st.slot = -1;
+	st.n_features = -1;
 }
 
-// Destroy: the state's slot goes back to the arena, which empties it on the device before handing it out again
+// Destroy: the state's slot goes back to its arena, which empties it on the device before handing it out again
 // (ols_aggregate.cpp:108-118 runs the row buffers' destructors)
 void HipAggDestroy(Vector &state_vector, AggregateInputData &aggr_input_data, idx_t count) {
 	UnifiedVectorFormat sdata;
 	state_vector.ToUnifiedFormat(count, sdata);
 	auto states = (HipAggState **)sdata.data;
-	auto &arena = *aggr_input_data.bind_data->Cast<HipAggBindData>().arena;
+	auto &arenas = *aggr_input_data.bind_data->Cast<HipAggBindData>().arenas;
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
-		if (state.slot >= 0) arena.ReleaseSlot((uint32_t)state.slot);
+		if (state.slot >= 0) arenas.ForWidth((size_t)state.n_features).ReleaseSlot((uint32_t)state.slot);
 		state.slot = -1;
+		state.n_features = -1;
 	}
 }
 
@@ -221,7 +248,7 @@ template <HipModel MODEL>
 void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, idx_t input_count, Vector &state_vector, idx_t count) {
 	constexpr bool kWeighted = MODEL == HipModel::WLS;
 	if (input_count < (kWeighted ? 3u : 2u)) throw InvalidInputException("anofox_stats fit_agg (HIP): too few arguments");
-	auto &arena = *aggr_input_data.bind_data->Cast<HipAggBindData>().arena;
+	auto &arenas = *aggr_input_data.bind_data->Cast<HipAggBindData>().arenas;
 	UnifiedVectorFormat y_data, x_data, w_data, sdata;
 	inputs[0].ToUnifiedFormat(count, y_data);
 	inputs[1].ToUnifiedFormat(count, x_data);
@@ -236,10 +263,13 @@ void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, idx_t in
 	auto states = (HipAggState **)sdata.data;
 	const idx_t max_features = anofox_hip_max_features();
 
-	anofox_shim::AggArena::Writer writer(arena);
+	// one Writer per feature count seen in this vector (one, unless the query's groups differ in width)
+	size_t cur_p = 0;
+	anofox_shim::AggArena *cur_arena = nullptr;
+	std::map<size_t, std::unique_ptr<anofox_shim::AggArena::Writer>> writers;
+	anofox_shim::AggArena::Writer *writer = nullptr;
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
-		if (state.slot < 0) state.slot = writer.NewSlot(); // the group exists even if every row of it is skipped
 		auto y_idx = y_data.sel->get_index(i);
 		if (!y_data.validity.RowIsValid(y_idx)) continue; // ols_aggregate.cpp:150-153
 		auto x_idx = x_data.sel->get_index(i);
@@ -251,21 +281,30 @@ void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, idx_t in
 			w = w_values[w_idx];
 		}
 		const auto entry = x_list[x_idx];
+		// the first accepted row of a state fixes its feature count; every later one must agree (:164-175)
+		if (state.n_features < 0) state.n_features = (int64_t)entry.length;
+		if ((int64_t)entry.length != state.n_features)
+			throw InvalidInputException("Inconsistent feature count: expected %llu, got %llu", (unsigned long long)state.n_features,
+			                            (unsigned long long)entry.length);
+		if (entry.length == 0) continue; // an empty x list: the reference buffers the row and its fit then fails -> NULL
 		if (entry.length > max_features)
 			throw InvalidInputException("anofox_stats fit_agg (HIP): at most %llu features are supported, got %llu", (unsigned long long)max_features,
 			                            (unsigned long long)entry.length);
-		double *row;
-		try {
-			row = writer.Begin((uint32_t)state.slot, y_values[y_idx], entry.length, w);
-		} catch (const std::invalid_argument &e) {
-			throw InvalidInputException(string(e.what())); // "Inconsistent feature count: expected N, got M" (:172-175)
+		if (!writer || cur_p != entry.length) {
+			cur_p = entry.length;
+			cur_arena = &arenas.ForWidth(cur_p);
+			auto &wslot = writers[cur_p];
+			if (!wslot) wslot.reset(new anofox_shim::AggArena::Writer(*cur_arena));
+			writer = wslot.get();
 		}
+		if (state.slot < 0) state.slot = writer->NewSlot();
+		double *row = writer->Begin((uint32_t)state.slot, y_values[y_idx], entry.length, w);
 		for (idx_t j = 0; j < entry.length; j++) // a NULL list element becomes NaN: the fit's row filter drops the row (ols.rs:59-66)
 			row[j] = x_child_validity.RowIsValid(entry.offset + j) ? x_child_data[entry.offset + j] : NAN;
 	}
 }
 
-// Combine: ols_aggregate.cpp:189-234.  A source without a slot has seen no Update.  A target without one adopts the
+// Combine: ols_aggregate.cpp:189-234.  A source without accepted rows is skipped.  A target without any adopts the
 // source's slot when the source may be consumed (the reference moves the buffers), and otherwise gets a slot of its
 // own that the source is merged into; pairs with slots on both sides are merged on the GPU, in the order given.
 void HipAggCombine(Vector &source_vector, Vector &target_vector, AggregateInputData &aggr_input_data, idx_t count) {
@@ -274,27 +313,34 @@ void HipAggCombine(Vector &source_vector, Vector &target_vector, AggregateInputD
 	target_vector.ToUnifiedFormat(count, target_data);
 	auto sources = (HipAggState **)source_data.data;
 	auto targets = (HipAggState **)target_data.data;
-	auto &arena = *aggr_input_data.bind_data->Cast<HipAggBindData>().arena;
+	auto &arenas = *aggr_input_data.bind_data->Cast<HipAggBindData>().arenas;
 	const bool preserve = aggr_input_data.combine_type == AggregateCombineType::PRESERVE_INPUT;
-	vector<uint32_t> src, dst;
+	std::map<size_t, std::pair<vector<uint32_t>, vector<uint32_t>>> pairs; // per feature count: sources, targets
 	for (idx_t i = 0; i < count; i++) {
 		auto &source = *sources[source_data.sel->get_index(i)];
 		auto &target = *targets[target_data.sel->get_index(i)];
-		if (source.slot < 0 || &source == &target) continue;
-		if (target.slot < 0) {
+		if (source.n_features < 0 || &source == &target) continue; // nothing to combine (:199-201)
+		if (target.n_features < 0) {
+			target.n_features = source.n_features;
+			if (source.slot < 0) continue; // (rows with empty x lists only)
 			if (!preserve) {
 				target.slot = source.slot;
 				source.slot = -1;
+				source.n_features = -1;
 				continue;
 			}
-			target.slot = arena.NewSlot();
+			target.slot = arenas.ForWidth((size_t)source.n_features).NewSlot();
+		} else if (source.n_features != target.n_features) {
+			throw InvalidInputException("Cannot combine states with different feature counts: %llu vs %llu", (unsigned long long)source.n_features,
+			                            (unsigned long long)target.n_features); // :217-220
 		}
-		src.push_back((uint32_t)source.slot);
-		dst.push_back((uint32_t)target.slot);
+		if (source.slot < 0) continue;
+		auto &pr = pairs[(size_t)source.n_features];
+		pr.first.push_back((uint32_t)source.slot);
+		pr.second.push_back((uint32_t)target.slot);
 	}
-	if (src.empty()) return;
 	try {
-		arena.Combine(src.data(), dst.data(), src.size(), preserve);
+		for (auto &kv : pairs) arenas.ForWidth(kv.first).Combine(kv.second.first.data(), kv.second.second.data(), kv.second.first.size(), preserve);
 	} catch (const std::runtime_error &e) {
 		throw InvalidInputException(string(e.what()));
 	}
@@ -311,66 +357,70 @@ void AppendList(Vector &list_vec, idx_t row, const double *src, idx_t n) {
 	ListVector::SetListSize(list_vec, offset + n);
 }
 
-// Finalize: ols_aggregate.cpp:249-338.  One arena call for the vector: it fits what changed since it was last fitted (a
-// GROUP BY: every group of the query, once) and returns this vector's records; they go into the STRUCT vector in the
-// field order of the result type.  NULL where the reference returns NULL: fewer than 2 accumulated rows (:263-267), a
-// fit that failed (:298-301) — and a group the device state could not bring to the contract's accuracy (status 101).
+// Finalize: ols_aggregate.cpp:249-338.  One arena call per feature count of the vector (one, normally): it fits what
+// changed since it was last fitted (a GROUP BY: every group of the query, once) and returns this vector's records; they go
+// into the STRUCT vector in the field order of the result type.  NULL where the reference returns NULL: fewer than 2
+// accumulated rows (:263-267), a fit that failed (:298-301) — and a group the device state could not bring to the
+// contract's accuracy (status 101).
 void HipAggFinalize(Vector &state_vector, AggregateInputData &aggr_input_data, Vector &result, idx_t count, idx_t offset) {
 	auto &bind = aggr_input_data.bind_data->Cast<HipAggBindData>();
-	auto &arena = *bind.arena;
+	auto &arenas = *bind.arenas;
 	UnifiedVectorFormat sdata;
 	state_vector.ToUnifiedFormat(count, sdata);
 	auto states = (HipAggState **)sdata.data;
-	vector<uint32_t> slots;
-	vector<idx_t> rows;
+	struct Batch {
+		vector<uint32_t> slots;
+		vector<idx_t> rows;
+	};
+	std::map<size_t, Batch> batches;
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
 		if (state.slot < 0) {
-			FlatVector::SetNull(result, i + offset, true); // never updated
+			FlatVector::SetNull(result, i + offset, true); // no accepted row (or only rows with empty x lists)
 			continue;
 		}
-		slots.push_back((uint32_t)state.slot);
-		rows.push_back(i + offset);
+		auto &b = batches[(size_t)state.n_features];
+		b.slots.push_back((uint32_t)state.slot);
+		b.rows.push_back(i + offset);
 	}
-	if (slots.empty()) return;
 	const bool inference = bind.opts.compute_inference;
-	vector<int> status(slots.size());
-	vector<double> core, inf;
-	try {
-		// (the feature count is known once any row of the query was accepted; 0 = every state of the query is empty)
-		core.resize(slots.size() * (arena.FeatureCount() + 6));
-		if (inference) inf.resize(slots.size() * (5 * arena.FeatureCount() + 2));
-		arena.Fetch(slots.data(), slots.size(), core.data(), inference ? inf.data() : nullptr, status.data());
-	} catch (const std::runtime_error &e) {
-		throw InvalidInputException(string(e.what()));
-	}
-	const idx_t p = arena.FeatureCount();
 	auto &entries = StructVector::GetEntries(result);
 	idx_t unrefined = 0;
-	for (idx_t k = 0; k < slots.size(); k++) {
-		const idx_t r = rows[k];
-		if (status[k] != 0) {
-			if (status[k] == ANOFOX_HIP_STATUS_UNREFINED) unrefined++;
-			FlatVector::SetNull(result, r, true);
-			continue;
+	for (auto &kv : batches) {
+		const idx_t p = kv.first;
+		auto &b = kv.second;
+		vector<int> status(b.slots.size());
+		vector<double> core(b.slots.size() * (p + 6)), inf(inference ? b.slots.size() * (5 * p + 2) : 0);
+		try {
+			arenas.ForWidth(p).Fetch(b.slots.data(), b.slots.size(), core.data(), inference ? inf.data() : nullptr, status.data());
+		} catch (const std::runtime_error &e) {
+			throw InvalidInputException(string(e.what()));
 		}
-		const double *rec = &core[k * (p + 6)];
-		AppendList(*entries[0], r, rec, p);
-		FlatVector::GetData<double>(*entries[1])[r] = rec[p];
-		FlatVector::GetData<double>(*entries[2])[r] = rec[p + 1];
-		FlatVector::GetData<double>(*entries[3])[r] = rec[p + 2];
-		FlatVector::GetData<double>(*entries[4])[r] = rec[p + 3];
-		FlatVector::GetData<int64_t>(*entries[5])[r] = (int64_t)rec[p + 4];
-		FlatVector::GetData<int64_t>(*entries[6])[r] = (int64_t)p;
-		if (inference) {
-			const double *ir = &inf[k * (5 * p + 2)];
-			for (idx_t f = 0; f < 5; f++) AppendList(*entries[7 + f], r, ir + f * p, p); // se, t, p, ci_lower, ci_upper
-			FlatVector::GetData<double>(*entries[12])[r] = ir[5 * p];
-			FlatVector::GetData<double>(*entries[13])[r] = ir[5 * p + 1];
+		for (idx_t k = 0; k < b.slots.size(); k++) {
+			const idx_t r = b.rows[k];
+			if (status[k] != 0) {
+				if (status[k] == ANOFOX_HIP_STATUS_UNREFINED) unrefined++;
+				FlatVector::SetNull(result, r, true);
+				continue;
+			}
+			const double *rec = &core[k * (p + 6)];
+			AppendList(*entries[0], r, rec, p);
+			FlatVector::GetData<double>(*entries[1])[r] = rec[p];
+			FlatVector::GetData<double>(*entries[2])[r] = rec[p + 1];
+			FlatVector::GetData<double>(*entries[3])[r] = rec[p + 2];
+			FlatVector::GetData<double>(*entries[4])[r] = rec[p + 3];
+			FlatVector::GetData<int64_t>(*entries[5])[r] = (int64_t)rec[p + 4];
+			FlatVector::GetData<int64_t>(*entries[6])[r] = (int64_t)p;
+			if (inference) {
+				const double *ir = &inf[k * (5 * p + 2)];
+				for (idx_t f = 0; f < 5; f++) AppendList(*entries[7 + f], r, ir + f * p, p); // se, t, p, ci_lower, ci_upper
+				FlatVector::GetData<double>(*entries[12])[r] = ir[5 * p];
+				FlatVector::GetData<double>(*entries[13])[r] = ir[5 * p + 1];
+			}
 		}
 	}
 	// Groups the device state could neither resolve nor refit are NULL, never a number outside the contract; a site
-	// that prefers a failing query sets ANOFOX_HIP_UNREFINED=error.  (AggArena::Unrefined() keeps the query's total.)
+	// that prefers a failing query sets ANOFOX_HIP_UNREFINED=error.  (HipAggStatsOf keeps the query's total.)
 	if (unrefined) {
 		const char *mode = getenv("ANOFOX_HIP_UNREFINED");
 		if (mode && string(mode) == "error")
@@ -430,9 +480,25 @@ void RegisterHipAggregate(ExtensionLoader &loader, const char *name, const char 
 
 } // namespace
 
-anofox_shim::AggArena *HipAggArenaOf(FunctionData &bind_data) {
+bool HipAggStatsOf(FunctionData &bind_data, HipAggStats &out) {
 	auto *b = dynamic_cast<HipAggBindData *>(&bind_data);
-	return b ? b->arena.get() : nullptr;
+	if (!b) return false;
+	out = HipAggStats {};
+	out.options = b->arenas->options;
+	b->arenas->ForEach([&](size_t, anofox_shim::AggArena &a) {
+		out.widths++;
+		out.rows_accepted += a.RowsAccepted();
+		out.unrefined += a.Unrefined();
+		out.slot_high_water += a.SlotCount();
+		out.live_slots += a.LiveSlots();
+		out.fit_calls += a.FitCalls();
+		out.slots_fitted += a.SlotsFitted();
+	});
+	return true;
+}
+const void *HipAggSharedStateOf(FunctionData &bind_data) {
+	auto *b = dynamic_cast<HipAggBindData *>(&bind_data);
+	return b ? (const void *)b->arenas.get() : nullptr;
 }
 
 void RegisterHipOlsAggregateFunction(ExtensionLoader &loader) {

@@ -25,6 +25,8 @@ def lib():
     lib.glue_group_by.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_char_p]
+    lib.glue_group_by_ragged.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
     lib.glue_window.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
     lib.glue_tree_window.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
@@ -96,6 +98,51 @@ def test_group_by_through_the_glue_matches_oracle(lib, fn, model, p, spec, kw):
     assert np.all(core[fitted, p + 5] == p)                       # n_features
     assert_records_match(_fix_last_column(core[fitted], p), rcore[fitted], p, None if inf is None else inf[fitted],
                          None if rinf is None else rinf[fitted], what=f"glue GROUP BY {fn} p={p}")
+
+
+def test_groups_of_different_widths_in_one_query(lib):
+    """The reference fixes the feature count per STATE, at the state's first accepted row (ols_aggregate.cpp:164-175): the
+    groups of one query may have x lists of different lengths, each result carries its own n_features and LIST lengths; a
+    row of another length inside a group is the reference's error.  Widths 3 (moment records), 11 (tiles solve over the
+    row log) and 0 (empty lists: NULL) in one GROUP BY, against the oracle run per width."""
+    rng = np.random.default_rng(404)
+    K, n, P = 300, 45_000, 11
+    width_of_key = np.where(np.arange(K) % 3 == 0, 11, 3).astype(np.uint32)
+    width_of_key[K - 1] = 0
+    key = rng.integers(0, K, n).astype(np.uint32)
+    X = rng.uniform(-5, 5, (n, P)) + 1.0
+    y = X[:, :3] @ np.array([1.5, -2.0, 0.5]) + 4.0 + rng.standard_normal(n)
+    x_len = width_of_key[key].copy()
+    msg = C.create_string_buffer(512)
+    q = lib.glue_open(b"ols_fit_agg", b"compute_inference=true", 0, msg)
+    assert q, msg.value
+    core = np.full((K, P + 6), np.nan)
+    inf = np.full((K, 5 * P + 2), np.nan)
+    nn = np.zeros(K, dtype=np.uint8)
+    rc = lib.glue_group_by_ragged(q, n, P, _ptr(x_len), _ptr(key), K, _ptr(y), _ptr(X), None, 4, 2048, _ptr(core), _ptr(inf), _ptr(nn), msg)
+    assert rc == 0, msg.value
+    st = _stats(lib, q)
+    assert st["live"] == 0 and st["unrefined"] == 0 and st["rows"] == int(np.sum(x_len > 0)) and st["fit_calls"] == 2
+    assert nn[K - 1] == 1 and np.all(nn[:K - 1] == 0)
+    for width in (3, 11):
+        ks = np.nonzero(width_of_key == width)[0]
+        sel = np.nonzero(np.isin(key, ks))[0]
+        order = sel[np.argsort(key[sel], kind="stable")]
+        offs = np.concatenate([[0], np.cumsum(np.bincount(key[sel], minlength=K)[ks])]).astype(np.int64)
+        rcore, rinf = oracle.fit_groups(y[order], [np.ascontiguousarray(X[order, j]) for j in range(width)], offs, compute_inference=True)
+        got = np.concatenate([core[ks, :width], core[ks, P:P + 6]], axis=1)
+        assert np.all(got[:, width + 5] == width)                              # n_features of each group
+        assert np.all(np.isnan(core[ks, width:P]))                              # ... and its LIST has exactly that many entries
+        got_inf = np.concatenate([inf[ks, l * P:l * P + width] for l in range(5)] + [inf[ks, 5 * P:]], axis=1)
+        assert_records_match(_fix_last_column(got, width), rcore, width, got_inf, rinf, what=f"mixed widths, p={width}")
+    # one row of another width inside a group: the reference's message, with the state's own count
+    x_len2 = x_len.copy()
+    victim = np.nonzero(key == 1)[0][5]
+    x_len2[victim] = 5
+    rc = lib.glue_group_by_ragged(q, n, P, _ptr(x_len2), _ptr(key), K, _ptr(y), _ptr(X), None, 1, 2048, _ptr(core), _ptr(inf), _ptr(nn), msg)
+    assert rc != 0 and msg.value == b"Inconsistent feature count: expected 3, got 5"
+    assert _stats(lib, q)["live"] == 0                                          # the failing query destroyed its states
+    lib.glue_close(q)
 
 
 def test_reference_window_test_through_the_glue(lib):

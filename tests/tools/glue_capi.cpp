@@ -29,13 +29,13 @@ GLUE_API void glue_close(void *q) { delete static_cast<Query *>(q); }
 GLUE_API int glue_result_fields(void *q) { return (int)static_cast<Query *>(q)->ReturnType().children().size(); }
 // arena statistics: [0] rows accepted [1] unrefined groups [2] slot high-water mark [3] live slots [4] fit calls [5] slots fitted
 GLUE_API void glue_stats(void *q, int64_t *out6) {
-	auto &a = static_cast<Query *>(q)->Arena();
-	out6[0] = (int64_t)a.RowsAccepted();
-	out6[1] = a.Unrefined();
-	out6[2] = a.SlotCount();
-	out6[3] = a.LiveSlots();
-	out6[4] = (int64_t)a.FitCalls();
-	out6[5] = (int64_t)a.SlotsFitted();
+	const auto a = static_cast<Query *>(q)->Stats();
+	out6[0] = (int64_t)a.rows_accepted;
+	out6[1] = a.unrefined;
+	out6[2] = (int64_t)a.slot_high_water;
+	out6[3] = (int64_t)a.live_slots;
+	out6[4] = (int64_t)a.fit_calls;
+	out6[5] = (int64_t)a.slots_fitted;
 }
 
 static Inputs make_inputs(size_t n, size_t p, const double *y, const double *x, const double *w, const uint8_t *y_null, const uint8_t *x_null,
@@ -62,6 +62,35 @@ GLUE_API int glue_group_by(void *q, size_t n, size_t p, const uint32_t *key, siz
 		Records r = static_cast<Query *>(q)->GroupBy(make_inputs(n, p, y, x, w, y_null, x_null, xe_null, w_null), key, n_keys, n_threads, vector_size,
 		                                             dictionary != 0);
 		copy_out(r, n_keys, p, out_core, out_inf, is_null);
+		return 0;
+	} catch (const std::exception &e) {
+		return fail(msg, e);
+	}
+}
+// the same with a LIST length per row (x_len[r] <= p): groups of different widths in one query.  Row k of out_core keeps the
+// p-wide layout; a group of q < p features has q coefficients, then NaN, and n_features = q in the last column
+GLUE_API int glue_group_by_ragged(void *q, size_t n, size_t p, const uint32_t *x_len, const uint32_t *key, size_t n_keys, const double *y,
+                                  const double *x, const double *w, int n_threads, size_t vector_size, double *out_core, double *out_inf,
+                                  uint8_t *is_null, char *msg) {
+	try {
+		Inputs in = make_inputs(n, p, y, x, w, nullptr, nullptr, nullptr, nullptr);
+		in.x_len = x_len;
+		Records r = static_cast<Query *>(q)->GroupBy(in, key, n_keys, n_threads, vector_size, false);
+		if (r.p > p) throw std::runtime_error("a result wider than the inputs");
+		for (size_t k = 0; k < n_keys; ++k) {
+			is_null[k] = r.is_null[k];
+			if (r.is_null[k]) continue;
+			const double *c = &r.core[k * (r.p + 6)];
+			for (size_t j = 0; j < p; ++j) out_core[k * (p + 6) + j] = j < r.p ? c[j] : NAN;
+			for (size_t j = 0; j < 6; ++j) out_core[k * (p + 6) + p + j] = c[r.p + j];
+			if (out_inf && r.inference) {
+				const double *f = &r.inf[k * (5 * r.p + 2)];
+				for (size_t l = 0; l < 5; ++l)
+					for (size_t j = 0; j < p; ++j) out_inf[k * (5 * p + 2) + l * p + j] = j < r.p ? f[l * r.p + j] : NAN;
+				out_inf[k * (5 * p + 2) + 5 * p] = f[5 * r.p];
+				out_inf[k * (5 * p + 2) + 5 * p + 1] = f[5 * r.p + 1];
+			}
+		}
 		return 0;
 	} catch (const std::exception &e) {
 		return fail(msg, e);

@@ -69,7 +69,7 @@ struct Inputs { // n rows; x row-major with p values per row
 };
 
 struct Records { // what Finalize wrote, per output row
-	size_t p = 0;
+	size_t p = 0;  // the widest row's feature count; a row of q < p features has its lists left-aligned in p-wide fields
 	bool inference = false;
 	std::vector<double> core, inf; // [rows x (p + 6)], [rows x (5 p + 2)]  (n_features at core[p + 5])
 	std::vector<uint8_t> is_null;
@@ -103,7 +103,11 @@ public:
 	const ExtensionLoader &Loader() const { return loader_; }
 	const LogicalType &ReturnType() const { return fn_->return_type; }
 	bool Inference() const { return inference_; }
-	anofox_shim::AggArena &Arena() { return *HipAggArenaOf(*bind_); }
+	HipAggStats Stats() {
+		HipAggStats st;
+		if (!HipAggStatsOf(*bind_, st)) throw std::runtime_error("not a bind data object of the HIP aggregates");
+		return st;
+	}
 	FunctionData &BindData() { return *bind_; }
 
 	// ---- a parallel hash aggregate ----
@@ -138,33 +142,33 @@ public:
 		std::vector<std::thread> th;
 		for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t);
 		for (auto &t : th) t.join();
+		ArenaAllocator alloc;
+		AggregateInputData aid(bind_.get(), alloc, AggregateCombineType::ALLOW_DESTRUCTIVE);
 		for (auto &e : errors)
-			if (!e.empty()) {
-				for (auto &l : local) FreeStates(l);
+			if (!e.empty()) { // (a failing query still destroys its states)
+				for (auto &l : local) DestroyStates(aid, l, vector_size);
 				throw std::runtime_error(e);
 			}
 		// Combine: thread-local states into the global ones, pairs in vectors
-		ArenaAllocator alloc;
-		AggregateInputData aid(bind_.get(), alloc, AggregateCombineType::ALLOW_DESTRUCTIVE);
 		std::vector<data_ptr_t> global(n_keys, nullptr);
 		for (size_t k = 0; k < n_keys; ++k) global[k] = NewState(); // the global table has a state per key
-		for (int t = 0; t < n_threads; ++t) {
-			std::vector<data_ptr_t> s, d;
-			for (size_t k = 0; k < n_keys; ++k)
-				if (local[t][k]) {
-					s.push_back(local[t][k]);
-					d.push_back(global[k]);
-				}
-			for (size_t c0 = 0; c0 < s.size(); c0 += vector_size) {
-				const size_t cnt = std::min(vector_size, s.size() - c0);
-				Vector sv = PointerVector(s.data() + c0, cnt), dv = PointerVector(d.data() + c0, cnt);
-				fn_->combine(sv, dv, aid, cnt);
-			}
-		}
 		Records out;
 		try {
+			for (int t = 0; t < n_threads; ++t) {
+				std::vector<data_ptr_t> s, d;
+				for (size_t k = 0; k < n_keys; ++k)
+					if (local[t][k]) {
+						s.push_back(local[t][k]);
+						d.push_back(global[k]);
+					}
+				for (size_t c0 = 0; c0 < s.size(); c0 += vector_size) {
+					const size_t cnt = std::min(vector_size, s.size() - c0);
+					Vector sv = PointerVector(s.data() + c0, cnt), dv = PointerVector(d.data() + c0, cnt);
+					fn_->combine(sv, dv, aid, cnt);
+				}
+			}
 			out = FinalizeStates(aid, global, vector_size);
-		} catch (...) { // (a failing query still destroys its states)
+		} catch (...) {
 			for (auto &l : local) DestroyStates(aid, l, vector_size);
 			DestroyStates(aid, global, vector_size);
 			throw;
@@ -346,10 +350,11 @@ private:
 				continue;
 			}
 			double *c = &out.core[r * (p + 6)];
+			const size_t q = (size_t)FlatVector::GetData<int64_t>(*entries[6])[r]; // this row's n_features
 			auto copy_list = [&](Vector &lv, double *dst) {
 				const list_entry_t e = ListVector::GetData(lv)[r];
-				if (e.length != p || e.offset + e.length > ListVector::GetListSize(lv)) throw std::runtime_error("finalize wrote a bad LIST entry");
-				memcpy(dst, FlatVector::GetData<double>(ListVector::GetEntry(lv)) + e.offset, p * sizeof(double));
+				if (e.length != q || q > p || e.offset + e.length > ListVector::GetListSize(lv)) throw std::runtime_error("finalize wrote a bad LIST entry");
+				memcpy(dst, FlatVector::GetData<double>(ListVector::GetEntry(lv)) + e.offset, q * sizeof(double));
 			};
 			copy_list(*entries[0], c);
 			for (int k = 0; k < 4; ++k) c[p + k] = FlatVector::GetData<double>(*entries[1 + k])[r];

@@ -47,32 +47,32 @@ static void registration_and_bind() {
 		CHECK(f1.arguments.back() == LogicalType(LogicalType::ANY) && f0.return_type == LogicalType(LogicalType::ANY));
 		if (k == 2) CHECK(f0.arguments[2] == LogicalType(LogicalType::DOUBLE));
 		CHECK(f0.bind && f0.destructor && f0.combine && f0.update && f0.finalize && f0.initialize && !f0.simple_update);
-		CHECK(f0.state_size(f0) == sizeof(int64_t));
+		CHECK(f0.state_size(f0) == 2 * sizeof(int64_t));
 	}
 	// defaults (ols_aggregate.cpp:48-52): 7 fields, intercept, no inference, 0.95, solver svd, no HC
 	CHECK(q.ReturnType().children().size() == 7 && q.ReturnType().children()[0].first == "coefficients" && q.ReturnType().children()[6].first == "n_features");
 	{
-		auto &o = q.Arena().Options();
+		const auto o = q.Stats().options;
 		CHECK(o.model == ANOFOX_HIP_MODEL_OLS && o.fit_intercept && !o.compute_inference && o.confidence_level == 0.95 && o.solver == ANOFOX_SOLVER_SVD &&
 		      o.hc_type == ANOFOX_HC_NONE);
 	}
 	// the options literal: STRUCT, aliases, case-insensitive keys, integers as booleans, unknown keys ignored
 	{
 		Query r("ols_fit_agg", "Intercept=0;INFERENCE=true;confidence=0.9;solver=QR;hc_type=HC3;full_output=true", false);
-		auto &o = r.Arena().Options();
+		const auto o = r.Stats().options;
 		CHECK(!o.fit_intercept && o.compute_inference && o.confidence_level == 0.9 && o.solver == ANOFOX_SOLVER_QR && o.hc_type == ANOFOX_HC_HC3);
 		CHECK(r.ReturnType().children().size() == 14 && r.ReturnType().children()[13].first == "f_pvalue" && r.Inference());
 	}
 	{ // ridge: alpha wins over lambda, lambda alone counts, scaling; a MAP literal; HC is not a ridge option
 		Query r1("anofox_stats_ridge_fit_agg", "lambda=3.0;alpha=0.25;lambda_scaling=glmnet;hc_type=hc1", false);
-		CHECK(r1.Arena().Options().model == ANOFOX_HIP_MODEL_RIDGE && r1.Arena().Options().alpha == 0.25 &&
-		      r1.Arena().Options().lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET && r1.Arena().Options().hc_type == ANOFOX_HC_NONE);
+		CHECK(r1.Stats().options.model == ANOFOX_HIP_MODEL_RIDGE && r1.Stats().options.alpha == 0.25 &&
+		      r1.Stats().options.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET && r1.Stats().options.hc_type == ANOFOX_HC_NONE);
 		Query r2("ridge_fit_agg", "lambda=3.0;fit_intercept=0.0", true);
-		CHECK(r2.Arena().Options().alpha == 3.0 && !r2.Arena().Options().fit_intercept);
+		CHECK(r2.Stats().options.alpha == 3.0 && !r2.Stats().options.fit_intercept);
 		Query r3("ridge_fit_agg", nullptr, false);
-		CHECK(r3.Arena().Options().alpha == 1.0 && r3.Arena().Options().lambda_scaling == ANOFOX_LAMBDA_SCALING_RAW); // ridge_aggregate.cpp:49-54
+		CHECK(r3.Stats().options.alpha == 1.0 && r3.Stats().options.lambda_scaling == ANOFOX_LAMBDA_SCALING_RAW); // ridge_aggregate.cpp:49-54
 		Query r4("anofox_stats_wls_fit_agg", "alpha=5;compute_inference=1", false);
-		CHECK(r4.Arena().Options().model == ANOFOX_HIP_MODEL_WLS && r4.Arena().Options().compute_inference && r4.Arena().Options().alpha == 0.0);
+		CHECK(r4.Stats().options.model == ANOFOX_HIP_MODEL_WLS && r4.Stats().options.compute_inference && r4.Stats().options.alpha == 0.0);
 	}
 	// the reference's error texts (map_options_parser.cpp:21-45,222-266)
 	CHECK(error_of("ols_fit_agg", "solver=lu") == "Invalid solver: 'lu'. Valid values are 'qr', 'svd', 'cholesky'");
@@ -87,7 +87,7 @@ static void registration_and_bind() {
 	// Copy() shares the query's arena (every thread must reach the same device state); Equals compares options + arena
 	{
 		auto c = q.BindData().Copy();
-		CHECK(HipAggArenaOf(*c) == &q.Arena() && c->Equals(q.BindData()) && q.BindData().Equals(*c));
+		CHECK(HipAggSharedStateOf(*c) == HipAggSharedStateOf(q.BindData()) && c->Equals(q.BindData()) && q.BindData().Equals(*c));
 		Query other("anofox_stats_ols_fit_agg", nullptr, false);
 		CHECK(!other.BindData().Equals(q.BindData())); // another aggregate of the query: its own state
 	}
@@ -155,8 +155,8 @@ static void group_by(const char *fn, size_t p, int threads, size_t vsize, bool d
 		for (size_t j = 0; j < p + 5; ++j) CHECK(c[j] == want[j]);
 		CHECK(c[p + 5] == (double)p); // n_features
 	}
-	CHECK(q.Arena().LiveSlots() == 0);                                     // every state was destroyed
-	CHECK(q.Arena().FitCalls() == 1 && q.Arena().SlotsFitted() >= K - 1); // ONE batched fit for the whole GROUP BY
+	CHECK(q.Stats().live_slots == 0);                                     // every state was destroyed
+	CHECK(q.Stats().fit_calls == 1 && q.Stats().slots_fitted >= K - 1); // ONE batched fit for the whole GROUP BY
 }
 
 static void window_replay() {
@@ -178,8 +178,8 @@ static void window_replay() {
 			CHECK(rec.core[r * 7] == sy); // the mock's first "coefficient": the frame's own rows
 		}
 		CHECK(n5 == 16);
-		CHECK(q.Arena().LiveSlots() == 0 && q.Arena().SlotsFitted() == 20); // every frame fitted once, nothing re-fitted
-		if (vsize == 4) CHECK(q.Arena().SlotCount() <= 8);                 // slots of destroyed states are handed out again
+		CHECK(q.Stats().live_slots == 0 && q.Stats().slots_fitted == 20); // every frame fitted once, nothing re-fitted
+		if (vsize == 4) CHECK(q.Stats().slot_high_water <= 8);                 // slots of destroyed states are handed out again
 	}
 	// a segment tree: leaves of 4 rows, frames of 3 leaves, every leaf the source of up to 3 targets in one Combine call
 	{
@@ -196,7 +196,7 @@ static void window_replay() {
 			CHECK(!rec.is_null[o]);
 			for (int j = 0; j < 7; ++j) CHECK(rec.core[o * 8 + j] == want[j]);
 		}
-		CHECK(q.Arena().LiveSlots() == 0);
+		CHECK(q.Stats().live_slots == 0);
 	}
 }
 
@@ -216,6 +216,48 @@ static void errors_and_flags() {
 		}
 		CHECK(msg == "Inconsistent feature count: expected 3, got 2");
 	}
+	{ // the feature count is per STATE (:164-175): groups of one query may differ in width, each result has its own LIST lengths
+		Data d = make_data(30, 4, 3, 11, false);
+		std::vector<uint32_t> len(30);
+		for (size_t i = 0; i < 30; ++i) len[i] = d.key[i] == 0 ? 4 : (d.key[i] == 1 ? 2 : 0); // group 2: empty x lists -> NULL
+		Inputs in = d.in();
+		in.x_len = len.data();
+		Query q("ols_fit_agg", "compute_inference=true", false);
+		Records rec = q.GroupBy(in, d.key.data(), 3, 2, 7, true);
+		CHECK(rec.p == 4 && !rec.is_null[0] && !rec.is_null[1] && rec.is_null[2]);
+		CHECK(rec.core[0 * 10 + 4 + 5] == 4.0 && rec.core[1 * 10 + 4 + 5] == 2.0 && std::isnan(rec.core[1 * 10 + 2])); // n_features per row
+		size_t n0 = 0, n1 = 0;
+		for (size_t i = 0; i < 30; ++i) (d.key[i] == 0 ? n0 : n1) += d.key[i] < 2;
+		CHECK(rec.core[0 * 10 + 4 + 4] == (double)n0 && rec.core[1 * 10 + 4 + 4] == (double)n1);
+		const auto st = q.Stats();
+		CHECK(st.widths == 2 && st.live_slots == 0 && st.rows_accepted == n0 + n1);
+		// a later row of another width in the SAME group is the reference's error, with the state's own count
+		len[0] = d.key[0] == 0 ? 2 : 4;
+		Query q2("ols_fit_agg", nullptr, false);
+		std::string msg;
+		try {
+			q2.GroupBy(in, d.key.data(), 3, 1, 2048, false);
+		} catch (const std::exception &e) {
+			msg = e.what();
+		}
+		CHECK(msg.rfind("Inconsistent feature count: expected ", 0) == 0);
+		CHECK(q2.Stats().live_slots == 0);
+	}
+	{ // Combine of states with different feature counts (:217-220): two threads see one group at different widths
+		Data d = make_data(8, 3, 1, 12, false);
+		std::vector<uint32_t> len = {3, 3, 3, 3, 2, 2, 2, 2};
+		Inputs in = d.in();
+		in.x_len = len.data();
+		Query q("ols_fit_agg", nullptr, false);
+		std::string msg;
+		try {
+			q.GroupBy(in, d.key.data(), 1, 2, 4, false); // vectors of 4 rows, dealt to 2 threads
+		} catch (const std::exception &e) {
+			msg = e.what();
+		}
+		CHECK(msg == "Cannot combine states with different feature counts: 3 vs 2" ||
+		      msg == "Cannot combine states with different feature counts: 2 vs 3");
+	}
 	{ // NULL list elements become NaN (the fit's row filter drops such rows): they reach the state as rows
 		Data d = make_data(6, 3, 1, 4, false);
 		d.xe_null[3 * 3 + 0] = 1;
@@ -229,7 +271,7 @@ static void errors_and_flags() {
 		for (size_t i = 0; i < 9; ++i) d.key[i] = i < 3 ? 0 : (i < 7 ? 1 : 2); // 3, 4 and 2 rows
 		Query q("ols_fit_agg", nullptr, false);
 		Records rec = q.GroupBy(d.in(), d.key.data(), 3, 1, 2048, false);
-		CHECK(rec.is_null[0] && !rec.is_null[1] && !rec.is_null[2] && q.Arena().Unrefined() == 1);
+		CHECK(rec.is_null[0] && !rec.is_null[1] && !rec.is_null[2] && q.Stats().unrefined == 1);
 		setenv("ANOFOX_HIP_UNREFINED", "error", 1);
 		Query q2("ols_fit_agg", nullptr, false);
 		std::string msg;

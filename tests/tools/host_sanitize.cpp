@@ -25,6 +25,8 @@ STUB(launch_ingest_chunk(const IngestArgs &, hipStream_t))
 STUB(launch_ingest_combine(double *, int64_t *, int64_t, const uint32_t *, const uint32_t *, int64_t, int, int, int, hipStream_t))
 STUB(launch_accumulate_wide(const WideArgs &, hipStream_t))
 STUB(launch_solve_wide(const WideArgs &, int, hipStream_t))
+STUB(launch_solve_tiles(const WideArgs &, hipStream_t))
+bool solve_tiles_supports(int) { return false; }
 STUB(launch_inference_wide_finish(const WideArgs &, hipStream_t))
 STUB(launch_residual_grad_wide(const WideArgs &, hipStream_t))
 STUB(launch_accumulate_mid(const WideArgs &, hipStream_t))

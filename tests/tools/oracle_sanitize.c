@@ -11,8 +11,8 @@
 typedef struct {
 	int32_t model, fit_intercept, compute_inference, lambda_scaling;
 	double confidence_level, alpha;
-	int32_t hc_type, plain_qr;
-} OracleOptions;
+	int32_t hc_type, plain_qr, plain_svd;
+} OracleOptions; /* (oracle/anofox_oracle.c:65-79) */
 
 int oracle_fit_groups(const double *y, const double *const *x, const double *w, const int64_t *offsets, int64_t n_groups, size_t p,
                       const OracleOptions *opt, double *core, double *inf, int n_threads);
@@ -69,11 +69,11 @@ int main(void) {
 		for (int icpt = 0; icpt < 2; ++icpt)
 			for (int infr = 0; infr < 2; ++infr)
 				for (int hc = 0; hc <= 4; hc += 2)
-					for (int plain = 0; plain < 2; ++plain) {
+					for (int plain = 0; plain < 3; ++plain) { /* refined (the checker), plain QR, plain SVD */
 						OracleOptions o;
 						memset(&o, 0, sizeof o);
-						o.model = model; o.fit_intercept = icpt; o.compute_inference = infr; o.lambda_scaling = plain;
-						o.confidence_level = 0.9; o.alpha = 0.7; o.hc_type = hc; o.plain_qr = plain;
+						o.model = model; o.fit_intercept = icpt; o.compute_inference = infr; o.lambda_scaling = plain & 1;
+						o.confidence_level = 0.9; o.alpha = 0.7; o.hc_type = hc; o.plain_qr = plain == 1; o.plain_svd = plain == 2;
 						oracle_fit_groups(y, (const double *const *)cols, model == 2 ? w : NULL, offs, G, P, &o, core, infr ? inf : NULL, 1 + runs % 4);
 						++runs;
 						/* a healthy group has status 0 and a finite r^2 in [0, 1] (uncentred without intercept) */
