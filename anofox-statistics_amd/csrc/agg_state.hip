@@ -631,7 +631,7 @@ bool run_solve(AnofoxHipAggState *s, int64_t n, double *d_moments, const int64_t
 	// workspace: refine list | refine vec | counters | t memo  (the refinement passes need the rows and do not run here;
 	// the queue only counts the groups that would have taken them)
 	const size_t b_lst = align_up((size_t)n * sizeof(int32_t), 256);
-	const size_t b_vec = align_up((size_t)n * (p + 2) * sizeof(double), 256);
+	const size_t b_vec = align_up((size_t)n * refine_vec_len((int)p) * sizeof(double), 256);
 	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_lst + b_vec + 256 + kTcritTableBytes, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 	BatchArgs a;

@@ -41,6 +41,13 @@ struct MomentLayout {
 	}
 };
 
+// Per queued group, the refinement passes hand the solve {sum w r^2, sum w r, X'Wr [p], sum w (y - ybar)^2}: the last
+// entry is the centred second moment of y summed over the rows about the mean — what glmnet's lambda = n alpha / sd_y
+// needs when the moments are uncentred (no intercept) and qyy - sy^2 / sw cancels.
+inline __host__ __device__ int refine_vec_len(int p) { return p + 3; }
+// (digits of sd_y lost to that cancellation ~ log10(qyy / cyy): beyond this ratio the group is queued for refinement)
+constexpr double kGlmnetCancelRatio = 1e4;
+
 inline __host__ __device__ int moment_record_len(int p) {
 	const int Z = p + 1;
 	return Z + Z * (Z + 1) / 2 + 1 + Z + 2;
@@ -68,7 +75,7 @@ struct BatchArgs {
 	double *inference;    // [G * (5p+2)] or nullptr
 	int32_t *refine_list; // [G]   groups whose RSS must be recomputed from residuals
 	int32_t *refine_count; // [1]
-	double *refine_vec;   // [G * (p+2)]  {sum w r^2, sum w r, X'Wr} of the queued groups
+	double *refine_vec;   // [G * refine_vec_len(p)]  {sum w r^2, sum w r, X'Wr, sum w (y - ybar)^2} of the queued groups
 	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
 	const int64_t *rule_counts; // optional [G]: the count the "< 2 rows -> NULL" rule looks at (default: rows of the group)
 	// row splitting of very large groups (accumulate_narrow.hip): groups with more than seg_rows rows are cut into
@@ -148,7 +155,7 @@ struct WideArgs {
 	double *inference;    // [G_total * (5p+2)] or nullptr
 	int32_t *refine_list; // [G_total]
 	int32_t *refine_count;
-	double *refine_vec;   // [G_total * (p+2)]
+	double *refine_vec;   // [G_total * refine_vec_len(p)]
 	void *tcrit_table;    // TcritSlot[kTcritSlots] (device_math.h), zeroed per call
 	const int64_t *rule_counts; // optional [G_total], see BatchArgs
 	double *hc_df;        // [n_groups of this launch] scratch of launch_hc_wide: residual df, NaN = group skipped

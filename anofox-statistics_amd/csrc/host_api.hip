@@ -39,7 +39,7 @@ struct Workspace {
 bool carve_workspace(AnofoxHipContext *ctx, int64_t G, int p, Workspace *out, AnofoxError *e) {
 	const size_t rec = (size_t)moment_record_len(p);
 	const size_t b_mom = align_up((size_t)G * rec * sizeof(double), 256);
-	const size_t b_rss = align_up((size_t)G * (size_t)(p + 2) * sizeof(double), 256);
+	const size_t b_rss = align_up((size_t)G * (size_t)refine_vec_len((int)p) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)G * sizeof(int32_t), 256);
 	const size_t b_seg = align_up(seg_table_bytes(p), 256);
 	const size_t total = b_mom + b_rss + b_lst + 256 + kTcritTableBytes + b_seg;
@@ -66,7 +66,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	if (slab < 256) slab = 256;
 	if (slab > G) slab = G;
 	const size_t b_mom = align_up((size_t)slab * rec_bytes, 256);
-	const size_t b_rss = align_up((size_t)G * (p + 2) * sizeof(double), 256);
+	const size_t b_rss = align_up((size_t)G * (size_t)refine_vec_len((int)p) * sizeof(double), 256);
 	const size_t b_lst = align_up((size_t)slab * sizeof(int32_t), 256);
 	const bool mid = solve_mid_supports((int)p);
 	static const bool mid_acc_on = !(getenv("ANOFOX_MID_ACC") && atoi(getenv("ANOFOX_MID_ACC")) == 0); // A/B switch for measurements

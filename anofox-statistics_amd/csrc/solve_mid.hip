@@ -39,7 +39,7 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 	const double *sc = vec + 4 * P16;
 	double *core = args.core + g * (int64_t)(p + 6);
 	double *inf = (args.inference && args.compute_inference) ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
-	const double *rvec = args.refine_vec + g * (int64_t)(p + 2); // {sum w r^2, sum w r, X'Wr}
+	const double *rvec = args.refine_vec + g * (int64_t)refine_vec_len(p); // {sum w r^2, sum w r, X'Wr, centred yy}
 	const int64_t nrows = args.rule_counts ? args.rule_counts[g] : args.row_offsets[g + 1] - args.row_offsets[g];
 
 	auto write_null = [&](int status, bool core_too) {
@@ -73,10 +73,17 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 	}
 	if (cnt < (double)(peff + (icpt ? 1 : 0))) { write_null(ANOFOX_ERROR_INSUFFICIENT_DATA, true); return; } // ols.rs:132-139
 
-	double lam = 0.0;
+	// ridge penalty: `lam` goes into the factor; the refinement steps aim at `lam_rows`, glmnet's lambda with sd_y re-summed
+	// over the rows about the mean (uncentred moments of a nearly constant y cancel; such groups are queued)
+	double lam = 0.0, lam_rows = 0.0;
+	bool glmnet_cancels = false;
 	if (model == ANOFOX_HIP_MODEL_RIDGE) {
-		lam = args.alpha;
-		if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) lam = cnt * args.alpha / sqrt(cyy_c / cnt);
+		lam = lam_rows = args.alpha;
+		if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) {
+			lam = lam_rows = cnt * args.alpha / sqrt(cyy_c / cnt);
+			glmnet_cancels = !icpt && !(cyy_c * kGlmnetCancelRatio > syy);
+			if (MODE != MODE_PRIMARY && !icpt) lam_rows = cnt * args.alpha / sqrt(rvec[p + 2] / cnt);
+		}
 	}
 	const double tss = icpt ? cyy_c : syy;
 
@@ -146,7 +153,7 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 			bb += beta[i] * beta[i];
 		}
 		rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
-		refine = !(rss > kRefineTolM * tss) || (min_ratio < kPivotWarnM);
+		refine = !(rss > kRefineTolM * tss) || (min_ratio < kPivotWarnM) || glmnet_cancels;
 	} else {
 		for (int i = 0; i < p; ++i) beta[i] = ((active >> i) & 1u) ? core[i] : 0.0; // residual_grad used exactly these
 		rss = rvec[0];
@@ -158,7 +165,7 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 		for (int i = 0; i < p; ++i) {
 			double gi = rvec[2 + i];
 			if (icpt) gi -= (sx[i] * inv_sw) * gs;
-			gc[i] = ((active >> i) & 1u) ? gi - lam * beta[i] : 0.0;
+			gc[i] = ((active >> i) & 1u) ? gi - lam_rows * beta[i] : 0.0;
 		}
 		solve_llt(gc, zf, delta);
 		for (int i = 0; i < p; ++i) beta[i] += delta[i];

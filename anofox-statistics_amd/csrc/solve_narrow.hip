@@ -45,7 +45,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 
 	double *core = args.core + g * (int64_t)(p + 6);
 	double *inf = (args.inference && args.compute_inference) ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
-	const double *rv = args.refine_vec + g * (int64_t)(p + 2); // [rss, sum w r, X'Wr] from residual_grad_wave
+	const double *rv = args.refine_vec + g * (int64_t)refine_vec_len(p); // [rss, sum w r, X'Wr, centred yy] from residual_grad_wave
 
 	int status = ANOFOX_ERROR_SUCCESS;
 	double coef[P];
@@ -106,10 +106,20 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 		}
 		const double tss = icpt ? cyy_centred : qyy;
 
-		double lam = 0.0;
+		double lam = 0.0, lam_rows = 0.0; // the penalty in the factor / the penalty the refinement aims at
+		bool glmnet_cancels = false;
 		if (model == ANOFOX_HIP_MODEL_RIDGE) {
 			lam = args.alpha;
-			if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) lam = cnt * args.alpha / sqrt(cyy_centred / cnt);
+			if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) {
+				// sd_y from the moments; a queued group's passes over the rows re-sum it about the mean (uncentred moments of
+				// a nearly constant y cancel), and the update steps then aim at that lambda with this factor as preconditioner
+				lam = cnt * args.alpha / sqrt(cyy_centred / cnt);
+				glmnet_cancels = !icpt && !(cyy_centred * kGlmnetCancelRatio > qyy);
+				if (MODE != MODE_PRIMARY && !icpt) lam_rows = cnt * args.alpha / sqrt(rv[p + 2] / cnt);
+				else lam_rows = lam;
+			} else {
+				lam_rows = lam;
+			}
 #pragma unroll
 			for (int i = 0; i < P; ++i) A[i][i] += lam;
 		}
@@ -173,7 +183,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 #pragma unroll
 			for (int i = 0; i < P; ++i) { zz += zf[i] * zf[i]; bc += beta[i] * c[i]; bb += beta[i] * beta[i]; }
 			rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
-			refine = !(rss > kRefineTol * tss) || (min_ratio < kPivotWarn);
+			refine = !(rss > kRefineTol * tss) || (min_ratio < kPivotWarn) || glmnet_cancels;
 		} else {
 			// current coefficients come from the record; residual_grad_wave used exactly these
 #pragma unroll
@@ -192,7 +202,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 			for (int i = 0; i < P; ++i) {
 				double gi = rv[2 + i];
 				if (icpt) gi -= (s[i] / sw) * gs;
-				gc[i] = active[i] ? gi - lam * beta[i] : 0.0;
+				gc[i] = active[i] ? gi - lam_rows * beta[i] : 0.0;
 			}
 			solve_llt(gc, u, delta);
 #pragma unroll
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(64) void solve_narrow_kernel(BatchArgs args) {
 }
 
 // One wavefront per queued group, straight from the data with the record's current coefficients:
-//   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ... },  r = y - b0 - x'b
+//   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ..., sum w (y - ybar)^2 },  r = y - b0 - x'b
 // over the valid rows (same row filter as the accumulate kernel); shift = first valid row when an intercept
 // is fitted (the shift of the moment record), 0 otherwise.
 __device__ __forceinline__ void residual_grad_wave(const BatchArgs &args, int64_t g, int lane) {
@@ -311,7 +321,9 @@ __device__ __forceinline__ void residual_grad_wave(const BatchArgs &args, int64_
 	{
 		const double *core = args.core + g * (int64_t)(p + 6);
 		const double *rec = args.moments + g * (int64_t)rec_len;
-		double b[kNarrowMaxP], sh[kNarrowMaxP], acc[kNarrowMaxP + 2];
+		double b[kNarrowMaxP], sh[kNarrowMaxP], acc[kNarrowMaxP + 3];
+		// mean of y over the valid rows, from the record (sum / weight, plus the shift an intercept fit accumulates about)
+		const double ybar = rec[p] / rec[Z + Z * (Z + 1) / 2] + (args.fit_intercept ? rec[off_first + p] : 0.0);
 #pragma unroll
 		for (int j = 0; j < kNarrowMaxP; ++j) {
 			b[j] = sh[j] = 0.0;
@@ -322,7 +334,7 @@ __device__ __forceinline__ void residual_grad_wave(const BatchArgs &args, int64_
 			}
 		}
 #pragma unroll
-		for (int k = 0; k < kNarrowMaxP + 2; ++k) acc[k] = 0.0;
+		for (int k = 0; k < kNarrowMaxP + 3; ++k) acc[k] = 0.0;
 		const double b0 = args.fit_intercept ? core[p] : 0.0;
 		const int64_t lo = args.row_offsets[g], hi = group_row_end(args, g);
 		for (int64_t r = lo + lane; r < hi; r += 64) {
@@ -352,16 +364,19 @@ __device__ __forceinline__ void residual_grad_wave(const BatchArgs &args, int64_
 #pragma unroll
 				for (int j = 0; j < kNarrowMaxP; ++j)
 					if (j < p) acc[2 + j] = fma(we, xv[j] - sh[j], acc[2 + j]);
+				const double dy = yv - ybar;
+				acc[kNarrowMaxP + 2] = fma(wv * dy, dy, acc[kNarrowMaxP + 2]);
 			}
 		}
 #pragma unroll
-		for (int k = 0; k < kNarrowMaxP + 2; ++k)
+		for (int k = 0; k < kNarrowMaxP + 3; ++k)
 			for (int m = 32; m >= 1; m >>= 1) acc[k] += __shfl_xor(acc[k], m, 64);
-		double *out = args.refine_vec + g * (int64_t)(p + 2);
+		double *out = args.refine_vec + g * (int64_t)refine_vec_len(p);
 		double mine = 0.0;
 #pragma unroll
 		for (int k = 0; k < kNarrowMaxP + 2; ++k) mine = (lane == k) ? acc[k] : mine;
-		if (lane < p + 2) out[lane] = mine;
+		if (lane == p + 2) mine = acc[kNarrowMaxP + 2];
+		if (lane < p + 3) out[lane] = mine;
 	}
 }
 
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(64) void refine_fused_kernel(BatchArgs args, int st
 			// loads without the agent-scope L2 write-back / invalidate of __threadfence(), which costs microseconds when
 			// the L2 is full of another kernel's dirty lines (7 801 queued window frames: 0.89 ms -> measured below)
 			residual_grad_wave(args, g, lane);
-			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // refine_vec[g] written by lanes 0..p+1, read by lane 0
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // refine_vec[g] written by lanes 0..p+2, read by lane 0
 			if (lane == 0) {
 				if (it < steps) solve_one<P, MODE_UPDATE>(args, g);
 				else solve_one<P, MODE_FINAL>(args, g);

@@ -199,9 +199,13 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		}
 
 		double lam = 0.0;
+		bool glmnet_cancels = false; // sd_y from uncentred moments of a nearly constant y: the refinement re-sums it over the rows
 		if (model == ANOFOX_HIP_MODEL_RIDGE) {
 			lam = args.alpha;
-			if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) lam = cnt * args.alpha / sqrt(cyy_c / cnt);
+			if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) {
+				lam = cnt * args.alpha / sqrt(cyy_c / cnt);
+				glmnet_cancels = !icpt && !(cyy_c * kGlmnetCancelRatio > syy);
+			}
 		}
 		const double tss = icpt ? cyy_c : syy;
 		const double inv_sw = 1.0 / sw;
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		// Nearly square designs (fewer residual degrees of freedom than a quarter of the columns) are ill conditioned
 		// whatever the column scales, and a ridge penalty hides that from the pivot test (it lifts every pivot): they take
 		// the refinement passes as well.  (Deep fuzz sweep, ridge p = 127, n = 129: 4.6e-9 without.)
-		const bool refine = !(rss > kRefineTol * tss) || mr < kPivotWarn || df < 0.25 * (double)rank;
+		const bool refine = !(rss > kRefineTol * tss) || mr < kPivotWarn || df < 0.25 * (double)rank || glmnet_cancels;
 		const double dfm = (double)rank;
 		const double r2 = 1.0 - rss / tss;
 		const double fstat = ((tss - rss) / dfm) / (rss / df);

@@ -432,7 +432,7 @@ __global__ __launch_bounds__(NTHR, OCC) void solve_wide_kernel(WideArgs args) {
 		const double *sc = vec + 4 * P16;
 		double *core = args.core + g * (int64_t)(p + 6);
 		double *inf = (args.inference && args.compute_inference) ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
-		const double *rvec = args.refine_vec + g * (int64_t)(p + 2); // {sum w r^2, sum w r, X'Wr}
+		const double *rvec = args.refine_vec + g * (int64_t)refine_vec_len(p); // {sum w r^2, sum w r, X'Wr, centred yy}
 		const int64_t nrows = args.rule_counts ? args.rule_counts[g] : args.row_offsets[g + 1] - args.row_offsets[g];
 
 		// a record whose fit failed (or has no inference block): everything NaN, status in the last slot
@@ -488,10 +488,17 @@ __global__ __launch_bounds__(NTHR, OCC) void solve_wide_kernel(WideArgs args) {
 			continue;
 		}
 
-		double lam = 0.0;
+		// ridge penalty: `lam` goes into the factor; the refinement steps aim at `lam_rows`, glmnet's lambda with sd_y
+		// re-summed over the rows about the mean (uncentred moments of a nearly constant y cancel; such groups are queued)
+		double lam = 0.0, lam_rows = 0.0;
+		bool glmnet_cancels = false;
 		if (model == ANOFOX_HIP_MODEL_RIDGE) {
-			lam = args.alpha;
-			if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) lam = cnt * args.alpha / sqrt(cyy_c / cnt);
+			lam = lam_rows = args.alpha;
+			if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) {
+				lam = lam_rows = cnt * args.alpha / sqrt(cyy_c / cnt);
+				glmnet_cancels = !icpt && !(cyy_c * kGlmnetCancelRatio > syy);
+				if (MODE != MODE_PRIMARY && !icpt) lam_rows = cnt * args.alpha / sqrt(rvec[p + 2] / cnt);
+			}
 		}
 		const double tss = icpt ? cyy_c : syy;
 
@@ -521,7 +528,7 @@ __global__ __launch_bounds__(NTHR, OCC) void solve_wide_kernel(WideArgs args) {
 					if (j < p && l.live[j]) {
 						gj = rvec[2 + j];
 						if (icpt) gj -= (l.sv[j] / sw) * gs;
-						gj -= lam * core[j];
+						gj -= lam_rows * core[j];
 					}
 					l.bv[j] = gj;
 				}
@@ -585,7 +592,7 @@ __global__ __launch_bounds__(NTHR, OCC) void solve_wide_kernel(WideArgs args) {
 		const int n_par = rank + (icpt ? 1 : 0);
 		const double df = cnt - (double)n_par;
 		// (nearly square designs as well: see solve_tiles_impl.h)
-		const bool refine = (MODE == MODE_PRIMARY) && (!(rss > kRefineTolW * tss) || min_ratio < kPivotWarnW || df < 0.25 * (double)rank);
+		const bool refine = (MODE == MODE_PRIMARY) && (!(rss > kRefineTolW * tss) || min_ratio < kPivotWarnW || df < 0.25 * (double)rank || glmnet_cancels);
 		const double dfm = (double)rank;
 		const double r2 = 1.0 - rss / tss;
 		const double fstat = ((tss - rss) / dfm) / (rss / df);
@@ -680,7 +687,7 @@ __device__ __forceinline__ void dd_add(double &hi, double &lo, double ahi, doubl
 }
 
 // One workgroup per queued group, straight from the data with the record's current coefficients:
-//   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ... },  r = y - b0 - x'b  over the valid rows.
+//   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ..., sum w (y - ybar)^2 },  r = y - b0 - x'b  over the valid rows.
 // The residual and the two gradient sums are formed in double-double arithmetic (compensated dot products): with the
 // residual in working precision the refinement stalls at cond(X) * 1e-13 — 1e-9 .. 5e-9 on nearly square designs of
 // 40 .. 128 columns (cond 1e3 .. 2e4), measured in round 2 — while an extended-precision residual takes the same
@@ -709,6 +716,9 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 		__syncthreads();
 		const double b0 = args.fit_intercept ? core[p] : 0.0;
 		const double shift = (tid < p && args.fit_intercept) ? vec[2 * P16 + tid] : 0.0; // x at the first valid row
+		const double *sc = vec + 4 * P16;                                                 // {sy, syy, sw, cnt, first_y}
+		const double ybar = sc[0] / sc[2] + (args.fit_intercept ? sc[4] : 0.0);           // mean of y over the valid rows
+		double cyy = 0.0;
 		const double *mycol = tid < p ? args.x_table[tid] : nullptr;
 		const int64_t lo = args.row_offsets[g], hi = group_row_end(args, g);
 		double rss = 0.0, gs_h = 0.0, gs_l = 0.0, gj_h = 0.0, gj_l = 0.0;
@@ -746,6 +756,8 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 					wl = pl - (wh - ph);
 					rss = fma(wh, e, rss);
 					dd_add(gs_h, gs_l, wh, wl);
+					const double dy = yv - ybar;
+					cyy = fma(wv * dy, dy, cyy);
 				}
 			}
 			weh[tid] = wh;
@@ -768,17 +780,20 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 		}
 		for (int m = 32; m >= 1; m >>= 1) {
 			rss += __shfl_xor(rss, m, 64);
+			cyy += __shfl_xor(cyy, m, 64);
 			dd_add(gs_h, gs_l, __shfl_xor(gs_h, m, 64), __shfl_xor(gs_l, m, 64));
 		}
 		if ((tid & 63) == 0) {
+			part[12 + (tid >> 6)] = cyy;
 			part[tid >> 6] = rss;
 			part[4 + (tid >> 6)] = gs_h;
 			part[8 + (tid >> 6)] = gs_l;
 		}
 		__syncthreads();
-		double *out = args.refine_vec + g * (int64_t)(p + 2);
+		double *out = args.refine_vec + g * (int64_t)refine_vec_len(p);
 		if (tid == 0) {
 			out[0] = part[0] + part[1] + part[2] + part[3];
+			out[p + 2] = part[12] + part[13] + part[14] + part[15];
 			double h = part[4], l = part[8];
 			for (int w2 = 1; w2 < 4; ++w2) dd_add(h, l, part[4 + w2], part[8 + w2]);
 			out[1] = h + l;
