@@ -35,6 +35,11 @@
 // p = 14); T = 2: 1 (2 spills: 4.9 -> 8.6 ms at p = 24).  More waves per SIMD do not help either (80 VGPRs, 6 waves:
 // 1.79 against 1.82 ms at p = 9; 64 VGPRs spill).
 #define ANOFOX_MID_S (T == 1 ? 2 : 1)
+// what-if builds (never shipped: results are wrong): bit 0 = no row filter, 1 = no constant-column test, 2 = no side sums,
+// 3 = no MFMA, 4 = no centring
+#ifndef ANOFOX_MID_SKIP
+#define ANOFOX_MID_SKIP 0
+#endif
 
 namespace anofox {
 
@@ -51,7 +56,9 @@ __device__ __forceinline__ double mid_mask(double v, long long m) {
 
 // Which row of a 16-row step lane group kk holds in its m-th value: rows 2 kk, 2 kk + 1 of the first half, then the
 // same of the second half — so that one load instruction covers a contiguous 64-byte half line per column.
-__device__ __forceinline__ int mid_row(int kk, int m) { return 8 * (m >> 1) + 2 * kk + (m & 1); }
+// SEQ (the LDS-staged path below): the lane group's four rows are consecutive, rows 4 kk .. 4 kk + 3.
+template <bool SEQ>
+__device__ __forceinline__ int mid_row(int kk, int m) { return SEQ ? 4 * kk + m : 8 * (m >> 1) + 2 * kk + (m & 1); }
 
 // the lane's four rows of one column, all inside the group: two 16-byte loads (r0 = first row of the step)
 __device__ __forceinline__ void load4_full(mid_gptr_t col, int64_t r0, int kk, double (&v)[4]) {
@@ -63,7 +70,7 @@ __device__ __forceinline__ void load4_full(mid_gptr_t col, int64_t r0, int kk, d
 __device__ __forceinline__ void load4_tail(mid_gptr_t col, int64_t r0, int kk, int64_t hi, double (&v)[4]) {
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
-		const int64_t r = r0 + mid_row(kk, m);
+		const int64_t r = r0 + mid_row<false>(kk, m);
 		v[m] = col[r < hi ? r : hi - 1];
 	}
 }
@@ -79,12 +86,12 @@ struct MidState {
 };
 
 // One 16-row step of a wave.  ALLVALID: every row of the step passed the row filter (the common case) — no masks.
-template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID, bool AUX>
+template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID, bool AUX, bool SEQ>
 __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4], const double (&y)[4], const double (&w)[4],
                                          unsigned rowmask, int kk, int lj, bool is_one) {
 	if (!st.have_first) {
 		const int r = __ffs((int)rowmask) - 1; // first valid row of the group; mid_row(kk, m) == r
-		const int src = 16 * ((r >> 1) & 3) + lj, m = ((r >> 3) << 1) | (r & 1);
+		const int src = SEQ ? 16 * (r >> 2) + lj : 16 * ((r >> 1) & 3) + lj, m = SEQ ? (r & 3) : (((r >> 3) << 1) | (r & 1));
 #pragma unroll
 		for (int I = 0; I < T; ++I) {
 			const double mine = m == 0 ? x[I][0] : (m == 1 ? x[I][1] : (m == 2 ? x[I][2] : x[I][3]));
@@ -101,14 +108,14 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 	st.cnt += ALLVALID ? 16 : __popc(rowmask);
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
-		const long long rm = ALLVALID ? -1ll : -(long long)((rowmask >> mid_row(kk, m)) & 1u); // all ones when the row is valid
+		const long long rm = ALLVALID ? -1ll : -(long long)((rowmask >> mid_row<SEQ>(kk, m)) & 1u); // all ones when the row is valid
 		double d[T], a[T];
 #pragma unroll
 		for (int I = 0; I < T; ++I) {
 			const double dev = ALLVALID ? x[I][m] - st.first[I] : mid_mask(x[I][m] - st.first[I], rm); // deviation from the first valid row
-			d[I] = CENTER ? dev : (ALLVALID ? x[I][m] : mid_mask(x[I][m], rm));
+			d[I] = (CENTER && !(ANOFOX_MID_SKIP & 16)) ? dev : (ALLVALID ? x[I][m] : mid_mask(x[I][m], rm));
 			// constant-column predicate of ols.rs:76-87: |x - x_first| < 1e-10 on every valid row
-			st.ncmask |= !(fabs(dev) < 1e-10) ? (1u << I) : 0u;
+			if (!(ANOFOX_MID_SKIP & 2)) st.ncmask |= !(fabs(dev) < 1e-10) ? (1u << I) : 0u;
 		}
 		const double dy0 = AUX ? 0.0 : (CENTER ? y[m] - st.first_y : y[m]);
 		const double dy = ALLVALID ? dy0 : mid_mask(dy0, rm);
@@ -120,11 +127,12 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 		for (int I = 0; I < T; ++I) {
 #pragma unroll
 			for (int J = I; J < T; ++J) {
-				st.acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[J], st.acc[tile], 0, 0, 0);
+				if (!(ANOFOX_MID_SKIP & 8)) st.acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[J], st.acc[tile], 0, 0, 0);
+				else st.acc[tile][0] += a[I] + d[J];
 				++tile;
 			}
 		}
-		if (!AUX) {
+		if (!AUX && !(ANOFOX_MID_SKIP & 4)) {
 #pragma unroll
 			for (int I = 0; I < T; ++I) {
 				st.sx[I] += a[I];
@@ -140,11 +148,17 @@ __device__ __forceinline__ void mid_step(MidState<T> &st, const double (&x)[T][4
 
 // Row validity of one 16-row step starting at row r0 (ols.rs:59-66, wls.rs:76-86), then the step itself.  Common case
 // first: a full step whose 16 rows all pass.
-template <int T, bool WEIGHTED, bool CENTER, bool AUX>
+template <int T, bool WEIGHTED, bool CENTER, bool AUX, bool SEQ>
 __device__ __forceinline__ void mid_process_step(MidState<T> &st, const double (&x)[T][4], const double (&y)[4], const double (&w)[4],
                                                  int64_t r0, int64_t hi, int kk, int lj, bool is_one) {
 	// (AUX: y is one of the x columns here — the lane that holds it tests it)
 	bool ok_all = true;
+	if (ANOFOX_MID_SKIP & 1) {
+		if (r0 + 16 <= hi) {
+			mid_step<T, WEIGHTED, CENTER, true, AUX, SEQ>(st, x, y, w, 0xFFFFu, kk, lj, is_one);
+			return;
+		}
+	}
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
 		if (!AUX) ok_all = ok_all && isfinite(y[m]);
@@ -153,23 +167,23 @@ __device__ __forceinline__ void mid_process_step(MidState<T> &st, const double (
 		for (int I = 0; I < T; ++I) ok_all = ok_all && isfinite(x[I][m]);
 	}
 	if (r0 + 16 <= hi && __ballot(ok_all) == ~0ull) {
-		mid_step<T, WEIGHTED, CENTER, true, AUX>(st, x, y, w, 0xFFFFu, kk, lj, is_one);
+		mid_step<T, WEIGHTED, CENTER, true, AUX, SEQ>(st, x, y, w, 0xFFFFu, kk, lj, is_one);
 		return;
 	}
 	unsigned rowmask = 0; // bit = row of the step
 #pragma unroll
 	for (int m = 0; m < 4; ++m) {
-		bool ok = (AUX || isfinite(y[m])) && (r0 + mid_row(kk, m) < hi);
+		bool ok = (AUX || isfinite(y[m])) && (r0 + mid_row<SEQ>(kk, m) < hi);
 		if (WEIGHTED) ok = ok && isfinite(w[m]) && (w[m] > 0.0);
 #pragma unroll
 		for (int I = 0; I < T; ++I) ok = ok && isfinite(x[I][m]);
 		const unsigned long long b = __ballot(ok);
 #pragma unroll
-		for (int k = 0; k < 4; ++k) rowmask |= (((b >> (16 * k)) & 0xFFFFull) == 0xFFFFull) ? (1u << mid_row(k, m)) : 0u;
+		for (int k = 0; k < 4; ++k) rowmask |= (((b >> (16 * k)) & 0xFFFFull) == 0xFFFFull) ? (1u << mid_row<SEQ>(k, m)) : 0u;
 	}
 	rowmask = __builtin_amdgcn_readfirstlane(rowmask);
 	if (rowmask == 0u) return;
-	mid_step<T, WEIGHTED, CENTER, false, AUX>(st, x, y, w, rowmask, kk, lj, is_one);
+	mid_step<T, WEIGHTED, CENTER, false, AUX, SEQ>(st, x, y, w, rowmask, kk, lj, is_one);
 }
 
 template <int T, bool AUX>
@@ -352,14 +366,276 @@ __device__ __forceinline__ void mid_accumulate_rows(const WideArgs &args, int64_
 			const double (&x)[T][4] = xs[q];
 			const double (&y)[4] = ys[q];
 			const double (&w)[4] = ws[q];
-			mid_process_step<T, WEIGHTED, CENTER, AUX>(st, x, y, w, r0, hi, kk, lj, is_one);
+			mid_process_step<T, WEIGHTED, CENTER, AUX, false>(st, x, y, w, r0, hi, kk, lj, is_one);
 		}
 	}
 
 	mid_write_record<T, AUX>(st, real, rec, lane, p);
 }
 
-template <int T, bool WEIGHTED, bool CENTER, bool AUX>
+// ---- the same with the rows staged through a wave-private slice of LDS -------------------------------------------------
+// The loop above asks for 64 contiguous bytes per column and instruction, 128 S per trip; with 10..34 column streams per
+// wave DRAM sees short runs and the kernel stays at 4.4-4.8 TB/s where the narrow kernel (1 KiB per column and tile)
+// reaches 6.  Here a block is 64 consecutive rows: lane l loads row l of EVERY column (512 contiguous bytes per
+// instruction), D blocks are in flight per wave (D = 2: 1 KiB per column, T = 1; D = 1 for T = 2, whose 33 column
+// registers per block are all the VGPR file has room for), the block is written to LDS column by column (stride 66
+// doubles: conflict-free for the 8-byte writes and for the 16-byte fragment reads) and read back in MFMA fragment
+// layout, lane (kk, lj) taking rows 16 s + 4 kk .. + 3 of column 16 I + lj (two ds_read_b128).  The slice belongs to one
+// wavefront: no barrier; LDS operations of a wave execute in order.  y is column p of the slice, the weights p + 1.
+typedef double mid_dbl2a __attribute__((ext_vector_type(2)));
+__host__ __device__ constexpr int mid_lds_stride(int RL) { return 64 * RL + 2; } // 66 / 130 doubles: an odd number of 16-byte units
+// columns of a wave's slice: x, y, (w), and — unless every fragment column is an x column — a column of zeros and one of ones
+__host__ __device__ constexpr int mid_lds_columns(int p, bool weighted, int T) { return p + 1 + (weighted ? 1 : 0) + (p != 16 * T ? 2 : 0); }
+
+// One 16-row step of the LDS-staged loop: mid_step without the bookkeeping that loop does per block (first valid row,
+// row count), rows 4 kk + m, and for one column block (T = 1) the K-steps alternate between two accumulators — four
+// back-to-back MFMAs into one accumulator wait for each other (16 passes each), and with 2 waves per SIMD nobody else fills
+// the gap.
+template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID, bool AUX>
+__device__ __forceinline__ void mid_step_lds(MidState<T> &st, mid_dbl4 (&acc2)[T * (T + 1) / 2], double (&dmax)[T], const double (&x)[T][4],
+                                             const double (&y)[4], const double (&w)[4], unsigned rowmask, int kk) {
+#pragma unroll
+	for (int m = 0; m < 4; ++m) {
+		const long long rm = ALLVALID ? -1ll : -(long long)((rowmask >> (4 * kk + m)) & 1u); // all ones when the row is valid
+		double d[T], a[T];
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			const double dev = ALLVALID ? x[I][m] - st.first[I] : mid_mask(x[I][m] - st.first[I], rm); // deviation from the first valid row
+			d[I] = (CENTER && !(ANOFOX_MID_SKIP & 16)) ? dev : (ALLVALID ? x[I][m] : mid_mask(x[I][m], rm));
+			// constant-column predicate of ols.rs:76-87, |x - x_first| < 1e-10 on every valid row: the largest |deviation| per
+			// lane and column block is kept (one instruction; 0 on rows that do not take part) and tested once per group
+			if (!(ANOFOX_MID_SKIP & 2)) dmax[I] = fmax(dmax[I], fabs(dev));
+		}
+		const double dy0 = AUX ? 0.0 : (CENTER ? y[m] - st.first_y : y[m]);
+		const double dy = ALLVALID ? dy0 : mid_mask(dy0, rm);
+		const double wv = ALLVALID ? w[m] : mid_mask(w[m], rm);
+#pragma unroll
+		for (int I = 0; I < T; ++I) a[I] = WEIGHTED ? wv * d[I] : d[I];
+		int tile = 0;
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+#pragma unroll
+			for (int J = I; J < T; ++J) {
+				if (ANOFOX_MID_SKIP & 8) st.acc[tile][0] += a[I] + d[J];
+				else if (T == 1 && (m & 1)) acc2[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[J], acc2[tile], 0, 0, 0);
+				else st.acc[tile] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[J], st.acc[tile], 0, 0, 0);
+				++tile;
+			}
+		}
+		if (!AUX && !(ANOFOX_MID_SKIP & 4)) {
+#pragma unroll
+			for (int I = 0; I < T; ++I) {
+				st.sx[I] += a[I];
+				st.sxy[I] = fma(a[I], dy, st.sxy[I]);
+			}
+			const double wdy = WEIGHTED ? wv * dy : dy;
+			st.sy += wdy;
+			st.syy = fma(wdy, dy, st.syy);
+			if (WEIGHTED) st.sw += wv; // (unweighted: the row count, added once per block)
+		}
+	}
+}
+
+__device__ __forceinline__ unsigned mid_spread8(unsigned x) { // bit i of the low byte -> bit 2 i
+	x = (x | (x << 4)) & 0x0F0Fu;
+	x = (x | (x << 2)) & 0x3333u;
+	x = (x | (x << 1)) & 0x5555u;
+	return x;
+}
+
+// RL = rows per lane and block: 1 = 64-row blocks, 8-byte loads, D = 2 (T = 1) or 1 blocks in flight;
+//                                2 = 128-row blocks, 16-byte loads (1 KiB contiguous per column and instruction, what the narrow kernel asks for), D = 1
+// The row filter (ols.rs:59-66, wls.rs:76-86) runs on the loaded registers, where a lane holds ITS rows of every column:
+// one ballot per block says whether all of its rows pass, and then its 4 RL steps are straight-line code without masks.
+template <int T, bool WEIGHTED, bool CENTER, bool AUX, int RL>
+__device__ __forceinline__ void mid_accumulate_rows_lds(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
+                                                        const double *forced_first, int lane, double *buf) {
+	constexpr int NCOL = 16 * T + 2; // most columns a block can have: x (<= 16 T), y, w
+	constexpr int NT = T * (T + 1) / 2;
+	constexpr int D = (T == 1 && RL == 1) ? 2 : 1;
+	constexpr int RS = mid_lds_stride(RL);
+	constexpr int BR = 64 * RL; // rows per block
+	const int p = args.p;
+	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
+	const int kk = lane >> 4, lj = lane & 15;
+	const bool is_one = AUX && 16 * (T - 1) + lj == p + 1;
+	const bool is_y = AUX && 16 * (T - 1) + lj == p;
+	bool real[T], rd[T];
+	int ccol[T]; // the slice column behind fragment column 16 I + lj (x, or y in the AUX layout)
+#pragma unroll
+	for (int I = 0; I < T; ++I) {
+		const int c = 16 * I + lj;
+		real[I] = c < p;
+		rd[I] = real[I] || (AUX && c == p);
+		ccol[I] = rd[I] ? c : ((AUX && I == T - 1 && is_one) ? ncol + 1 : ncol);
+	}
+	MidState<T> st;
+	mid_init_state<T, AUX>(st, real, forced_first, lj, is_y);
+	mid_dbl4 acc2[NT];
+#pragma unroll
+	for (int t = 0; t < NT; ++t) acc2[t] = mid_dbl4{0.0, 0.0, 0.0, 0.0};
+	double dmax[T];
+#pragma unroll
+	for (int I = 0; I < T; ++I) dmax[I] = 0.0;
+	// two constant columns behind the data in the slice: zeros for the padding columns of the last block, ones for the AUX
+	// layout's column of ones — every lane reads its fragment from SOME column and no select follows the read
+	// (p = 16 T has neither padding columns nor room for the AUX layout: no lane reads them and the slice ends at ncol)
+	if (p != 16 * T) {
+		const int czero = ncol, cone = ncol + 1;
+#pragma unroll
+		for (int e = 0; e < RL; ++e) {
+			buf[czero * RS + RL * lane + e] = 0.0;
+			buf[cone * RS + RL * lane + e] = 1.0;
+		}
+	}
+
+	double reg[D][NCOL][RL];
+	// Every block issues the same NCOL loads — a load behind a branch of its own (column c exists?) makes the compiler
+	// wait for ALL outstanding loads, the prefetched block's included, before the first use; the slots past the last
+	// column read y again (the line is in L1) and are not written to LDS.
+	auto colp = [&](int c) -> mid_gptr_t {
+		const double *ptr = c < p ? args.x_table[c < kWideMaxP ? c : 0] : ((WEIGHTED && c == p + 1) ? args.w : args.y);
+		return (mid_gptr_t)(uintptr_t)ptr;
+	};
+	// all loads of a block in one arm of the wave-uniform full / tail branch (see above)
+	auto issue = [&](double (&r)[NCOL][RL], int64_t b) {
+		if (b + BR <= hi) {
+			const int64_t row = b + RL * lane;
+#pragma unroll
+			for (int c = 0; c < NCOL; ++c) {
+				if (RL == 2) {
+					const mid_dbl2u v = *reinterpret_cast<mid_gptr2_t>(colp(c) + row);
+					r[c][0] = v.x;
+					r[c][RL - 1] = v.y;
+				} else {
+					r[c][0] = colp(c)[row];
+				}
+			}
+		} else { // clamped; rows past the end fail the row filter below
+#pragma unroll
+			for (int c = 0; c < NCOL; ++c) {
+#pragma unroll
+				for (int e = 0; e < RL; ++e) {
+					const int64_t row = b + RL * lane + e;
+					r[c][e] = colp(c)[row < hi ? row : hi - 1];
+				}
+			}
+		}
+	};
+	// the fragments of step sidx: lane (kk, lj) takes rows 16 sidx + 4 kk .. + 3 of its columns
+	auto fragments = [&](int sidx, double (&x)[T][4], double (&y)[4], double (&w)[4]) {
+		const int ro = 16 * sidx + 4 * kk;
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			const mid_dbl2a a = *reinterpret_cast<const mid_dbl2a *>(buf + ccol[I] * RS + ro);
+			const mid_dbl2a c2 = *reinterpret_cast<const mid_dbl2a *>(buf + ccol[I] * RS + ro + 2);
+			x[I][0] = a.x;
+			x[I][1] = a.y;
+			x[I][2] = c2.x;
+			x[I][3] = c2.y;
+		}
+		if (!AUX) {
+			const mid_dbl2a a = *reinterpret_cast<const mid_dbl2a *>(buf + p * RS + ro);
+			const mid_dbl2a c2 = *reinterpret_cast<const mid_dbl2a *>(buf + p * RS + ro + 2);
+			y[0] = a.x; y[1] = a.y; y[2] = c2.x; y[3] = c2.y;
+		} else {
+			y[0] = y[1] = y[2] = y[3] = 0.0;
+		}
+		if (WEIGHTED) {
+			const mid_dbl2a a = *reinterpret_cast<const mid_dbl2a *>(buf + (p + 1) * RS + ro);
+			const mid_dbl2a c2 = *reinterpret_cast<const mid_dbl2a *>(buf + (p + 1) * RS + ro + 2);
+			w[0] = a.x; w[1] = a.y; w[2] = c2.x; w[3] = c2.y;
+		} else {
+			w[0] = w[1] = w[2] = w[3] = 1.0;
+		}
+	};
+	auto block = [&](double (&r)[NCOL][RL], int64_t b, int64_t b_next) {
+		// row filter on this lane's rows
+		bool ok[RL];
+#pragma unroll
+		for (int e = 0; e < RL; ++e) {
+			ok[e] = b + RL * lane + e < hi;
+			if (!(ANOFOX_MID_SKIP & 1)) {
+#pragma unroll
+				for (int c = 0; c < NCOL; ++c)
+					if (c < ncol) ok[e] = ok[e] && isfinite(r[c][e]) && (!(WEIGHTED && c == p + 1) || r[c][e] > 0.0);
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < NCOL; ++c) {
+			if (c < ncol) {
+				if (RL == 2) *reinterpret_cast<mid_dbl2a *>(buf + c * RS + 2 * lane) = mid_dbl2a{r[c][0], r[c][RL - 1]};
+				else buf[c * RS + lane] = r[c][0];
+			}
+		}
+		if (b_next < hi) issue(r, b_next);
+		__builtin_amdgcn_wave_barrier();
+		const unsigned long long v0 = __ballot(ok[0]), v1 = RL == 2 ? __ballot(ok[RL - 1]) : v0;
+		const bool all = (v0 & v1) == ~0ull;
+		if ((v0 | v1) != 0ull) {
+			if (!st.have_first) { // the first valid row of the group: every lane fetches its columns' values of that row
+				const int f0 = __ffsll((long long)v0) - 1, f1 = __ffsll((long long)v1) - 1;
+				int fr;
+				if (RL == 2) {
+					const int r0 = v0 ? 2 * f0 : 1 << 20, r1 = v1 ? 2 * f1 + 1 : 1 << 20;
+					fr = r0 < r1 ? r0 : r1;
+				} else {
+					fr = f0;
+				}
+#pragma unroll
+				for (int I = 0; I < T; ++I) st.first[I] = rd[I] ? buf[ccol[I] * RS + fr] : 0.0; // (constant columns are not shifted)
+				if (AUX) {
+					if (is_one) st.first[T - 1] = 0.0; // the column of ones is not shifted
+				} else {
+					st.first_y = buf[p * RS + fr];
+				}
+				st.have_first = true;
+			}
+			if (all) {
+				st.cnt += BR;
+#pragma unroll
+				for (int sidx = 0; sidx < 4 * RL; ++sidx) {
+					double x[T][4], y[4], w[4];
+					fragments(sidx, x, y, w);
+					mid_step_lds<T, WEIGHTED, CENTER, true, AUX>(st, acc2, dmax, x, y, w, 0xFFFFu, kk);
+				}
+			} else {
+				st.cnt += __popcll(v0) + (RL == 2 ? __popcll(v1) : 0);
+#pragma unroll
+				for (int sidx = 0; sidx < 4 * RL; ++sidx) {
+					unsigned rowmask;
+					if (RL == 2) rowmask = mid_spread8((unsigned)(v0 >> (8 * sidx)) & 0xFFu) | (mid_spread8((unsigned)(v1 >> (8 * sidx)) & 0xFFu) << 1);
+					else rowmask = (unsigned)(v0 >> (16 * sidx)) & 0xFFFFu;
+					if (rowmask == 0u) continue; // wave-uniform
+					double x[T][4], y[4], w[4];
+					fragments(sidx, x, y, w);
+					mid_step_lds<T, WEIGHTED, CENTER, false, AUX>(st, acc2, dmax, x, y, w, rowmask, kk);
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier(); // the reads above before the next block's writes
+	};
+#pragma unroll
+	for (int d = 0; d < D; ++d)
+		if (lo + BR * d < hi) issue(reg[d], lo + BR * d);
+	for (int64_t b = lo; b < hi; b += BR * D) {
+#pragma unroll
+		for (int d = 0; d < D; ++d) {
+			const int64_t bd = b + BR * d;
+			if (bd < hi) block(reg[d], bd, bd + BR * D); // wave-uniform
+		}
+	}
+	if (T == 1) {
+#pragma unroll
+		for (int t = 0; t < NT; ++t) st.acc[t] += acc2[t];
+	}
+#pragma unroll
+	for (int I = 0; I < T; ++I) st.ncmask |= !(dmax[I] < 1e-10) ? (1u << I) : 0u;
+	if (!AUX && !WEIGHTED) st.sw = 0.25 * (double)st.cnt; // every lane group adds its quarter: the record sums the four
+	mid_write_record<T, AUX>(st, real, rec, lane, p);
+}
+
+template <int T, bool WEIGHTED, bool CENTER, bool AUX, int LDSX> // LDSX: 0 = straight into fragment layout, 1 / 2 = through LDS, rows per lane
 __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const int lane = threadIdx.x & 63;
 	const int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -369,7 +645,15 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	if (args.seg_table && hi - lo > args.seg_rows) {
 		if (wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments)) return;
 	}
-	mid_accumulate_rows<T, WEIGHTED, CENTER, AUX>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), nullptr, lane);
+	double *rec = args.moments + gl * (int64_t)wide_record_len(T);
+	if (LDSX) {
+		extern __shared__ double mid_lds[];
+		const int ncol = args.p + 1 + (WEIGHTED ? 1 : 0);
+		constexpr int RLX = LDSX ? LDSX : 1;
+		mid_accumulate_rows_lds<T, WEIGHTED, CENTER, AUX, RLX>(args, lo, hi, rec, nullptr, lane, mid_lds + (threadIdx.x >> 6) * mid_lds_columns(args.p, WEIGHTED, T) * mid_lds_stride(RLX));
+	} else {
+		mid_accumulate_rows<T, WEIGHTED, CENTER, AUX>(args, lo, hi, rec, nullptr, lane);
+	}
 }
 
 // One wavefront per registered segment; every segment of a group uses the group's first valid row as its shift,
@@ -418,15 +702,38 @@ hipError_t launch_mid_T(const WideArgs &a, hipStream_t stream) {
 	const dim3 seg_grid((unsigned)((kSegMaxSegments + 3) / 4)); // idle unless some group exceeded seg_rows
 	static const bool aux_on = !(getenv("ANOFOX_MID_AUX") && atoi(getenv("ANOFOX_MID_AUX")) == 0); // A/B switch
 	const bool aux = aux_on && a.p + 2 <= 16 * T; // room for y and the ones in the last block
+	// The rows are loaded straight into fragment layout (0) or staged through LDS in 64-row (1) / 128-row (2) blocks.  By
+	// measurement (100 000 groups x 1000 rows, profiles/r03_mid_paths.txt): 128-row blocks win at p = 12 .. 16 while two
+	// workgroups' slices fit a CU (4.6-4.9 against 4.4-4.6 TB/s), 64-row blocks at p >= 29 (4.2-4.4 against 3.9-4.3), the
+	// direct loads elsewhere (p <= 11: the staged loop always issues 18 column loads; 17 <= p <= 28: three tiles of MFMAs
+	// set the pace and the fewer VGPRs of the direct loop keep one more wave per SIMD).  ANOFOX_MID_LDS=0/1/2 forces one.
+	static const int forced = getenv("ANOFOX_MID_LDS") ? atoi(getenv("ANOFOX_MID_LDS")) : -1;
+	int ldsx = 0;
+	if (T == 1 && a.p >= 12 && 4 * (size_t)mid_lds_columns(a.p, weighted, T) * mid_lds_stride(2) * sizeof(double) <= 80 * 1024) ldsx = 2;
+	if (T == 2 && a.p >= 29) ldsx = 1;
+	if (forced >= 0 && forced <= 2) ldsx = forced;
+	const size_t lds_bytes = 4 * (size_t)mid_lds_columns(a.p, weighted, T) * mid_lds_stride(ldsx == 2 ? 2 : 1) * sizeof(double); // 4 waves' slices
+	static const bool attr_set = [] {
+#define ANOFOX_MID_ATTR(W, C, X) \
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_mid_kernel<T, W, C, X, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_mid_kernel<T, W, C, X, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+		ANOFOX_MID_ATTR(true, true, true); ANOFOX_MID_ATTR(true, true, false); ANOFOX_MID_ATTR(true, false, true); ANOFOX_MID_ATTR(true, false, false);
+		ANOFOX_MID_ATTR(false, true, true); ANOFOX_MID_ATTR(false, true, false); ANOFOX_MID_ATTR(false, false, true); ANOFOX_MID_ATTR(false, false, false);
+#undef ANOFOX_MID_ATTR
+		return true;
+	}();
+	(void)attr_set;
+#define ANOFOX_MID_LAUNCH2(W, C, X)                                                                              \
+	do {                                                                                                         \
+		if (ldsx == 2) hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C, X, 2>), grid, block, lds_bytes, stream, a); \
+		else if (ldsx == 1) hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C, X, 1>), grid, block, lds_bytes, stream, a); \
+		else hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C, X, 0>), grid, block, 0, stream, a);             \
+		if (a.seg_table) hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C, X>), seg_grid, block, 0, stream, a); \
+	} while (0)
 #define ANOFOX_MID_LAUNCH(W, C)                                                                                  \
 	do {                                                                                                         \
-		if (aux) {                                                                                               \
-			hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C, true>), grid, block, 0, stream, a);               \
-			if (a.seg_table) hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C, true>), seg_grid, block, 0, stream, a); \
-		} else {                                                                                                 \
-			hipLaunchKernelGGL((accumulate_mid_kernel<T, W, C, false>), grid, block, 0, stream, a);              \
-			if (a.seg_table) hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C, false>), seg_grid, block, 0, stream, a); \
-		}                                                                                                        \
+		if (aux) ANOFOX_MID_LAUNCH2(W, C, true);                                                                 \
+		else ANOFOX_MID_LAUNCH2(W, C, false);                                                                    \
 	} while (0)
 	if (weighted) {
 		if (center) ANOFOX_MID_LAUNCH(true, true);
@@ -436,6 +743,7 @@ hipError_t launch_mid_T(const WideArgs &a, hipStream_t stream) {
 		else ANOFOX_MID_LAUNCH(false, false);
 	}
 #undef ANOFOX_MID_LAUNCH
+#undef ANOFOX_MID_LAUNCH2
 	return hipGetLastError();
 }
 
