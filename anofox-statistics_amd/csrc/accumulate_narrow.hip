@@ -20,6 +20,11 @@
 // that is idle otherwise); the wave that finishes a group's last segment merges the segment records, moving
 // each to the group's shift.  1 x 50M x 8 went from 698 ms to the HBM-bound time.
 //
+// (Measured and removed in round 3: a resident grid whose waves draw groups from a counter and run one loop over the tiles of
+// all their groups, requesting the next group's first tile before the current group's reduction — 12.06-12.09 ms against
+// 11.96-12.05 ms per 1M x 1000 x 8 step; the group-start latency is not what holds the kernel at 6.0 TB/s.  A draw per
+// group (a million atomics on one address) cost 2.4 ms by itself.  profiles/r03_hbm_read_variants.txt.)
+//
 // Roofline: HBM-bound.  Algorithmic bytes per row 8(p+1) (+8 with weights); 63 f64 VALU ops per row at
 // p = 8 (~20 % of the f64 vector rate at the HBM-bound row rate).
 #include <stdlib.h>
@@ -41,167 +46,173 @@ __device__ __forceinline__ dbl2u load2(const double *p) {
 	return *reinterpret_cast<const dbl2u *>(p);
 }
 
-// The rows [lo, hi) of one group (or of one segment of a very large group) -> one moment record at `rec`.
-template <int P, bool WEIGHTED, bool CENTER, bool PREFETCH>
-__device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t lo, int64_t hi, double *rec, int lane) {
-	using L = MomentLayout<P>;
-	constexpr int Z = L::Z;
-	constexpr int ZZ = L::ZZ;
+// the loads of one 128-row tile, in flight or landed: rows 2 lane and 2 lane + 1 of every column
+template <int Z>
+struct NarrowTile {
+	double n0[Z], n1[Z], nw0, nw1;
+};
 
+template <int P, bool WEIGHTED>
+__device__ __forceinline__ void narrow_load_tile(const BatchArgs &args, int64_t base, int64_t hi, int lane, NarrowTile<P + 1> &t) {
+	const int64_t r0 = base + 2 * lane;
+	// A group's last, partial tile is loaded like a full one whenever the ARRAYS reach that far (n_rows): the rows past the
+	// group's end belong to the next group, are masked by the caller, and are in cache for the wave that owns them; only
+	// the last rows of the whole batch take the clamped path.
+	if (base + 128 <= hi || base + 128 <= args.n_rows) { // one 16-byte load per column
+#pragma unroll
+		for (int j = 0; j < P; ++j) {
+			const dbl2u v = load2<ANOFOX_NARROW_NT>(args.x[j] + r0);
+			t.n0[j] = v.x;
+			t.n1[j] = v.y;
+		}
+		{
+			const dbl2u v = load2<ANOFOX_NARROW_NT>(args.y + r0);
+			t.n0[P] = v.x;
+			t.n1[P] = v.y;
+		}
+		if (WEIGHTED) {
+			const dbl2u v = load2<ANOFOX_NARROW_NT>(args.w + r0);
+			t.nw0 = v.x;
+			t.nw1 = v.y;
+		}
+	} else { // ragged tail: unconditional 8-byte loads from clamped (valid) rows; a guarded load per element
+		// would sit behind its own branch and wait.  Rows past the end are masked by in0 / in1 in the caller.
+		const int64_t c0 = r0 < hi ? r0 : hi - 1, c1 = r0 + 1 < hi ? r0 + 1 : hi - 1;
+#pragma unroll
+		for (int j = 0; j < P; ++j) {
+			t.n0[j] = args.x[j][c0];
+			t.n1[j] = args.x[j][c1];
+		}
+		t.n0[P] = args.y[c0];
+		t.n1[P] = args.y[c1];
+		if (WEIGHTED) {
+			t.nw0 = args.w[c0];
+			t.nw1 = args.w[c1];
+		}
+	}
+}
+
+// The per-lane partial moments of one group while its tiles stream through.
+template <int P>
+struct NarrowAcc {
+	static constexpr int Z = P + 1;
+	static constexpr int ZZ = Z * (Z + 1) / 2;
 	double s[Z];
 	double q[ZZ];
-	double sw = 0.0;
-#pragma unroll
-	for (int a = 0; a < Z; ++a) s[a] = 0.0;
-#pragma unroll
-	for (int k = 0; k < ZZ; ++k) q[k] = 0.0;
-
+	double sw;
 	double first[Z]; // wave-uniform: z at the first valid row
-#pragma unroll
-	for (int a = 0; a < Z; ++a) first[a] = 0.0;
-	bool have_first = false;
-	int cnt = 0;
-	unsigned mask = 0;
+	bool have_first;
+	int cnt;
+	unsigned mask;
 	// CENTER: the constant-column test (|x - x_first| < 1e-10 on every valid row, ols.rs:76-87) keeps the largest
 	// |d| per column and lane — d is already there, and 0 on rows that do not take part — and is decided once per
 	// group; a ballot per column and tile (the version without intercept below) cost 8 vector + 4 scalar
 	// instructions per column and tile, a fifth of the kernel's instructions
 	double dmax[P];
-#pragma unroll
-	for (int j = 0; j < P; ++j) dmax[j] = 0.0;
+};
 
-	// the loads of tile t + 1 are issued before the arithmetic of tile t (PREFETCH), so that a wave always has
-	// one tile of loads in flight; all loads of a tile sit in one arm of the (wave-uniform) full / ragged branch
-	double n0[Z], n1[Z], nw0 = 1.0, nw1 = 1.0;
-	auto load_tile = [&](int64_t base) {
-		const int64_t r0 = base + 2 * lane;
-		if (base + 128 <= hi) { // full tile: one 16-byte load per column
+template <int P>
+__device__ __forceinline__ void narrow_acc_init(NarrowAcc<P> &c) {
+	constexpr int Z = P + 1, ZZ = Z * (Z + 1) / 2;
 #pragma unroll
-			for (int j = 0; j < P; ++j) {
-				const dbl2u v = load2<ANOFOX_NARROW_NT>(args.x[j] + r0);
-				n0[j] = v.x;
-				n1[j] = v.y;
-			}
-			{
-				const dbl2u v = load2<ANOFOX_NARROW_NT>(args.y + r0);
-				n0[P] = v.x;
-				n1[P] = v.y;
-			}
-			if (WEIGHTED) {
-				const dbl2u v = load2<ANOFOX_NARROW_NT>(args.w + r0);
-				nw0 = v.x;
-				nw1 = v.y;
-			}
-		} else { // ragged tail: unconditional 8-byte loads from clamped (valid) rows; a guarded load per element
-			// would sit behind its own branch and wait.  Rows past the end are masked by in0 / in1 below.
-			const int64_t c0 = r0 < hi ? r0 : hi - 1, c1 = r0 + 1 < hi ? r0 + 1 : hi - 1;
+	for (int a = 0; a < Z; ++a) c.s[a] = c.first[a] = 0.0;
 #pragma unroll
-			for (int j = 0; j < P; ++j) {
-				n0[j] = args.x[j][c0];
-				n1[j] = args.x[j][c1];
-			}
-			n0[P] = args.y[c0];
-			n1[P] = args.y[c1];
-			if (WEIGHTED) {
-				nw0 = args.w[c0];
-				nw1 = args.w[c1];
-			}
-		}
-	};
-	if (PREFETCH && lo < hi) load_tile(lo);
-	for (int64_t base = lo; base < hi; base += 128) {
-		const int64_t r0 = base + 2 * lane;
-		if (!PREFETCH) load_tile(base);
-		double z0[Z], z1[Z];
-		double w0 = 1.0, w1 = 1.0;
+	for (int k = 0; k < ZZ; ++k) c.q[k] = 0.0;
+	c.sw = 0.0;
+	c.have_first = false;
+	c.cnt = 0;
+	c.mask = 0;
 #pragma unroll
-		for (int a = 0; a < Z; ++a) {
-			z0[a] = n0[a];
-			z1[a] = n1[a];
-		}
-		if (WEIGHTED) {
-			w0 = nw0;
-			w1 = nw1;
-		}
-		const bool in0 = r0 < hi, in1 = r0 + 1 < hi;
-		if (PREFETCH && base + 128 < hi) load_tile(base + 128);
+	for (int j = 0; j < P; ++j) c.dmax[j] = 0.0;
+}
 
-		// row filter: everything finite (and w > 0), ols.rs:59-66 / wls.rs:76-86
-		bool v0 = in0, v1 = in1;
+// One 128-row tile (this lane: rows r0 and r0 + 1, values z0 / z1, weights w0 / w1) into the partial moments.
+template <int P, bool WEIGHTED, bool CENTER>
+__device__ __forceinline__ void narrow_tile_compute(NarrowAcc<P> &c, const double (&z0)[P + 1], const double (&z1)[P + 1], double w0, double w1,
+                                                    int64_t r0, int64_t hi) {
+	constexpr int Z = P + 1;
+	const bool in0 = r0 < hi, in1 = r0 + 1 < hi;
+	// row filter: everything finite (and w > 0), ols.rs:59-66 / wls.rs:76-86
+	bool v0 = in0, v1 = in1;
 #pragma unroll
-		for (int a = 0; a < Z; ++a) {
-			v0 = v0 && isfinite(z0[a]);
-			v1 = v1 && isfinite(z1[a]);
-		}
-		if (WEIGHTED) {
-			v0 = v0 && (w0 > 0.0) && isfinite(w0);
-			v1 = v1 && (w1 > 0.0) && isfinite(w1);
-		}
+	for (int a = 0; a < Z; ++a) {
+		v0 = v0 && isfinite(z0[a]);
+		v1 = v1 && isfinite(z1[a]);
+	}
+	if (WEIGHTED) {
+		v0 = v0 && (w0 > 0.0) && isfinite(w0);
+		v1 = v1 && (w1 > 0.0) && isfinite(w1);
+	}
 
-		const unsigned long long b0 = __ballot(v0);
-		const unsigned long long b1 = __ballot(v1);
-		const unsigned long long bany = b0 | b1;
-		if (bany == 0ull) continue; // no valid row in this tile (wave-uniform)
+	const unsigned long long b0 = __ballot(v0);
+	const unsigned long long b1 = __ballot(v1);
+	const unsigned long long bany = b0 | b1;
+	if (bany == 0ull) return; // no valid row in this tile (wave-uniform)
 
-		if (!have_first) {
-			const int fl = __ffsll((long long)bany) - 1; // lowest lane with a valid row = lowest row index
+	if (!c.have_first) {
+		const int fl = __ffsll((long long)bany) - 1; // lowest lane with a valid row = lowest row index
 #pragma unroll
-			for (int a = 0; a < Z; ++a) first[a] = readlane_f64(v0 ? z0[a] : z1[a], fl);
-			have_first = true;
-		}
-		cnt += __popcll(b0) + __popcll(b1);
+		for (int a = 0; a < Z; ++a) c.first[a] = readlane_f64(v0 ? z0[a] : z1[a], fl);
+		c.have_first = true;
+	}
+	c.cnt += __popcll(b0) + __popcll(b1);
 
-		// constant-column test against the first valid row: |x - x_first| >= 1e-10 anywhere -> not constant
-		if (!CENTER) {
+	// constant-column test against the first valid row: |x - x_first| >= 1e-10 anywhere -> not constant
+	if (!CENTER) {
 #pragma unroll
-			for (int j = 0; j < P; ++j) {
-				const unsigned long long nc = __ballot((v0 && !(fabs(z0[j] - first[j]) < 1e-10)) ||
-				                                       (v1 && !(fabs(z1[j] - first[j]) < 1e-10)));
-				mask |= (nc != 0ull) ? (1u << j) : 0u;
-			}
-		}
-
-		double d0[Z], d1[Z];
-#pragma unroll
-		for (int a = 0; a < Z; ++a) {
-			const double sh = CENTER ? first[a] : 0.0;
-			d0[a] = v0 ? z0[a] - sh : 0.0;
-			d1[a] = v1 ? z1[a] - sh : 0.0;
-		}
-		if (CENTER) {
-#pragma unroll
-			for (int j = 0; j < P; ++j) dmax[j] = fmax(dmax[j], fmax(fabs(d0[j]), fabs(d1[j])));
-		}
-		const double ww0 = v0 ? w0 : 0.0;
-		const double ww1 = v1 ? w1 : 0.0;
-		sw += ww0 + ww1;
-#pragma unroll
-		for (int a = 0; a < Z; ++a) {
-			const double wd0 = WEIGHTED ? ww0 * d0[a] : d0[a];
-			const double wd1 = WEIGHTED ? ww1 * d1[a] : d1[a];
-			s[a] += wd0 + wd1;
-#pragma unroll
-			for (int b = a; b < Z; ++b) {
-				const int k = a * Z - a * (a - 1) / 2 + (b - a);
-				q[k] = fma(wd0, d0[b], q[k]);
-				q[k] = fma(wd1, d1[b], q[k]);
-			}
+		for (int j = 0; j < P; ++j) {
+			const unsigned long long nc = __ballot((v0 && !(fabs(z0[j] - c.first[j]) < 1e-10)) ||
+			                                       (v1 && !(fabs(z1[j] - c.first[j]) < 1e-10)));
+			c.mask |= (nc != 0ull) ? (1u << j) : 0u;
 		}
 	}
 
+	double d0[Z], d1[Z];
+#pragma unroll
+	for (int a = 0; a < Z; ++a) {
+		const double sh = CENTER ? c.first[a] : 0.0;
+		d0[a] = v0 ? z0[a] - sh : 0.0;
+		d1[a] = v1 ? z1[a] - sh : 0.0;
+	}
 	if (CENTER) {
 #pragma unroll
-		for (int j = 0; j < P; ++j) mask |= (__ballot(!(dmax[j] < 1e-10)) != 0ull) ? (1u << j) : 0u;
+		for (int j = 0; j < P; ++j) c.dmax[j] = fmax(c.dmax[j], fmax(fabs(d0[j]), fabs(d1[j])));
 	}
-	// ---- cross-lane reduction: transposing butterfly, moment k lands on lane k ----
+	const double ww0 = v0 ? w0 : 0.0;
+	const double ww1 = v1 ? w1 : 0.0;
+	c.sw += ww0 + ww1;
+#pragma unroll
+	for (int a = 0; a < Z; ++a) {
+		const double wd0 = WEIGHTED ? ww0 * d0[a] : d0[a];
+		const double wd1 = WEIGHTED ? ww1 * d1[a] : d1[a];
+		c.s[a] += wd0 + wd1;
+#pragma unroll
+		for (int b = a; b < Z; ++b) {
+			const int k = a * Z - a * (a - 1) / 2 + (b - a);
+			c.q[k] = fma(wd0, d0[b], c.q[k]);
+			c.q[k] = fma(wd1, d1[b], c.q[k]);
+		}
+	}
+}
+
+// The group's record: cross-lane sums (transposing butterfly, moment k lands on lane k), then the wave-uniform extras.
+template <int P, bool CENTER>
+__device__ __forceinline__ void narrow_acc_finish(NarrowAcc<P> &c, double *rec, int lane) {
+	using L = MomentLayout<P>;
+	constexpr int Z = L::Z;
+	constexpr int ZZ = L::ZZ;
+	if (CENTER) {
+#pragma unroll
+		for (int j = 0; j < P; ++j) c.mask |= (__ballot(!(c.dmax[j] < 1e-10)) != 0ull) ? (1u << j) : 0u;
+	}
 	double v[64];
 #pragma unroll
 	for (int k = 0; k < 64; ++k) v[k] = 0.0;
 #pragma unroll
-	for (int a = 0; a < Z; ++a) v[L::OFF_S + a] = s[a];
+	for (int a = 0; a < Z; ++a) v[L::OFF_S + a] = c.s[a];
 #pragma unroll
-	for (int k = 0; k < ZZ; ++k) v[L::OFF_Q + k] = q[k];
-	v[L::OFF_SW] = sw;
+	for (int k = 0; k < ZZ; ++k) v[L::OFF_Q + k] = c.q[k];
+	v[L::OFF_SW] = c.sw;
 
 	transpose_reduce64(v, lane);
 
@@ -210,10 +221,39 @@ __device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t l
 	// wave-uniform extras: first[], cnt, mask
 	double e = 0.0;
 #pragma unroll
-	for (int a = 0; a < Z; ++a) e = (lane == a) ? first[a] : e;
-	e = (lane == Z) ? (double)cnt : e;
-	e = (lane == Z + 1) ? (double)mask : e;
+	for (int a = 0; a < Z; ++a) e = (lane == a) ? c.first[a] : e;
+	e = (lane == Z) ? (double)c.cnt : e;
+	e = (lane == Z + 1) ? (double)c.mask : e;
 	if (lane < Z + 2) rec[L::KRED + lane] = e;
+}
+
+// The rows [lo, hi) of one group (or of one segment of a very large group) -> one moment record at `rec`.
+template <int P, bool WEIGHTED, bool CENTER, bool PREFETCH>
+__device__ __forceinline__ void accumulate_rows(const BatchArgs &args, int64_t lo, int64_t hi, double *rec, int lane) {
+	constexpr int Z = P + 1;
+	NarrowAcc<P> c;
+	narrow_acc_init<P>(c);
+	NarrowTile<Z> t;
+	// the loads of tile t + 1 are issued before the arithmetic of tile t (PREFETCH), so that a wave always has
+	// one tile of loads in flight; all loads of a tile sit in one arm of the (wave-uniform) full / ragged branch
+	if (PREFETCH && lo < hi) narrow_load_tile<P, WEIGHTED>(args, lo, hi, lane, t);
+	for (int64_t base = lo; base < hi; base += 128) {
+		if (!PREFETCH) narrow_load_tile<P, WEIGHTED>(args, base, hi, lane, t);
+		double z0[Z], z1[Z];
+		double w0 = 1.0, w1 = 1.0;
+#pragma unroll
+		for (int a = 0; a < Z; ++a) {
+			z0[a] = t.n0[a];
+			z1[a] = t.n1[a];
+		}
+		if (WEIGHTED) {
+			w0 = t.nw0;
+			w1 = t.nw1;
+		}
+		if (PREFETCH && base + 128 < hi) narrow_load_tile<P, WEIGHTED>(args, base + 128, hi, lane, t);
+		narrow_tile_compute<P, WEIGHTED, CENTER>(c, z0, z1, w0, w1, base + 2 * lane, hi);
+	}
+	narrow_acc_finish<P, CENTER>(c, rec, lane);
 }
 
 __device__ __forceinline__ SegHeader *seg_header(void *t) { return static_cast<SegHeader *>(t); }
@@ -221,13 +261,9 @@ __device__ __forceinline__ SegBigGroup *seg_big(void *t) { return reinterpret_ca
 __device__ __forceinline__ SegEntry *seg_entries(void *t) { return reinterpret_cast<SegEntry *>(seg_big(t) + kSegMaxBig); }
 __device__ __forceinline__ double *seg_records(void *t) { return reinterpret_cast<double *>(seg_entries(t) + kSegMaxSegments); }
 
-// One group per wavefront: accumulate it, or register it for row splitting when it is very large.
-template <int P, bool WEIGHTED, bool CENTER, bool PF>
-__device__ __forceinline__ void accumulate_group(const BatchArgs &args, int64_t g, int lane) {
-	using L = MomentLayout<P>;
-	const int64_t lo = args.row_offsets[g];
-	const int64_t hi = group_row_end(args, g);
-	if (args.seg_table && hi - lo > args.seg_rows) {
+// A very large group is handed to accumulate_segments_kernel in pieces; false: it stays with the calling wavefront.
+__device__ __forceinline__ bool narrow_register_big_group(const BatchArgs &args, int64_t g, int64_t lo, int64_t hi, int lane) {
+	{
 		// a single wavefront streams at ~5 GB/s: hand the group to accumulate_segments_kernel in pieces (unless the
 		// tables are full, which only happens when the caller understated n_rows: then it stays with this wave)
 		SegHeader *h = seg_header(args.seg_table);
@@ -254,9 +290,19 @@ __device__ __forceinline__ void accumulate_group(const BatchArgs &args, int64_t 
 				if (slot < 0) e.hi = e.lo; // reserved without a group slot: empty, unclaimed
 				seg_entries(args.seg_table)[base + k] = e;
 			}
-			if (slot >= 0) return;
+			if (slot >= 0) return true;
 		}
 	}
+	return false;
+}
+
+// One group per wavefront: accumulate it, or register it for row splitting when it is very large.
+template <int P, bool WEIGHTED, bool CENTER, bool PF>
+__device__ __forceinline__ void accumulate_group(const BatchArgs &args, int64_t g, int lane) {
+	using L = MomentLayout<P>;
+	const int64_t lo = args.row_offsets[g];
+	const int64_t hi = group_row_end(args, g);
+	if (args.seg_table && hi - lo > args.seg_rows && narrow_register_big_group(args, g, lo, hi, lane)) return;
 	accumulate_rows<P, WEIGHTED, CENTER, PF>(args, lo, hi, args.moments + g * (int64_t)L::REC, lane);
 }
 
