@@ -648,7 +648,6 @@ __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	double *rec = args.moments + gl * (int64_t)wide_record_len(T);
 	if (LDSX) {
 		extern __shared__ double mid_lds[];
-		const int ncol = args.p + 1 + (WEIGHTED ? 1 : 0);
 		constexpr int RLX = LDSX ? LDSX : 1;
 		mid_accumulate_rows_lds<T, WEIGHTED, CENTER, AUX, RLX>(args, lo, hi, rec, nullptr, lane, mid_lds + (threadIdx.x >> 6) * mid_lds_columns(args.p, WEIGHTED, T) * mid_lds_stride(RLX));
 	} else {

@@ -25,6 +25,10 @@ struct AnofoxHipContext {
 	// small auxiliary device buffer (t-quantile memo of the predict kernel)
 	void *aux = nullptr;
 	size_t aux_bytes = 0;
+	// run_wide_batch with several slabs of groups: the solve / refinement kernels of slab k run on this stream while the
+	// main stream accumulates slab k + 1 (two moment buffers); events per buffer parity
+	hipStream_t solve_stream = nullptr;
+	hipEvent_t slab_acc_done[2] = {nullptr, nullptr}, slab_solve_done[2] = {nullptr, nullptr};
 	const int32_t *last_refine_count = nullptr; // device address of the most recent launch's queue counter
 	hipEvent_t gate_wait = nullptr, gate_record = nullptr; // anofox_hip_context_set_accumulate_gate
 	// set around a fit call by the window-frame path (frames.hip): group g owns rows [row_offsets[g], frame_ends[g])

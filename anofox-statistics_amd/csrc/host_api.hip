@@ -71,11 +71,22 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	const bool mid = solve_mid_supports((int)p);
 	static const bool mid_acc_on = !(getenv("ANOFOX_MID_ACC") && atoi(getenv("ANOFOX_MID_ACC")) == 0); // A/B switch for measurements
 	const bool mid_acc = mid_acc_on && accumulate_mid_supports((int)p);
+	// Several slabs: slab k's solve / refinement kernels run on a second stream while the main stream accumulates slab k + 1
+	// into the other moment buffer.  Measured (profiles/r03_slab_overlap.txt): the time between the accumulate kernels
+	// drops (cfg5: 5.05 -> 1.66 ms per step) but the accumulate kernels stretch by almost as much (69.7 -> 72.3 ms) — the
+	// one-wavefront-per-group solve keeps the CUs busy, it is not idle time to hide: 74.7 -> 73.9 ms per cfg5 step, nothing
+	// at n = 1000.  ANOFOX_WIDE_OVERLAP=0: everything on the one stream, as for a single slab.
+	static const bool overlap_on = !(getenv("ANOFOX_WIDE_OVERLAP") && atoi(getenv("ANOFOX_WIDE_OVERLAP")) == 0);
+	const bool overlap = overlap_on && G > slab;
+	const int n_buf = overlap ? 2 : 1;
 	// very large groups are split into row segments (accumulate_mid.hip: a wave each; accumulate_wide.hip: a workgroup each)
 	const size_t b_seg = align_up(mid_acc ? wide_seg_table_bytes(T, kSegMaxBig, kSegMaxSegments)
 	                                      : wide_seg_table_bytes(T, kWideSegMaxBig, kWideSegMaxSegments), 256);
-	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, b_mom + b_rss + b_lst + 256 + kTcritTableBytes + b_seg, "workspace", e)) return false;
+	// workspace: moments x n_buf | refine vectors (all groups) | refine list x n_buf | counters (256 B) x n_buf | t table | segment table
+	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, n_buf * (b_mom + b_lst + 256) + b_rss + kTcritTableBytes + b_seg, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
+	char *const w_rss = base + n_buf * b_mom, *const w_lst = w_rss + b_rss, *const w_cnt = w_lst + n_buf * b_lst;
+	char *const w_tcrit = w_cnt + n_buf * 256, *const w_seg = w_tcrit + kTcritTableBytes;
 
 	WideArgs a;
 	memset(&a, 0, sizeof a);
@@ -91,12 +102,8 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.hc_type = (int)opt.hc_type;
 	a.confidence_level = opt.confidence_level;
 	a.alpha = opt.alpha;
-	a.moments = (double *)base;
-	a.refine_vec = (double *)(base + b_mom);
-	a.refine_list = (int32_t *)(base + b_mom + b_rss);
-	a.refine_count = (int32_t *)(base + b_mom + b_rss + b_lst);
-	ctx->last_refine_count = a.refine_count;
-	a.tcrit_table = base + b_mom + b_rss + b_lst + 256;
+	a.refine_vec = (double *)w_rss;
+	a.tcrit_table = w_tcrit;
 	a.core = d_core;
 	a.inference = opt.compute_inference ? d_inf : nullptr;
 	a.rule_counts = d_rule_counts;
@@ -105,12 +112,29 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.no_fast_path = wide_fast_on ? 0 : 1;
 
 	hipStream_t st = ctx->stream;
-	a.seg_table = base + b_mom + b_rss + b_lst + 256 + kTcritTableBytes;
+	hipStream_t ss = st; // the stream of the solve / refinement kernels
+	if (overlap) {
+		if (!ctx->solve_stream && hip_fail(hipStreamCreateWithFlags(&ctx->solve_stream, hipStreamNonBlocking), "hipStreamCreate", e)) return false;
+		for (int b = 0; b < 2; ++b) {
+			if (!ctx->slab_acc_done[b] && hip_fail(hipEventCreateWithFlags(&ctx->slab_acc_done[b], hipEventDisableTiming), "hipEventCreate", e)) return false;
+			if (!ctx->slab_solve_done[b] && hip_fail(hipEventCreateWithFlags(&ctx->slab_solve_done[b], hipEventDisableTiming), "hipEventCreate", e)) return false;
+		}
+		ss = ctx->solve_stream;
+	}
+	a.seg_table = w_seg;
 	a.seg_rows = mid_acc ? seg_rows_for(n_rows) : wide_seg_rows_for(n_rows);
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
-	for (int64_t g0 = 0; g0 < G; g0 += slab) {
+	int64_t k_slab = 0;
+	for (int64_t g0 = 0; g0 < G; g0 += slab, ++k_slab) {
+		const int buf = overlap ? (int)(k_slab & 1) : 0;
 		a.group_base = g0;
 		a.n_groups = (G - g0 < slab) ? G - g0 : slab;
+		a.moments = (double *)(base + buf * b_mom);
+		a.refine_list = (int32_t *)(w_lst + buf * b_lst);
+		a.refine_count = (int32_t *)(w_cnt + buf * 256);
+		ctx->last_refine_count = a.refine_count;
+		// this buffer's previous tenant (slab k - 2) must be through its solve before the buffer is written again
+		if (overlap && k_slab >= 2 && hip_fail(hipStreamWaitEvent(st, ctx->slab_solve_done[buf], 0), "hipStreamWaitEvent", e)) return false;
 		if (hip_fail(hipMemsetAsync(a.refine_count, 0, 64, st), "hipMemsetAsync", e)) return false; // [0] refine queue, [8] accumulate_wide's redo list
 		if (a.seg_table && hip_fail(hipMemsetAsync(a.seg_table, 0, sizeof(SegHeader), st), "hipMemsetAsync", e)) return false;
 		hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
@@ -135,39 +159,49 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 			ctx->gate_record = nullptr;
 			if (hip_fail(hipEventRecord(gr, st), "hipEventRecord", e)) return false;
 		}
+		if (overlap) {
+			if (hip_fail(hipEventRecord(ctx->slab_acc_done[buf], st), "hipEventRecord", e)) return false;
+			if (hip_fail(hipStreamWaitEvent(ss, ctx->slab_acc_done[buf], 0), "hipStreamWaitEvent", e)) return false;
+		}
 		// moderately wide designs: one lane per group (solve_mid.hip); beyond that one workgroup per group
-		auto solve = [&](int mode) { return mid ? launch_solve_mid(a, mode, st) : launch_solve_wide(a, mode, st); };
+		auto solve = [&](int mode) { return mid ? launch_solve_mid(a, mode, ss) : launch_solve_wide(a, mode, ss); };
 		// the primary solve of every width runs with one wavefront per group and the matrix in registers (solve_tiles.hip);
 		// the lane-per-group / workgroup-per-group kernels keep the refinement modes.  ANOFOX_SOLVE_TILES=0: without it.
 		static const bool tiles_on = !(getenv("ANOFOX_SOLVE_TILES") && atoi(getenv("ANOFOX_SOLVE_TILES")) == 0);
 		// (p <= 10: a 16 x 16 tile is mostly padding and the lane-per-group solve is as fast — 200 000 x 1000 x 9: 0.58 vs 0.70 ms;
 		// from there on the tiles win: p = 16 1.74 -> 0.69 ms, 100 000 x 1000 x 32 4.24 -> 0.76 ms, x 24 with inference 3.40 -> 1.77 ms)
 		const bool tiles_mid = mid && tiles_on && p >= 11 && solve_tiles_supports((int)p);
-		if (hip_fail(tiles_mid ? launch_solve_tiles(a, st) : solve(0), "wide solve kernel launch", e)) return false;
+		if (hip_fail(tiles_mid ? launch_solve_tiles(a, ss) : solve(0), "wide solve kernel launch", e)) return false;
 		// (solve_mid writes complete inference records itself; after the tiles kernel t, p and the interval come from the
 		// finish kernel — before the refinement modes, whose final pass rewrites the queued groups' records in full)
-		if (tiles_mid && hip_fail(launch_inference_wide_finish(a, st), "wide inference finish kernel launch", e)) return false;
+		if (tiles_mid && hip_fail(launch_inference_wide_finish(a, ss), "wide inference finish kernel launch", e)) return false;
 		// four updates on the wide path: with the residual in double-double every update gains about two digits even at
 		// cond(X) = 2e7 (an exactly determined 67 x 67 system of the deep fuzz sweep: 5.4e-7 after two, 4.3e-9 after three,
 		// 2.3e-11 after four); the launches are idle unless groups are queued.  ANOFOX_WIDE_REFINE_STEPS overrides (measurements).
 		static const int wide_steps = getenv("ANOFOX_WIDE_REFINE_STEPS") ? atoi(getenv("ANOFOX_WIDE_REFINE_STEPS")) : 2 * kRefineSteps;
 		for (int it = 0; it < wide_steps; ++it) { // queued groups only: b += (X'WX)^-1 X'Wr
-			if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
+			if (hip_fail(launch_residual_grad_wide(a, ss), "wide residual kernel launch", e)) return false;
 			if (hip_fail(solve(1), "wide refine kernel launch", e)) return false;
 		}
-		if (hip_fail(launch_residual_grad_wide(a, st), "wide residual kernel launch", e)) return false;
+		if (hip_fail(launch_residual_grad_wide(a, ss), "wide residual kernel launch", e)) return false;
 		if (hip_fail(solve(2), "wide final kernel launch", e)) return false;
-		if (!mid && hip_fail(launch_inference_wide_finish(a, st), "wide inference finish kernel launch", e)) return false;
+		if (!mid && hip_fail(launch_inference_wide_finish(a, ss), "wide inference finish kernel launch", e)) return false;
 		if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE) {
 			if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, (size_t)slab * sizeof(double), "hc scratch", e)) return false;
 			a.hc_df = (double *)ctx->aux;
-			if (hip_fail(launch_hc_wide(a, st), "wide hc kernel launch", e)) return false;
+			if (hip_fail(launch_hc_wide(a, ss), "wide hc kernel launch", e)) return false;
 		}
+		if (overlap && hip_fail(hipEventRecord(ctx->slab_solve_done[buf], ss), "hipEventRecord", e)) return false;
 		if (ctx->timing) {
-			(void)hipEventRecord(e2, st);
+			(void)hipEventRecord(e2, ss);
 			ctx->acc_events.emplace_back(e0, e1);
 			ctx->solve_events.emplace_back(e1, e2);
 		}
+	}
+	// whatever the caller enqueues next on the main stream comes after the last solves
+	if (overlap) {
+		for (int b = 0; b < 2 && b < k_slab; ++b)
+			if (hip_fail(hipStreamWaitEvent(st, ctx->slab_solve_done[b], 0), "hipStreamWaitEvent", e)) return false;
 	}
 	return true;
 }
@@ -372,6 +406,14 @@ void anofox_hip_context_destroy(AnofoxHipContext *ctx) {
 	if (ctx->aux) (void)hipFree(ctx->aux);
 	if (ctx->wtab) (void)hipFree(ctx->wtab);
 	for (auto &pr : ctx->predict_events) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+	if (ctx->solve_stream) {
+		(void)hipStreamSynchronize(ctx->solve_stream);
+		(void)hipStreamDestroy(ctx->solve_stream);
+	}
+	for (int b = 0; b < 2; ++b) {
+		if (ctx->slab_acc_done[b]) (void)hipEventDestroy(ctx->slab_acc_done[b]);
+		if (ctx->slab_solve_done[b]) (void)hipEventDestroy(ctx->slab_solve_done[b]);
+	}
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
 }
