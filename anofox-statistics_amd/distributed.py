@@ -114,6 +114,12 @@ class ShardedBatchFit:
                 w.wait()
         b["work"] = []
 
+    def last_stream(self):
+        """The stream the most recent `fit` was enqueued on (None before the first one): an event recorded there marks the
+        end of that step's kernels."""
+        b = self._bufs[(self._slot - 1) % self.depth]
+        return b["stream"]
+
     def contexts(self):
         """The contexts in use (for timing collection)."""
         return [b["ctx"] for b in self._bufs if b["ctx"] is not None]

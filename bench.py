@@ -319,14 +319,24 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = []                # an event at the end of every step's kernels (on the stream the step ran on): per-step spread
     for _ in range(args.steps):
         core_all, inf_all = step()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(sharded.last_stream() or torch.cuda.current_stream(dev))
+        marks.append(ev)
     sharded.finish()          # every all-gather issued inside the timed region completes inside it
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # spacing of those marks (steady state: the steps are pipelined); SURVEY.md 8(d) asks for median and min.  Consecutive
+    # steps alternate between two streams and a step's tail (solve, refinement) ends under the NEXT step's accumulate kernel,
+    # so marks are compared two steps apart — the same stream's consecutive steps — and halved
+    gaps = sorted(marks[i].elapsed_time(marks[i + 2]) / 2 for i in range(len(marks) - 2))
+    step_ms_median = gaps[len(gaps) // 2] if gaps else None
+    step_ms_min = gaps[0] if gaps else None
     kt = None
     for c in timed:   # the sharded driver alternates between contexts: sum their kernel times
         k = c.collect_timing()
@@ -438,6 +448,7 @@ def main():
             "metric": "group_fits_per_sec", "value": fits_per_s if ok else None, "unit": "fits/s", **extra,
             "ns_per_row": (elapsed / args.steps) * 1e9 / (G * n),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "ms_per_step_median": step_ms_median, "ms_per_step_min": step_ms_min,   # rank 0's own steps (HIP events)
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": (f"vif_agg: {G} groups x n={n} x p={p}, device-resident grouped columns" if args.vif else "") or f"{args.model}_fit{'_predict' if (args.predict or args.window) else ''}{(' OVER (ROWS BETWEEN ' + ('UNBOUNDED' if frame[0] is None else str(frame[0])) + ' PRECEDING AND ' + str(frame[1]) + ' PRECEDING)') if args.window else '_agg'}: {G} groups x n={n} x p={p}, device-resident grouped columns, "
