@@ -154,30 +154,42 @@ def multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, steps,
         torch.cuda.synchronize()
         gather_ms = e0.elapsed_time(e1) / 5
         mine["gather_ms"] = gather_ms
-        # the exchange step behind the C ABI: RCCL's own count of the ranks, and the same gather through it
+        # the exchange step behind the C ABI: RCCL's own count of the ranks, and the same gather through it.  Every step
+        # below is a collective: the ranks first AGREE that each of them got as far as the unique id (a rank that raised
+        # alone would leave the others waiting in the broadcast), and the audit must not cost the run its number
+        lib = abi = err = None
+        uid = (C.c_uint8 * 128)()
+        problem = None
         try:
             abi = importlib.import_module(PKG + "._abi")
             lib = abi.load()
             err = abi.AnofoxError()
-            uid = (C.c_uint8 * 128)()
             if rank == 0 and not lib.anofox_hip_comm_unique_id(uid, C.byref(err)):
-                raise RuntimeError(err.text())
-            t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
-            dist.broadcast(t, 0)
-            uid = (C.c_uint8 * 128)(*t.cpu().tolist())
-            comm = C.c_void_p()
-            ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-            if not lib.anofox_hip_comm_create(ctx._h, world, rank, uid, C.byref(comm), C.byref(err)):
-                raise RuntimeError(err.text())
-            mine["n_ranks_seen"] = int(lib.anofox_hip_comm_ranks_seen(comm))
-            out2 = torch.empty_like(outb)
-            if not lib.anofox_hip_gather_records_device(comm, C.c_void_p(local.data_ptr()), per, p + 6, C.c_void_p(out2.data_ptr()), C.byref(err)):
-                raise RuntimeError(err.text())
-            torch.cuda.synchronize()
-            mine["c_abi_gather_matches_torch"] = bool(torch.equal(torch.nan_to_num(out2, nan=-1.0), torch.nan_to_num(outb, nan=-1.0)))
-            lib.anofox_hip_comm_destroy(comm)
-        except Exception as exc:      # the audit must not cost the run its number
-            mine["c_abi_comm_error"] = str(exc)[:200]
+                problem = err.text()
+        except Exception as exc:
+            problem = str(exc)[:200]
+        flags = [None] * world
+        dist.all_gather_object(flags, problem)
+        if any(f is not None for f in flags):
+            mine["c_abi_comm_error"] = next(f for f in flags if f is not None)
+        else:
+            try:
+                t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+                dist.broadcast(t, 0)
+                uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+                comm = C.c_void_p()
+                ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+                if not lib.anofox_hip_comm_create(ctx._h, world, rank, uid, C.byref(comm), C.byref(err)):
+                    raise RuntimeError(err.text())
+                mine["n_ranks_seen"] = int(lib.anofox_hip_comm_ranks_seen(comm))
+                out2 = torch.empty_like(outb)
+                if not lib.anofox_hip_gather_records_device(comm, C.c_void_p(local.data_ptr()), per, p + 6, C.c_void_p(out2.data_ptr()), C.byref(err)):
+                    raise RuntimeError(err.text())
+                torch.cuda.synchronize()
+                mine["c_abi_gather_matches_torch"] = bool(torch.equal(torch.nan_to_num(out2, nan=-1.0), torch.nan_to_num(outb, nan=-1.0)))
+                lib.anofox_hip_comm_destroy(comm)
+            except Exception as exc:
+                mine["c_abi_comm_error"] = str(exc)[:200]
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     if rank != 0:
