@@ -784,9 +784,11 @@ def test_wide_random_groups_match_oracle(pkg, ctx, p, model):
         assert (rcore[:, p + 5] == 0).sum() >= G // 2
 
 
-def test_wide_edge_cases_match_oracle(pkg, ctx):
-    rng = np.random.default_rng(123)
-    p = 20
+@pytest.mark.parametrize("p", [13, 16, 20, 30, 32])
+def test_wide_edge_cases_match_oracle(pkg, ctx, p):
+    """8 < p <= 32, every load path of accumulate_mid: p = 13 / 16 rows staged through LDS in 128-row blocks (with / without
+    y and the ones inside the column block), 20 straight into fragment layout, 30 / 32 staged in 64-row blocks."""
+    rng = np.random.default_rng(123 + p)
     groups = []
 
     def add(n, mutate=None):
@@ -797,17 +799,23 @@ def test_wide_edge_cases_match_oracle(pkg, ctx):
             mutate(X, y, w)
         groups.append((X, y, w))
 
-    add(0); add(1); add(5); add(21); add(22); add(15); add(16); add(17); add(31); add(32); add(33); add(100)
+    add(0); add(1); add(5); add(p + 1); add(p + 2); add(15); add(16); add(17); add(31); add(32); add(33); add(100)
+    for n in (63, 64, 65, 127, 128, 129, 130, 191, 192, 193, 255, 256, 257, 300):           # around the 64- / 128-row blocks
+        add(n)
     add(90, lambda X, y, w: X.__setitem__((slice(None), 3), 7.0))                     # constant column
-    add(90, lambda X, y, w: X.__setitem__((slice(None), 19), -2.0 + 5e-11))           # constant within 1e-10 (last column)
+    add(90, lambda X, y, w: X.__setitem__((slice(None), p - 1), -2.0 + 5e-11))        # constant within 1e-10 (last column)
     add(90, lambda X, y, w: X.__setitem__((slice(None), slice(None)), 3.0))           # all constant
-    add(90, lambda X, y, w: X.__setitem__((slice(None), 17), 2 * X[:, 0] - X[:, 5] + 3))  # collinear -> aliased
+    add(90, lambda X, y, w: X.__setitem__((slice(None), p - 3), 2 * X[:, 0] - X[:, 5] + 3))  # collinear -> aliased
     add(90, lambda X, y, w: y.__setitem__(slice(0, 90, 7), np.nan))
-    add(90, lambda X, y, w: X.__setitem__((slice(5, 90, 11), 18), np.inf))
+    add(90, lambda X, y, w: X.__setitem__((slice(5, 90, 11), p - 2), np.inf))
     add(90, lambda X, y, w: y.__setitem__(slice(None), np.nan))
     add(90, lambda X, y, w: w.__setitem__(slice(0, 90, 3), 0.0))
     add(90, lambda X, y, w: w.__setitem__(slice(0, 90, 5), -1.0))
     add(90, lambda X, y, w: X.__setitem__((slice(0, 40), slice(None)), np.nan))        # first chunks entirely invalid
+    add(400, lambda X, y, w: X.__setitem__((slice(0, 131), 2), np.nan))                # first valid row: an odd row of the second block
+    add(400, lambda X, y, w: y.__setitem__(slice(128, 256), np.nan))                   # a whole block invalid in the middle
+    add(400, lambda X, y, w: y.__setitem__(slice(1, 400, 2), np.inf))                  # every odd row invalid
+    add(333, lambda X, y, w: X.__setitem__((slice(300, 333), 0), np.nan))              # the partial last block entirely invalid
     ns = [len(g[1]) for g in groups]
     offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
     X = np.concatenate([g[0] for g in groups])
@@ -822,7 +830,7 @@ def test_wide_edge_cases_match_oracle(pkg, ctx):
             rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, **_oracle_kw(model, kw))
             # groups 3 / 4 (n = 21 / 22) have zero residual degrees of freedom with / without... n == p + 1 or n == p
             zero_df = (3,) if icpt else ()
-            assert_records_match(core, rcore, p, inf, rinf, what=f"wide edge {model} icpt={icpt}", skip_diag_groups=zero_df)
+            assert_records_match(core, rcore, p, inf, rinf, what=f"wide edge {model} p={p} icpt={icpt}", skip_diag_groups=zero_df)
 
 
 @pytest.mark.parametrize("p", [40, 128])
