@@ -36,3 +36,17 @@ def test_sanitizer_unit(built, unit):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr
     assert "all" in r.stdout
+
+
+@pytest.mark.parametrize("unit", ["arena_tsan", "glue_tsan"])
+def test_thread_sanitizer_unit(built, unit):
+    """The DuckDB shim from several threads under ThreadSanitizer (mock C ABI): no data race in the arena's per-thread
+    chunks / shipping lock / slot hand-out, nor in the glue's per-width arena set."""
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([os.path.join(built, unit)], env=env, capture_output=True, text=True, timeout=600)
+    if "FATAL: ThreadSanitizer" in r.stderr and "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this environment")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ThreadSanitizer" not in r.stderr, r.stderr
+    assert "all" in r.stdout

@@ -11,6 +11,7 @@
 
 #include <map>
 #include <mutex>
+#include <atomic>
 #include <vector>
 
 #include "../../include/anofox_stats_hip.h"
@@ -33,8 +34,9 @@ void mock_fit(const std::vector<Row> &rows, size_t p, double *core) {
 	core[p + 4] = (double)rows.size();
 	core[p + 5] = rows.size() < 2 ? (double)ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS : 0.0;
 }
-int g_contexts = 0, g_states = 0, g_host_allocs = 0, g_batch_calls = 0, g_update_calls = 0, g_combine_calls = 0, g_release_calls = 0,
-    g_subset_calls = 0, g_full_calls = 0, g_fail_state_create = 0;
+// (atomic: the glue keeps one arena per feature count, and arenas of different widths initialise concurrently)
+std::atomic<int> g_contexts {0}, g_states {0}, g_host_allocs {0}, g_batch_calls {0}, g_update_calls {0}, g_combine_calls {0}, g_release_calls {0},
+    g_subset_calls {0}, g_full_calls {0}, g_fail_state_create {0};
 int g_mock_unrefined_rows = -1; // >= 0: a group of exactly that many rows is flagged ANOFOX_HIP_STATUS_UNREFINED
 
 
