@@ -750,6 +750,40 @@ hipError_t launch_mid_T(const WideArgs &a, hipStream_t stream) {
 
 bool accumulate_mid_supports(int p) { return p > kNarrowMaxP && p <= 32; }
 
+namespace {
+template <int T>
+hipError_t launch_mid_segments_T(const WideArgs &a, hipStream_t stream) {
+	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
+	const bool center = a.fit_intercept != 0;
+	const dim3 block(256), seg_grid((unsigned)((kSegMaxSegments + 3) / 4));
+	const bool aux = a.p + 2 <= 16 * T;
+#define ANOFOX_MID_SEG(W, C)                                                                                       \
+	do {                                                                                                           \
+		if (aux) hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C, true>), seg_grid, block, 0, stream, a); \
+		else hipLaunchKernelGGL((accumulate_mid_segments_kernel<T, W, C, false>), seg_grid, block, 0, stream, a);  \
+	} while (0)
+	if (weighted) {
+		if (center) ANOFOX_MID_SEG(true, true);
+		else ANOFOX_MID_SEG(true, false);
+	} else {
+		if (center) ANOFOX_MID_SEG(false, true);
+		else ANOFOX_MID_SEG(false, false);
+	}
+#undef ANOFOX_MID_SEG
+	return hipGetLastError();
+}
+} // namespace
+
+// only the row-segment kernel (accumulate_quad.hip registers its very large groups in the same table)
+hipError_t launch_accumulate_mid_segments(const WideArgs &a, hipStream_t stream) {
+	if (!a.seg_table) return hipSuccess;
+	switch (wide_tiles(a.p)) {
+	case 1: return launch_mid_segments_T<1>(a, stream);
+	case 2: return launch_mid_segments_T<2>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
 hipError_t launch_accumulate_mid(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
 	switch (wide_tiles(a.p)) {

@@ -1,0 +1,368 @@
+// accumulate_quad.hip — moment accumulation for 8 < p <= 32 on v_mfma_f64_4x4x4_4b_f64: one WAVEFRONT per group, the
+// Gram matrix of the p + 2 columns (x, y, ones) in 4 x 4 blocks.
+//
+// Same role and the same record as accumulate_mid.hip (reference: the row buffering + dense decomposition of
+// src/aggregate_functions/ols_aggregate.cpp:120-186,249-296, row filter / constant test of
+// crates/anofox-stats-core/src/models/ols.rs:59-87).  accumulate_mid pads every column block to 16: 18 columns (p = 16) cost
+// two blocks = three 16 x 16 tiles, of which a third is padding and half of each diagonal tile a mirror image — and on this
+// part the matrix cores ARE the bound of these widths (f64 VALU and MFMA time add up; profiles/r03_mid_paths.txt).  The small
+// f64 shape runs at the same flop rate (csrc/tools/mfma_f64_4x4_rate: 69-71 TFLOP/s against 66 for 16x16x4, 16 cycles per
+// instruction) and takes FOUR independent 4 x 4 x 4 products per instruction:
+//   operands  A[b][i][k] on lane 16 k + 4 b + i,  B[b][k][j] on lane 16 k + 4 b + j,  D[b][i][j] on lane 16 i + 4 b + j
+//   (csrc/tools/mfma_4x4_layout prints this from one-hot inputs).
+// Let the four blocks b be four ROW QUADS of a 16-row step (row 4 k + b of the step in block b, K-step k) and let lane
+// (k, b, c4) hold its row's values of the columns 4 g + c4, g = 0 .. NB - 1, one register per column group g.  Then register
+// g IS the A operand of "column group g as rows" and the B operand of "column group g as columns" — as in the 16 x 16 kernels
+// — and one instruction per pair g <= h accumulates the 4 x 4 block (g, h) of the Gram matrix over 16 rows, as four partial
+// sums (one per row quad) that are added once per group.  NB (NB + 1) / 2 instructions of 16 cycles per 16 rows, NB =
+// ceil((p + 2) / 4): p = 16: 15 x 16 = 240 cycles (accumulate_mid: 256 + the side sums on the vector unit), p = 24: 448 (768),
+// p = 32: 720 (768 + side sums).  y and the column of ones are columns p and p + 1 of the matrix, so X'Wy, the column sums
+// and the y moments come out of the same instructions.
+//
+// Rows arrive as in accumulate_mid's staged path: lane l loads ITS rows of every column (128-row blocks and 16-byte loads
+// up to p = 16, 64-row blocks beyond), the row filter runs on those registers (one ballot per block), the block goes to a
+// wave-private LDS slice column by column (stride = 8 mod 32 doubles: the 32 lanes of a half wave read rows 0..7 of four
+// columns, 32 different banks) and every lane reads one double per column group and step.  No barrier.
+#include <stdlib.h>
+
+#include "common.h"
+
+// what-if builds (never shipped: results are wrong): bit 0 = no MFMA, 1 = no row filter, 2 = no constant-column test,
+// 3 = a block's rows are not written to LDS, 4 = one step per block instead of 4 RL
+#ifndef ANOFOX_QUAD_SKIP
+#define ANOFOX_QUAD_SKIP 0
+#endif
+
+namespace anofox {
+
+hipError_t launch_accumulate_mid_segments(const WideArgs &a, hipStream_t stream); // accumulate_mid.hip
+
+namespace {
+
+typedef double quad_dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+typedef double quad_dbl2a __attribute__((ext_vector_type(2)));
+typedef const double __attribute__((address_space(1))) *quad_gptr_t;
+typedef const quad_dbl2u __attribute__((address_space(1))) *quad_gptr2_t;
+
+__host__ __device__ constexpr int quad_lds_stride(int RL) { return 64 * RL + 8; } // 72 / 136 doubles
+__host__ __device__ constexpr int quad_blocks(int p) { return (p + 2 + 3) / 4; }  // NB: 4 x 4 column groups of x, y, ones
+// a wave's slice: the data columns (x, y, w) of a block, and at the end of the group the Gram image + first row + flags
+__host__ __device__ constexpr int quad_slice_doubles(int p, bool weighted, int RL) {
+	const int data = (p + 1 + (weighted ? 1 : 0)) * quad_lds_stride(RL);
+	const int R = 4 * quad_blocks(p);
+	const int image = R * R + 2 * R;
+	return data > image ? data : image;
+}
+
+__device__ __forceinline__ double quad_mask(double v, long long m) { return __longlong_as_double(__double_as_longlong(v) & m); }
+
+__device__ __forceinline__ unsigned quad_spread8(unsigned x) { // bit i of the low byte -> bit 2 i
+	x = (x | (x << 4)) & 0x0F0Fu;
+	x = (x | (x << 2)) & 0x3333u;
+	x = (x | (x << 1)) & 0x5555u;
+	return x;
+}
+
+template <int NB, bool WEIGHTED, bool CENTER, int RL>
+__device__ __forceinline__ void quad_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
+	constexpr int NCOL = 4 * NB; // load slots per block: x (p), y, (w) — p + 2 <= 4 NB
+	constexpr int NPAIR = NB * (NB + 1) / 2;
+	constexpr int RS = quad_lds_stride(RL);
+	constexpr int BR = 64 * RL;
+	const int p = args.p;
+	const int T = wide_tiles(p), P16 = 16 * T, NT = T * (T + 1) / 2;
+	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
+	const int k = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3;
+	const int rsub = 4 * k + b; // this lane's row of every 16-row step
+
+	// This lane's columns: 4 g + c4.  NB = ceil((p + 2) / 4), so the columns of the groups g < NB - 1 are all <= p — x columns
+	// or y, read from the slice at base_off + 4 g RS (a compile-time offset per group: no address registers) — and only
+	// the LAST group can hold the column of ones (p + 1) or padding, which are constants and read nothing.
+	const int base_off = c4 * RS + rsub;
+	const int c_last = 4 * (NB - 1) + c4;
+	const bool rd_last = c_last <= p;
+	const int last_off = (rd_last ? c_last : p) * RS + rsub;
+	const double fill_last = c_last == p + 1 ? 1.0 : 0.0;
+	const bool isx_prev = 4 * (NB - 2) + c4 < p, isx_last = c_last < p; // x columns take part in the constant-column test
+	double acc[NPAIR];
+#pragma unroll
+	for (int t = 0; t < NPAIR; ++t) acc[t] = 0.0;
+	double first[NB], dmax[NB];
+#pragma unroll
+	for (int g = 0; g < NB; ++g) first[g] = dmax[g] = 0.0;
+	bool have_first = false;
+	int cnt = 0;
+
+	double reg[NCOL][RL];
+	// every block issues the same NCOL loads (a load behind a branch of its own makes the compiler wait for all outstanding
+	// loads before the first use); the slots past the last column read y again (the line is in L1) and are not written to LDS
+	auto colp = [&](int c) -> quad_gptr_t {
+		const double *ptr = c < p ? args.x_table[c < kWideMaxP ? c : 0] : ((WEIGHTED && c == p + 1) ? args.w : args.y);
+		return (quad_gptr_t)(uintptr_t)ptr;
+	};
+	auto issue = [&](int64_t blk) {
+		if (blk + BR <= hi) {
+			const int64_t row = blk + RL * lane;
+#pragma unroll
+			for (int c = 0; c < NCOL; ++c) {
+				if (RL == 2) {
+					const quad_dbl2u v = *reinterpret_cast<quad_gptr2_t>(colp(c) + row);
+					reg[c][0] = v.x;
+					reg[c][RL - 1] = v.y;
+				} else {
+					reg[c][0] = colp(c)[row];
+				}
+			}
+		} else { // clamped; rows past the end fail the row filter below
+#pragma unroll
+			for (int c = 0; c < NCOL; ++c) {
+#pragma unroll
+				for (int e = 0; e < RL; ++e) {
+					const int64_t row = blk + RL * lane + e;
+					reg[c][e] = colp(c)[row < hi ? row : hi - 1];
+				}
+			}
+		}
+	};
+	// one 16-row step: this lane's row is rsub of the step
+	auto step = [&](int sidx, bool valid_all, unsigned rowmask) {
+		const long long rm = valid_all ? -1ll : -(long long)((rowmask >> rsub) & 1u);
+		double d[NB], a[NB];
+		double wv = 1.0;
+		if (WEIGHTED) {
+			wv = buf[(p + 1) * RS + 16 * sidx + rsub];
+			if (!valid_all) wv = quad_mask(wv, rm);
+		}
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+			double v;
+			if (g < NB - 1) {
+				v = buf[base_off + 16 * sidx + 4 * g * RS];
+			} else {
+				const double raw = buf[last_off + 16 * sidx];
+				v = rd_last ? raw : fill_last;
+			}
+			double dev = v - first[g];
+			if (!valid_all) dev = quad_mask(dev, rm);
+			// CENTER: deviations from the group's first valid row (first = 0 for the ones); otherwise raw values, masked
+			d[g] = CENTER ? dev : (valid_all ? v : quad_mask(v, rm));
+			// constant-column predicate of ols.rs:76-87: the largest |x - x_first| per lane and column, tested once per group
+			if (!(ANOFOX_QUAD_SKIP & 4)) dmax[g] = fmax(dmax[g], fabs(dev));
+			a[g] = WEIGHTED ? wv * d[g] : d[g];
+		}
+		int t = 0;
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+#pragma unroll
+			for (int h = g; h < NB; ++h) {
+				if (ANOFOX_QUAD_SKIP & 1) acc[t] += a[g] + d[h];
+				else acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[g], d[h], acc[t], 0, 0, 0);
+				++t;
+			}
+		}
+	};
+	auto block = [&](int64_t blk, int64_t blk_next) {
+		// row filter on this lane's rows (ols.rs:59-66, wls.rs:76-86)
+		// (finiteness of a whole row as ONE number: z = sum 0 * v is NaN iff some v is not finite — an FMA per value instead
+		// of a class test and a mask AND per value; the slots past the last column hold y again)
+		bool ok[RL];
+#pragma unroll
+		for (int e = 0; e < RL; ++e) {
+			double z = 0.0;
+			if (!(ANOFOX_QUAD_SKIP & 2)) {
+#pragma unroll
+				for (int c = 0; c < NCOL; ++c) z = fma(0.0, reg[c][e], z);
+			}
+			ok[e] = (blk + RL * lane + e < hi) && (z == 0.0);
+			if (WEIGHTED) { // the weight sits in slot p + 1, one of the last four (p + 2 <= 4 NB <= p + 5)
+				double wv = 1.0;
+#pragma unroll
+				for (int c = NCOL - 4; c < NCOL; ++c) wv = (c == p + 1) ? reg[c][e] : wv;
+				ok[e] = ok[e] && (wv > 0.0);
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < NCOL; ++c) {
+			if (c < ncol && !(ANOFOX_QUAD_SKIP & 8)) {
+				if (RL == 2) *reinterpret_cast<quad_dbl2a *>(buf + c * RS + 2 * lane) = quad_dbl2a{reg[c][0], reg[c][RL - 1]};
+				else buf[c * RS + lane] = reg[c][0];
+			}
+		}
+		if (blk_next < hi) issue(blk_next);
+		__builtin_amdgcn_wave_barrier();
+		const unsigned long long v0 = __ballot(ok[0]), v1 = RL == 2 ? __ballot(ok[RL - 1]) : v0;
+		if ((v0 | v1) != 0ull) {
+			if (!have_first) { // the first valid row of the group: every lane fetches its columns' values of that row
+				const int f0 = __ffsll((long long)v0) - 1, f1 = __ffsll((long long)v1) - 1;
+				int fr;
+				if (RL == 2) {
+					const int r0 = v0 ? 2 * f0 : 1 << 20, r1 = v1 ? 2 * f1 + 1 : 1 << 20;
+					fr = r0 < r1 ? r0 : r1;
+				} else {
+					fr = f0;
+				}
+#pragma unroll
+				for (int g = 0; g < NB - 1; ++g) first[g] = buf[c4 * RS + 4 * g * RS + fr];
+				first[NB - 1] = rd_last ? buf[(rd_last ? c_last : p) * RS + fr] : 0.0; // (the constants are not shifted)
+				have_first = true;
+			}
+			if ((v0 & v1) == ~0ull) {
+				cnt += BR;
+#pragma unroll 2
+				for (int sidx = 0; sidx < ((ANOFOX_QUAD_SKIP & 16) ? 1 : 4 * RL); ++sidx) step(sidx, true, 0xFFFFu);
+			} else {
+				cnt += __popcll(v0) + (RL == 2 ? __popcll(v1) : 0);
+#pragma unroll 1
+				for (int sidx = 0; sidx < 4 * RL; ++sidx) {
+					unsigned rowmask;
+					if (RL == 2) rowmask = quad_spread8((unsigned)(v0 >> (8 * sidx)) & 0xFFu) | (quad_spread8((unsigned)(v1 >> (8 * sidx)) & 0xFFu) << 1);
+					else rowmask = (unsigned)(v0 >> (16 * sidx)) & 0xFFFFu;
+					if (rowmask == 0u) continue; // wave-uniform
+					step(sidx, false, rowmask);
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier(); // the reads above before the next block's writes
+	};
+	if (lo < hi) issue(lo);
+	for (int64_t blk = lo; blk < hi; blk += BR) block(blk, blk + BR);
+
+	// ---- the record: the four row quads' partial sums, the Gram image through LDS, then accumulate_mid's layout ----
+#pragma unroll
+	for (int t = 0; t < NPAIR; ++t) {
+		acc[t] += __shfl_xor(acc[t], 4, 64);
+		acc[t] += __shfl_xor(acc[t], 8, 64);
+	}
+#pragma unroll
+	for (int g = 0; g < NB; ++g) { // the largest deviation of column 4 g + c4 over all rows: the 16 lanes that share c4
+		double m = dmax[g];
+		m = fmax(m, __shfl_xor(m, 4, 64));
+		m = fmax(m, __shfl_xor(m, 8, 64));
+		m = fmax(m, __shfl_xor(m, 16, 64));
+		m = fmax(m, __shfl_xor(m, 32, 64));
+		dmax[g] = m;
+	}
+	constexpr int R = 4 * NB;
+	double *G = buf, *F = buf + R * R, *NC = F + R;
+	{
+		const int i = lane >> 4, j = lane & 3; // D[b][i][j] on lane 16 i + 4 b + j: the b = 0 lanes write
+		int t = 0;
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+#pragma unroll
+			for (int h = g; h < NB; ++h) {
+				if (b == 0) {
+					G[(4 * g + i) * R + 4 * h + j] = acc[t];
+					if (h != g) G[(4 * h + j) * R + 4 * g + i] = acc[t];
+				}
+				++t;
+			}
+		}
+		if (lane < 4) {
+#pragma unroll
+			for (int g = 0; g < NB; ++g) {
+				F[4 * g + lane] = first[g];
+				const bool isx = g < NB - 2 ? true : (g == NB - 2 ? isx_prev : isx_last);
+				NC[4 * g + lane] = (isx && !(dmax[g] < 1e-10)) ? 1.0 : 0.0;
+			}
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	for (int tile = 0, I = 0; I < T; ++I) {
+		for (int J = I; J < T; ++J, ++tile) {
+			double *tp = rec + (int64_t)tile * 256; // tile-major, element (row, col) at row * 16 + col
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int e = lane + 64 * q, r = 16 * I + (e >> 4), c = 16 * J + (e & 15);
+				tp[e] = (r < p && c < p) ? G[r * R + c] : 0.0;
+			}
+		}
+	}
+	double *vec = rec + (int64_t)NT * 256;
+	for (int j = lane; j < P16; j += 64) {
+		const bool in = j < p;
+		vec[0 * P16 + j] = in ? G[j * R + p + 1] : 0.0; // sum w d_j
+		vec[1 * P16 + j] = in ? G[j * R + p] : 0.0;     // sum w d_j dy
+		vec[2 * P16 + j] = in ? F[j] : 0.0;             // x at the first valid row
+		vec[3 * P16 + j] = in ? NC[j] : 0.0;            // not constant
+	}
+	double *sc = vec + 4 * P16;
+	if (lane == 0) {
+		sc[0] = G[p * R + p + 1];       // sum w dy
+		sc[1] = G[p * R + p];           // sum w dy^2
+		sc[2] = G[(p + 1) * R + p + 1]; // sum w
+		sc[3] = (double)cnt;
+		sc[4] = F[p];                   // y of the first valid row
+	}
+}
+
+template <int NB, bool WEIGHTED, bool CENTER, int RL, int WPS> // WPS: waves per SIMD the register budget is cut for
+__global__ __launch_bounds__(256, WPS) void accumulate_quad_kernel(WideArgs args) {
+	extern __shared__ double quad_lds[];
+	const int lane = threadIdx.x & 63;
+	const int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (gl >= args.n_groups) return;
+	const int T = wide_tiles(args.p);
+	const int64_t lo = args.row_offsets[args.group_base + gl];
+	const int64_t hi = group_row_end(args, args.group_base + gl);
+	if (args.seg_table && hi - lo > args.seg_rows) {
+		if (wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments)) return;
+	}
+	quad_accumulate_rows<NB, WEIGHTED, CENTER, RL>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), lane,
+	                                               quad_lds + (threadIdx.x >> 6) * quad_slice_doubles(args.p, WEIGHTED, RL));
+}
+
+template <int NB, int RL, int WPS>
+hipError_t launch_quad_nb(const WideArgs &a, hipStream_t stream) {
+	const bool weighted = a.model == ANOFOX_HIP_MODEL_WLS;
+	const bool center = a.fit_intercept != 0;
+	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
+	const size_t lds_bytes = 4 * (size_t)quad_slice_doubles(a.p, weighted, RL) * sizeof(double);
+	static const bool attr_set = [] {
+#define ANOFOX_QUAD_ATTR(W, C) \
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_quad_kernel<NB, W, C, RL, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+		ANOFOX_QUAD_ATTR(true, true); ANOFOX_QUAD_ATTR(true, false); ANOFOX_QUAD_ATTR(false, true); ANOFOX_QUAD_ATTR(false, false);
+#undef ANOFOX_QUAD_ATTR
+		return true;
+	}();
+	(void)attr_set;
+	if (weighted) {
+		if (center) hipLaunchKernelGGL((accumulate_quad_kernel<NB, true, true, RL, WPS>), grid, block, lds_bytes, stream, a);
+		else hipLaunchKernelGGL((accumulate_quad_kernel<NB, true, false, RL, WPS>), grid, block, lds_bytes, stream, a);
+	} else {
+		if (center) hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, true, RL, WPS>), grid, block, lds_bytes, stream, a);
+		else hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, false, RL, WPS>), grid, block, lds_bytes, stream, a);
+	}
+	hipError_t rc = hipGetLastError();
+	if (rc != hipSuccess) return rc;
+	// very large groups were registered for row splitting: accumulate_mid's segment kernel takes them (idle otherwise)
+	return a.seg_table ? launch_accumulate_mid_segments(a, stream) : hipSuccess;
+}
+
+} // namespace
+
+// p = 27 .. 32 (NB = 8, 9) stay with accumulate_mid: 36 / 45 accumulators + the staged block do not fit the 256 registers of two
+// waves per SIMD (168-456 bytes of spills: 2.9-3.0 TB/s against 4.3), and the saving in matrix instructions is small there
+bool accumulate_quad_supports(int p) { return p > kNarrowMaxP && p <= 26; }
+
+hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	if (!accumulate_quad_supports(a.p)) return hipErrorInvalidValue;
+	// rows per lane and block, by measurement (profiles/r03_quad.txt): 128-row blocks for p <= 11 and p = 15..17, 64-row
+	// blocks elsewhere (from p = 18 the larger slice would leave one workgroup per CU).  A register budget for three waves
+	// per SIMD was measured slower for every NB >= 4 (spills).  ANOFOX_QUAD_RL=1/2 forces one.
+	static const int env_rl = getenv("ANOFOX_QUAD_RL") ? atoi(getenv("ANOFOX_QUAD_RL")) : 0;
+	const int nb = quad_blocks(a.p);
+	int rl = (a.p <= 11 || (a.p >= 15 && a.p <= 17)) ? 2 : 1;
+	if (env_rl == 1 || (env_rl == 2 && a.p <= 18)) rl = env_rl;
+	switch (nb) { // p = 9, 10 | 11..14 | 15..18 | 19..22 | 23..26
+	case 3: return rl == 2 ? launch_quad_nb<3, 2, 3>(a, stream) : launch_quad_nb<3, 1, 3>(a, stream);
+	case 4: return rl == 2 ? launch_quad_nb<4, 2, 2>(a, stream) : launch_quad_nb<4, 1, 2>(a, stream);
+	case 5: return rl == 2 ? launch_quad_nb<5, 2, 2>(a, stream) : launch_quad_nb<5, 1, 2>(a, stream);
+	case 6: return launch_quad_nb<6, 1, 2>(a, stream);
+	case 7: return launch_quad_nb<7, 1, 2>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
+}
+
+} // namespace anofox

@@ -493,6 +493,10 @@ hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);
 // accumulate_mid.hip: wave-per-group accumulation into the same records for 8 < p <= 32
 bool accumulate_mid_supports(int p);
 hipError_t launch_accumulate_mid(const WideArgs &a, hipStream_t stream);
+hipError_t launch_accumulate_mid_segments(const WideArgs &a, hipStream_t stream);
+// accumulate_quad.hip: the same on 4 x 4 blocks of v_mfma_f64_4x4x4_4b_f64 (no padding to 16 columns)
+bool accumulate_quad_supports(int p);
+hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream);
 // solve_mid.hip: lane-per-group solve on the same records for 8 < p <= 32 (same modes as launch_solve_wide)
 bool solve_mid_supports(int p);
 hipError_t launch_solve_mid(const WideArgs &a, int mode, hipStream_t stream);

@@ -152,7 +152,12 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 			if (hip_fail(hipStreamWaitEvent(st, gw, 0), "hipStreamWaitEvent", e)) return false;
 			if (ctx->timing) (void)hipEventRecord(e0, st);
 		}
-		if (hip_fail(mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st), "wide accumulate kernel launch", e)) return false;
+		// 8 < p <= 32: 4 x 4-block MFMAs (accumulate_quad.hip) or 16 x 16 tiles (accumulate_mid.hip); ANOFOX_MID_QUAD=0/1
+		static const bool quad_on = !(getenv("ANOFOX_MID_QUAD") && atoi(getenv("ANOFOX_MID_QUAD")) == 0);
+		const bool quad = mid_acc && quad_on && accumulate_quad_supports((int)p);
+		if (hip_fail(quad ? launch_accumulate_quad(a, st) : (mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st)),
+		             "wide accumulate kernel launch", e))
+			return false;
 		if (ctx->timing) (void)hipEventRecord(e1, st);
 		if (g0 + slab >= G && ctx->gate_record) {
 			hipEvent_t gr = ctx->gate_record;

@@ -30,6 +30,8 @@ bool solve_tiles_supports(int) { return false; }
 STUB(launch_inference_wide_finish(const WideArgs &, hipStream_t))
 STUB(launch_residual_grad_wide(const WideArgs &, hipStream_t))
 STUB(launch_accumulate_mid(const WideArgs &, hipStream_t))
+STUB(launch_accumulate_quad(const WideArgs &, hipStream_t))
+bool accumulate_quad_supports(int) { return false; }
 STUB(launch_solve_mid(const WideArgs &, int, hipStream_t))
 STUB(launch_hc_wide(const WideArgs &, hipStream_t))
 STUB(launch_accumulate_narrow(const BatchArgs &, hipStream_t))
