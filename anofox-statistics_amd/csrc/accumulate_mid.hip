@@ -556,9 +556,15 @@ __device__ __forceinline__ void mid_accumulate_rows_lds(const WideArgs &args, in
 		for (int e = 0; e < RL; ++e) {
 			ok[e] = b + RL * lane + e < hi;
 			if (!(ANOFOX_MID_SKIP & 1)) {
+				// finiteness of the row as ONE number: z = sum 0 * v is NaN iff some v is not finite (the slots past the last
+				// column hold y again) — a class test and a mask AND per value cost 14 % of accumulate_quad before this
+				double z = 0.0, wv = 1.0;
 #pragma unroll
-				for (int c = 0; c < NCOL; ++c)
-					if (c < ncol) ok[e] = ok[e] && isfinite(r[c][e]) && (!(WEIGHTED && c == p + 1) || r[c][e] > 0.0);
+				for (int c = 0; c < NCOL; ++c) {
+					z = fma(0.0, r[c][e], z);
+					if (WEIGHTED) wv = (c == p + 1) ? r[c][e] : wv;
+				}
+				ok[e] = ok[e] && (z == 0.0) && (wv > 0.0);
 			}
 		}
 #pragma unroll
@@ -709,7 +715,7 @@ hipError_t launch_mid_T(const WideArgs &a, hipStream_t stream) {
 	static const int forced = getenv("ANOFOX_MID_LDS") ? atoi(getenv("ANOFOX_MID_LDS")) : -1;
 	int ldsx = 0;
 	if (T == 1 && a.p >= 12 && 4 * (size_t)mid_lds_columns(a.p, weighted, T) * mid_lds_stride(2) * sizeof(double) <= 80 * 1024) ldsx = 2;
-	if (T == 2 && a.p >= 29) ldsx = 1;
+	if (T == 2 && a.p >= 27) ldsx = 1; // (since the row filter became one FMA per value: 4.4-4.6 against 3.9-4.3 TB/s at p = 27 .. 32)
 	if (forced >= 0 && forced <= 2) ldsx = forced;
 	const size_t lds_bytes = 4 * (size_t)mid_lds_columns(a.p, weighted, T) * mid_lds_stride(ldsx == 2 ? 2 : 1) * sizeof(double); // 4 waves' slices
 	static const bool attr_set = [] {
