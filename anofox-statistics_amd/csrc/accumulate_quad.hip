@@ -345,7 +345,8 @@ hipError_t launch_quad_nb(const WideArgs &a, hipStream_t stream) {
 // waves per SIMD (168-456 bytes of spills: 2.9-3.0 TB/s against 4.3), and the saving in matrix instructions is small there.
 // (Also measured and not kept: TWO wavefronts per group sharing the slice — each loads every other column and owns every other
 // block pair, the block written to LDS centred and masked, two barriers per 64-row block: correct, 164-188 registers, but
-// 3.5-4.1 TB/s against accumulate_mid's 4.2-4.4 at p = 27 .. 32; profiles/r03_quad.txt.)
+// 3.5-4.1 TB/s against accumulate_mid's 4.2-4.4 at p = 27 .. 32; and this kernel with the registers of ONE wave per SIMD:
+// no spills, 3.5-4.0 TB/s.  profiles/r03_quad.txt.)
 bool accumulate_quad_supports(int p) { return p > kNarrowMaxP && p <= 26; }
 
 hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
