@@ -784,6 +784,34 @@ def test_wide_random_groups_match_oracle(pkg, ctx, p, model):
         assert (rcore[:, p + 5] == 0).sum() >= G // 2
 
 
+@pytest.mark.parametrize("p", list(range(9, 33)))
+def test_every_mid_width_matches_oracle(pkg, ctx, p):
+    """Every width 9 .. 32 on its own: the 4 x 4-block kernel's last column group holds y, the ones and 0 .. 3 padding
+    columns depending on p mod 4 (accumulate_quad.hip), accumulate_mid switches load paths at 12, 16/17 and 27 — ragged
+    groups (some with n < p + 1), NaN / inf rows, every model with and without intercept, inference on."""
+    rng = np.random.default_rng(9000 + p)
+    G = 40
+    offs, y, x_cols, w = _random_groups(rng, G, p, max(2, p - 3), 3 * p + 150)
+    X = np.stack(x_cols, 1)
+    for g in range(0, G, 5):                                   # NaN / inf rows in every fifth group
+        lo, hi = offs[g], offs[g + 1]
+        if hi - lo > 6:
+            X[lo + 1, rng.integers(0, p)] = np.nan
+            y[lo + (hi - lo) // 2] = np.inf
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    for model in ("ols", "ridge", "wls"):
+        for icpt in (True, False):
+            kw = dict(fit_intercept=icpt, compute_inference=True, confidence_level=0.9)
+            if model == "ridge":
+                kw["alpha"] = 0.7
+            wv = w if model == "wls" else None
+            core, inf = _host_fit(pkg, ctx, model, offs, y, x_cols, wv, **kw)
+            rcore, rinf = oracle.fit_groups(y, x_cols, offs, w=wv, n_threads=8, **_oracle_kw(model, kw))
+            n_par = np.sum(~np.isnan(rcore[:, :p]), axis=1) + (1 if icpt else 0)
+            tight = [g for g in range(G) if rcore[g, p + 5] == 0 and rcore[g, p + 4] - n_par[g] <= 0]
+            assert_records_match(core, rcore, p, inf, rinf, what=f"width {p} {model} icpt={icpt}", skip_diag_groups=tight)
+
+
 @pytest.mark.parametrize("p", [13, 16, 20, 30, 32])
 def test_wide_edge_cases_match_oracle(pkg, ctx, p):
     """8 < p <= 32, every load path of accumulate_mid: p = 13 / 16 rows staged through LDS in 128-row blocks (with / without
