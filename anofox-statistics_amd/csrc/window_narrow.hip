@@ -342,7 +342,9 @@ __global__ __launch_bounds__(256) void expanding_predict_kernel(WindowArgs args)
 		// Finalize of the window aggregate for the frame ending at this row
 		double yhat = nanv, ylo = nanv, yhi = nanv;
 		bool suspect = false;
-		if (in && xfinite && n_y > (double)(P + (icpt ? 1 : 0))) {       // ols_fit_predict.cpp:257-262 (strictly more)
+		// (a NaN in this row's x only matters where the fit kept the column: the prediction skips NaN coefficients and is NULL
+		// when IT is not finite — lib.rs:2264-2349; an intercept-only fit predicts whatever x holds)
+		if (in && n_y > (double)(P + (icpt ? 1 : 0))) {       // ols_fit_predict.cpp:257-262 (strictly more)
 			PrefixFit<P> f;
 			fit_from_moments<P>(rec, args.model, icpt, args.alpha, args.lambda_scaling, f);
 			suspect = f.ok && f.suspect;
@@ -513,18 +515,14 @@ __global__ __launch_bounds__(256) void rolling_predict_kernel(WindowArgs args) {
 		}
 		// the x to predict is the LAST row of the frame (offset kl): read it again (an L1 hit) instead of tracking it
 		const bool any_live = in && kh >= kl;
-		bool xfl = true;
 		{
 			const int64_t rl = any_live ? e - kl : (hi > 0 ? hi - 1 : 0);
 #pragma unroll
-			for (int j = 0; j < P; ++j) {
-				z[j] = args.x[j][rl];
-				xfl = xfl && isfinite(z[j]);
-			}
+			for (int j = 0; j < P; ++j) z[j] = args.x[j][rl];
 		}
 		double yhat = nanv, ylo = nanv, yhi = nanv;
 		bool suspect = false;
-		if (any_live && xfl && n_y > (double)(P + (icpt ? 1 : 0))) { // ols_fit_predict.cpp:253-262
+		if (any_live && n_y > (double)(P + (icpt ? 1 : 0))) { // ols_fit_predict.cpp:253-262 (x is judged by the prediction itself)
 			double rec[L::REC];
 #pragma unroll
 			for (int a = 0; a < Z; ++a) { rec[L::OFF_S + a] = s[a]; rec[L::OFF_FIRST + a] = first[a]; }
