@@ -668,6 +668,12 @@ __global__ __launch_bounds__(128) void inference_wide_finish_kernel(WideArgs arg
 }
 
 // Error-free transformations for the residual pass below (round-to-nearest, no fast-math: -fno-fast-math in the Makefile).
+// hipcc's default -ffp-contract=fast fuses a product with the sum that consumes it ACROSS statements; inside two_sum that
+// turns s = a + RN(x b) into fma(x, b, a), whose rounding error the rest of two_sum does not recover, and the compensated
+// residual degrades to working precision (r3, seed 46944 of the deep fuzz sweep: a 15 x 15 system that stalled at 1.4e-8
+// and converges to 1e-13 in two updates without the fusion).  So: no contraction from here to the end of the residual kernel;
+// the fma() calls below are the only fused operations.
+#pragma clang fp contract(off)
 __device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
 	s = a + b;
 	const double bb = s - a;
@@ -801,6 +807,8 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 		if (tid < p) out[2 + tid] = gj_h + gj_l;
 	}
 }
+
+#pragma clang fp contract(fast)
 
 size_t solve_wide_lds_bytes(int p) {
 	const int T = wide_tiles(p), P16 = 16 * T, LD = P16 + 1;
