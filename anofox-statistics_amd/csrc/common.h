@@ -48,6 +48,20 @@ inline __host__ __device__ int refine_vec_len(int p) { return p + 3; }
 // (digits of sd_y lost to that cancellation ~ log10(qyy / cyy): beyond this ratio the group is queued for refinement)
 constexpr double kGlmnetCancelRatio = 1e4;
 
+// A-priori error of coefficient j from the Cholesky factor of the moment matrix: ~ eps / (smallest pivot ratio) *
+// sqrt(tss / diag_j) — the size coefficient j would have if its column alone explained y, times the rounding the
+// factorisation amplifies.  A coefficient whose own contribution to y is tiny next to the others' (a small column norm
+// with a small coefficient) is wrong by far more than eps cond^2 relative to ITSELF: the deep narrow sweep's three misses
+// (1.5 .. 2.5e-9 at pivot ratios 1.1 .. 1.6e-3, just above the pivot test) are within 3 x of this estimate.  The primary
+// solves queue the group for the refinement passes when the estimate exceeds 1e-10 of max(|b_j|, 1e-3 max|b|) — the
+// scale the parity bar of 1e-9 is measured on.  Benchmark-like designs (comparable contributions, pivot ratios ~ 1) sit
+// five orders of magnitude below it.
+constexpr double kCoefBoundEps = 1.1e-16, kCoefBoundTol = 1e-10;
+inline __host__ __device__ bool coef_bound_weak(double beta, double beta_max, double diag0, double tss, double min_ratio) {
+	const double scale = fmax(fabs(beta), 1e-3 * beta_max);
+	return kCoefBoundEps * sqrt(tss / diag0) > kCoefBoundTol * min_ratio * scale;
+}
+
 inline __host__ __device__ int moment_record_len(int p) {
 	const int Z = p + 1;
 	return Z + Z * (Z + 1) / 2 + 1 + Z + 2;

@@ -1,0 +1,77 @@
+// dd_arith.h — error-free transformations and double-double accumulation for the residual passes of the refinement
+// (solve_narrow.hip: residual_grad_wave; solve_wide.hip: residual_grad_wide_kernel).  Round-to-nearest, no fast-math.
+//
+// hipcc's default -ffp-contract=fast-honor-pragmas fuses a product with the sum that consumes it ACROSS statements; inside
+// two_sum that turns s = a + RN(x b) into fma(x, b, a), whose rounding error the rest of two_sum does not recover, and a
+// "compensated" residual then carries working-precision noise (r3: a 15 x 15 system of the deep fuzz sweep wandered between
+// 4e-10 and 1.4e-8 whatever the number of updates, and converges to 3e-12 in two without the fusion).  Every function here
+// switches contraction off for its own body — an add without the `contract` flag is not fused with a product from the
+// caller — and the kernels that call them do the same for theirs; the fma() calls are the only fused operations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace anofox {
+
+// s + e = a + b exactly (Knuth)
+__device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
+#pragma clang fp contract(off)
+	s = a + b;
+	const double bb = s - a;
+	e = (a - (s - bb)) + (b - bb);
+}
+
+// p + e = a b exactly
+__device__ __forceinline__ void two_prod(double a, double b, double &p, double &e) {
+#pragma clang fp contract(off)
+	p = a * b;
+	e = fma(a, b, -p);
+}
+
+// (hi, lo) += (ahi, alo), kept as an unevaluated sum with |lo| <= ulp(hi)
+__device__ __forceinline__ void dd_add(double &hi, double &lo, double ahi, double alo) {
+#pragma clang fp contract(off)
+	double s, e;
+	two_sum(hi, ahi, s, e);
+	e += lo + alo;
+	hi = s + e;
+	lo = e - (hi - s);
+}
+
+// (hi, lo) += (wh + wl) (x - shift), the difference taken exactly
+__device__ __forceinline__ void dd_add_scaled_diff(double &hi, double &lo, double wh, double wl, double x, double shift) {
+#pragma clang fp contract(off)
+	double dh, dl, ph, pl;
+	two_sum(x, -shift, dh, dl);
+	two_prod(wh, dh, ph, pl);
+	pl = fma(wl, dh, pl);
+	pl = fma(wh, dl, pl);
+	dd_add(hi, lo, ph, pl);
+}
+
+// One row's residual in double-double: (e, e_l) = y - b0 - sum_j b[j] x[j]; fit accumulated as (fh, fl) by the caller
+// through dd_fit_term.
+__device__ __forceinline__ void dd_fit_term(double &fh, double &fl, double b, double x) {
+#pragma clang fp contract(off)
+	double ph, pl, sh, sl;
+	two_prod(b, x, ph, pl);
+	two_sum(fh, ph, sh, sl);
+	fh = sh;
+	fl += pl + sl;
+}
+
+// (wh, wl) = w (y - (fh + fl)) to twice the working precision; e = the residual rounded to working precision
+__device__ __forceinline__ void dd_weighted_residual(double y, double fh, double fl, double w, double &e, double &wh, double &wl) {
+#pragma clang fp contract(off)
+	double eh, el;
+	two_sum(y, -fh, eh, el);
+	el -= fl;
+	e = eh + el;
+	const double e_l = el - (e - eh);
+	double ph, pl;
+	two_prod(w, e, ph, pl);
+	pl = fma(w, e_l, pl);
+	wh = ph + pl;
+	wl = pl - (wh - ph);
+}
+
+} // namespace anofox

@@ -154,6 +154,9 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 		}
 		rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
 		refine = !(rss > kRefineTolM * tss) || (min_ratio < kPivotWarnM) || glmnet_cancels;
+		double bmax = 0.0;
+		for (int i = 0; i < p; ++i) bmax = fmax(bmax, ((active >> i) & 1u) ? fabs(beta[i]) : 0.0);
+		for (int i = 0; i < p; ++i) refine = refine || (((active >> i) & 1u) && coef_bound_weak(beta[i], bmax, diag0[i], tss, min_ratio));
 	} else {
 		for (int i = 0; i < p; ++i) beta[i] = ((active >> i) & 1u) ? core[i] : 0.0; // residual_grad used exactly these
 		rss = rvec[0];

@@ -20,6 +20,7 @@
 // This restores the accuracy of a QR on the design (the reference's algorithm class) for the queued groups.
 #include "common.h"
 #include "device_math.h"
+#include "dd_arith.h"
 
 namespace anofox {
 
@@ -184,6 +185,11 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 			for (int i = 0; i < P; ++i) { zz += zf[i] * zf[i]; bc += beta[i] * c[i]; bb += beta[i] * beta[i]; }
 			rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
 			refine = !(rss > kRefineTol * tss) || (min_ratio < kPivotWarn) || glmnet_cancels;
+			double bmax = 0.0;
+#pragma unroll
+			for (int i = 0; i < P; ++i) bmax = fmax(bmax, active[i] ? fabs(beta[i]) : 0.0);
+#pragma unroll
+			for (int i = 0; i < P; ++i) refine = refine || (active[i] && coef_bound_weak(beta[i], bmax, diag0[i], tss, min_ratio));
 		} else {
 			// current coefficients come from the record; residual_grad_wave used exactly these
 #pragma unroll
@@ -311,73 +317,81 @@ __global__ __launch_bounds__(64) void solve_narrow_kernel(BatchArgs args) {
 // One wavefront per queued group, straight from the data with the record's current coefficients:
 //   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ..., sum w (y - ybar)^2 },  r = y - b0 - x'b
 // over the valid rows (same row filter as the accumulate kernel); shift = first valid row when an intercept
-// is fitted (the shift of the moment record), 0 otherwise.
+// is fitted (the shift of the moment record), 0 otherwise.  The residual and the gradient sums are formed in
+// double-double arithmetic (dd_arith.h), as on the wide path: with the residual in working precision the update stalls
+// at cond(X) eps — designs without an intercept whose columns sit far from zero reach cond 1e7 at p <= 8 (3 of 240 000
+// cases of the deep narrow sweep were 1.5 .. 2.5e-9 off).  Only queued groups pay for it.
 __device__ __forceinline__ void residual_grad_wave(const BatchArgs &args, int64_t g, int lane) {
+#pragma clang fp contract(off)
 	const int p = args.p;
 	const bool weighted = args.model == ANOFOX_HIP_MODEL_WLS;
 	const int Z = p + 1;
 	const int off_first = Z + Z * (Z + 1) / 2 + 1;
 	const int rec_len = moment_record_len(p);
-	{
-		const double *core = args.core + g * (int64_t)(p + 6);
-		const double *rec = args.moments + g * (int64_t)rec_len;
-		double b[kNarrowMaxP], sh[kNarrowMaxP], acc[kNarrowMaxP + 3];
-		// mean of y over the valid rows, from the record (sum / weight, plus the shift an intercept fit accumulates about)
-		const double ybar = rec[p] / rec[Z + Z * (Z + 1) / 2] + (args.fit_intercept ? rec[off_first + p] : 0.0);
+	const double *core = args.core + g * (int64_t)(p + 6);
+	const double *rec = args.moments + g * (int64_t)rec_len;
+	// acc: [0] sum w r, [1 + j] sum w r (x_j - shift_j), as (hi, lo) pairs; rss and the centred yy in working precision
+	double b[kNarrowMaxP], sh[kNarrowMaxP], acc_h[kNarrowMaxP + 1], acc_l[kNarrowMaxP + 1];
+	// mean of y over the valid rows, from the record (sum / weight, plus the shift an intercept fit accumulates about)
+	const double ybar = rec[p] / rec[Z + Z * (Z + 1) / 2] + (args.fit_intercept ? rec[off_first + p] : 0.0);
+#pragma unroll
+	for (int j = 0; j < kNarrowMaxP; ++j) {
+		b[j] = sh[j] = 0.0;
+		if (j < p) {
+			const double bj = core[j];
+			b[j] = isnan(bj) ? 0.0 : bj; // dropped / aliased columns do not enter the fit
+			sh[j] = args.fit_intercept ? rec[off_first + j] : 0.0;
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < kNarrowMaxP + 1; ++k) acc_h[k] = acc_l[k] = 0.0;
+	double rss = 0.0, cyy = 0.0;
+	const double b0 = args.fit_intercept ? core[p] : 0.0;
+	const int64_t lo = args.row_offsets[g], hi = group_row_end(args, g);
+	for (int64_t r = lo + lane; r < hi; r += 64) {
+		const double yv = args.y[r];
+		bool ok = isfinite(yv);
+		double fh = b0, fl = 0.0; // fit = fh + fl
+		double xv[kNarrowMaxP];
 #pragma unroll
 		for (int j = 0; j < kNarrowMaxP; ++j) {
-			b[j] = sh[j] = 0.0;
+			xv[j] = 0.0;
 			if (j < p) {
-				const double bj = core[j];
-				b[j] = isnan(bj) ? 0.0 : bj; // dropped / aliased columns do not enter the fit
-				sh[j] = args.fit_intercept ? rec[off_first + j] : 0.0;
+				xv[j] = args.x[j][r];
+				ok = ok && isfinite(xv[j]);
+				dd_fit_term(fh, fl, b[j], xv[j]);
 			}
 		}
-#pragma unroll
-		for (int k = 0; k < kNarrowMaxP + 3; ++k) acc[k] = 0.0;
-		const double b0 = args.fit_intercept ? core[p] : 0.0;
-		const int64_t lo = args.row_offsets[g], hi = group_row_end(args, g);
-		for (int64_t r = lo + lane; r < hi; r += 64) {
-			const double yv = args.y[r];
-			bool ok = isfinite(yv);
-			double fit = b0;
-			double xv[kNarrowMaxP];
-#pragma unroll
-			for (int j = 0; j < kNarrowMaxP; ++j) {
-				xv[j] = 0.0;
-				if (j < p) {
-					xv[j] = args.x[j][r];
-					ok = ok && isfinite(xv[j]);
-					fit = fma(b[j], xv[j], fit);
-				}
-			}
-			double wv = 1.0;
-			if (weighted) {
-				wv = args.w[r];
-				ok = ok && (wv > 0.0) && isfinite(wv);
-			}
-			if (ok) {
-				const double e = yv - fit;
-				const double we = wv * e;
-				acc[0] = fma(we, e, acc[0]);
-				acc[1] += we;
-#pragma unroll
-				for (int j = 0; j < kNarrowMaxP; ++j)
-					if (j < p) acc[2 + j] = fma(we, xv[j] - sh[j], acc[2 + j]);
-				const double dy = yv - ybar;
-				acc[kNarrowMaxP + 2] = fma(wv * dy, dy, acc[kNarrowMaxP + 2]);
-			}
+		double wv = 1.0;
+		if (weighted) {
+			wv = args.w[r];
+			ok = ok && (wv > 0.0) && isfinite(wv);
 		}
+		if (ok) {
+			double e, wh, wl;
+			dd_weighted_residual(yv, fh, fl, wv, e, wh, wl); // wh + wl = w (y - fit) to twice the working precision
+			rss = fma(wh, e, rss);
+			dd_add(acc_h[0], acc_l[0], wh, wl);
 #pragma unroll
-		for (int k = 0; k < kNarrowMaxP + 3; ++k)
-			for (int m = 32; m >= 1; m >>= 1) acc[k] += __shfl_xor(acc[k], m, 64);
-		double *out = args.refine_vec + g * (int64_t)refine_vec_len(p);
-		double mine = 0.0;
-#pragma unroll
-		for (int k = 0; k < kNarrowMaxP + 2; ++k) mine = (lane == k) ? acc[k] : mine;
-		if (lane == p + 2) mine = acc[kNarrowMaxP + 2];
-		if (lane < p + 3) out[lane] = mine;
+			for (int j = 0; j < kNarrowMaxP; ++j)
+				if (j < p) dd_add_scaled_diff(acc_h[1 + j], acc_l[1 + j], wh, wl, xv[j], sh[j]);
+			const double dy = yv - ybar;
+			cyy = fma(wv * dy, dy, cyy);
+		}
 	}
+	for (int m = 32; m >= 1; m >>= 1) {
+		rss += __shfl_xor(rss, m, 64);
+		cyy += __shfl_xor(cyy, m, 64);
+#pragma unroll
+		for (int k = 0; k < kNarrowMaxP + 1; ++k)
+			if (k < p + 1) dd_add(acc_h[k], acc_l[k], __shfl_xor(acc_h[k], m, 64), __shfl_xor(acc_l[k], m, 64));
+	}
+	double *out = args.refine_vec + g * (int64_t)refine_vec_len(p);
+	double mine = rss;
+#pragma unroll
+	for (int k = 0; k < kNarrowMaxP + 1; ++k) mine = (lane == 1 + k) ? acc_h[k] + acc_l[k] : mine;
+	if (lane == p + 2) mine = cyy;
+	if (lane < p + 3) out[lane] = mine;
 }
 
 // The whole refinement of the queued groups in ONE launch: a wavefront takes a queued group through

@@ -435,7 +435,22 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		// Nearly square designs (fewer residual degrees of freedom than a quarter of the columns) are ill conditioned
 		// whatever the column scales, and a ridge penalty hides that from the pivot test (it lifts every pivot): they take
 		// the refinement passes as well.  (Deep fuzz sweep, ridge p = 127, n = 129: 4.6e-9 without.)
-		const bool refine = !(rss > kRefineTol * tss) || mr < kPivotWarn || df < 0.25 * (double)rank || glmnet_cancels;
+		bool refine = !(rss > kRefineTol * tss) || mr < kPivotWarn || df < 0.25 * (double)rank || glmnet_cancels;
+		{ // a coefficient whose a-priori error exceeds the parity scale (coef_bound_weak, common.h)
+			double bmax = 0.0;
+			sfor<0, T>([&](auto J_) __attribute__((always_inline)) {
+				constexpr int J = decltype(J_)::value;
+				bmax = fmax(bmax, (q == 0 && live[J]) ? fabs(beta[J]) : 0.0);
+			});
+#pragma unroll
+			for (int m = 32; m >= 1; m >>= 1) bmax = fmax(bmax, __shfl_xor(bmax, m, 64));
+			bool weak = false;
+			sfor<0, T>([&](auto J_) __attribute__((always_inline)) {
+				constexpr int J = decltype(J_)::value;
+				if (q == 0 && live[J]) weak = weak || coef_bound_weak(beta[J], bmax, d0s[16 * J + n], tss, mr);
+			});
+			refine = refine || __any(weak);
+		}
 		const double dfm = (double)rank;
 		const double r2 = 1.0 - rss / tss;
 		const double fstat = ((tss - rss) / dfm) / (rss / df);

@@ -14,6 +14,7 @@
 #include "common.h"
 #include <mutex>
 #include "device_math.h"
+#include "dd_arith.h"
 
 namespace anofox {
 
@@ -667,30 +668,8 @@ __global__ __launch_bounds__(128) void inference_wide_finish_kernel(WideArgs arg
 	if (tid == 0) inf[5 * p + 1] = dm_f_sf(fstat, dfm, df); // every thread read df before the barrier above
 }
 
-// Error-free transformations for the residual pass below (round-to-nearest, no fast-math: -fno-fast-math in the Makefile).
-// hipcc's default -ffp-contract=fast fuses a product with the sum that consumes it ACROSS statements; inside two_sum that
-// turns s = a + RN(x b) into fma(x, b, a), whose rounding error the rest of two_sum does not recover, and the compensated
-// residual degrades to working precision (r3, seed 46944 of the deep fuzz sweep: a 15 x 15 system that stalled at 1.4e-8
-// and converges to 1e-13 in two updates without the fusion).  So: no contraction from here to the end of the residual kernel;
-// the fma() calls below are the only fused operations.
+// (error-free transformations: dd_arith.h; no FMA contraction from here to the end of the residual kernel)
 #pragma clang fp contract(off)
-__device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
-	s = a + b;
-	const double bb = s - a;
-	e = (a - (s - bb)) + (b - bb);
-}
-__device__ __forceinline__ void two_prod(double a, double b, double &p, double &e) {
-	p = a * b;
-	e = fma(a, b, -p);
-}
-// (hi, lo) += (ahi, alo), kept as an unevaluated sum with |lo| <= ulp(hi)
-__device__ __forceinline__ void dd_add(double &hi, double &lo, double ahi, double alo) {
-	double s, e;
-	two_sum(hi, ahi, s, e);
-	e += lo + alo;
-	hi = s + e;
-	lo = e - (hi - s);
-}
 
 // One workgroup per queued group, straight from the data with the record's current coefficients:
 //   refine_vec[g] = { sum w r^2, sum w r, sum w r (x_j - shift_j) ..., sum w (y - ybar)^2 },  r = y - b0 - x'b  over the valid rows.
@@ -738,11 +717,7 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 				for (int j = 0; j < p; ++j) {
 					const double xv = args.x_table[j][r];
 					ok = ok && isfinite(xv);
-					double ph, pl, sh, sl;
-					two_prod(bsh[j], xv, ph, pl);
-					two_sum(fh, ph, sh, sl);
-					fh = sh;
-					fl += pl + sl;
+					dd_fit_term(fh, fl, bsh[j], xv);
 				}
 				double wv = 1.0;
 				if (weighted) {
@@ -750,16 +725,8 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 					ok = ok && (wv > 0.0) && isfinite(wv);
 				}
 				if (ok) {
-					double eh, el;
-					two_sum(yv, -fh, eh, el);
-					el -= fl;
-					const double e = eh + el;
-					const double e_l = el - (e - eh); // e + e_l = y - fit to twice the working precision
-					double ph, pl;
-					two_prod(wv, e, ph, pl);
-					pl = fma(wv, e_l, pl);
-					wh = ph + pl;
-					wl = pl - (wh - ph);
+					double e;
+					dd_weighted_residual(yv, fh, fl, wv, e, wh, wl); // wh + wl = w (y - fit) to twice the working precision
 					rss = fma(wh, e, rss);
 					dd_add(gs_h, gs_l, wh, wl);
 					const double dy = yv - ybar;
@@ -773,13 +740,8 @@ __global__ __launch_bounds__(256) void residual_grad_wide_kernel(WideArgs args) 
 				const int64_t m = (hi - r0 < 256) ? hi - r0 : 256;
 				for (int64_t t = 0; t < m; ++t) {
 					const double wt = weh[t];
-					if (wt != 0.0) { // invalid rows carry 0 and are skipped
-						const double dx = mycol[r0 + t] - shift;
-						double ph, pl;
-						two_prod(wt, dx, ph, pl);
-						pl = fma(wel[t], dx, pl);
-						dd_add(gj_h, gj_l, ph, pl);
-					}
+					if (wt != 0.0) // invalid rows carry 0 and are skipped
+						dd_add_scaled_diff(gj_h, gj_l, wt, wel[t], mycol[r0 + t], shift);
 				}
 			}
 			__syncthreads();
