@@ -73,7 +73,7 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 	}
 	if (cnt < (double)(peff + (icpt ? 1 : 0))) { write_null(ANOFOX_ERROR_INSUFFICIENT_DATA, true); return; } // ols.rs:132-139
 
-	// ridge penalty: `lam` goes into the factor; the refinement steps aim at `lam_rows`, glmnet's lambda with sd_y re-summed
+	// ridge penalty: `lam` goes into the primary factor; the refinement modes factor with and aim at `lam_rows`, glmnet's lambda with sd_y re-summed
 	// over the rows about the mean (uncentred moments of a nearly constant y cancel; such groups are queued)
 	double lam = 0.0, lam_rows = 0.0;
 	bool glmnet_cancels = false;
@@ -99,7 +99,7 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 			const int tile = I * T - I * (I - 1) / 2 + (J - I);
 			double v = rec[(int64_t)tile * 256 + (j & 15) * 16 + ci]; // M[16I + r][16J + c], r = j & 15, c = i & 15
 			if (icpt) v -= si * sx[j] * inv_sw;
-			if (i == j) v += lam;
+			if (i == j) v += (MODE == MODE_PRIMARY) ? lam : lam_rows; // the refinement modes factor with the re-summed lambda
 			A[tri(i, j)] = v;
 		}
 		c[i] = icpt ? sxy[i] - si * sy * inv_sw : sxy[i];

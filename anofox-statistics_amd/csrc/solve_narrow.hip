@@ -113,7 +113,8 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 			lam = args.alpha;
 			if (args.lambda_scaling == ANOFOX_LAMBDA_SCALING_GLMNET) {
 				// sd_y from the moments; a queued group's passes over the rows re-sum it about the mean (uncentred moments of
-				// a nearly constant y cancel), and the update steps then aim at that lambda with this factor as preconditioner
+				// a nearly constant y cancel), and the refinement modes factor with and aim at that lambda (the standard errors
+				// come from the same matrix: two nearly equal y values gave a lambda 3e-5 off and standard errors 1.6e-5 off)
 				lam = cnt * args.alpha / sqrt(cyy_centred / cnt);
 				glmnet_cancels = !icpt && !(cyy_centred * kGlmnetCancelRatio > qyy);
 				if (MODE != MODE_PRIMARY && !icpt) lam_rows = cnt * args.alpha / sqrt(rv[p + 2] / cnt);
@@ -122,7 +123,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 				lam_rows = lam;
 			}
 #pragma unroll
-			for (int i = 0; i < P; ++i) A[i][i] += lam;
+			for (int i = 0; i < P; ++i) A[i][i] += (MODE == MODE_PRIMARY) ? lam : lam_rows; // the refinement modes factor with the re-summed lambda
 		}
 
 		// Cholesky (left-looking, in place), deactivating constant and aliased columns

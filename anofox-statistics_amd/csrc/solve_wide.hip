@@ -489,7 +489,7 @@ __global__ __launch_bounds__(NTHR, OCC) void solve_wide_kernel(WideArgs args) {
 			continue;
 		}
 
-		// ridge penalty: `lam` goes into the factor; the refinement steps aim at `lam_rows`, glmnet's lambda with sd_y
+		// ridge penalty: `lam` goes into the primary factor; the refinement modes factor with and aim at `lam_rows`, glmnet's lambda with sd_y
 		// re-summed over the rows about the mean (uncentred moments of a nearly constant y cancel; such groups are queued)
 		double lam = 0.0, lam_rows = 0.0;
 		bool glmnet_cancels = false;
@@ -503,7 +503,9 @@ __global__ __launch_bounds__(NTHR, OCC) void solve_wide_kernel(WideArgs args) {
 		}
 		const double tss = icpt ? cyy_c : syy;
 
-		load_moment_matrix<NTHR>(l, rec, p, icpt, lam, sw, sy, tid);
+		// (the refinement modes factor the matrix with the re-summed lambda: the update is then an exact Newton step and the
+		// standard errors come from the matrix the coefficients solve)
+		load_moment_matrix<NTHR>(l, rec, p, icpt, MODE == MODE_PRIMARY ? lam : lam_rows, sw, sy, tid);
 		__syncthreads();
 		for (int j = tid; j < P16; j += NTHR) l.diag0[j] = j < p ? A[(size_t)j * LD + j] : 1.0;
 		// blocked_cholesky starts with a barrier

@@ -331,3 +331,16 @@ def test_fuzz_wide_window_frames(pkg, ctx, seed):
     if m.any():
         scale = np.maximum(np.abs(ref[m, 0]), 1.0)
         assert (np.abs(pred[m, 0] - ref[m, 0]) / scale).max() < 1e-8, what
+
+
+# Cases the deep sweeps (ANOFOX_FUZZ_SCALE=1000) missed before round 3's fixes, pinned by seed:
+#   wide 46944     — exactly determined 15 x 15 system, cond 6.7e6: FMA contraction inside two_sum left working-precision
+#                    noise in the "double-double" residual (dd_arith.h)
+#   narrow 150447, 167199, 218686 — a coefficient whose own contribution to y is tiny, pivot ratio just above the pivot
+#                    test: queued by the a-priori coefficient bound now (coef_bound_weak, common.h)
+#   narrow 186170  — glmnet ridge without an intercept on two nearly equal y values: the standard errors came from the
+#                    factor with the cancelled lambda
+@pytest.mark.parametrize("family,seed", [("wide", 46944), ("narrow", 150447), ("narrow", 167199), ("narrow", 218686),
+                                         ("narrow", 186170)])
+def test_deep_sweep_regressions(pkg, ctx, family, seed):
+    _run(pkg, ctx, seed, {"narrow": False, "wide": True}[family])
