@@ -420,6 +420,15 @@ def main():
             bound, unit, peak = "mfma", "TFLOP/s", FP64_MFMA_PEAK_TFLOPS
             per_step = G_local * algorithmic_flops_per_fit(n, p)
             achieved = per_step / (acc_step_ms * 1e-3) / 1e12 if acc_step_ms > 0 else 0.0
+        if args.window:
+            # the window path has its own kernel: one fit per ROW from running / rolling moments, 8 (p + 1 [+ 1]) B in and the
+            # three prediction doubles out per row; its time is what the predict events bracket
+            kernel = "expanding_predict_kernel" if frame[0] is None else "rolling_predict_kernel"
+            bound, unit, peak = "hbm", "GB/s", HBM_PEAK_GBS
+            acc_step_ms = kt["predict_ms"] / args.steps
+            acc_ms = kt["predict_ms"] / max(kt["predict_count"], 1)
+            per_step = G_local * n * (8 * (p + 1 + (1 if weighted else 0)) + 24)
+            achieved = per_step / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0
         # the same work over the WHOLE step (accumulate + solve + refinement [+ gather]) — what `value` is quoted on
         step_achieved = per_step / (ms_per_step * 1e-3) / (1e9 if bound == "hbm" else 1e12)
         kernel_achieved = achieved
@@ -435,7 +444,7 @@ def main():
         exposed_ms = max(0.0, ms_per_step - acc_step_ms)
         traffic = None   # HBM bytes per launch from the rocprofv3 PMC passes (profiles/hbm_traffic.json), if recorded
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath) and not args.vif:
+        if os.path.exists(tpath) and not (args.vif or args.window):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get(f"{args.model}_G{G_local}_n{n}_p{p}")
@@ -475,10 +484,11 @@ def main():
                          "traffic_source": ("profiles/hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                             "passes of this kernel on this workload; not measured in this run)"
                                             if traffic is not None else None),
-                         "kernel": kernel, "avg_launch_ms": acc_ms, "launches_per_step": kt["accumulate_count"] / args.steps,
+                         "kernel": kernel, "avg_launch_ms": acc_ms,
+                         "launches_per_step": kt["predict_count" if args.window else "accumulate_count"] / args.steps,
                          "kernel_ms_per_step": acc_step_ms, "groups_refined_last_launch": refined,
                          ("algorithmic_bytes_per_step" if bound == "hbm" else "algorithmic_flops_per_step"): per_step,
-                         "hbm_GBps_algorithmic": G_local * bytes_fit / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0,
+                         "hbm_GBps_algorithmic": (per_step if args.window else G_local * bytes_fit) / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0,
                          # solve_span: from the end of an accumulate kernel to the end of its solve / refinement.  For
                          # p <= 8 consecutive steps alternate between two streams and the span runs under the NEXT
                          # step's accumulate kernel; for wide designs the slabs of a step run on one stream and only
