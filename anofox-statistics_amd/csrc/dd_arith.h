@@ -13,7 +13,7 @@
 namespace anofox {
 
 // s + e = a + b exactly (Knuth)
-__device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
+__host__ __device__ __forceinline__ void two_sum(double a, double b, double &s, double &e) {
 #pragma clang fp contract(off)
 	s = a + b;
 	const double bb = s - a;
@@ -21,14 +21,14 @@ __device__ __forceinline__ void two_sum(double a, double b, double &s, double &e
 }
 
 // p + e = a b exactly
-__device__ __forceinline__ void two_prod(double a, double b, double &p, double &e) {
+__host__ __device__ __forceinline__ void two_prod(double a, double b, double &p, double &e) {
 #pragma clang fp contract(off)
 	p = a * b;
 	e = fma(a, b, -p);
 }
 
 // (hi, lo) += (ahi, alo), kept as an unevaluated sum with |lo| <= ulp(hi)
-__device__ __forceinline__ void dd_add(double &hi, double &lo, double ahi, double alo) {
+__host__ __device__ __forceinline__ void dd_add(double &hi, double &lo, double ahi, double alo) {
 #pragma clang fp contract(off)
 	double s, e;
 	two_sum(hi, ahi, s, e);
@@ -38,7 +38,7 @@ __device__ __forceinline__ void dd_add(double &hi, double &lo, double ahi, doubl
 }
 
 // (hi, lo) += (wh + wl) (x - shift), the difference taken exactly
-__device__ __forceinline__ void dd_add_scaled_diff(double &hi, double &lo, double wh, double wl, double x, double shift) {
+__host__ __device__ __forceinline__ void dd_add_scaled_diff(double &hi, double &lo, double wh, double wl, double x, double shift) {
 #pragma clang fp contract(off)
 	double dh, dl, ph, pl;
 	two_sum(x, -shift, dh, dl);
@@ -50,7 +50,7 @@ __device__ __forceinline__ void dd_add_scaled_diff(double &hi, double &lo, doubl
 
 // One row's residual in double-double: (e, e_l) = y - b0 - sum_j b[j] x[j]; fit accumulated as (fh, fl) by the caller
 // through dd_fit_term.
-__device__ __forceinline__ void dd_fit_term(double &fh, double &fl, double b, double x) {
+__host__ __device__ __forceinline__ void dd_fit_term(double &fh, double &fl, double b, double x) {
 #pragma clang fp contract(off)
 	double ph, pl, sh, sl;
 	two_prod(b, x, ph, pl);
@@ -60,7 +60,7 @@ __device__ __forceinline__ void dd_fit_term(double &fh, double &fl, double b, do
 }
 
 // (wh, wl) = w (y - (fh + fl)) to twice the working precision; e = the residual rounded to working precision
-__device__ __forceinline__ void dd_weighted_residual(double y, double fh, double fl, double w, double &e, double &wh, double &wl) {
+__host__ __device__ __forceinline__ void dd_weighted_residual(double y, double fh, double fl, double w, double &e, double &wh, double &wl) {
 #pragma clang fp contract(off)
 	double eh, el;
 	two_sum(y, -fh, eh, el);
