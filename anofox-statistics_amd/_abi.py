@@ -80,7 +80,8 @@ class AnofoxHipBatchOptions(C.Structure):
 
 class AnofoxHipKernelTimes(C.Structure):
     _fields_ = [("accumulate_ms", C.c_double), ("accumulate_count", C.c_int64), ("solve_ms", C.c_double),
-                ("solve_count", C.c_int64), ("predict_ms", C.c_double), ("predict_count", C.c_int64)]
+                ("solve_count", C.c_int64), ("predict_ms", C.c_double), ("predict_count", C.c_int64),
+                ("accumulate_ms_min", C.c_double), ("accumulate_ms_max", C.c_double)]
 
 
 class AnofoxHipWindowFrame(C.Structure):

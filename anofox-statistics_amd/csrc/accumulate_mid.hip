@@ -644,11 +644,16 @@ __device__ __forceinline__ void mid_accumulate_rows_lds(const WideArgs &args, in
 template <int T, bool WEIGHTED, bool CENTER, bool AUX, int LDSX> // LDSX: 0 = straight into fragment layout, 1 / 2 = through LDS, rows per lane
 __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const int lane = threadIdx.x & 63;
-	const int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	if (gl >= args.n_groups) return;
+	int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (args.from_redo_list) { // the groups a speculative kernel (accumulate_quad.hip) gave up on
+		if (gl >= args.refine_count[kWideRedoCounter]) return;
+		gl = args.refine_list[gl];
+	} else if (gl >= args.n_groups) {
+		return;
+	}
 	const int64_t lo = args.row_offsets[args.group_base + gl];
 	const int64_t hi = group_row_end(args, args.group_base + gl);
-	if (args.seg_table && hi - lo > args.seg_rows) {
+	if (!args.from_redo_list && args.seg_table && hi - lo > args.seg_rows) {
 		if (wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments)) return;
 	}
 	double *rec = args.moments + gl * (int64_t)wide_record_len(T);
@@ -788,6 +793,15 @@ hipError_t launch_accumulate_mid_segments(const WideArgs &a, hipStream_t stream)
 	case 2: return launch_mid_segments_T<2>(a, stream);
 	default: return hipErrorInvalidValue;
 	}
+}
+
+// the full version on the redo list of a speculative kernel: the batch's grid, the segment kernel not launched again
+hipError_t launch_accumulate_mid_redo(const WideArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	WideArgs b = a;
+	b.from_redo_list = 1;
+	b.seg_table = nullptr;
+	return launch_accumulate_mid(b, stream);
 }
 
 hipError_t launch_accumulate_mid(const WideArgs &a, hipStream_t stream) {

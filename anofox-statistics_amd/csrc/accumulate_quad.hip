@@ -32,6 +32,9 @@
 #ifndef ANOFOX_QUAD_SKIP
 #define ANOFOX_QUAD_SKIP 0
 #endif
+#ifndef ANOFOX_QUAD_NOUNROLL_NB
+#define ANOFOX_QUAD_NOUNROLL_NB 8 // from this many column groups on the steps of a block are not unrolled in pairs (registers)
+#endif
 
 namespace anofox {
 
@@ -63,14 +66,102 @@ __device__ __forceinline__ unsigned quad_spread8(unsigned x) { // bit i of the l
 	return x;
 }
 
-template <int NB, bool WEIGHTED, bool CENTER, int RL>
-__device__ __forceinline__ void quad_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
+// The end of a group, shared by the loaders: the four row quads' partial sums, the Gram image through LDS, (SPEC) the check of what
+// the speculation assumed, then accumulate_mid's record layout.
+template <int NB, bool SPEC>
+__device__ __forceinline__ bool quad_finish(const WideArgs &args, double *rec, int lane, double *buf, double (&acc)[NB * (NB + 1) / 2],
+                                            const double (&first)[NB], double (&dmax)[NB], bool isx_prev, bool isx_last, int cnt,
+                                            int64_t lo, int64_t hi) {
+	constexpr int NPAIR = NB * (NB + 1) / 2;
+	const int p = args.p;
+	const int T = wide_tiles(p), P16 = 16 * T, NT = T * (T + 1) / 2;
+	const int b = (lane >> 2) & 3;
+	// ---- the record: the four row quads' partial sums, the Gram image through LDS, then accumulate_mid's layout ----
+#pragma unroll
+	for (int t = 0; t < NPAIR; ++t) {
+		acc[t] += __shfl_xor(acc[t], 4, 64);
+		acc[t] += __shfl_xor(acc[t], 8, 64);
+	}
+#pragma unroll
+	for (int g = 0; g < (SPEC ? 0 : NB); ++g) { // the largest deviation of column 4 g + c4 over all rows: the 16 lanes that share c4
+		double m = dmax[g];
+		m = fmax(m, __shfl_xor(m, 4, 64));
+		m = fmax(m, __shfl_xor(m, 8, 64));
+		m = fmax(m, __shfl_xor(m, 16, 64));
+		m = fmax(m, __shfl_xor(m, 32, 64));
+		dmax[g] = m;
+	}
+	constexpr int R = 4 * NB;
+	double *G = buf, *F = buf + R * R, *NC = F + R;
+	{
+		const int i = lane >> 4, j = lane & 3; // D[b][i][j] on lane 16 i + 4 b + j: the b = 0 lanes write
+		int t = 0;
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+#pragma unroll
+			for (int h = g; h < NB; ++h) {
+				if (b == 0) {
+					G[(4 * g + i) * R + 4 * h + j] = acc[t];
+					if (h != g) G[(4 * h + j) * R + 4 * g + i] = acc[t];
+				}
+				++t;
+			}
+		}
+		if (lane < 4) {
+#pragma unroll
+			for (int g = 0; g < NB; ++g) {
+				F[4 * g + lane] = first[g];
+				const bool isx = g < NB - 2 ? true : (g == NB - 2 ? isx_prev : isx_last);
+				NC[4 * g + lane] = (isx && !(dmax[g] < 1e-10)) ? 1.0 : 0.0;
+			}
+		}
+	}
+	__builtin_amdgcn_wave_barrier();
+	for (int tile = 0, I = 0; I < T; ++I) {
+		for (int J = I; J < T; ++J, ++tile) {
+			double *tp = rec + (int64_t)tile * 256; // tile-major, element (row, col) at row * 16 + col
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const int e = lane + 64 * q, r = 16 * I + (e >> 4), c = 16 * J + (e & 15);
+				tp[e] = (r < p && c < p) ? G[r * R + c] : 0.0;
+			}
+		}
+	}
+	double *vec = rec + (int64_t)NT * 256;
+	for (int j = lane; j < P16; j += 64) {
+		const bool in = j < p;
+		vec[0 * P16 + j] = in ? G[j * R + p + 1] : 0.0; // sum w d_j
+		vec[1 * P16 + j] = in ? G[j * R + p] : 0.0;     // sum w d_j dy
+		vec[2 * P16 + j] = in ? F[j] : 0.0;             // x at the first valid row
+		vec[3 * P16 + j] = in ? NC[j] : 0.0;            // not constant
+	}
+	double *sc = vec + 4 * P16;
+	if (lane == 0) {
+		sc[0] = G[p * R + p + 1];       // sum w dy
+		sc[1] = G[p * R + p];           // sum w dy^2
+		sc[2] = G[(p + 1) * R + p + 1]; // sum w
+		sc[3] = (double)cnt;
+		sc[4] = F[p];                   // y of the first valid row
+	}
+	return true;
+}
+
+// SPEC (r4): the speculative version for the common case — no weights, an intercept.  It takes every row for valid and the
+// first row for the shift, so the per-row finiteness test, the per-step constant-column test (NB running maxima in
+// registers) and every mask disappear from the loop; what it assumed is checked ON THE RESULT: every moment finite (a NaN /
+// inf anywhere in a row poisons at least one sum) and every x column clearly constant (sum d^2 < 1e-20, which implies every
+// |d| < 1e-10) or clearly not (sum d^2 >= n 1e-20, which rules out "every |d| < 1e-10") — the predicate of ols.rs:76-87
+// decided exactly in both cases.  Anything else returns false and the group goes to the full version through the redo
+// list (the scheme of accumulate_wide's speculative kernel).  The registers it frees are what lets NB = 8, 9 (p = 27 .. 34)
+// run here at two waves per SIMD.
+template <int NB, bool WEIGHTED, bool CENTER, int RL, bool SPEC = false>
+__device__ __forceinline__ bool quad_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
+	static_assert(!SPEC || (CENTER && !WEIGHTED), "the speculative version exists for the unweighted fit with an intercept");
 	constexpr int NCOL = 4 * NB; // load slots per block: x (p), y, (w) — p + 2 <= 4 NB
 	constexpr int NPAIR = NB * (NB + 1) / 2;
 	constexpr int RS = quad_lds_stride(RL);
 	constexpr int BR = 64 * RL;
 	const int p = args.p;
-	const int T = wide_tiles(p), P16 = 16 * T, NT = T * (T + 1) / 2;
 	const int ncol = p + 1 + (WEIGHTED ? 1 : 0);
 	const int k = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3;
 	const int rsub = 4 * k + b; // this lane's row of every 16-row step
@@ -147,7 +238,7 @@ __device__ __forceinline__ void quad_accumulate_rows(const WideArgs &args, int64
 			// CENTER: deviations from the group's first valid row (first = 0 for the ones); otherwise raw values, masked
 			d[g] = CENTER ? dev : (valid_all ? v : quad_mask(v, rm));
 			// constant-column predicate of ols.rs:76-87: the largest |x - x_first| per lane and column, tested once per group
-			if (!(ANOFOX_QUAD_SKIP & 4)) dmax[g] = fmax(dmax[g], fabs(dev));
+			if (!SPEC && !(ANOFOX_QUAD_SKIP & 4)) dmax[g] = fmax(dmax[g], fabs(dev));
 			a[g] = WEIGHTED ? wv * d[g] : d[g];
 		}
 		int t = 0;
@@ -169,7 +260,7 @@ __device__ __forceinline__ void quad_accumulate_rows(const WideArgs &args, int64
 #pragma unroll
 		for (int e = 0; e < RL; ++e) {
 			double z = 0.0;
-			if (!(ANOFOX_QUAD_SKIP & 2)) {
+			if (!SPEC && !(ANOFOX_QUAD_SKIP & 2)) {
 #pragma unroll
 				for (int c = 0; c < NCOL; ++c) z = fma(0.0, reg[c][e], z);
 			}
@@ -208,8 +299,13 @@ __device__ __forceinline__ void quad_accumulate_rows(const WideArgs &args, int64
 			}
 			if ((v0 & v1) == ~0ull) {
 				cnt += BR;
+				if (NB >= ANOFOX_QUAD_NOUNROLL_NB) {
+#pragma unroll 1
+					for (int sidx = 0; sidx < 4 * RL; ++sidx) step(sidx, true, 0xFFFFu);
+				} else {
 #pragma unroll 2
-				for (int sidx = 0; sidx < ((ANOFOX_QUAD_SKIP & 16) ? 1 : 4 * RL); ++sidx) step(sidx, true, 0xFFFFu);
+					for (int sidx = 0; sidx < ((ANOFOX_QUAD_SKIP & 16) ? 1 : 4 * RL); ++sidx) step(sidx, true, 0xFFFFu);
+				}
 			} else {
 				cnt += __popcll(v0) + (RL == 2 ? __popcll(v1) : 0);
 #pragma unroll 1
@@ -227,89 +323,182 @@ __device__ __forceinline__ void quad_accumulate_rows(const WideArgs &args, int64
 	if (lo < hi) issue(lo);
 	for (int64_t blk = lo; blk < hi; blk += BR) block(blk, blk + BR);
 
-	// ---- the record: the four row quads' partial sums, the Gram image through LDS, then accumulate_mid's layout ----
+	return quad_finish<NB, SPEC>(args, rec, lane, buf, acc, first, dmax, isx_prev, isx_last, cnt, lo, hi);
+}
+
+// ---- (r4) the speculative version on LDS-DMA, NB = 8, 9 (p = 27 .. 33) -------------------------------------------------
+// The full version and the register-staged speculative one do not fit two waves per SIMD from NB = 8 on (45 accumulators + 36
+// staged columns: the compiler spills the STAGED LOADS one by one, each behind its own vmcnt(0)).  Here no row passes through a
+// register on its way in: `global_load_lds_dword` moves 256 bytes = 32 rows of one column per wave-instruction straight into the
+// wave's slice (M0 = destination, a scalar base per column + the lane's constant 4-byte offset: no vector instruction at all),
+// block k + 1 lands in one half of a 64-row ring while the steps of block k read the other half.  The instructions are inline asm
+// (M0 is written in the statement that uses it), so the compiler neither counts nor waits for them: the loop waits with
+// vmcnt(number of columns) — one block stays in flight — before it reads a half.  What is left per 32-row block: 4 NB - 1 DMA
+// instructions, 2 x (NB ds_read_b64 + NB subtractions + NB (NB + 1) / 2 v_mfma_f64_4x4x4) and nothing else.
+constexpr int kQuadDmaStride = 72; // doubles per column of the ring: 2 x 32 rows + 8 (= 8 mod 32: conflict-free ds_read_b64, see above)
+__host__ __device__ constexpr int quad_dma_slice_doubles(int p) {
+	const int data = (p + 1) * kQuadDmaStride;
+	const int R = 4 * quad_blocks(p);
+	const int image = R * R + 2 * R;
+	return data > image ? data : image;
+}
+
+// four columns per statement: M0 is saved, stepped by one column (576 bytes) per load and restored
+__device__ __forceinline__ void quad_dma4(unsigned voff, unsigned lds_dst, const double *c0, const double *c1, const double *c2, const double *c3) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\t"
+	             "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
+	             "s_add_u32 m0, m0, 576\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
+	             "s_add_u32 m0, m0, 576\n\ts_nop 0\n\tglobal_load_lds_dword %1, %5\n\t"
+	             "s_add_u32 m0, m0, 576\n\ts_nop 0\n\tglobal_load_lds_dword %1, %6\n\t"
+	             "s_mov_b32 m0, %0"
+	             : "=&s"(keep)
+	             : "v"(voff), "s"(lds_dst), "s"(c0), "s"(c1), "s"(c2), "s"(c3)
+	             : "memory", "scc");
+}
+__device__ __forceinline__ void quad_dma1(unsigned voff, unsigned lds_dst, const double *c0) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(c0) : "memory");
+}
+
+template <int NB>
+__device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
+	constexpr int NPAIR = NB * (NB + 1) / 2;
+	constexpr int RS = kQuadDmaStride;
+	constexpr int NDMA = 4 * NB - 1; // p + 1 <= 4 NB - 1 columns; the slots past column p load y again (onto itself)
+	static_assert(NDMA <= 63, "vmcnt is a 6-bit field");
+	const int p = args.p;
+	const int k = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3;
+	const int rsub = 4 * k + b;
+	const int base_off = c4 * RS + rsub;
+	const int c_last = 4 * (NB - 1) + c4;
+	const bool rd_last = c_last <= p;
+	const int last_off = (rd_last ? c_last : p) * RS + rsub;
+	const double fill_last = c_last == p + 1 ? 1.0 : 0.0;
+	const bool isx_prev = 4 * (NB - 2) + c4 < p, isx_last = c_last < p;
+	const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)buf); // wave-uniform
+	double acc[NPAIR];
 #pragma unroll
-	for (int t = 0; t < NPAIR; ++t) {
-		acc[t] += __shfl_xor(acc[t], 4, 64);
-		acc[t] += __shfl_xor(acc[t], 8, 64);
-	}
+	for (int t = 0; t < NPAIR; ++t) acc[t] = 0.0;
+	double first[NB], dmax[NB];
 #pragma unroll
-	for (int g = 0; g < NB; ++g) { // the largest deviation of column 4 g + c4 over all rows: the 16 lanes that share c4
-		double m = dmax[g];
-		m = fmax(m, __shfl_xor(m, 4, 64));
-		m = fmax(m, __shfl_xor(m, 8, 64));
-		m = fmax(m, __shfl_xor(m, 16, 64));
-		m = fmax(m, __shfl_xor(m, 32, 64));
-		dmax[g] = m;
-	}
-	constexpr int R = 4 * NB;
-	double *G = buf, *F = buf + R * R, *NC = F + R;
-	{
-		const int i = lane >> 4, j = lane & 3; // D[b][i][j] on lane 16 i + 4 b + j: the b = 0 lanes write
+	for (int g = 0; g < NB; ++g) first[g] = dmax[g] = 0.0;
+
+	auto colp = [&](int c) -> const double * { return c < p ? args.x_table[c < kWideMaxP ? c : 0] : args.y; };
+	// one 32-row block into half `h` of the ring; a partial block clamps the lanes' offsets to its last row (the rows past the
+	// end are masked by the steps), so nothing is read beyond the group
+	auto dma = [&](int64_t blk, int h) {
+		const int64_t left = hi - blk;
+		unsigned voff = (unsigned)lane * 4u;
+		if (left < 32) {
+			const unsigned last = (unsigned)left * 8u - 4u;
+			voff = voff < last ? voff : (last - 4u + (voff & 4u)); // keep the dword's half: the pair (lo, hi) of one double stays a double
+		}
+		const unsigned dst = lds0 + (unsigned)h * 256u;
+#pragma unroll
+		for (int c = 0; c + 4 <= NDMA; c += 4)
+			quad_dma4(voff, dst + (unsigned)c * (RS * 8u), colp(c) + blk, colp(c + 1) + blk, colp(c + 2) + blk, colp(c + 3) + blk);
+		// the last three slots: columns 4 NB - 4 .. p (at least one of them exists); the slots past column p load y once more
+		// ONTO ITSELF — the slice ends with column p, and the instruction count per block must not depend on p
+#pragma unroll
+		for (int c = NDMA / 4 * 4; c < NDMA; ++c) {
+			const int cc = c < p ? c : p;
+			quad_dma1(voff, dst + (unsigned)cc * (RS * 8u), colp(cc) + blk);
+		}
+	};
+	auto step = [&](const double *hb, int s, bool valid_all, unsigned rowmask) {
+		const long long rm = valid_all ? -1ll : -(long long)((rowmask >> rsub) & 1u);
+		double d[NB];
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+			double v;
+			if (g < NB - 1) {
+				v = hb[base_off + 16 * s + 4 * g * RS];
+			} else {
+				const double raw = hb[last_off + 16 * s];
+				v = rd_last ? raw : fill_last;
+			}
+			double dev = v - first[g];
+			if (!valid_all) dev = quad_mask(dev, rm);
+			d[g] = dev;
+		}
 		int t = 0;
 #pragma unroll
 		for (int g = 0; g < NB; ++g) {
 #pragma unroll
 			for (int h = g; h < NB; ++h) {
-				if (b == 0) {
-					G[(4 * g + i) * R + 4 * h + j] = acc[t];
-					if (h != g) G[(4 * h + j) * R + 4 * g + i] = acc[t];
-				}
+				acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(d[g], d[h], acc[t], 0, 0, 0);
 				++t;
 			}
 		}
-		if (lane < 4) {
-#pragma unroll
-			for (int g = 0; g < NB; ++g) {
-				F[4 * g + lane] = first[g];
-				const bool isx = g < NB - 2 ? true : (g == NB - 2 ? isx_prev : isx_last);
-				NC[4 * g + lane] = (isx && !(dmax[g] < 1e-10)) ? 1.0 : 0.0;
-			}
+	};
+	int h = 0;
+	dma(lo, 0);
+	for (int64_t blk = lo; blk < hi; blk += 32, h ^= 1) {
+		if (blk + 32 < hi) {
+			dma(blk + 32, h ^ 1);
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); // this block has landed, the next one stays in flight
+		} else {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
-	}
-	__builtin_amdgcn_wave_barrier();
-	for (int tile = 0, I = 0; I < T; ++I) {
-		for (int J = I; J < T; ++J, ++tile) {
-			double *tp = rec + (int64_t)tile * 256; // tile-major, element (row, col) at row * 16 + col
+		__builtin_amdgcn_wave_barrier();
+		const double *hb = buf + 32 * h;
+		if (blk == lo) { // the shift: the group's first row (the constants are not shifted)
 #pragma unroll
-			for (int q = 0; q < 4; ++q) {
-				const int e = lane + 64 * q, r = 16 * I + (e >> 4), c = 16 * J + (e & 15);
-				tp[e] = (r < p && c < p) ? G[r * R + c] : 0.0;
-			}
+			for (int g = 0; g < NB - 1; ++g) first[g] = buf[c4 * RS + 4 * g * RS];
+			first[NB - 1] = rd_last ? buf[(rd_last ? c_last : p) * RS] : 0.0;
 		}
+		const int64_t left = hi - blk;
+		if (left >= 32) {
+			step(hb, 0, true, 0xFFFFu);
+			step(hb, 1, true, 0xFFFFu);
+		} else {
+			const unsigned m32 = (1u << (unsigned)left) - 1u; // 1 <= left < 32
+			step(hb, 0, false, m32 & 0xFFFFu);
+			if (left > 16) step(hb, 1, false, m32 >> 16);
+		}
+		__builtin_amdgcn_wave_barrier(); // the reads of this half before the DMA that refills it (next iteration but one)
 	}
-	double *vec = rec + (int64_t)NT * 256;
-	for (int j = lane; j < P16; j += 64) {
-		const bool in = j < p;
-		vec[0 * P16 + j] = in ? G[j * R + p + 1] : 0.0; // sum w d_j
-		vec[1 * P16 + j] = in ? G[j * R + p] : 0.0;     // sum w d_j dy
-		vec[2 * P16 + j] = in ? F[j] : 0.0;             // x at the first valid row
-		vec[3 * P16 + j] = in ? NC[j] : 0.0;            // not constant
-	}
-	double *sc = vec + 4 * P16;
-	if (lane == 0) {
-		sc[0] = G[p * R + p + 1];       // sum w dy
-		sc[1] = G[p * R + p];           // sum w dy^2
-		sc[2] = G[(p + 1) * R + p + 1]; // sum w
-		sc[3] = (double)cnt;
-		sc[4] = F[p];                   // y of the first valid row
-	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	return quad_finish<NB, true>(args, rec, lane, buf, acc, first, dmax, isx_prev, isx_last, 0, lo, hi);
 }
 
-template <int NB, bool WEIGHTED, bool CENTER, int RL, int WPS> // WPS: waves per SIMD the register budget is cut for
+// MODE 0: the full version on every group; 1: the speculative version, give-ups (and empty groups) listed for the full one —
+// the list borrows the refine queue and its counter word kWideRedoCounter, as accumulate_wide's does; 2: the full version on
+// the listed groups (launched with the batch's grid: one scalar load and out for the wavefronts beyond the list).
+template <int NB, bool WEIGHTED, bool CENTER, int RL, int WPS, int MODE = 0> // WPS: waves per SIMD the register budget is cut for
 __global__ __launch_bounds__(256, WPS) void accumulate_quad_kernel(WideArgs args) {
 	extern __shared__ double quad_lds[];
 	const int lane = threadIdx.x & 63;
-	const int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	if (gl >= args.n_groups) return;
+	int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (MODE == 2) {
+		if (gl >= args.refine_count[kWideRedoCounter]) return;
+		gl = args.refine_list[gl];
+	} else if (gl >= args.n_groups) {
+		return;
+	}
 	const int T = wide_tiles(args.p);
 	const int64_t lo = args.row_offsets[args.group_base + gl];
 	const int64_t hi = group_row_end(args, args.group_base + gl);
-	if (args.seg_table && hi - lo > args.seg_rows) {
-		if (wide_register_big_group(args, gl, lo, hi, T, lane, kSegMaxBig, kSegMaxSegments)) return;
+	if (MODE != 2 && args.seg_table && hi - lo > args.seg_rows) {
+		// (three column tiles, p = 33, 34: the host sized the table for accumulate_wide's workgroup-per-segment kernel)
+		if (wide_register_big_group(args, gl, lo, hi, T, lane, T <= 2 ? kSegMaxBig : kWideSegMaxBig, T <= 2 ? kSegMaxSegments : kWideSegMaxSegments)) return;
 	}
-	quad_accumulate_rows<NB, WEIGHTED, CENTER, RL>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), lane,
-	                                               quad_lds + (threadIdx.x >> 6) * quad_slice_doubles(args.p, WEIGHTED, RL));
+	double *rec = args.moments + gl * (int64_t)wide_record_len(T);
+	if constexpr (MODE == 3) { // the speculative version on LDS-DMA (its own slice size)
+		double *slice = quad_lds + (threadIdx.x >> 6) * quad_dma_slice_doubles(args.p);
+		if (hi > lo && quad_spec_dma_rows<NB>(args, lo, hi, rec, lane, slice)) return;
+		if (lane == 0) args.refine_list[atomicAdd(args.refine_count + kWideRedoCounter, 1)] = (int32_t)gl;
+		return;
+	}
+	double *slice = quad_lds + (threadIdx.x >> 6) * quad_slice_doubles(args.p, WEIGHTED, RL);
+	if constexpr (MODE == 1) {
+		if (hi > lo && quad_accumulate_rows<NB, WEIGHTED, CENTER, RL, true>(args, lo, hi, rec, lane, slice)) return;
+		if (lane == 0) args.refine_list[atomicAdd(args.refine_count + kWideRedoCounter, 1)] = (int32_t)gl;
+	} else {
+		quad_accumulate_rows<NB, WEIGHTED, CENTER, RL>(args, lo, hi, rec, lane, slice);
+	}
 }
 
 template <int NB, int RL, int WPS>
@@ -319,39 +508,77 @@ hipError_t launch_quad_nb(const WideArgs &a, hipStream_t stream) {
 	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
 	const size_t lds_bytes = 4 * (size_t)quad_slice_doubles(a.p, weighted, RL) * sizeof(double);
 	static const bool attr_set = [] {
-#define ANOFOX_QUAD_ATTR(W, C) \
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_quad_kernel<NB, W, C, RL, WPS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-		ANOFOX_QUAD_ATTR(true, true); ANOFOX_QUAD_ATTR(true, false); ANOFOX_QUAD_ATTR(false, true); ANOFOX_QUAD_ATTR(false, false);
+#define ANOFOX_QUAD_ATTR(W, C, M) \
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_quad_kernel<NB, W, C, RL, WPS, M>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+		ANOFOX_QUAD_ATTR(true, true, 0); ANOFOX_QUAD_ATTR(true, false, 0); ANOFOX_QUAD_ATTR(false, true, 0); ANOFOX_QUAD_ATTR(false, false, 0);
+		ANOFOX_QUAD_ATTR(false, true, 1); ANOFOX_QUAD_ATTR(false, true, 2);
 #undef ANOFOX_QUAD_ATTR
 		return true;
 	}();
 	(void)attr_set;
+	// the unweighted fit with an intercept first runs the speculative kernel, then the full version on what it listed (the
+	// counter is zeroed by the caller; ANOFOX_WIDE_FAST=0 / ANOFOX_QUAD_SPEC=0: the full version only)
+	static const bool spec_on = !(getenv("ANOFOX_QUAD_SPEC") && atoi(getenv("ANOFOX_QUAD_SPEC")) == 0);
+	const bool spec = spec_on && !a.no_fast_path && !weighted && center;
 	if (weighted) {
 		if (center) hipLaunchKernelGGL((accumulate_quad_kernel<NB, true, true, RL, WPS>), grid, block, lds_bytes, stream, a);
 		else hipLaunchKernelGGL((accumulate_quad_kernel<NB, true, false, RL, WPS>), grid, block, lds_bytes, stream, a);
 	} else {
-		if (center) hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, true, RL, WPS>), grid, block, lds_bytes, stream, a);
-		else hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, false, RL, WPS>), grid, block, lds_bytes, stream, a);
+		if (!center) hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, false, RL, WPS>), grid, block, lds_bytes, stream, a);
+		else if (spec) hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, true, RL, WPS, 1>), grid, block, lds_bytes, stream, a);
+		else hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, true, RL, WPS>), grid, block, lds_bytes, stream, a);
 	}
 	hipError_t rc = hipGetLastError();
 	if (rc != hipSuccess) return rc;
 	// very large groups were registered for row splitting: accumulate_mid's segment kernel takes them (idle otherwise)
-	return a.seg_table ? launch_accumulate_mid_segments(a, stream) : hipSuccess;
+	if (a.seg_table && (rc = launch_accumulate_mid_segments(a, stream)) != hipSuccess) return rc;
+	if (spec) hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, true, RL, WPS, 2>), grid, block, lds_bytes, stream, a);
+	return hipGetLastError();
+}
+
+// NB = 8, 9 (p = 27 .. 34): only the speculative kernel exists here (the full version's registers do not fit two waves per
+// SIMD, see below); its give-ups go to accumulate_mid (p <= 32) or accumulate_wide (p = 33, 34: three column tiles, whose
+// segment table also takes this kernel's very large groups).
+template <int NB, int WPS>
+hipError_t launch_quad_spec_only(const WideArgs &a, hipStream_t stream) {
+	constexpr int RL = 1;
+	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
+	const size_t lds_bytes = 4 * (size_t)quad_dma_slice_doubles(a.p) * sizeof(double);
+	static const bool attr_set = [] {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_quad_kernel<NB, false, true, RL, WPS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		return true;
+	}();
+	(void)attr_set;
+	hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, true, RL, WPS, 3>), grid, block, lds_bytes, stream, a);
+	hipError_t rc = hipGetLastError();
+	if (rc != hipSuccess) return rc;
+	if (wide_tiles(a.p) <= 2) {
+		if (a.seg_table && (rc = launch_accumulate_mid_segments(a, stream)) != hipSuccess) return rc;
+		return launch_accumulate_mid_redo(a, stream);
+	}
+	return launch_accumulate_wide_followup(a, stream);
 }
 
 } // namespace
 
-// p = 27 .. 32 (NB = 8, 9) stay with accumulate_mid: 36 / 45 accumulators + the staged block do not fit the 256 registers of two
-// waves per SIMD (168-456 bytes of spills: 2.9-3.0 TB/s against 4.3), and the saving in matrix instructions is small there.
-// (Also measured and not kept: TWO wavefronts per group sharing the slice — each loads every other column and owns every other
-// block pair, the block written to LDS centred and masked, two barriers per 64-row block: correct, 164-188 registers, but
-// 3.5-4.1 TB/s against accumulate_mid's 4.2-4.4 at p = 27 .. 32; and this kernel with the registers of ONE wave per SIMD:
-// no spills, 3.5-4.0 TB/s.  profiles/r03_quad.txt.)
-bool accumulate_quad_supports(int p) { return p > kNarrowMaxP && p <= 26; }
+// The full version at p = 27 .. 32 (NB = 8, 9) stays with accumulate_mid: 36 / 45 accumulators + the staged block + the running
+// maxima of the constant-column test do not fit the 256 registers of two waves per SIMD (168-456 bytes of spills: 2.9-3.0 TB/s
+// against 4.3).  (Also measured and not kept: TWO wavefronts per group sharing the slice — each loads every other column and
+// owns every other block pair, the block written to LDS centred and masked, two barriers per 64-row block: correct, 164-188
+// registers, but 3.5-4.1 TB/s against accumulate_mid's 4.2-4.4 at p = 27 .. 32; and this kernel with the registers of ONE wave
+// per SIMD: no spills, 3.5-4.0 TB/s.  profiles/r03_quad.txt.)  (r4) The SPECULATIVE version needs neither the maxima nor the
+// masks and takes p = 27 .. 34 for the unweighted fit with an intercept.
+bool accumulate_quad_supports(int p, bool weighted, bool center, bool no_fast_path) {
+	static const bool spec_on = !(getenv("ANOFOX_QUAD_SPEC") && atoi(getenv("ANOFOX_QUAD_SPEC")) == 0);
+	// (p = 34: 35 columns x 576 bytes x 8 waves exceed the CU's 160 KB of LDS by one kilobyte)
+	static const int spec_max_p = getenv("ANOFOX_QUAD_SPEC_MAXP") ? atoi(getenv("ANOFOX_QUAD_SPEC_MAXP")) : 33;
+	if (p > kNarrowMaxP && p <= 26) return true;
+	return p > 26 && p <= 33 && p <= spec_max_p && spec_on && !weighted && center && !no_fast_path;
+}
 
 hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
-	if (!accumulate_quad_supports(a.p)) return hipErrorInvalidValue;
+	if (!accumulate_quad_supports(a.p, a.model == ANOFOX_HIP_MODEL_WLS, a.fit_intercept != 0, a.no_fast_path != 0)) return hipErrorInvalidValue;
 	// rows per lane and block, by measurement (profiles/r03_quad.txt): 128-row blocks for p <= 11 and p = 15..17, 64-row
 	// blocks elsewhere (from p = 18 the larger slice would leave one workgroup per CU).  A register budget for three waves
 	// per SIMD was measured slower for every NB >= 4 (spills).  ANOFOX_QUAD_RL=1/2 forces one.
@@ -359,12 +586,14 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	const int nb = quad_blocks(a.p);
 	int rl = (a.p <= 11 || (a.p >= 15 && a.p <= 17)) ? 2 : 1;
 	if (env_rl == 1 || (env_rl == 2 && a.p <= 18)) rl = env_rl;
-	switch (nb) { // p = 9, 10 | 11..14 | 15..18 | 19..22 | 23..26
+	switch (nb) { // p = 9, 10 | 11..14 | 15..18 | 19..22 | 23..26 | 27..30 | 31..34
 	case 3: return rl == 2 ? launch_quad_nb<3, 2, 3>(a, stream) : launch_quad_nb<3, 1, 3>(a, stream);
 	case 4: return rl == 2 ? launch_quad_nb<4, 2, 2>(a, stream) : launch_quad_nb<4, 1, 2>(a, stream);
 	case 5: return rl == 2 ? launch_quad_nb<5, 2, 2>(a, stream) : launch_quad_nb<5, 1, 2>(a, stream);
 	case 6: return launch_quad_nb<6, 1, 2>(a, stream);
 	case 7: return launch_quad_nb<7, 1, 2>(a, stream);
+	case 8: return launch_quad_spec_only<8, 2>(a, stream);
+	case 9: return launch_quad_spec_only<9, 2>(a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

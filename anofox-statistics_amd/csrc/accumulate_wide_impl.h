@@ -66,7 +66,7 @@ constexpr int kWaves = ANOFOX_WIDE_WAVES;   // wavefronts per workgroup (4 or 8:
 constexpr int kThreads = 64 * kWaves;
 constexpr int kWavesPerSimd = kWaves / 2; // two workgroups per CU either way
 static_assert(kWaves == 4 || kWaves == 8, "4 or 8 wavefronts per workgroup");
-constexpr int kWideRedoCounter = 8; // word of the refine counter block that counts the speculative kernel's give-ups
+// (kWideRedoCounter — the word of the refine counter block that counts the speculative kernels' give-ups — lives in common.h)
 constexpr int kWideFastMinT = 3;    // (narrower designs go through accumulate_mid.hip)
 
 __device__ __forceinline__ double readlane_d(double v, int src) {
@@ -842,6 +842,18 @@ hipError_t launch_accumulate_wide_T(const WideArgs &a, hipStream_t stream) {
 		hipLaunchKernelGGL((accumulate_wide_redo_kernel<T, false, true>), grid, block, lds, stream, a);
 	}
 #undef ANOFOX_WIDE_LAUNCH
+	return hipGetLastError();
+}
+
+// What follows a speculative kernel that is NOT this file's (accumulate_quad.hip at p = 33, 34 registers its very large groups in
+// the workgroup-per-segment table and lists its give-ups in the redo list): the segment kernel and the full version on the list.
+template <int T>
+hipError_t launch_accumulate_wide_followup_T(const WideArgs &a, hipStream_t stream) {
+	const int ncol_pad = wide_ncol_pad(a.p, false);
+	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::stride(false, true) * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
+	const dim3 grid((unsigned)a.n_groups), block(kThreads), seg_grid((unsigned)kWideSegMaxSegments);
+	if (a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, false, true>), seg_grid, block, lds, stream, a);
+	hipLaunchKernelGGL((accumulate_wide_redo_kernel<T, false, true>), grid, block, lds, stream, a);
 	return hipGetLastError();
 }
 

@@ -178,8 +178,12 @@ struct WideArgs {
 	void *seg_table;
 	int64_t seg_rows;
 	const int64_t *row_ends; // optional [G_total], see BatchArgs
-	int no_fast_path;        // accumulate_wide: 1 = skip the speculative version (A/B switch ANOFOX_WIDE_FAST=0, tests)
+	int no_fast_path;        // accumulate_wide / accumulate_quad: 1 = skip the speculative version (A/B switch ANOFOX_WIDE_FAST=0, tests)
+	int from_redo_list;      // accumulate_mid: 1 = wavefront k takes group refine_list[k], k < refine_count[kWideRedoCounter]
 };
+// word of the refine counter block that counts the give-ups of the speculative accumulate kernels (accumulate_wide_impl.h,
+// accumulate_quad.hip); the list itself borrows refine_list, which the solve that follows starts to fill only later
+constexpr int kWideRedoCounter = 8;
 inline __host__ __device__ int64_t group_row_end(const WideArgs &a, int64_t g) { return a.row_ends ? a.row_ends[g] : a.row_offsets[g + 1]; }
 
 // wide-record segment table: SegHeader | SegBigGroup[kSegMaxBig] | SegEntry[kSegMaxSegments] |
@@ -509,8 +513,12 @@ bool accumulate_mid_supports(int p);
 hipError_t launch_accumulate_mid(const WideArgs &a, hipStream_t stream);
 hipError_t launch_accumulate_mid_segments(const WideArgs &a, hipStream_t stream);
 // accumulate_quad.hip: the same on 4 x 4 blocks of v_mfma_f64_4x4x4_4b_f64 (no padding to 16 columns)
-bool accumulate_quad_supports(int p);
+bool accumulate_quad_supports(int p, bool weighted, bool center, bool no_fast_path);
 hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream);
+// accumulate_wide.hip: the segment kernel + the full version on the redo list, behind accumulate_quad's speculative kernel at p = 33, 34
+hipError_t launch_accumulate_wide_followup(const WideArgs &a, hipStream_t stream);
+// accumulate_mid.hip: the full version on the redo list (p = 27 .. 32)
+hipError_t launch_accumulate_mid_redo(const WideArgs &a, hipStream_t stream);
 // solve_mid.hip: lane-per-group solve on the same records for 8 < p <= 32 (same modes as launch_solve_wide)
 bool solve_mid_supports(int p);
 hipError_t launch_solve_mid(const WideArgs &a, int mode, hipStream_t stream);

@@ -154,7 +154,8 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		}
 		// 8 < p <= 32: 4 x 4-block MFMAs (accumulate_quad.hip) or 16 x 16 tiles (accumulate_mid.hip); ANOFOX_MID_QUAD=0/1
 		static const bool quad_on = !(getenv("ANOFOX_MID_QUAD") && atoi(getenv("ANOFOX_MID_QUAD")) == 0);
-		const bool quad = mid_acc && quad_on && accumulate_quad_supports((int)p);
+		// (r4: its speculative kernel also takes p = 27 .. 34 of the unweighted fit with an intercept)
+		const bool quad = mid_acc_on && quad_on && accumulate_quad_supports((int)p, opt.model == ANOFOX_HIP_MODEL_WLS, opt.fit_intercept, a.no_fast_path != 0);
 		if (hip_fail(quad ? launch_accumulate_quad(a, st) : (mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st)),
 		             "wide accumulate kernel launch", e))
 			return false;
@@ -495,7 +496,12 @@ bool anofox_hip_context_collect_timing(AnofoxHipContext *ctx, AnofoxHipKernelTim
 	memset(out, 0, sizeof *out);
 	for (auto &pr : ctx->acc_events) {
 		float ms = 0.f;
-		if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { out->accumulate_ms += ms; out->accumulate_count++; }
+		if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+			out->accumulate_ms_min = out->accumulate_count == 0 ? ms : fmin(out->accumulate_ms_min, (double)ms);
+			out->accumulate_ms_max = fmax(out->accumulate_ms_max, (double)ms);
+			out->accumulate_ms += ms;
+			out->accumulate_count++;
+		}
 	}
 	for (auto &pr : ctx->solve_events) {
 		float ms = 0.f;

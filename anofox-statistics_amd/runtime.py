@@ -71,7 +71,8 @@ class Context:
         self._check(self._lib.anofox_hip_context_collect_timing(self._h, C.byref(t), C.byref(err)), err)
         return {"accumulate_ms": t.accumulate_ms, "accumulate_count": t.accumulate_count,
                 "solve_ms": t.solve_ms, "solve_count": t.solve_count,
-                "predict_ms": t.predict_ms, "predict_count": t.predict_count}
+                "predict_ms": t.predict_ms, "predict_count": t.predict_count,
+                "accumulate_ms_min": t.accumulate_ms_min, "accumulate_ms_max": t.accumulate_ms_max}
 
     # ---- device-resident batch (torch tensors on this context's GPU) -------------------------
     def fit_batch_device(self, row_offsets, y, x_cols: Sequence, w, options: _abi.AnofoxHipBatchOptions,

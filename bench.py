@@ -129,13 +129,97 @@ def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=8.0):
                    "sample": f"{qr_passes} passes over {what}: dense Householder QR per group (solver = qr), {qr_t:.1f} s"}}
 
 
-def multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, steps, rehearsal, dev):
+def end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, model, kw, G, n, p, batch_groups=65536, chunk_rows=1 << 22):
+    """SURVEY.md 8(d) "also report end-to-end including H2D separately": the path as the DuckDB aggregate drives it.  Rows
+    lie in page-locked HOST memory in shuffled group order (row-major x, a slot number per row — the arena's chunk layout),
+    stream over PCIe into the GPU-resident aggregate state (anofox_hip_agg_state_update_host, `chunk_rows` rows per call),
+    and Finalize copies one record per group back to the host.  All G slots x n rows are streamed: every batch of
+    `batch_groups` slots re-sends the same host block (the first `batch_groups` groups of the bench data, shuffled once) under
+    new slot numbers, so the host needs 5 GB, not 72.  Timed: first Update -> records on the host.  Never part of `value`."""
+    import ctypes as C
+    import oracle  # checker only
+    weighted = w is not None
+    n_batches = (G + batch_groups - 1) // batch_groups
+    B = min((G + n_batches - 1) // n_batches, offs.numel() - 1)      # equal batches where G allows (1M: 16 x 62 500)
+    nr = int(offs[B].item())
+    dev = y.device
+    perm = torch.randperm(nr, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+    gid = torch.searchsorted(offs[1:B + 1].contiguous(), perm, right=True).to(torch.int32)
+    hx = torch.stack([c[:nr][perm] for c in x_cols], dim=1).contiguous().cpu().pin_memory()
+    hy = y[:nr][perm].contiguous().cpu().pin_memory()
+    hw = w[:nr][perm].contiguous().cpu().pin_memory() if weighted else None
+    n_batches = (G + B - 1) // B
+    hslots = [(gid + k * B).cpu().pin_memory() for k in range(n_batches)]     # batch k: the same rows under slots k B ...
+    last = G - (n_batches - 1) * B         # the last batch may be partial: rows of groups >= `last` are skipped (valid = 0)
+    hvalid_last = None
+    if last < B:
+        hslots[-1] = torch.where(gid < last, gid + (n_batches - 1) * B, torch.zeros_like(gid)).cpu().pin_memory()
+        hvalid_last = (gid < last).to(torch.uint8).cpu().pin_memory()
+    rows_valid_last = int(hvalid_last.sum()) if hvalid_last is not None else nr
+    del perm
+    abi = importlib.import_module(PKG + "._abi")
+    best = None
+    for _rep in range(2):
+        st = pkg.AggState(ctx, p, opts, initial_slots=G, retain_bytes=0)
+        lib = st._lib
+        err = abi.AnofoxError()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        rows_sent = (n_batches - 1) * nr + (nr if hvalid_last is None else rows_valid_last)
+        for k in range(n_batches):
+            hs = hslots[k]
+            for r0 in range(0, nr, chunk_rows):
+                r1 = min(nr, r0 + chunk_rows)
+                valid = hvalid_last[r0:r1].data_ptr() if (hvalid_last is not None and k == n_batches - 1) else None
+                ok = lib.anofox_hip_agg_state_update_host(st._h, r1 - r0, G, hs[r0:r1].data_ptr(), hy[r0:r1].data_ptr(),
+                                                          hx[r0:r1].data_ptr(), hw[r0:r1].data_ptr() if weighted else None,
+                                                          valid, C.byref(err))
+                if not ok:
+                    raise RuntimeError(err.text())
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        core, _inf, unref = st.finalize()
+        t2 = time.perf_counter()
+        st.close()
+        if best is None or (t2 - t0) < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1, core, int(unref), rows_sent)
+    total, t_upd, t_fin, core, unref, rows_sent = best
+    # parity: the first 256 slots of the LAST batch (their rows in arrival order) against the oracle
+    S = min(256, last)
+    g = gid.cpu().numpy().astype(np.int64)
+    rows = np.nonzero(g < S)[0]
+    order = rows[np.argsort(g[rows], kind="stable")]
+    go = np.concatenate([[0], np.cumsum(np.bincount(g[rows], minlength=S))]).astype(np.int64)
+    hxn, hyn = hx.numpy(), hy.numpy()
+    rcore, _ = oracle.fit_groups(hyn[order], [np.ascontiguousarray(hxn[order, j]) for j in range(p)], go,
+                                 w=hw.numpy()[order] if weighted else None, model=model,
+                                 **{k: v for k, v in kw.items() if k != "compute_inference"})
+    c = np.asarray(core)[(n_batches - 1) * B:(n_batches - 1) * B + S]
+    scale = np.max(np.abs(rcore[:, :p + 1]), axis=1, keepdims=True)
+    cerr = float(np.max(np.abs(c[:, :p + 1] - rcore[:, :p + 1]) / np.maximum(np.abs(rcore[:, :p + 1]), 1e-3 * scale)))
+    derr = float(np.max(np.abs(c[:, p + 1:p + 4] / rcore[:, p + 1:p + 4] - 1.0)))
+    ok = bool(np.array_equal(c[:, p + 5], rcore[:, p + 5]) and cerr < 1e-9 and derr < 1e-6)
+    bytes_row = 8 * (p + 1) + (8 if weighted else 0) + 4
+    return {"path": "anofox_hip_agg_state_update_host (page-locked host rows, shuffled group order) -> finalize (records on the host)",
+            "fits_per_s": (G / total) if ok else None, "rows_per_s": rows_sent / total, "seconds": total,
+            "update_seconds": t_upd, "finalize_seconds": t_fin, "GBps_pcie": rows_sent * bytes_row / t_upd / 1e9,
+            "bytes_per_row_over_pcie": bytes_row, "groups": G, "rows_per_group": n, "rows_streamed": rows_sent,
+            "batch_groups": B, "rows_per_update_call": chunk_rows, "groups_flagged_unrefined": unref,
+            "parity": {"ok": ok, "sample_groups": S, "max_coef_rel_err": cerr, "max_diag_rel_err": derr},
+            "note": "PCIe-bound; reported beside `value`, never mixed into it (SURVEY.md 8d)"}
+
+
+def multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, steps, rehearsal, dev, stage=None):
     """Per-rank figures of an N-rank run, gathered to rank 0: each rank's accumulate-kernel time per step, the time of one
     all-gather of the records alone, and the number of ranks RCCL itself counts in a communicator created through the
     library's C ABI (anofox_hip_comm_create -> ncclCommCount) — over which the same records are gathered once more
     (anofox_hip_gather_records_device) and compared with torch.distributed's result."""
     import ctypes as C
     world, rank = dist.get_world_size(), dist.get_rank()
+    stage = stage if stage is not None else [""]
+    if os.environ.get("ANOFOX_BENCH_TEST_HANG_RANK") == str(rank):      # test hook of the watchdog path: this rank never joins
+        stage[0] = "(test hook: rank held back on purpose)"
+        time.sleep(10 ** 6)
     mine = {"rank": rank, "groups": hi - lo, "kernel_ms_per_step": kt["accumulate_ms"] / steps, "solve_span_ms_per_step": kt["solve_ms"] / steps}
     # one gather alone, timed with events on this rank's stream (5 repetitions after a warm-up)
     gather_ms = None
@@ -144,8 +228,10 @@ def multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, steps,
         local = torch.full((per, p + 6), float("nan"), dtype=torch.float64, device=dev)
         local[: hi - lo] = core_all[lo:hi]
         outb = torch.empty((per * world, p + 6), dtype=torch.float64, device=dev)
+        stage[0] = "torch.distributed all_gather_into_tensor of the records (warm-up)"
         dist.all_gather_into_tensor(outb, local)
         torch.cuda.synchronize()
+        stage[0] = "torch.distributed all_gather_into_tensor of the records (5 timed repetitions)"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(5):
@@ -169,20 +255,24 @@ def multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, steps,
         except Exception as exc:
             problem = str(exc)[:200]
         flags = [None] * world
+        stage[0] = "all_gather_object of the ranks' unique-id status"
         dist.all_gather_object(flags, problem)
         if any(f is not None for f in flags):
             mine["c_abi_comm_error"] = next(f for f in flags if f is not None)
         else:
             try:
                 t = torch.tensor(list(uid), dtype=torch.uint8, device=dev)
+                stage[0] = "broadcast of the RCCL unique id"
                 dist.broadcast(t, 0)
                 uid = (C.c_uint8 * 128)(*t.cpu().tolist())
                 comm = C.c_void_p()
                 ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+                stage[0] = "anofox_hip_comm_create (ncclCommInitRank of the second communicator)"
                 if not lib.anofox_hip_comm_create(ctx._h, world, rank, uid, C.byref(comm), C.byref(err)):
                     raise RuntimeError(err.text())
                 mine["n_ranks_seen"] = int(lib.anofox_hip_comm_ranks_seen(comm))
                 out2 = torch.empty_like(outb)
+                stage[0] = "anofox_hip_gather_records_device (ncclAllGather through the C ABI)"
                 if not lib.anofox_hip_gather_records_device(comm, C.c_void_p(local.data_ptr()), per, p + 6, C.c_void_p(out2.data_ptr()), C.byref(err)):
                     raise RuntimeError(err.text())
                 torch.cuda.synchronize()
@@ -191,7 +281,9 @@ def multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, steps,
             except Exception as exc:
                 mine["c_abi_comm_error"] = str(exc)[:200]
     everyone = [None] * world
+    stage[0] = "all_gather_object of the per-rank figures"
     dist.all_gather_object(everyone, mine)
+    stage[0] = "(audit complete)"
     if rank != 0:
         return None
     return {"backend": dist.get_backend(), "world_size": world, "per_rank": everyone,
@@ -235,6 +327,8 @@ def main():
     ap.add_argument("--predict", action="store_true",
                     help="fit + per-row predictions (*_fit_predict_agg); every 5th row is a prediction row (NULL y)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the host-memory -> aggregate state -> records leg (p <= 8 only; reported as `end_to_end`)")
     ap.add_argument("--parity-sample", type=int, default=1024)
     args = ap.parse_args()
 
@@ -354,7 +448,13 @@ def main():
     for c in timed:   # the sharded driver alternates between contexts: sum their kernel times
         k = c.collect_timing()
         c.enable_timing(False)
-        kt = k if kt is None else {key: kt[key] + k[key] for key in kt}
+        if kt is None:
+            kt = k
+        elif k["accumulate_count"]:     # min / max of single launches do not add
+            lo_ms = min(kt["accumulate_ms_min"], k["accumulate_ms_min"]) if kt["accumulate_count"] else k["accumulate_ms_min"]
+            hi_ms = max(kt["accumulate_ms_max"], k["accumulate_ms_max"])
+            kt = {key: kt[key] + k[key] for key in kt}
+            kt["accumulate_ms_min"], kt["accumulate_ms_max"] = lo_ms, hi_ms
     refined = ctx.last_refine_count() if not (args.window or args.vif) else 0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
@@ -417,9 +517,18 @@ def main():
             achieved = per_step / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0
         else:
             kernel = "accumulate_quad_kernel" if p <= 26 else ("accumulate_mid_kernel" if p <= 32 else "accumulate_wide_kernel")
-            bound, unit, peak = "mfma", "TFLOP/s", FP64_MFMA_PEAK_TFLOPS
-            per_step = G_local * algorithmic_flops_per_fit(n, p)
-            achieved = per_step / (acc_step_ms * 1e-3) / 1e12 if acc_step_ms > 0 else 0.0
+            # which roof bounds this width: arithmetic intensity against the ridge point peak_flops / peak_bytes
+            # (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B).  p + 1 = 2 * 9.8 - 3 => widths up to p ~ 75 are HBM-bound
+            intensity = algorithmic_flops_per_fit(n, p) / bytes_fit
+            ridge = FP64_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+            if intensity < ridge:
+                bound, unit, peak = "hbm", "GB/s", HBM_PEAK_GBS
+                per_step = G_local * bytes_fit
+                achieved = per_step / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0
+            else:
+                bound, unit, peak = "mfma", "TFLOP/s", FP64_MFMA_PEAK_TFLOPS
+                per_step = G_local * algorithmic_flops_per_fit(n, p)
+                achieved = per_step / (acc_step_ms * 1e-3) / 1e12 if acc_step_ms > 0 else 0.0
         if args.window:
             # the window path has its own kernel: one fit per ROW from running / rolling moments, 8 (p + 1 [+ 1]) B in and the
             # three prediction doubles out per row; its time is what the predict events bracket
@@ -432,7 +541,7 @@ def main():
         # the same work over the WHOLE step (accumulate + solve + refinement [+ gather]) — what `value` is quoted on
         step_achieved = per_step / (ms_per_step * 1e-3) / (1e9 if bound == "hbm" else 1e12)
         kernel_achieved = achieved
-        if bound == "mfma":
+        if p > 8 and not args.window:
             # wide designs: the per-slab solve is a material part of the step, so the headline fraction is the step's;
             # the accumulate kernel's own rate stays in kernel_achieved / kernel_frac
             achieved = step_achieved
@@ -485,6 +594,9 @@ def main():
                                             "passes of this kernel on this workload; not measured in this run)"
                                             if traffic is not None else None),
                          "kernel": kernel, "avg_launch_ms": acc_ms,
+                         # shortest / longest single launch of that kernel inside the timed region (HIP events in the library)
+                         "kernel_ms_min": kt.get("accumulate_ms_min") if not args.window else None,
+                         "kernel_ms_max": kt.get("accumulate_ms_max") if not args.window else None,
                          "launches_per_step": kt["predict_count" if args.window else "accumulate_count"] / args.steps,
                          "kernel_ms_per_step": acc_step_ms, "groups_refined_last_launch": refined,
                          ("algorithmic_bytes_per_step" if bound == "hbm" else "algorithmic_flops_per_step"): per_step,
@@ -497,6 +609,12 @@ def main():
                          # hbm_read_rate, mfma_f64_rate; profiles/r01_hbm_read_rate.txt): the practical ceiling under `peak`
                          "measured_ceiling": MEASURED_STREAM_READ_GBS if bound == "hbm" else MEASURED_MFMA_F64_TFLOPS,
                          "frac_of_measured_ceiling": kernel_achieved / (MEASURED_STREAM_READ_GBS if bound == "hbm" else MEASURED_MFMA_F64_TFLOPS),
+                         **({"arithmetic_intensity_flop_per_B": algorithmic_flops_per_fit(n, p) / bytes_fit,
+                             "ridge_point_flop_per_B": FP64_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9),
+                             # both roofs, whichever one bounds (SURVEY.md 8d asks for both on the wide configs)
+                             "kernel_frac_of_hbm_peak": G_local * bytes_fit / (acc_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if acc_step_ms > 0 else 0.0,
+                             "kernel_frac_of_mfma_peak": G_local * algorithmic_flops_per_fit(n, p) / (acc_step_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if acc_step_ms > 0 else 0.0}
+                            if (p > 8 and not (args.window or args.vif)) else {}),
                          "solve_span_ms_per_step": solve_step_ms,
                          "solve_overlap_ms_per_step": overlap_ms,
                          "exposed_non_accumulate_ms_per_step": exposed_ms,
@@ -509,24 +627,35 @@ def main():
     if world > 1:
         import threading
         finished = threading.Event()
+        audit_stage = ["(not started)"]      # the collective this rank entered last, for the watchdog's report
 
         def give_up():
             if finished.is_set():
                 return
+            # a collective that never returns is a FAILED run (exit code 3 on every rank), whatever the timing says: the line
+            # is still printed — the timed region is complete — and names the collective each rank was waiting in
+            sys.stderr.write(f"[bench rank {rank}] multi-rank audit hung in: {audit_stage[0]}\n")
+            sys.stderr.flush()
             if rank == 0 and out is not None:
-                out["multi_gpu"] = {"error": "the multi-rank audit did not finish within 180 s; the timed region above is complete"}
+                out["multi_gpu"] = {"error": "the multi-rank audit did not finish in time (a collective never returned); the timed region above is complete",
+                                    "rank0_pending_collective": audit_stage[0]}
                 print(json.dumps(out), flush=True)
-            os._exit(0 if ok else 1)
+            os._exit(3)
 
-        watchdog = threading.Timer(180.0, give_up)
+        watchdog = threading.Timer(float(os.environ.get("ANOFOX_BENCH_AUDIT_TIMEOUT_S", "180")), give_up)
         watchdog.daemon = True
         watchdog.start()
-        multi = multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, args.steps, rehearsal, dev)
+        multi = multi_rank_audit(pkg, ctx, dmod, sharded, core_all, lo, hi, G, p, kt, args.steps, rehearsal, dev, audit_stage)
         finished.set()
         watchdog.cancel()
         if rank == 0 and multi is not None:
             out["multi_gpu"] = multi
     if rank == 0:
+        if world == 1 and p <= 8 and not (args.no_end_to_end or args.vif or args.window or args.predict or args.inference):
+            try:
+                out["end_to_end"] = end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, args.model, kw, G, n, p)
+            except Exception as exc:      # the leg is an addition to the line, never a reason to lose it
+                out["end_to_end"] = {"error": str(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(offs, y, x_cols, w, args.model, kw, n, p)
         print(json.dumps(out), flush=True)

@@ -587,6 +587,8 @@ typedef struct {
 	int64_t solve_count;
 	double predict_ms;        /* summed duration of the per-row prediction kernel */
 	int64_t predict_count;
+	double accumulate_ms_min; /* (r4) shortest / longest single launch of the dominant kernel in the interval (0 if none) */
+	double accumulate_ms_max;
 } AnofoxHipKernelTimes;
 ANOFOX_HIP_API bool anofox_hip_context_enable_timing(AnofoxHipContext *ctx, bool enable, AnofoxError *out_error);
 /* synchronises, returns the sums since the last call and resets them */

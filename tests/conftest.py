@@ -27,6 +27,29 @@ def pytest_configure(config):
         pass
 
 
+def release_device_memory():
+    """Hand every block torch's caching allocator holds back to the device.  The full-size tests (cfg3: 80 GB, cfg5:
+    213 GB) size themselves from `torch.cuda.mem_get_info()`, which counts cached blocks of EARLIER tests as used: round 3's
+    full suite skipped cfg5 at its BASELINE size for that reason alone."""
+    import gc
+    gc.collect()
+    try:
+        import torch
+    except Exception:        # pragma: no cover
+        return
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+@pytest.fixture(autouse=True)
+def _free_gpu_blocks_after_gpu_tests(request):
+    """After every GPU test: drop the references the test frame held and empty the allocator's cache."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        release_device_memory()
+
+
 def load_csv(rel):
     """Return dict column-name -> float64 array for a fixture CSV under tests/golden."""
     with open(os.path.join(GOLDEN, rel), newline="") as f:

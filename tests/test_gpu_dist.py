@@ -171,12 +171,42 @@ def test_bench_launches_its_own_ranks(tmp_path):
     rec = json.loads(line)
     assert rec["n_gpus"] == 2 and rec["parity"]["ok"] and rec["value"] > 0
     assert rec["config"]["groups_per_gpu"] == 10_000
+    # the audit block the driver's SCALE run is read with: one entry per rank, group counts that add up, kernel times
+    mg = rec["multi_gpu"]
+    assert "error" not in mg and mg["world_size"] == 2
+    ranks = sorted(mg["per_rank"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == [0, 1]
+    assert sum(r["groups"] for r in ranks) == 20_000
+    assert all(r["kernel_ms_per_step"] > 0 and r["solve_span_ms_per_step"] >= 0 for r in ranks)
+    assert mg["kernel_ms_per_step_min"] <= mg["kernel_ms_per_step_max"]
+    assert rec["roofline"]["kernel_ms_min"] > 0
 
 
-def _run_bench(out):
+def test_bench_audit_watchdog_fails_the_run(tmp_path):
+    """A collective of the multi-rank audit that never returns must FAIL the run (non-zero exit), with the timing line
+    still printed and the pending collective named — a hung RCCL call reported as rc 0 would never be investigated."""
+    import json
+    import multiprocessing as mp
+    mpc = mp.get_context("forkserver")
+    out = str(tmp_path / "bench.json")
+    pr = mpc.Process(target=_run_bench, args=(out, {"ANOFOX_BENCH_TEST_HANG_RANK": "1", "ANOFOX_BENCH_AUDIT_TIMEOUT_S": "8"}))
+    pr.start()
+    pr.join(600)
+    if pr.is_alive():
+        pr.kill()
+        pytest.fail("bench.py --gpus 2 with a held-back rank did not end")
+    assert pr.exitcode != 0
+    lines = [ln for ln in open(out).read().splitlines() if ln.startswith("{")]
+    assert lines, "the timing line is printed even when the audit hangs"
+    rec = json.loads(lines[-1])
+    assert rec["parity"]["ok"] and rec["value"] > 0
+    assert "error" in rec["multi_gpu"] and rec["multi_gpu"]["rank0_pending_collective"]
+
+
+def _run_bench(out, extra_env=None):
     """Runs in a process forked from the clean fork server (no GPU state): exec is allowed here."""
     import subprocess
-    env = dict(os.environ, ANOFOX_BENCH_REHEARSAL="1")
+    env = dict(os.environ, ANOFOX_BENCH_REHEARSAL="1", **(extra_env or {}))
     env.pop("WORLD_SIZE", None)
     with open(out, "w") as f:
         rc = subprocess.call([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--groups", "20000",

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import COEF_RTOL, DIAG_RTOL, assert_records_match, import_pkg
+from conftest import COEF_RTOL, DIAG_RTOL, assert_records_match, import_pkg, release_device_memory
 
 pytestmark = pytest.mark.gpu
 
@@ -111,9 +111,11 @@ def test_cfg5_at_its_baseline_size():
     synth = import_pkg("synth")
     G, n, p = 50_000, 4096, 128
     need = G * n * (p + 2) * 8
-    free, _ = torch.cuda.mem_get_info()
-    if need > 0.92 * free:
-        pytest.skip(f"needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} GB free")
+    release_device_memory()            # blocks cached by earlier tests count as used in mem_get_info
+    free, total = torch.cuda.mem_get_info()
+    # no skip: BASELINE's config 5 is a 1-GPU config of an MI355X (288 GB); a box that cannot hold it must say so
+    assert need <= 0.92 * free, (f"cfg5 needs {need / 1e9:.0f} GB of HBM, {free / 1e9:.0f} of {total / 1e9:.0f} GB free "
+                                 f"after emptying the allocator cache")
     slab = _slab_groups(p)
     assert (G + slab - 1) // slab == 4
     offs, y, x_cols, _ = synth.make_grouped(G, n, p, device="cuda:0", chunk_groups=max(1, (1 << 25) // n))
