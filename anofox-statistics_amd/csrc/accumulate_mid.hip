@@ -27,9 +27,11 @@
 //   * a group with more than seg_rows rows (>= 1/2048 of the batch) is cut into segments, one wavefront each
 //     (accumulate_mid_segments_kernel, idle otherwise), all shifted by the group's first valid row, and the wave
 //     that finishes the last segment sums the segment records.
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "common.h"
+#include "lds_dma.h"
 
 // steps per loop trip, by measurement (100 000 x 1000 rows): T = 1: 2 (4 changes nothing; weighted 1 -> 2: 3.19 -> 2.92 ms at
 // p = 14); T = 2: 1 (2 spills: 4.9 -> 8.6 ms at p = 24).  More waves per SIMD do not help either (80 VGPRs, 6 waves:
@@ -391,7 +393,7 @@ __host__ __device__ constexpr int mid_lds_columns(int p, bool weighted, int T) {
 // row count), rows 4 kk + m, and for one column block (T = 1) the K-steps alternate between two accumulators — four
 // back-to-back MFMAs into one accumulator wait for each other (16 passes each), and with 2 waves per SIMD nobody else fills
 // the gap.
-template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID, bool AUX>
+template <int T, bool WEIGHTED, bool CENTER, bool ALLVALID, bool AUX, bool SPEC = false>
 __device__ __forceinline__ void mid_step_lds(MidState<T> &st, mid_dbl4 (&acc2)[T * (T + 1) / 2], double (&dmax)[T], const double (&x)[T][4],
                                              const double (&y)[4], const double (&w)[4], unsigned rowmask, int kk) {
 #pragma unroll
@@ -404,7 +406,7 @@ __device__ __forceinline__ void mid_step_lds(MidState<T> &st, mid_dbl4 (&acc2)[T
 			d[I] = (CENTER && !(ANOFOX_MID_SKIP & 16)) ? dev : (ALLVALID ? x[I][m] : mid_mask(x[I][m], rm));
 			// constant-column predicate of ols.rs:76-87, |x - x_first| < 1e-10 on every valid row: the largest |deviation| per
 			// lane and column block is kept (one instruction; 0 on rows that do not take part) and tested once per group
-			if (!(ANOFOX_MID_SKIP & 2)) dmax[I] = fmax(dmax[I], fabs(dev));
+			if (!SPEC && !(ANOFOX_MID_SKIP & 2)) dmax[I] = fmax(dmax[I], fabs(dev));
 		}
 		const double dy0 = AUX ? 0.0 : (CENTER ? y[m] - st.first_y : y[m]);
 		const double dy = ALLVALID ? dy0 : mid_mask(dy0, rm);
@@ -641,6 +643,181 @@ __device__ __forceinline__ void mid_accumulate_rows_lds(const WideArgs &args, in
 	mid_write_record<T, AUX>(st, real, rec, lane, p);
 }
 
+// ---- (r4) the speculative version on LDS-DMA for THREE and FOUR column tiles (p = 34 .. 64) --------------------------------
+// accumulate_wide's workgroup-per-group kernel runs these widths at 0.46-0.49 of the HBM peak with the matrix pipe 62-65 % busy
+// (profiles/r04_pmc_wide_t3_t4.md): f64 vector and matrix time ADD, and per 32-row chunk its waves issue ~220 vector / scalar /
+// LDS instructions next to 24-40 matrix ones.  Here a wavefront owns its group as in the kernels above, and — the scheme of
+// accumulate_quad's speculative kernel — no row passes through a register on its way in: `global_load_lds_dword` moves 32 rows
+// of one column per instruction into one half of the wave's 64-row ring (stride 66 doubles, the slice layout of the staged loop
+// above), block k + 1 lands while the two 16-row steps of block k read the other half, every row is taken for valid and the
+// first row for the shift, and what that assumed is checked on the result: every moment finite, every x column clearly constant
+// (sum d^2 < 1e-20) or clearly not (>= n 1e-20).  Anything else goes to the redo list for accumulate_wide's full version.
+// Per 32-row block a wave issues p + 1 DMA instructions, 2 x (2 T ds_read_b128 + 4 T subtractions) and the matrix instructions.
+// One wavefront per workgroup: the slice is 18-34 KB and the CU holds as many groups as its LDS admits (8 at p = 36, 6 at
+// p = 48, 4 at p = 64).
+__host__ __device__ constexpr int mid_dma_slice_doubles(int p, int T) { return mid_lds_columns(p, false, T) * mid_lds_stride(1); }
+
+template <int T, bool AUX>
+__device__ __forceinline__ bool mid_spec_dma_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
+	constexpr int NT = T * (T + 1) / 2;
+	constexpr int RS = mid_lds_stride(1);
+	const int p = args.p;
+	const int ncol = p + 1;
+	const int kk = lane >> 4, lj = lane & 15;
+	const bool is_one = AUX && 16 * (T - 1) + lj == p + 1;
+	const bool is_y = AUX && 16 * (T - 1) + lj == p;
+	bool real[T], rd[T];
+	int ccol[T];
+#pragma unroll
+	for (int I = 0; I < T; ++I) {
+		const int c = 16 * I + lj;
+		real[I] = c < p;
+		rd[I] = real[I] || (AUX && c == p);
+		ccol[I] = rd[I] ? c : ((AUX && I == T - 1 && is_one) ? ncol + 1 : ncol);
+	}
+	MidState<T> st;
+	mid_init_state<T, AUX>(st, real, nullptr, lj, is_y);
+	mid_dbl4 acc2[NT]; // (only the one-tile kernels use it)
+	double dmax[T];
+#pragma unroll
+	for (int I = 0; I < T; ++I) dmax[I] = 0.0;
+	if (p != 16 * T) { // the constant columns of the slice, both halves of the ring
+		buf[ncol * RS + lane] = 0.0;
+		buf[(ncol + 1) * RS + lane] = 1.0;
+	}
+	const unsigned lds0 = lds_dma_address(buf);
+	// the column pointers are re-read from the kernel arguments for every block (lds_dma.h: kept resident they spill into VGPR lanes)
+	const lds_dma_table_t tab = lds_dma_table((unsigned)offsetof(WideArgs, x_table)); // (y sits behind the last feature: host_api.hip)
+	auto dma = [&](int64_t blk, int h) {
+		lds_dma_block<RS * 8, 16 * T + 1>(tab, ncol, blk, lds_dma_offsets(lane, hi - blk), lds0 + (unsigned)h * 256u);
+	};
+	auto fragments = [&](const double *hb, int sidx, double (&x)[T][4], double (&y)[4]) {
+		const int ro = 16 * sidx + 4 * kk;
+#pragma unroll
+		for (int I = 0; I < T; ++I) {
+			const mid_dbl2a a = *reinterpret_cast<const mid_dbl2a *>(hb + ccol[I] * RS + ro);
+			const mid_dbl2a c2 = *reinterpret_cast<const mid_dbl2a *>(hb + ccol[I] * RS + ro + 2);
+			x[I][0] = a.x; x[I][1] = a.y; x[I][2] = c2.x; x[I][3] = c2.y;
+		}
+		if (!AUX) {
+			const mid_dbl2a a = *reinterpret_cast<const mid_dbl2a *>(hb + p * RS + ro);
+			const mid_dbl2a c2 = *reinterpret_cast<const mid_dbl2a *>(hb + p * RS + ro + 2);
+			y[0] = a.x; y[1] = a.y; y[2] = c2.x; y[3] = c2.y;
+		} else {
+			y[0] = y[1] = y[2] = y[3] = 0.0;
+		}
+	};
+	const double w1[4] = {1.0, 1.0, 1.0, 1.0};
+	int h = 0;
+	dma(lo, 0);
+	lds_dma_wait_all();
+	__builtin_amdgcn_wave_barrier();
+	{ // the shift: the group's first row (constant columns are not shifted)
+#pragma unroll
+		for (int I = 0; I < T; ++I) st.first[I] = rd[I] ? buf[ccol[I] * RS] : 0.0;
+		if (AUX) {
+			if (is_one) st.first[T - 1] = 0.0;
+		} else {
+			st.first_y = buf[p * RS];
+		}
+		st.have_first = true;
+	}
+	// Full blocks in a loop WITHOUT a branch around the matrix instructions (with the full / partial choice inside the loop the
+	// compiler moved the 40-80 accumulator registers between register banks at every join: 240 v_accvgpr_mov per trip), the
+	// partial last block after it.
+	int64_t blk = lo;
+	for (; blk + 32 <= hi; blk += 32, h ^= 1) {
+		if (blk + 32 < hi) dma(blk + 32, h ^ 1); // lands while this block's steps run
+		__builtin_amdgcn_wave_barrier();
+		const double *hb = buf + 32 * h;
+#pragma unroll
+		for (int sidx = 0; sidx < 2; ++sidx) {
+			double x[T][4], y[4];
+			fragments(hb, sidx, x, y);
+			mid_step_lds<T, false, true, true, AUX, true>(st, acc2, dmax, x, y, w1, 0xFFFFu, kk);
+		}
+		__builtin_amdgcn_wave_barrier();
+		lds_dma_wait_all(); // the next block has landed (it had this block's steps to do so)
+	}
+	if (blk < hi) {
+		const int64_t left = hi - blk;
+		const unsigned m32 = (1u << (unsigned)left) - 1u; // 1 <= left < 32
+		const double *hb = buf + 32 * h;
+#pragma unroll
+		for (int sidx = 0; sidx < 2; ++sidx) {
+			const unsigned rowmask = (m32 >> (16 * sidx)) & 0xFFFFu;
+			if (rowmask == 0u) continue; // wave-uniform
+			double x[T][4], y[4];
+			fragments(hb, sidx, x, y);
+			mid_step_lds<T, false, true, false, AUX, true>(st, acc2, dmax, x, y, w1, rowmask, kk);
+		}
+	}
+	// ---- what the speculation assumed, checked on the result ----
+	double zs = 0.0;
+#pragma unroll
+	for (int t = 0; t < NT; ++t) zs = fma(st.acc[t][0], 0.0, fma(st.acc[t][1], 0.0, fma(st.acc[t][2], 0.0, fma(st.acc[t][3], 0.0, zs))));
+	if (!AUX) {
+#pragma unroll
+		for (int I = 0; I < T; ++I) zs = fma(st.sx[I], 0.0, fma(st.sxy[I], 0.0, zs));
+		zs = fma(st.sy, 0.0, fma(st.syy, 0.0, zs));
+	}
+	bool bad = isnan(zs);
+	const double n_d = (double)(hi - lo);
+	st.ncmask = 0u;
+#pragma unroll
+	for (int I = 0; I < T; ++I) {
+		// diagonal element (j, j) of tile (I, I), j = lj: on the lane with kk == j % 4, in element j / 4
+		const int t = I * T - I * (I - 1) / 2; // tile (I, I)
+		if (kk == (lj & 3)) {
+			double mjj = st.acc[t][0];
+#pragma unroll
+			for (int r = 1; r < 4; ++r) mjj = (lj >> 2) == r ? st.acc[t][r] : mjj;
+			const bool moved = mjj >= n_d * 1e-20;
+			if (real[I]) {
+				bad = bad || (!moved && !(mjj < 1e-20));
+				if (moved) st.ncmask |= 1u << I;
+			}
+		}
+	}
+	if (__ballot(bad) != 0ull) return false;
+	st.cnt = (int)(hi - lo);
+	if (!AUX) st.sw = 0.25 * (double)st.cnt; // every lane group adds its quarter: the record sums the four
+	mid_write_record<T, AUX>(st, real, rec, lane, p);
+	return true;
+}
+
+template <int T, bool AUX>
+__global__ __launch_bounds__(64) void accumulate_tile_spec_kernel(WideArgs args) {
+	extern __shared__ double tile_lds[];
+	const int lane = threadIdx.x;
+	const int64_t gl = blockIdx.x;
+	const int64_t lo = args.row_offsets[args.group_base + gl];
+	const int64_t hi = group_row_end(args, args.group_base + gl);
+	if (args.seg_table && hi - lo > args.seg_rows) {
+		// (the host sized the table for accumulate_wide's workgroup-per-segment kernel, which takes these groups)
+		if (wide_register_big_group(args, gl, lo, hi, T, lane, kWideSegMaxBig, kWideSegMaxSegments)) return;
+	}
+	if (hi > lo && mid_spec_dma_rows<T, AUX>(args, lo, hi, args.moments + gl * (int64_t)wide_record_len(T), lane, tile_lds)) return;
+	if (lane == 0) args.refine_list[atomicAdd(args.refine_count + kWideRedoCounter, 1)] = (int32_t)gl;
+}
+
+template <int T>
+hipError_t launch_tile_spec_T(const WideArgs &a, hipStream_t stream) {
+	const dim3 grid((unsigned)a.n_groups), block(64);
+	const size_t lds_bytes = (size_t)mid_dma_slice_doubles(a.p, T) * sizeof(double);
+	static const bool attr_set = [] {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_tile_spec_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_tile_spec_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		return true;
+	}();
+	(void)attr_set;
+	if (a.p + 2 <= 16 * T) hipLaunchKernelGGL((accumulate_tile_spec_kernel<T, true>), grid, block, lds_bytes, stream, a);
+	else hipLaunchKernelGGL((accumulate_tile_spec_kernel<T, false>), grid, block, lds_bytes, stream, a);
+	const hipError_t rc = hipGetLastError();
+	if (rc != hipSuccess) return rc;
+	return launch_accumulate_wide_followup(a, stream); // its segment kernel, and the full version on the redo list
+}
+
 template <int T, bool WEIGHTED, bool CENTER, bool AUX, int LDSX> // LDSX: 0 = straight into fragment layout, 1 / 2 = through LDS, rows per lane
 __global__ __launch_bounds__(256) void accumulate_mid_kernel(WideArgs args) {
 	const int lane = threadIdx.x & 63;
@@ -802,6 +979,22 @@ hipError_t launch_accumulate_mid_redo(const WideArgs &a, hipStream_t stream) {
 	b.from_redo_list = 1;
 	b.seg_table = nullptr;
 	return launch_accumulate_mid(b, stream);
+}
+
+// (r4) p = 34 .. 64, unweighted with an intercept: the speculative LDS-DMA kernel (ANOFOX_TILE_SPEC=0: accumulate_wide as before)
+bool accumulate_tile_supports(int p, bool weighted, bool center, bool no_fast_path) {
+	static const bool on = !(getenv("ANOFOX_TILE_SPEC") && atoi(getenv("ANOFOX_TILE_SPEC")) == 0);
+	static const int max_p = getenv("ANOFOX_TILE_SPEC_MAXP") ? atoi(getenv("ANOFOX_TILE_SPEC_MAXP")) : 64;
+	return on && p >= 34 && p <= 64 && p <= max_p && !weighted && center && !no_fast_path;
+}
+
+hipError_t launch_accumulate_tile(const WideArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	switch (wide_tiles(a.p)) {
+	case 3: return launch_tile_spec_T<3>(a, stream);
+	case 4: return launch_tile_spec_T<4>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 hipError_t launch_accumulate_mid(const WideArgs &a, hipStream_t stream) {

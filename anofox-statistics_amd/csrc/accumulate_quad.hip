@@ -23,9 +23,11 @@
 // up to p = 16, 64-row blocks beyond), the row filter runs on those registers (one ballot per block), the block goes to a
 // wave-private LDS slice column by column (stride = 8 mod 32 doubles: the 32 lanes of a half wave read rows 0..7 of four
 // columns, 32 different banks) and every lane reads one double per column group and step.  No barrier.
+#include <stddef.h>
 #include <stdlib.h>
 
 #include "common.h"
+#include "lds_dma.h"
 
 // what-if builds (never shipped: results are wrong): bit 0 = no MFMA, 1 = no row filter, 2 = no constant-column test,
 // 3 = a block's rows are not written to LDS, 4 = one step per block instead of 4 RL
@@ -112,11 +114,29 @@ __device__ __forceinline__ bool quad_finish(const WideArgs &args, double *rec, i
 			for (int g = 0; g < NB; ++g) {
 				F[4 * g + lane] = first[g];
 				const bool isx = g < NB - 2 ? true : (g == NB - 2 ? isx_prev : isx_last);
-				NC[4 * g + lane] = (isx && !(dmax[g] < 1e-10)) ? 1.0 : 0.0;
+				if (!SPEC) NC[4 * g + lane] = (isx && !(dmax[g] < 1e-10)) ? 1.0 : 0.0;
 			}
 		}
 	}
 	__builtin_amdgcn_wave_barrier();
+	if (SPEC) {
+		// what the speculation assumed, checked on the result (see quad_accumulate_rows): every moment finite, every x column
+		// clearly constant (sum d^2 < 1e-20) or clearly not (sum d^2 >= n 1e-20)
+		double zs = 0.0;
+#pragma unroll
+		for (int t = 0; t < NPAIR; ++t) zs = fma(acc[t], 0.0, zs);
+		bool bad = isnan(zs);
+		const double n_d = (double)(hi - lo);
+		for (int j = lane; j < R; j += 64) {
+			const double mjj = G[j * R + j];
+			const bool moved = mjj >= n_d * 1e-20;
+			if (j < p) bad = bad || (!moved && !(mjj < 1e-20));
+			NC[j] = (j < p && moved) ? 1.0 : 0.0;
+		}
+		if (__ballot(bad) != 0ull) return false;
+		cnt = (int)(hi - lo);
+		__builtin_amdgcn_wave_barrier();
+	}
 	for (int tile = 0, I = 0; I < T; ++I) {
 		for (int J = I; J < T; ++J, ++tile) {
 			double *tp = rec + (int64_t)tile * 256; // tile-major, element (row, col) at row * 16 + col
@@ -343,31 +363,10 @@ __host__ __device__ constexpr int quad_dma_slice_doubles(int p) {
 	return data > image ? data : image;
 }
 
-// four columns per statement: M0 is saved, stepped by one column (576 bytes) per load and restored
-__device__ __forceinline__ void quad_dma4(unsigned voff, unsigned lds_dst, const double *c0, const double *c1, const double *c2, const double *c3) {
-	unsigned keep;
-	asm volatile("s_mov_b32 %0, m0\n\t"
-	             "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
-	             "s_add_u32 m0, m0, 576\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
-	             "s_add_u32 m0, m0, 576\n\ts_nop 0\n\tglobal_load_lds_dword %1, %5\n\t"
-	             "s_add_u32 m0, m0, 576\n\ts_nop 0\n\tglobal_load_lds_dword %1, %6\n\t"
-	             "s_mov_b32 m0, %0"
-	             : "=&s"(keep)
-	             : "v"(voff), "s"(lds_dst), "s"(c0), "s"(c1), "s"(c2), "s"(c3)
-	             : "memory", "scc");
-}
-__device__ __forceinline__ void quad_dma1(unsigned voff, unsigned lds_dst, const double *c0) {
-	unsigned keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-	             : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(c0) : "memory");
-}
-
 template <int NB>
 __device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
 	constexpr int NPAIR = NB * (NB + 1) / 2;
 	constexpr int RS = kQuadDmaStride;
-	constexpr int NDMA = 4 * NB - 1; // p + 1 <= 4 NB - 1 columns; the slots past column p load y again (onto itself)
-	static_assert(NDMA <= 63, "vmcnt is a 6-bit field");
 	const int p = args.p;
 	const int k = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3;
 	const int rsub = 4 * k + b;
@@ -377,7 +376,7 @@ __device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t
 	const int last_off = (rd_last ? c_last : p) * RS + rsub;
 	const double fill_last = c_last == p + 1 ? 1.0 : 0.0;
 	const bool isx_prev = 4 * (NB - 2) + c4 < p, isx_last = c_last < p;
-	const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)buf); // wave-uniform
+	const unsigned lds0 = lds_dma_address(buf);
 	double acc[NPAIR];
 #pragma unroll
 	for (int t = 0; t < NPAIR; ++t) acc[t] = 0.0;
@@ -385,27 +384,11 @@ __device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t
 #pragma unroll
 	for (int g = 0; g < NB; ++g) first[g] = dmax[g] = 0.0;
 
-	auto colp = [&](int c) -> const double * { return c < p ? args.x_table[c < kWideMaxP ? c : 0] : args.y; };
-	// one 32-row block into half `h` of the ring; a partial block clamps the lanes' offsets to its last row (the rows past the
-	// end are masked by the steps), so nothing is read beyond the group
+	// one 32-row block into half `h` of the ring: the column pointers are re-read from the kernel arguments (lds_dma.h); a partial
+	// block clamps the lanes' offsets to its last row (the rows past the end are masked by the steps)
+	const lds_dma_table_t tab = lds_dma_table((unsigned)offsetof(WideArgs, x_table)); // (y sits behind the last feature: host_api.hip)
 	auto dma = [&](int64_t blk, int h) {
-		const int64_t left = hi - blk;
-		unsigned voff = (unsigned)lane * 4u;
-		if (left < 32) {
-			const unsigned last = (unsigned)left * 8u - 4u;
-			voff = voff < last ? voff : (last - 4u + (voff & 4u)); // keep the dword's half: the pair (lo, hi) of one double stays a double
-		}
-		const unsigned dst = lds0 + (unsigned)h * 256u;
-#pragma unroll
-		for (int c = 0; c + 4 <= NDMA; c += 4)
-			quad_dma4(voff, dst + (unsigned)c * (RS * 8u), colp(c) + blk, colp(c + 1) + blk, colp(c + 2) + blk, colp(c + 3) + blk);
-		// the last three slots: columns 4 NB - 4 .. p (at least one of them exists); the slots past column p load y once more
-		// ONTO ITSELF — the slice ends with column p, and the instruction count per block must not depend on p
-#pragma unroll
-		for (int c = NDMA / 4 * 4; c < NDMA; ++c) {
-			const int cc = c < p ? c : p;
-			quad_dma1(voff, dst + (unsigned)cc * (RS * 8u), colp(cc) + blk);
-		}
+		lds_dma_block<RS * 8, 4 * NB - 1>(tab, p + 1, blk, lds_dma_offsets(lane, hi - blk), lds0 + (unsigned)h * 256u);
 	};
 	auto step = [&](const double *hb, int s, bool valid_all, unsigned rowmask) {
 		const long long rm = valid_all ? -1ll : -(long long)((rowmask >> rsub) & 1u);
@@ -435,32 +418,33 @@ __device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t
 	};
 	int h = 0;
 	dma(lo, 0);
-	for (int64_t blk = lo; blk < hi; blk += 32, h ^= 1) {
-		if (blk + 32 < hi) {
-			dma(blk + 32, h ^ 1);
-			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory"); // this block has landed, the next one stays in flight
-		} else {
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		}
+	lds_dma_wait_all();
+	__builtin_amdgcn_wave_barrier();
+	{ // the shift: the group's first row (the constants are not shifted)
+#pragma unroll
+		for (int g = 0; g < NB - 1; ++g) first[g] = buf[c4 * RS + 4 * g * RS];
+		first[NB - 1] = rd_last ? buf[(rd_last ? c_last : p) * RS] : 0.0;
+	}
+	// full blocks in a loop without a branch around the matrix instructions, the partial last block after it (with the choice
+	// inside the loop the compiler copies the accumulators at every join)
+	int64_t blk = lo;
+	for (; blk + 32 <= hi; blk += 32, h ^= 1) {
+		if (blk + 32 < hi) dma(blk + 32, h ^ 1); // lands while this block's steps run
 		__builtin_amdgcn_wave_barrier();
 		const double *hb = buf + 32 * h;
-		if (blk == lo) { // the shift: the group's first row (the constants are not shifted)
-#pragma unroll
-			for (int g = 0; g < NB - 1; ++g) first[g] = buf[c4 * RS + 4 * g * RS];
-			first[NB - 1] = rd_last ? buf[(rd_last ? c_last : p) * RS] : 0.0;
-		}
-		const int64_t left = hi - blk;
-		if (left >= 32) {
-			step(hb, 0, true, 0xFFFFu);
-			step(hb, 1, true, 0xFFFFu);
-		} else {
-			const unsigned m32 = (1u << (unsigned)left) - 1u; // 1 <= left < 32
-			step(hb, 0, false, m32 & 0xFFFFu);
-			if (left > 16) step(hb, 1, false, m32 >> 16);
-		}
-		__builtin_amdgcn_wave_barrier(); // the reads of this half before the DMA that refills it (next iteration but one)
+		step(hb, 0, true, 0xFFFFu);
+		step(hb, 1, true, 0xFFFFu);
+		__builtin_amdgcn_wave_barrier(); // the reads of this half before the DMA that refills it (next trip but one)
+		lds_dma_wait_all();              // the next block has landed (it had this block's steps to do so)
 	}
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (blk < hi) {
+		const int64_t left = hi - blk;
+		const unsigned m32 = (1u << (unsigned)left) - 1u; // 1 <= left < 32
+		const double *hb = buf + 32 * h;
+		step(hb, 0, false, m32 & 0xFFFFu);
+		if (left > 16) step(hb, 1, false, m32 >> 16);
+	}
+	lds_dma_wait_all();
 	return quad_finish<NB, true>(args, rec, lane, buf, acc, first, dmax, isx_prev, isx_last, 0, lo, hi);
 }
 

@@ -30,10 +30,15 @@ hipError_t launch_accumulate_wide(const WideArgs &a, hipStream_t stream) {
 }
 
 template hipError_t launch_accumulate_wide_followup_T<3>(const WideArgs &, hipStream_t);
+template hipError_t launch_accumulate_wide_followup_T<4>(const WideArgs &, hipStream_t);
 
 hipError_t launch_accumulate_wide_followup(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups <= 0) return hipSuccess;
-	return wide_tiles(a.p) == 3 ? launch_accumulate_wide_followup_T<3>(a, stream) : hipErrorInvalidValue;
+	switch (wide_tiles(a.p)) {
+	case 3: return launch_accumulate_wide_followup_T<3>(a, stream);
+	case 4: return launch_accumulate_wide_followup_T<4>(a, stream);
+	default: return hipErrorInvalidValue;
+	}
 }
 
 } // namespace anofox

@@ -823,10 +823,13 @@ hipError_t launch_accumulate_wide_T(const WideArgs &a, hipStream_t stream) {
 	const size_t lds = (size_t)2 * ncol_pad * WideCfg<T>::stride(weighted, center) * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
 	const dim3 grid((unsigned)a.n_groups), block(kThreads);
 	const dim3 seg_grid((unsigned)kWideSegMaxSegments); // idle unless some group exceeded seg_rows
+	// launch_part (host_api.hip, several slabs): the idle-unless-needed kernels behind the main one run on the stream of the slab's
+	// solve, so that they never queue on the accumulate stream behind the previous slab's solve (which holds every SIMD's registers)
+	const bool main_part = a.launch_part != 2, rest_part = a.launch_part != 1;
 #define ANOFOX_WIDE_LAUNCH(W, C)                                                                                  \
 	do {                                                                                                          \
-		hipLaunchKernelGGL((accumulate_wide_kernel<T, W, C, false>), grid, block, lds, stream, a);                \
-		if (a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, W, C>), seg_grid, block, lds, stream, a); \
+		if (main_part) hipLaunchKernelGGL((accumulate_wide_kernel<T, W, C, false>), grid, block, lds, stream, a); \
+		if (rest_part && a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, W, C>), seg_grid, block, lds, stream, a); \
 	} while (0)
 	if (weighted) {
 		if (center) ANOFOX_WIDE_LAUNCH(true, true);
@@ -837,9 +840,9 @@ hipError_t launch_accumulate_wide_T(const WideArgs &a, hipStream_t stream) {
 		ANOFOX_WIDE_LAUNCH(false, true);
 	} else {
 		// speculative kernel, then the full version on whatever it listed (the counter is zeroed by the caller)
-		hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT)>), grid, block, lds, stream, a);
-		if (a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, false, true>), seg_grid, block, lds, stream, a);
-		hipLaunchKernelGGL((accumulate_wide_redo_kernel<T, false, true>), grid, block, lds, stream, a);
+		if (main_part) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT)>), grid, block, lds, stream, a);
+		if (rest_part && a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, false, true>), seg_grid, block, lds, stream, a);
+		if (rest_part) hipLaunchKernelGGL((accumulate_wide_redo_kernel<T, false, true>), grid, block, lds, stream, a);
 	}
 #undef ANOFOX_WIDE_LAUNCH
 	return hipGetLastError();

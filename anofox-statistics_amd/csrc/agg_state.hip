@@ -20,6 +20,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include <algorithm>
+
 #include "context.h"
 
 using namespace anofox;
@@ -878,6 +880,16 @@ bool anofox_hip_agg_state_finalize_slots_host(AnofoxHipAggState *s, int64_t n_li
 	if (!attached(s, out_error)) return false;
 	for (int64_t k = 0; k < n_list; ++k)
 		if ((int64_t)slots[k] >= s->n_slots) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "finalize: slot index out of range"); return false; }
+	{
+		// record k belongs to slots[k]: a slot listed twice would leave one of its two rows unwritten (stale staging memory
+		// handed out as a fit).  The arena passes a sorted unique list; direct callers get an error instead.
+		std::vector<uint32_t> sorted(slots, slots + n_list);
+		std::sort(sorted.begin(), sorted.end());
+		if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) {
+			set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "finalize: a slot is listed twice");
+			return false;
+		}
+	}
 	std::lock_guard<std::mutex> lk(s->ctx->mu);
 	AnofoxHipContext *ctx = s->ctx;
 	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;

@@ -180,6 +180,7 @@ struct WideArgs {
 	const int64_t *row_ends; // optional [G_total], see BatchArgs
 	int no_fast_path;        // accumulate_wide / accumulate_quad: 1 = skip the speculative version (A/B switch ANOFOX_WIDE_FAST=0, tests)
 	int from_redo_list;      // accumulate_mid: 1 = wavefront k takes group refine_list[k], k < refine_count[kWideRedoCounter]
+	int launch_part;         // launch_accumulate_wide: 0 = everything, 1 = the main kernel only, 2 = only what follows it (segment + redo kernels)
 };
 // word of the refine counter block that counts the give-ups of the speculative accumulate kernels (accumulate_wide_impl.h,
 // accumulate_quad.hip); the list itself borrows refine_list, which the solve that follows starts to fill only later
@@ -508,6 +509,8 @@ hipError_t launch_inference_wide_finish(const WideArgs &a, hipStream_t stream); 
 bool solve_tiles_supports(int p);
 hipError_t launch_solve_tiles(const WideArgs &a, hipStream_t stream);
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);
+// refit_dd.hip: the queued groups' records once more, from the rows in double-double (standard errors, R's aliasing rule)
+hipError_t launch_refit_dd_wide(const WideArgs &a, hipStream_t stream);
 // accumulate_mid.hip: wave-per-group accumulation into the same records for 8 < p <= 32
 bool accumulate_mid_supports(int p);
 hipError_t launch_accumulate_mid(const WideArgs &a, hipStream_t stream);
@@ -519,6 +522,9 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream);
 hipError_t launch_accumulate_wide_followup(const WideArgs &a, hipStream_t stream);
 // accumulate_mid.hip: the full version on the redo list (p = 27 .. 32)
 hipError_t launch_accumulate_mid_redo(const WideArgs &a, hipStream_t stream);
+// accumulate_mid.hip: the speculative LDS-DMA kernel for three and four column tiles (p = 34 .. 64, no weights, an intercept)
+bool accumulate_tile_supports(int p, bool weighted, bool center, bool no_fast_path);
+hipError_t launch_accumulate_tile(const WideArgs &a, hipStream_t stream);
 // solve_mid.hip: lane-per-group solve on the same records for 8 < p <= 32 (same modes as launch_solve_wide)
 bool solve_mid_supports(int p);
 hipError_t launch_solve_mid(const WideArgs &a, int mode, hipStream_t stream);

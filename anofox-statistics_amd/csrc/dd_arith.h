@@ -74,4 +74,62 @@ __host__ __device__ __forceinline__ void dd_weighted_residual(double y, double f
 	wl = pl - (wh - ph);
 }
 
+// ---- a double-double number and its arithmetic (refit_dd.hip): ~32 significant digits, round-to-nearest, no contraction ----
+struct dd {
+	double h, l;
+};
+__host__ __device__ __forceinline__ dd dd_make(double h, double l = 0.0) { return dd{h, l}; }
+__host__ __device__ __forceinline__ dd dd_renorm(double s, double e) {
+#pragma clang fp contract(off)
+	const double h = s + e;
+	return dd{h, e - (h - s)};
+}
+__host__ __device__ __forceinline__ dd operator+(dd a, dd b) {
+#pragma clang fp contract(off)
+	const double s = a.h + b.h;
+	const double bb = s - a.h;
+	double e = (a.h - (s - bb)) + (b.h - bb);
+	e += a.l + b.l;
+	return dd_renorm(s, e);
+}
+__host__ __device__ __forceinline__ dd operator-(dd a) { return dd{-a.h, -a.l}; }
+__host__ __device__ __forceinline__ dd operator-(dd a, dd b) { return a + (-b); }
+__host__ __device__ __forceinline__ dd operator*(dd a, dd b) {
+#pragma clang fp contract(off)
+	const double p = a.h * b.h;
+	double e = fma(a.h, b.h, -p);
+	e = fma(a.h, b.l, e);
+	e = fma(a.l, b.h, e);
+	return dd_renorm(p, e);
+}
+__host__ __device__ __forceinline__ dd dd_mul_d(dd a, double b) {
+#pragma clang fp contract(off)
+	const double p = a.h * b;
+	double e = fma(a.h, b, -p);
+	e = fma(a.l, b, e);
+	return dd_renorm(p, e);
+}
+__host__ __device__ __forceinline__ dd dd_prod(double a, double b) { // a b exactly
+	const double p = a * b;
+	return dd{p, fma(a, b, -p)};
+}
+__host__ __device__ __forceinline__ dd operator/(dd a, dd b) {
+#pragma clang fp contract(off)
+	const double q1 = a.h / b.h;
+	dd r = a - dd_mul_d(b, q1);
+	const double q2 = r.h / b.h;
+	r = r - dd_mul_d(b, q2);
+	const double q3 = r.h / b.h;
+	return dd_renorm(q1, q2) + dd_make(q3);
+}
+__host__ __device__ __forceinline__ dd dd_sqrt(dd a) {
+#pragma clang fp contract(off)
+	if (!(a.h > 0.0)) return dd{a.h == 0.0 ? 0.0 : __builtin_nan(""), 0.0};
+	const double x = sqrt(a.h);
+	const dd r = a - dd_prod(x, x);
+	return dd_renorm(x, r.h / (2.0 * x));
+}
+__host__ __device__ __forceinline__ double dd_to_double(dd a) { return a.h + a.l; }
+
+
 } // namespace anofox

@@ -83,7 +83,8 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	const size_t b_seg = align_up(mid_acc ? wide_seg_table_bytes(T, kSegMaxBig, kSegMaxSegments)
 	                                      : wide_seg_table_bytes(T, kWideSegMaxBig, kWideSegMaxSegments), 256);
 	// workspace: moments x n_buf | refine vectors (all groups) | refine list x n_buf | counters (256 B) x n_buf | t table | segment table
-	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, n_buf * (b_mom + b_lst + 256) + b_rss + kTcritTableBytes + b_seg, "workspace", e)) return false;
+	// (the segment table per moment buffer: slab k's segment kernel runs on the solve stream while slab k + 1 registers its groups)
+	if (!ensure_buffer(&ctx->ws, &ctx->ws_bytes, n_buf * (b_mom + b_lst + 256 + b_seg) + b_rss + kTcritTableBytes, "workspace", e)) return false;
 	char *base = (char *)ctx->ws;
 	char *const w_rss = base + n_buf * b_mom, *const w_lst = w_rss + b_rss, *const w_cnt = w_lst + n_buf * b_lst;
 	char *const w_tcrit = w_cnt + n_buf * 256, *const w_seg = w_tcrit + kTcritTableBytes;
@@ -93,6 +94,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.row_offsets = d_off;
 	a.y = d_y;
 	for (size_t j = 0; j < p; ++j) a.x_table[j] = x_cols[j];
+	if (p < (size_t)kWideMaxP) a.x_table[p] = d_y; // the LDS-DMA kernels walk ONE table: features, then y (lds_dma.h)
 	a.w = d_w;
 	a.p = (int)p;
 	a.model = (int)opt.model;
@@ -121,7 +123,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		}
 		ss = ctx->solve_stream;
 	}
-	a.seg_table = w_seg;
+	a.seg_table = w_seg; // (per buffer below)
 	a.seg_rows = mid_acc ? seg_rows_for(n_rows) : wide_seg_rows_for(n_rows);
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
 	int64_t k_slab = 0;
@@ -132,6 +134,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		a.moments = (double *)(base + buf * b_mom);
 		a.refine_list = (int32_t *)(w_lst + buf * b_lst);
 		a.refine_count = (int32_t *)(w_cnt + buf * 256);
+		a.seg_table = w_seg + buf * b_seg;
 		ctx->last_refine_count = a.refine_count;
 		// this buffer's previous tenant (slab k - 2) must be through its solve before the buffer is written again
 		if (overlap && k_slab >= 2 && hip_fail(hipStreamWaitEvent(st, ctx->slab_solve_done[buf], 0), "hipStreamWaitEvent", e)) return false;
@@ -156,7 +159,15 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		static const bool quad_on = !(getenv("ANOFOX_MID_QUAD") && atoi(getenv("ANOFOX_MID_QUAD")) == 0);
 		// (r4: its speculative kernel also takes p = 27 .. 34 of the unweighted fit with an intercept)
 		const bool quad = mid_acc_on && quad_on && accumulate_quad_supports((int)p, opt.model == ANOFOX_HIP_MODEL_WLS, opt.fit_intercept, a.no_fast_path != 0);
-		if (hip_fail(quad ? launch_accumulate_quad(a, st) : (mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st)),
+		// (r4) 34 <= p <= 64: the wave-per-group speculative kernel on LDS-DMA (accumulate_mid.hip) before accumulate_wide's full version
+		const bool tile = mid_acc_on && !quad && accumulate_tile_supports((int)p, opt.model == ANOFOX_HIP_MODEL_WLS, opt.fit_intercept, a.no_fast_path != 0);
+		// the workgroup-per-group kernel with several slabs: its segment / redo kernels (idle unless a group needs them) go to the
+		// solve stream — on this one they queued behind the PREVIOUS slab's solve, whose wavefronts hold every SIMD's registers:
+		// 5 us or ~1 ms per launch depending on how far that solve had got (profiles/r04_idle_launches.md)
+		const bool plain_wide = !quad && !tile && !mid_acc;
+		a.launch_part = (plain_wide && overlap) ? 1 : 0;
+		if (hip_fail(quad ? launch_accumulate_quad(a, st)
+		                  : (tile ? launch_accumulate_tile(a, st) : (mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st))),
 		             "wide accumulate kernel launch", e))
 			return false;
 		if (ctx->timing) (void)hipEventRecord(e1, st);
@@ -168,6 +179,11 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		if (overlap) {
 			if (hip_fail(hipEventRecord(ctx->slab_acc_done[buf], st), "hipEventRecord", e)) return false;
 			if (hip_fail(hipStreamWaitEvent(ss, ctx->slab_acc_done[buf], 0), "hipStreamWaitEvent", e)) return false;
+			if (a.launch_part == 1) {
+				a.launch_part = 2;
+				if (hip_fail(launch_accumulate_wide(a, ss), "wide accumulate follow-up launch", e)) return false;
+				a.launch_part = 0;
+			}
 		}
 		// moderately wide designs: one lane per group (solve_mid.hip); beyond that one workgroup per group
 		auto solve = [&](int mode) { return mid ? launch_solve_mid(a, mode, ss) : launch_solve_wide(a, mode, ss); };
@@ -192,6 +208,13 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		if (hip_fail(launch_residual_grad_wide(a, ss), "wide residual kernel launch", e)) return false;
 		if (hip_fail(solve(2), "wide final kernel launch", e)) return false;
 		if (!mid && hip_fail(launch_inference_wide_finish(a, ss), "wide inference finish kernel launch", e)) return false;
+		// (r4) the queued groups once more, from their rows in double-double: standard errors that do not carry cond(X)^2 eps and
+		// the reference's aliasing rule instead of the 1e-11 pivot test (refit_dd.hip).  HC errors keep the sandwich kernel's
+		// factorisation.  ANOFOX_REFIT_DD=0: without it (measurements).
+		static const bool refit_dd_on = !(getenv("ANOFOX_REFIT_DD") && atoi(getenv("ANOFOX_REFIT_DD")) == 0);
+		const bool hc_active = a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE;
+		(void)hc_active; // (with HC errors the refit keeps the solve's active set and leaves the per-coefficient arrays to the sandwich kernel)
+		if (refit_dd_on && hip_fail(launch_refit_dd_wide(a, ss), "double-double refit kernel launch", e)) return false;
 		if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE) {
 			if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, (size_t)slab * sizeof(double), "hc scratch", e)) return false;
 			a.hc_df = (double *)ctx->aux;

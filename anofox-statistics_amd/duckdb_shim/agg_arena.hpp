@@ -111,8 +111,13 @@ private:
 		double *y = nullptr, *x = nullptr, *w = nullptr;
 		size_t fill = 0, cap = 0;
 		std::thread::id owner;
-		bool busy = false; // an Update call (or a flush) is using it
+		std::atomic<bool> busy {false}; // an Update call (or a flush) is using it: whoever flips it false -> true owns the chunk
+		// slots the Update calls of this chunk's thread touched since the marks were last merged into the arena's dirty list:
+		// appended by the owner without a lock, merged when the chunk ships or is flushed (r4: one lock per 256 Ki rows
+		// instead of two per 2048-row vector — with 32 and more writer threads those were the arena's bottleneck)
+		std::vector<uint32_t> touched;
 	};
+	static constexpr size_t kMaxChunks = 4096; // writer threads of one query
 
 public:
 	// One Update call.  Not shared between threads; appends take no lock.
@@ -121,7 +126,7 @@ public:
 		explicit Writer(AggArena &a) : a_(a) {}
 		Writer(const Writer &) = delete;
 		Writer &operator=(const Writer &) = delete;
-		~Writer() { a_.EndWriter(chunk_, touched_, n_rows_); }
+		~Writer() { a_.EndWriter(chunk_, n_rows_); }
 		// Initialize of a state that this Update call is the first to touch
 		uint32_t NewSlot() { return a_.NewSlot(); }
 		// Starts a row and returns where its n_features values go (NULL list entries as NaN: the fit's row filter drops
@@ -137,7 +142,7 @@ public:
 			chunk_->slot[i] = slot;
 			chunk_->y[i] = y;
 			if (chunk_->w) chunk_->w[i] = w;
-			if (touched_.empty() || touched_.back() != slot) touched_.push_back(slot);
+			if (chunk_->touched.empty() || chunk_->touched.back() != slot) chunk_->touched.push_back(slot);
 			++n_rows_;
 			return chunk_->x + i * p;
 		}
@@ -150,7 +155,6 @@ public:
 		friend class AggArena;
 		AggArena &a_;
 		Chunk *chunk_ = nullptr;
-		std::vector<uint32_t> touched_;
 		uint64_t n_rows_ = 0;
 	};
 
@@ -254,17 +258,34 @@ private:
 		return n_features;
 	}
 
-	// the calling thread's chunk buffer (created on its first Update)
+	// the calling thread's chunk buffer (created on its first Update).  No lock on the way: the chunk table is an array of
+	// pointers that only grows, and the thread remembers its chunk of the arena it wrote to last.
 	Chunk *AcquireChunk() {
-		const std::thread::id me = std::this_thread::get_id();
-		{
-			std::unique_lock<std::mutex> lk(mu_);
-			for (auto &c : chunks_)
-				if (c->owner == me) {
-					cv_.wait(lk, [&] { return !c->busy; }); // (a flush from another thread may hold it for a moment)
-					c->busy = true;
-					return c.get();
+		static thread_local uint64_t tl_arena_id = 0;
+		static thread_local Chunk *tl_chunk = nullptr;
+		Chunk *mine = nullptr;
+		if (tl_arena_id == id_ && tl_chunk) {
+			mine = tl_chunk;
+		} else {
+			const std::thread::id me = std::this_thread::get_id();
+			const size_t n = n_chunks_.load(std::memory_order_acquire);
+			for (size_t k = 0; k < n; ++k) {
+				Chunk *c = chunk_tab_[k].load(std::memory_order_acquire);
+				if (c && c->owner == me) {
+					mine = c;
+					break;
 				}
+			}
+		}
+		if (mine) {
+			bool expect = false;
+			while (!mine->busy.compare_exchange_weak(expect, true, std::memory_order_acquire)) { // (a flush from another thread may hold it for a moment)
+				expect = false;
+				std::this_thread::yield();
+			}
+			tl_arena_id = id_;
+			tl_chunk = mine;
+			return mine;
 		}
 		const size_t p = p_.load(std::memory_order_acquire);
 		auto c = std::make_unique<Chunk>();
@@ -272,8 +293,8 @@ private:
 		const size_t max_rows = ((size_t)32 << 20) / (p * sizeof(double));
 		if (cap > max_rows) cap = max_rows < 2048 ? 2048 : max_rows;
 		c->cap = cap;
-		c->owner = me;
-		c->busy = true;
+		c->owner = std::this_thread::get_id();
+		c->busy.store(true, std::memory_order_relaxed);
 		const bool weighted = opt_.model == ANOFOX_HIP_MODEL_WLS;
 		c->slot = (uint32_t *)anofox_hip_host_alloc(cap * sizeof(uint32_t));
 		c->y = (double *)anofox_hip_host_alloc(cap * sizeof(double));
@@ -284,8 +305,18 @@ private:
 			throw std::bad_alloc();
 		}
 		std::lock_guard<std::mutex> lk(mu_);
+		const size_t k = n_chunks_.load(std::memory_order_relaxed);
+		if (k >= kMaxChunks) {
+			FreeChunk(*c);
+			throw std::runtime_error("anofox_stats fit_agg (HIP): more than " + std::to_string(kMaxChunks) + " writer threads in one query");
+		}
 		chunks_.push_back(std::move(c));
-		return chunks_.back().get();
+		Chunk *raw = chunks_.back().get();
+		chunk_tab_[k].store(raw, std::memory_order_release);
+		n_chunks_.store(k + 1, std::memory_order_release);
+		tl_arena_id = id_;
+		tl_chunk = raw;
+		return raw;
 	}
 	static void FreeChunk(Chunk &c) {
 		anofox_hip_host_free(c.slot);
@@ -295,14 +326,16 @@ private:
 		c.slot = nullptr;
 		c.y = c.x = c.w = nullptr;
 	}
-	void EndWriter(Chunk *c, const std::vector<uint32_t> &touched, uint64_t n_rows) noexcept {
+	void EndWriter(Chunk *c, uint64_t n_rows) noexcept {
 		rows_.fetch_add(n_rows, std::memory_order_relaxed);
+		if (c) c->busy.store(false, std::memory_order_release); // (its dirty marks travel with the chunk: MergeTouched)
+	}
+	// the slots a chunk's Update calls touched -> the arena's dirty list; the caller owns the chunk (busy)
+	void MergeTouched(Chunk &c) {
+		if (c.touched.empty()) return;
 		std::lock_guard<std::mutex> lk(mu_);
-		for (uint32_t s : touched) MarkDirtyLocked(s);
-		if (c) {
-			c->busy = false;
-			cv_.notify_all();
-		}
+		for (uint32_t s : c.touched) MarkDirtyLocked(s);
+		c.touched.clear();
 	}
 	void MarkDirtyLocked(uint32_t slot) {
 		if (slot >= dirty_.size()) dirty_.resize((size_t)slot + 1 + dirty_.size() / 2, 0);
@@ -317,6 +350,7 @@ private:
 		ShipLocked(c);
 	}
 	void ShipLocked(Chunk &c) {
+		MergeTouched(c);
 		if (c.fill == 0) return;
 		AnofoxError err;
 		if (!anofox_hip_agg_state_update_host(state_, (int64_t)c.fill, (int64_t)n_slots_.load(std::memory_order_relaxed), c.slot, c.y, c.x, c.w, nullptr, &err))
@@ -329,26 +363,18 @@ private:
 	// no row of the states this call is about.  (Waiting for it instead would deadlock: its thread may be waiting for the
 	// shipping lock this thread holds.)
 	void FlushAllShipLocked() {
-		for (size_t k = 0;; ++k) {
-			Chunk *c = nullptr;
-			{
-				std::lock_guard<std::mutex> lk(mu_);
-				if (k >= chunks_.size()) break;
-				c = chunks_[k].get();
-				if (c->busy || c->fill == 0) continue;
-				c->busy = true;
-			}
+		const size_t n = n_chunks_.load(std::memory_order_acquire);
+		for (size_t k = 0; k < n; ++k) {
+			Chunk *c = chunk_tab_[k].load(std::memory_order_acquire);
+			bool expect = false;
+			if (!c || !c->busy.compare_exchange_strong(expect, true, std::memory_order_acquire)) continue; // inside an Update call: see above
 			try {
-				ShipLocked(*c);
+				ShipLocked(*c); // (also merges the chunk's dirty marks when it holds no row)
 			} catch (...) {
-				std::lock_guard<std::mutex> lk(mu_);
-				c->busy = false;
-				cv_.notify_all();
+				c->busy.store(false, std::memory_order_release);
 				throw;
 			}
-			std::lock_guard<std::mutex> lk(mu_);
-			c->busy = false;
-			cv_.notify_all();
+			c->busy.store(false, std::memory_order_release);
 		}
 	}
 	// the slots Destroy gave back: emptied on the device (their pending rows have been flushed before), then reusable
@@ -429,14 +455,20 @@ private:
 	int device_;
 	mutable std::mutex mu_; // slots, dirty marks, the chunk table
 	std::mutex ship_mu_;    // every call into the library (taken before mu_, never while holding it)
-	std::condition_variable cv_;
 	AnofoxHipContext *ctx_ = nullptr;
 	AnofoxHipAggState *state_ = nullptr;
 	std::atomic<size_t> p_ {0};
 	std::atomic<uint32_t> n_slots_ {0};
 	uint32_t live_slots_ = 0;
 	std::vector<uint32_t> free_, pending_release_;
-	std::vector<std::unique_ptr<Chunk>> chunks_;
+	std::vector<std::unique_ptr<Chunk>> chunks_;           // owns the chunks (under mu_)
+	std::atomic<Chunk *> chunk_tab_[kMaxChunks] = {};        // the same pointers for lock-free readers; only grows
+	std::atomic<size_t> n_chunks_ {0};
+	static uint64_t NextId() {
+		static std::atomic<uint64_t> next {1};
+		return next.fetch_add(1, std::memory_order_relaxed);
+	}
+	const uint64_t id_ = NextId();                           // (a thread's cached chunk belongs to THIS arena, not to one that lived at its address)
 	std::vector<uint8_t> dirty_; // 1 = changed since its last fit, 2 = released while dirty
 	std::vector<uint32_t> dirty_list_;
 	std::atomic<uint64_t> rows_ {0}, fit_calls_ {0}, slots_fitted_ {0};

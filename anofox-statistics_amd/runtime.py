@@ -251,7 +251,10 @@ class AggState:
         if retain_bytes is None:      # (a log-only state IS its log: uncapped unless the caller caps it)
             retain_bytes = 0 if log_only else int(os.environ.get("ANOFOX_HIP_RETAIN_BYTES", 64 << 30))
         if retain_host_bytes is None:
-            retain_host_bytes = int(os.environ.get("ANOFOX_HIP_RETAIN_HOST_BYTES", 32 << 30))
+            # (an explicit retain_bytes = 0 on a moment state means "moments only", as documented: round 3 left the host
+            # continuation on in that case, and every chunk was copied back into page-locked slabs — 9 GB/s instead of 55)
+            moments_only = (not log_only) and retain_bytes == 0
+            retain_host_bytes = 0 if moments_only else int(os.environ.get("ANOFOX_HIP_RETAIN_HOST_BYTES", 32 << 30))
         self._lib = _abi.load()
         self._ctx = ctx          # keeps the context alive
         self.p = int(n_features)

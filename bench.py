@@ -129,7 +129,7 @@ def cpu_baseline(offs, y, x_cols, w, model, kw, n, p, budget_s=8.0):
                    "sample": f"{qr_passes} passes over {what}: dense Householder QR per group (solver = qr), {qr_t:.1f} s"}}
 
 
-def end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, model, kw, G, n, p, batch_groups=65536, chunk_rows=1 << 22):
+def end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, model, kw, G, n, p, batch_groups=65536, chunk_rows=1 << 22, with_row_log=False):
     """SURVEY.md 8(d) "also report end-to-end including H2D separately": the path as the DuckDB aggregate drives it.  Rows
     lie in page-locked HOST memory in shuffled group order (row-major x, a slot number per row — the arena's chunk layout),
     stream over PCIe into the GPU-resident aggregate state (anofox_hip_agg_state_update_host, `chunk_rows` rows per call),
@@ -160,7 +160,9 @@ def end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, model, kw, G, n, p, batch
     abi = importlib.import_module(PKG + "._abi")
     best = None
     for _rep in range(2):
-        st = pkg.AggState(ctx, p, opts, initial_slots=G, retain_bytes=0)
+        # moments only: the state keeps no row log (a log lets Finalize refit the groups its moments cannot resolve; the DuckDB
+        # arena keeps one by default, 64 GiB of HBM then 32 GiB of host memory — `with_row_log` below times that configuration)
+        st = pkg.AggState(ctx, p, opts, initial_slots=G, retain_bytes=(None if with_row_log else 0))
         lib = st._lib
         err = abi.AnofoxError()
         ctx.synchronize()
@@ -205,6 +207,8 @@ def end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, model, kw, G, n, p, batch
             "update_seconds": t_upd, "finalize_seconds": t_fin, "GBps_pcie": rows_sent * bytes_row / t_upd / 1e9,
             "bytes_per_row_over_pcie": bytes_row, "groups": G, "rows_per_group": n, "rows_streamed": rows_sent,
             "batch_groups": B, "rows_per_update_call": chunk_rows, "groups_flagged_unrefined": unref,
+            "row_log": ("HBM up to ANOFOX_HIP_RETAIN_BYTES (64 GiB), then page-locked host memory (32 GiB), then dropped: the arena's default"
+                        if with_row_log else "none (moments only)"),
             "parity": {"ok": ok, "sample_groups": S, "max_coef_rel_err": cerr, "max_diag_rel_err": derr},
             "note": "PCIe-bound; reported beside `value`, never mixed into it (SURVEY.md 8d)"}
 
@@ -327,6 +331,8 @@ def main():
     ap.add_argument("--predict", action="store_true",
                     help="fit + per-row predictions (*_fit_predict_agg); every 5th row is a prediction row (NULL y)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--end-to-end-row-log", action="store_true",
+                    help="also time the end-to-end leg with the aggregate state's row log on (the DuckDB arena's default budgets)")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the host-memory -> aggregate state -> records leg (p <= 8 only; reported as `end_to_end`)")
     ap.add_argument("--parity-sample", type=int, default=1024)
@@ -516,7 +522,9 @@ def main():
             per_step = G_local * bytes_fit
             achieved = per_step / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0
         else:
-            kernel = "accumulate_quad_kernel" if p <= 26 else ("accumulate_mid_kernel" if p <= 32 else "accumulate_wide_kernel")
+            # (the speculative accumulate_quad kernel also takes p = 27 .. 33 of the unweighted fit with an intercept)
+            quad_max = 33 if (not weighted and os.environ.get("ANOFOX_QUAD_SPEC", "1") != "0") else 26
+            kernel = "accumulate_quad_kernel" if p <= quad_max else ("accumulate_mid_kernel" if p <= 32 else "accumulate_wide_kernel")
             # which roof bounds this width: arithmetic intensity against the ridge point peak_flops / peak_bytes
             # (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B).  p + 1 = 2 * 9.8 - 3 => widths up to p ~ 75 are HBM-bound
             intensity = algorithmic_flops_per_fit(n, p) / bytes_fit
@@ -654,6 +662,8 @@ def main():
         if world == 1 and p <= 8 and not (args.no_end_to_end or args.vif or args.window or args.predict or args.inference):
             try:
                 out["end_to_end"] = end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, args.model, kw, G, n, p)
+                if args.end_to_end_row_log:
+                    out["end_to_end_with_row_log"] = end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, args.model, kw, G, n, p, with_row_log=True)
             except Exception as exc:      # the leg is an addition to the line, never a reason to lose it
                 out["end_to_end"] = {"error": str(exc)[:300]}
         if world == 1 and not args.no_cpu_baseline:

@@ -862,12 +862,15 @@ def test_wide_edge_cases_match_oracle(pkg, ctx, p):
             assert_records_match(core, rcore, p, inf, rinf, what=f"wide edge {model} p={p} icpt={icpt}", skip_diag_groups=zero_df)
 
 
-@pytest.mark.parametrize("p", [40, 128])
+@pytest.mark.parametrize("p", [9, 10, 12, 15, 16, 18, 22, 26, 27, 30, 31, 33, 34, 40, 46, 47, 48, 49, 62, 63, 64, 100, 128])
 def test_wide_speculative_kernel_and_its_fallback(pkg, ctx, p):
-    """p > 32, OLS with an intercept: accumulate_wide's speculative kernel (every row valid, first row as the shift,
-    constant columns read off the diagonal of the moments) and the groups it has to hand to the full kernel — a NaN /
-    inf anywhere, an invalid first row, columns in the band where sum d^2 does not decide |x - x_first| < 1e-10 —
-    next to groups it keeps, of every chunk-count shape (0, 1, 2 rows; exactly k x 32 rows; one row more or less)."""
+    """p > 8, OLS with an intercept: the speculative accumulate kernels (every row valid, first row as the shift, constant
+    columns read off the diagonal of the moments) — accumulate_quad's register-staged one (p <= 26: every column-group count
+    and both block sizes), its LDS-DMA one (27 .. 33), accumulate_mid's LDS-DMA kernel on three / four column tiles (34 .. 64:
+    with y and the ones inside the last tile, 46 / 62, and with side sums, 47 / 48 / 63 / 64) and accumulate_wide's (65 .. 128)
+    — and the groups they have to hand to the full kernel: a NaN / inf anywhere, an invalid first row, columns in the band
+    where sum d^2 does not decide |x - x_first| < 1e-10 — next to groups they keep, of every block-count shape (0, 1, 2
+    rows; exactly k x 32 rows; one row more or less)."""
     rng = np.random.default_rng(1000 + p)
     groups = []
 
@@ -890,7 +893,7 @@ def test_wide_speculative_kernel_and_its_fallback(pkg, ctx, p):
     # tolerances, which the oracle takes against the uncentred and the Cholesky against the centred column norm.)
     add(big, lambda X, y: X.__setitem__((slice(None), p - 1), -2.0 + 5e-11 * (np.arange(big) % 2)))
     add(big, lambda X, y: X.__setitem__((0, 7), np.nan))                                  # invalid first row
-    add(big, lambda X, y: y.__setitem__(70, np.nan))                                      # NaN in a middle chunk
+    add(big, lambda X, y: y.__setitem__(min(70, big // 2 + 3), np.nan))                   # NaN in a middle chunk
     add(big, lambda X, y: X.__setitem__((big - 1, p - 2), np.inf))                        # inf in the last row
     add(big, lambda X, y: X.__setitem__((slice(0, 40), slice(None)), np.nan))             # first chunk entirely invalid
     add(big, lambda X, y: X.__setitem__((slice(None), p // 2), 2 * X[:, 0] - X[:, 1] + 3))   # aliased column

@@ -64,6 +64,58 @@ int main() {
 		printf("FAILED: the compensated dot product lost its low part (FMA contraction inside two_sum?)\n");
 		return 1;
 	}
+#ifndef DD_UNGUARDED
+	// the double-double type of refit_dd.hip: sums, products, quotients and square roots against __float128
+	{
+		using anofox::dd;
+		auto rnd = [&]() { // a double-double of magnitude 1e-8 .. 1e8 with a full low part
+			const double h = (uniform() - 0.5) * pow(10.0, 16.0 * uniform() - 8.0);
+			const double l = h * (uniform() - 0.5) * 1e-16;
+			return anofox::dd_renorm(h, l);
+		};
+		auto q = [](dd a) { return (__float128)a.h + (__float128)a.l; };
+		auto rel = [](__float128 got, __float128 want) {
+			__float128 d = got - want;
+			if (d < 0) d = -d;
+			__float128 sc = want < 0 ? -want : want;
+			return (double)(d / sc);
+		};
+		double w_add = 0, w_mul = 0, w_div = 0, w_sqrt = 0, w_chain = 0;
+		for (int t = 0; t < 200000; ++t) {
+			const dd a = rnd(), b = rnd();
+			// (a sum may cancel: measure it against the larger operand)
+			{
+				__float128 want = q(a) + q(b), got = q(a + b), d = got - want;
+				if (d < 0) d = -d;
+				__float128 sc = q(a) < 0 ? -q(a) : q(a), sb = q(b) < 0 ? -q(b) : q(b);
+				if (sb > sc) sc = sb;
+				const double r = (double)(d / sc);
+				if (r > w_add) w_add = r;
+			}
+			w_mul = fmax(w_mul, rel(q(a * b), q(a) * q(b)));
+			w_div = fmax(w_div, rel(q(a / b), q(a) / q(b)));
+			const dd aa = a.h < 0 ? -a : a;
+			const dd s = anofox::dd_sqrt(aa);
+			w_sqrt = fmax(w_sqrt, rel(q(s) * q(s), q(aa)));
+		}
+		// a Cholesky-like chain: c - sum l_k^2 with 100 terms, the shape of a pivot
+		for (int t = 0; t < 2000; ++t) {
+			dd c = anofox::dd_make(0.0);
+			__float128 want = 0;
+			for (int k = 0; k < 100; ++k) {
+				const dd lk = rnd();
+				c = c + lk * lk;
+				want += q(lk) * q(lk);
+			}
+			w_chain = fmax(w_chain, rel(q(c), want));
+		}
+		printf("dd type: worst relative errors  add %.2e  mul %.2e  div %.2e  sqrt %.2e  sum of 100 squares %.2e\n", w_add, w_mul, w_div, w_sqrt, w_chain);
+		if (!(w_add < 1e-30 && w_mul < 1e-30 && w_div < 1e-29 && w_sqrt < 1e-29 && w_chain < 1e-29)) {
+			printf("FAILED: double-double arithmetic below twice the working precision\n");
+			return 1;
+		}
+	}
+#endif
 	printf("ok\n");
 	return 0;
 }

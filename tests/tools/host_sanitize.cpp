@@ -31,7 +31,10 @@ STUB(launch_inference_wide_finish(const WideArgs &, hipStream_t))
 STUB(launch_residual_grad_wide(const WideArgs &, hipStream_t))
 STUB(launch_accumulate_mid(const WideArgs &, hipStream_t))
 STUB(launch_accumulate_quad(const WideArgs &, hipStream_t))
-bool accumulate_quad_supports(int) { return false; }
+bool accumulate_quad_supports(int, bool, bool, bool) { return false; }
+STUB(launch_accumulate_tile(const WideArgs &, hipStream_t))
+bool accumulate_tile_supports(int, bool, bool, bool) { return false; }
+STUB(launch_refit_dd_wide(const WideArgs &, hipStream_t))
 STUB(launch_solve_mid(const WideArgs &, int, hipStream_t))
 STUB(launch_hc_wide(const WideArgs &, hipStream_t))
 STUB(launch_accumulate_narrow(const BatchArgs &, hipStream_t))
