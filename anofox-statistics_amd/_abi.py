@@ -211,6 +211,10 @@ SYMBOLS = {
     "anofox_hip_agg_state_combine_ex": (C.c_bool, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_bool, _ERRP]),
     "anofox_hip_agg_state_finalize_slots_host": (C.c_bool, [C.c_void_p, C.c_int64, C.c_void_p, _DP, _DP, C.POINTER(C.c_int64), _ERRP]),
     "anofox_hip_agg_state_release_slots": (C.c_bool, [C.c_void_p, C.c_int64, C.c_void_p, _ERRP]),
+    "anofox_hip_agg_state_reset": (C.c_bool, [C.c_void_p, _ERRP]),
+    "anofox_hip_agg_state_record_len": (C.c_size_t, [C.c_void_p]),
+    "anofox_hip_agg_state_export_slots_host": (C.c_bool, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _ERRP]),
+    "anofox_hip_agg_state_import_slots_host": (C.c_bool, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _ERRP]),
     "anofox_hip_agg_state_finalize_host": (C.c_bool, [C.c_void_p, C.c_int64, _DP, _DP, C.POINTER(C.c_int64), C.c_void_p, _ERRP]),
     "anofox_hip_agg_state_finalize_device": (C.c_bool, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, _ERRP]),
     "anofox_hip_host_alloc": (C.c_void_p, [C.c_size_t]),

@@ -981,9 +981,13 @@ hipError_t launch_accumulate_mid_redo(const WideArgs &a, hipStream_t stream) {
 	return launch_accumulate_mid(b, stream);
 }
 
-// (r4) p = 34 .. 64, unweighted with an intercept: the speculative LDS-DMA kernel (ANOFOX_TILE_SPEC=0: accumulate_wide as before)
+// (r4) p = 34 .. 64, unweighted with an intercept: the speculative LDS-DMA kernel on 16 x 16 tiles.  OFF by default — measured
+// SLOWER than accumulate_wide's workgroup-per-group kernel at every one of these widths (100 000 x 1000 rows, same box: p = 34
+// 3.7 against 3.8 TB/s, p = 48 3.9 against 4.3, p = 64 2.9-3.1 against 3.9; docs/HISTORY.md): three or four column tiles cost 96 /
+// 160 matrix cycles per row whatever is done about the loads, and one wavefront per 20-35 KB slice leaves 4-6 waves per CU to hide
+// them.  Kept as a measurement switch (ANOFOX_TILE_SPEC=1) and as the test vehicle of lds_dma.h's partial-block handling.
 bool accumulate_tile_supports(int p, bool weighted, bool center, bool no_fast_path) {
-	static const bool on = !(getenv("ANOFOX_TILE_SPEC") && atoi(getenv("ANOFOX_TILE_SPEC")) == 0);
+	static const bool on = getenv("ANOFOX_TILE_SPEC") && atoi(getenv("ANOFOX_TILE_SPEC")) == 1;
 	static const int max_p = getenv("ANOFOX_TILE_SPEC_MAXP") ? atoi(getenv("ANOFOX_TILE_SPEC_MAXP")) : 64;
 	return on && p >= 34 && p <= 64 && p <= max_p && !weighted && center && !no_fast_path;
 }

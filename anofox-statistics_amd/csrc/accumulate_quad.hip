@@ -455,7 +455,8 @@ template <int NB, bool WEIGHTED, bool CENTER, int RL, int WPS, int MODE = 0> // 
 __global__ __launch_bounds__(256, WPS) void accumulate_quad_kernel(WideArgs args) {
 	extern __shared__ double quad_lds[];
 	const int lane = threadIdx.x & 63;
-	int64_t gl = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	// (four wavefronts per workgroup; the LDS-DMA kernel of the widest designs is launched with two, so that three workgroups' slices fit a CU)
+	int64_t gl = (int64_t)blockIdx.x * (int64_t)(blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 	if (MODE == 2) {
 		if (gl >= args.refine_count[kWideRedoCounter]) return;
 		gl = args.refine_list[gl];
@@ -526,8 +527,12 @@ hipError_t launch_quad_nb(const WideArgs &a, hipStream_t stream) {
 template <int NB, int WPS>
 hipError_t launch_quad_spec_only(const WideArgs &a, hipStream_t stream) {
 	constexpr int RL = 1;
-	const dim3 grid((unsigned)((a.n_groups + 3) / 4)), block(256);
-	const size_t lds_bytes = 4 * (size_t)quad_dma_slice_doubles(a.p) * sizeof(double);
+	// eight wavefronts per CU while their slices fit its 160 KB of LDS (p <= 34: 35 columns x 576 bytes x 8 = 161 280 bytes), six
+	// in workgroups of two beyond
+	const size_t slice_bytes = (size_t)quad_dma_slice_doubles(a.p) * sizeof(double);
+	const int waves = 8 * slice_bytes <= (size_t)160 * 1024 ? 4 : 2;
+	const dim3 grid((unsigned)((a.n_groups + waves - 1) / waves)), block(64 * waves);
+	const size_t lds_bytes = (size_t)waves * slice_bytes;
 	static const bool attr_set = [] {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_quad_kernel<NB, false, true, RL, WPS, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		return true;
@@ -554,10 +559,10 @@ hipError_t launch_quad_spec_only(const WideArgs &a, hipStream_t stream) {
 // masks and takes p = 27 .. 34 for the unweighted fit with an intercept.
 bool accumulate_quad_supports(int p, bool weighted, bool center, bool no_fast_path) {
 	static const bool spec_on = !(getenv("ANOFOX_QUAD_SPEC") && atoi(getenv("ANOFOX_QUAD_SPEC")) == 0);
-	// (p = 34: 35 columns x 576 bytes x 8 waves exceed the CU's 160 KB of LDS by one kilobyte)
-	static const int spec_max_p = getenv("ANOFOX_QUAD_SPEC_MAXP") ? atoi(getenv("ANOFOX_QUAD_SPEC_MAXP")) : 33;
+	// (NB = 10, 11: p = 35 .. 42 — 55 / 66 accumulators, six wavefronts per CU; measured against accumulate_wide in docs/MEASUREMENTS.md)
+	static const int spec_max_p = getenv("ANOFOX_QUAD_SPEC_MAXP") ? atoi(getenv("ANOFOX_QUAD_SPEC_MAXP")) : 42;
 	if (p > kNarrowMaxP && p <= 26) return true;
-	return p > 26 && p <= 33 && p <= spec_max_p && spec_on && !weighted && center && !no_fast_path;
+	return p > 26 && p <= 42 && p <= spec_max_p && spec_on && !weighted && center && !no_fast_path;
 }
 
 hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
@@ -578,6 +583,8 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	case 7: return launch_quad_nb<7, 1, 2>(a, stream);
 	case 8: return launch_quad_spec_only<8, 2>(a, stream);
 	case 9: return launch_quad_spec_only<9, 2>(a, stream);
+	case 10: return launch_quad_spec_only<10, 2>(a, stream);
+	case 11: return launch_quad_spec_only<11, 2>(a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

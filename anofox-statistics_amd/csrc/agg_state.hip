@@ -981,6 +981,94 @@ bool anofox_hip_agg_state_release_slots(AnofoxHipAggState *s, int64_t n_list, co
 	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error); // the list is pageable host memory
 }
 
+// Every slot empty, the row log released, the slot count back to zero — the state as it was created, its device buffers kept.
+// (The DuckDB arena calls it between two executions of a prepared statement: the arena lives in the bind data.)
+bool anofox_hip_agg_state_reset(AnofoxHipAggState *s, AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!s) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL"); return false; }
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
+	hipStream_t st = s->ctx->stream;
+	if (s->copy_stream && hip_fail(hipStreamSynchronize(s->copy_stream), "hipStreamSynchronize", out_error)) return false;
+	if (s->moments && s->capacity > 0) {
+		const size_t rec = (size_t)moment_record_len((int)s->p) * sizeof(double);
+		if (hip_fail(hipMemsetAsync(s->moments, 0, (size_t)s->capacity * rec, st), "hipMemsetAsync", out_error)) return false;
+		if (hip_fail(hipMemsetAsync(s->n_accum, 0, (size_t)s->capacity * sizeof(int64_t), st), "hipMemsetAsync", out_error)) return false;
+	}
+	log_free(s); // (synchronises the stream)
+	s->log_dropped = false;
+	s->n_slots = 0;
+	s->rows = 0;
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
+}
+
+size_t anofox_hip_agg_state_record_len(const AnofoxHipAggState *s) { return (s && !s->log_only) ? (size_t)moment_record_len((int)s->p) : 0; }
+
+// Cross-device Combine of moment states (the DuckDB glue shards a query's aggregate states over the node's GPUs):
+// the records of the listed slots as the device keeps them, out of one state and into another.  Rows kept in a row log do not
+// travel: both calls give this state's log up — a group its moments cannot resolve is then FLAGGED by Finalize (status 101),
+// never handed out as a number.
+static bool slots_transfer(AnofoxHipAggState *s, int64_t n_list, const uint32_t *slots, double *records, int64_t *counts, bool import,
+                           AnofoxError *out_error) {
+	reset_error(out_error);
+	if (!s || n_list < 0) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "state is NULL or n_list negative"); return false; }
+	if (n_list == 0) return true;
+	if (!slots || !records || !counts) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "slots, records or counts is NULL"); return false; }
+	std::lock_guard<std::mutex> lk0(s->mu);
+	if (!attached(s, out_error)) return false;
+	if (s->log_only) {
+		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT,
+		          "designs of more than 8 features and HC standard errors keep rows, not moment records: their states stay on one device");
+		return false;
+	}
+	for (int64_t k = 0; k < n_list; ++k)
+		if ((int64_t)slots[k] >= s->n_slots) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "slot index out of range"); return false; }
+	if (import) { // (a slot written twice by one call would depend on the kernel's scheduling)
+		std::vector<uint32_t> sorted(slots, slots + n_list);
+		std::sort(sorted.begin(), sorted.end());
+		if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) { set_error(out_error, ANOFOX_ERROR_INVALID_INPUT, "import: a slot is listed twice"); return false; }
+	}
+	std::lock_guard<std::mutex> lk(s->ctx->mu);
+	AnofoxHipContext *ctx = s->ctx;
+	if (hip_fail(hipSetDevice(ctx->device), "hipSetDevice", out_error)) return false;
+	if (!state_reserve(s, s->n_slots, out_error)) return false;
+	hipStream_t st = ctx->stream;
+	const size_t K = (size_t)n_list, rec = (size_t)moment_record_len((int)s->p);
+	const size_t b_list = align_up(K * sizeof(uint32_t), 256), b_mom = align_up(K * rec * sizeof(double), 256), b_cnt = align_up(K * sizeof(int64_t), 256);
+	if (!ensure_buffer(&ctx->stage, &ctx->stage_bytes, b_list + b_mom + b_cnt, "staging", out_error)) return false;
+	char *sb = (char *)ctx->stage;
+	uint32_t *d_sel = (uint32_t *)sb;
+	double *d_mom = (double *)(sb + b_list);
+	int64_t *d_cnt = (int64_t *)(sb + b_list + b_mom);
+	if (hip_fail(hipMemcpyAsync(d_sel, slots, K * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
+	if (import) {
+		if (hip_fail(hipMemcpyAsync(d_mom, records, K * rec * sizeof(double), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
+		if (hip_fail(hipMemcpyAsync(d_cnt, counts, K * sizeof(int64_t), hipMemcpyHostToDevice, st), "H2D", out_error)) return false;
+		if (hip_fail(launch_ingest_scatter_slots(s->moments, s->n_accum, d_sel, n_list, (int)s->p, d_mom, d_cnt, st), "scatter kernel launch", out_error)) return false;
+	} else {
+		if (hip_fail(launch_ingest_gather_slots(s->moments, s->n_accum, d_sel, n_list, (int)s->p, d_mom, d_cnt, st), "gather kernel launch", out_error)) return false;
+		if (hip_fail(hipMemcpyAsync(records, d_mom, K * rec * sizeof(double), hipMemcpyDeviceToHost, st), "D2H", out_error)) return false;
+		if (hip_fail(hipMemcpyAsync(counts, d_cnt, K * sizeof(int64_t), hipMemcpyDeviceToHost, st), "D2H", out_error)) return false;
+	}
+	if (s->retain && !s->log_dropped) { // the rows behind these records are on the other side, or about to be
+		log_free(s);
+		s->log_dropped = true;
+	}
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", out_error);
+}
+
+bool anofox_hip_agg_state_export_slots_host(AnofoxHipAggState *s, int64_t n_list, const uint32_t *slots, double *records, int64_t *counts,
+                                            AnofoxError *out_error) {
+	return slots_transfer(s, n_list, slots, records, counts, false, out_error);
+}
+
+bool anofox_hip_agg_state_import_slots_host(AnofoxHipAggState *s, int64_t n_list, const uint32_t *slots, const double *records,
+                                            const int64_t *counts, AnofoxError *out_error) {
+	return slots_transfer(s, n_list, slots, const_cast<double *>(records), const_cast<int64_t *>(counts), true, out_error);
+}
+
 void *anofox_hip_host_alloc(size_t bytes) {
 	void *p = nullptr;
 	if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {

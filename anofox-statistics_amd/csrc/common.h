@@ -436,6 +436,8 @@ hipError_t launch_ingest_combine(double *moments, int64_t *n_accum, int64_t n_sl
                                  int64_t n_pairs, int p, int center, int preserve, hipStream_t stream);
 hipError_t launch_ingest_gather_slots(const double *moments, const int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, double *out_m,
                                       int64_t *out_n, hipStream_t st);
+hipError_t launch_ingest_scatter_slots(double *moments, int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, const double *in_m,
+                                       const int64_t *in_n, hipStream_t st);
 hipError_t launch_ingest_clear_slots(double *moments, int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, hipStream_t st);
 
 // ---- row log of a streaming aggregate state (rowlog.hip): the rows kept for the refit of queued groups ----
@@ -511,6 +513,7 @@ hipError_t launch_solve_tiles(const WideArgs &a, hipStream_t stream);
 hipError_t launch_residual_grad_wide(const WideArgs &a, hipStream_t stream);
 // refit_dd.hip: the queued groups' records once more, from the rows in double-double (standard errors, R's aliasing rule)
 hipError_t launch_refit_dd_wide(const WideArgs &a, hipStream_t stream);
+hipError_t launch_refit_dd_narrow(const BatchArgs &a, hipStream_t stream);
 // accumulate_mid.hip: wave-per-group accumulation into the same records for 8 < p <= 32
 bool accumulate_mid_supports(int p);
 hipError_t launch_accumulate_mid(const WideArgs &a, hipStream_t stream);

@@ -208,18 +208,17 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		if (hip_fail(launch_residual_grad_wide(a, ss), "wide residual kernel launch", e)) return false;
 		if (hip_fail(solve(2), "wide final kernel launch", e)) return false;
 		if (!mid && hip_fail(launch_inference_wide_finish(a, ss), "wide inference finish kernel launch", e)) return false;
-		// (r4) the queued groups once more, from their rows in double-double: standard errors that do not carry cond(X)^2 eps and
-		// the reference's aliasing rule instead of the 1e-11 pivot test (refit_dd.hip).  HC errors keep the sandwich kernel's
-		// factorisation.  ANOFOX_REFIT_DD=0: without it (measurements).
-		static const bool refit_dd_on = !(getenv("ANOFOX_REFIT_DD") && atoi(getenv("ANOFOX_REFIT_DD")) == 0);
-		const bool hc_active = a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE;
-		(void)hc_active; // (with HC errors the refit keeps the solve's active set and leaves the per-coefficient arrays to the sandwich kernel)
-		if (refit_dd_on && hip_fail(launch_refit_dd_wide(a, ss), "double-double refit kernel launch", e)) return false;
 		if (a.hc_type != ANOFOX_HC_NONE && a.inference && a.model != ANOFOX_HIP_MODEL_RIDGE) {
 			if (!ensure_buffer(&ctx->aux, &ctx->aux_bytes, (size_t)slab * sizeof(double), "hc scratch", e)) return false;
 			a.hc_df = (double *)ctx->aux;
 			if (hip_fail(launch_hc_wide(a, ss), "wide hc kernel launch", e)) return false;
 		}
+		// (r4) LAST: the queued groups once more, from their rows in double-double — standard errors (classical and HC) that do not
+		// carry cond(X)^2 eps, and the reference's aliasing rule instead of the 1e-11 pivot test (refit_dd.hip).
+		// ANOFOX_REFIT_DD=0: without it (measurements).
+		static const bool refit_dd_on = !(getenv("ANOFOX_REFIT_DD") && atoi(getenv("ANOFOX_REFIT_DD")) == 0);
+		if (refit_dd_on && hip_fail(launch_refit_dd_wide(a, ss), "double-double refit kernel launch", e)) return false;
+
 		if (overlap && hip_fail(hipEventRecord(ctx->slab_solve_done[buf], ss), "hipEventRecord", e)) return false;
 		if (ctx->timing) {
 			(void)hipEventRecord(e2, ss);
@@ -320,6 +319,11 @@ bool run_device_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows
 		if (hip_fail(hipMemsetAsync(ctx->aux, 0, 64, st), "hipMemsetAsync", e)) return false;
 		if (hip_fail(launch_hc_narrow(a, (double *)((char *)ctx->aux + b_tab), ctx->aux, st), "hc kernel launch", e)) return false;
 	}
+	// (r4) LAST: the queued groups once more, from their rows in double-double (refit_dd.hip) — the reference's aliasing rule
+	// instead of the 1e-11 pivot test (round 3's narrow sweeps: 12 "rank band" groups of 240 000 cases), standard errors without
+	// cond(X)^2 eps.  ANOFOX_REFIT_DD=0: without it.
+	static const bool refit_dd_on = !(getenv("ANOFOX_REFIT_DD") && atoi(getenv("ANOFOX_REFIT_DD")) == 0);
+	if (refit_dd_on && hip_fail(launch_refit_dd_narrow(a, st), "double-double refit kernel launch", e)) return false;
 	if (ctx->timing) {
 		(void)hipEventRecord(e2, st);
 		ctx->acc_events.emplace_back(e0, e1);   // owns e0 and e1

@@ -417,6 +417,26 @@ hipError_t launch_ingest_gather_slots(const double *moments, const int64_t *n_ac
 	return hipGetLastError();
 }
 
+namespace {
+// the inverse of ingest_gather_slots_kernel: contiguous records k = 0 .. n_list - 1 -> the listed slots (cross-device Combine)
+__global__ void ingest_scatter_slots_kernel(double *moments, int64_t *n_accum, const uint32_t *list, int64_t n_list, int rec,
+                                            const double *in_m, const int64_t *in_n) {
+	for (int64_t k = blockIdx.x; k < n_list; k += gridDim.x) {
+		const int64_t s = list[k];
+		for (int j = threadIdx.x; j < rec; j += blockDim.x) moments[s * rec + j] = in_m[k * rec + j];
+		if (threadIdx.x == 0) n_accum[s] = in_n[k];
+	}
+}
+} // namespace
+
+hipError_t launch_ingest_scatter_slots(double *moments, int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, const double *in_m,
+                                       const int64_t *in_n, hipStream_t st) {
+	if (n_list <= 0) return hipSuccess;
+	const unsigned grid = (unsigned)(n_list < 65535 ? n_list : 65535);
+	hipLaunchKernelGGL(ingest_scatter_slots_kernel, dim3(grid), dim3(64), 0, st, moments, n_accum, list, n_list, moment_record_len(p), in_m, in_n);
+	return hipGetLastError();
+}
+
 hipError_t launch_ingest_clear_slots(double *moments, int64_t *n_accum, const uint32_t *list, int64_t n_list, int p, hipStream_t st) {
 	if (n_list <= 0) return hipSuccess;
 	const unsigned grid = (unsigned)(n_list < 65535 ? n_list : 65535);

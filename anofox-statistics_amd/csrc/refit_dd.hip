@@ -18,6 +18,9 @@
 // Reference semantics restated (crates/anofox-stats-core/src/models/{ols,ridge,wls}.rs; oracle/anofox_oracle.c:300-600):
 // row filter ols.rs:59-66 / wls.rs:76-86, constant columns and first valid row taken from the moment record (ols.rs:76-87),
 // statistics of SURVEY.md Appendix B.7, ridge = (Xc'Xc + lambda I) beta = Xc'yc with glmnet scaling lambda n / sd_y.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "device_math.h"
 #include "dd_arith.h"
@@ -28,6 +31,20 @@ namespace {
 #pragma clang fp contract(off)
 
 __device__ __forceinline__ double nan64w() { return __builtin_nan(""); }
+
+// what the kernel needs of a launch, whichever path (narrow / wide) queued the groups
+struct RefitArgs {
+	const int64_t *row_offsets, *row_ends; // group g owns rows [row_offsets[g], row_ends ? row_ends[g] : row_offsets[g + 1])
+	const double *y, *w;
+	const double *x[kWideMaxP];
+	int64_t group_base;
+	int p, model, fit_intercept, lambda_scaling, hc_type;
+	double confidence_level, alpha;
+	double *core, *inference;
+	const int32_t *refine_list, *refine_count;
+	void *tcrit_table;
+	int max_items; // more queued groups than this: the kernel leaves all of them as the refinement passes left them
+};
 
 constexpr int kDdThreads = 256;
 constexpr int kDdMaxM = kWideMaxP + 2;                         // ones, x (<= 128), y
@@ -43,11 +60,16 @@ struct DdLds {
 	double *wrow;   // [kDdTileRows] weight of the row (0 = row does not take part)
 	dd *zv;         // [m] the y row of L
 	dd *beta;       // [m]
+	dd *dg;         // [m] diag((L L')^-1), or the sandwich's diagonal with HC errors
+	double *hc_c;   // [2 m] HC pass: the centred row (hi, lo pairs)
+	double *hc_t;   // [2 m] HC pass: t = W c
 	double *first;  // [m] shift of every variable (0 for the ones)
 	int *col;       // [m] original feature of variable v (1 .. pe), -1 otherwise
 	int *live;      // [m] 1 = accepted pivot
 	double *red;    // [kDdThreads / 64 * 4 + 8] block reductions
 	int *flag;      // [kDdTileRows] row validity of the tile being loaded
+	int *nc;        // [p] feature is not constant over the valid rows (ols.rs:76-87)
+	double *fx;     // [p + 1] the first valid row: x, then y
 };
 
 __device__ __forceinline__ dd block_sum_dd(dd v, double *red, int tid) {
@@ -69,10 +91,9 @@ __device__ __forceinline__ dd block_sum_dd(dd v, double *red, int tid) {
 	return t;
 }
 
-__global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args) {
+__global__ __launch_bounds__(kDdThreads) void refit_dd_kernel(RefitArgs args) {
 	extern __shared__ double dd_lds[];
 	const int p = args.p;
-	const int T = wide_tiles(p), P16 = 16 * T, NT = T * (T + 1) / 2;
 	const int tid = threadIdx.x;
 	const int model = args.model;
 	const bool icpt = args.fit_intercept != 0;
@@ -86,44 +107,99 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args
 		l.wrow = q; q += kDdTileRows;
 		l.zv = reinterpret_cast<dd *>(q); q += 2 * kDdMaxM;
 		l.beta = reinterpret_cast<dd *>(q); q += 2 * kDdMaxM;
+		l.dg = reinterpret_cast<dd *>(q); q += 2 * kDdMaxM;
+		l.hc_c = q; q += 2 * kDdMaxM;
+		l.hc_t = q; q += 2 * kDdMaxM;
 		l.first = q; q += kDdMaxM;
 		l.red = q; q += 16;
 		l.col = reinterpret_cast<int *>(q); q += (kDdMaxM + 1) / 2;
 		l.live = reinterpret_cast<int *>(q); q += (kDdMaxM + 1) / 2;
-		l.flag = reinterpret_cast<int *>(q);
+		l.flag = reinterpret_cast<int *>(q); q += kDdTileRows;
+		l.nc = reinterpret_cast<int *>(q); q += (kWideMaxP + 1) / 2;
+		l.fx = q;
 	}
 	const int n_items = *args.refine_count;
+	// A workgroup per queued group and dozens of barriers per row tile: right for the handful of hard groups of an ordinary
+	// batch, hopeless for a batch that is ALL exact fits (1e8 noise-free window frames would take hours where the residual
+	// passes take a second).  Beyond the cap the groups keep what those passes gave them (round 3's behaviour).
+	if (n_items > args.max_items) return;
 	for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
 		const int64_t gl = args.refine_list[item];
 		const int64_t g = args.group_base + gl;
 		double *core = args.core + g * (int64_t)(p + 6);
 		double *inf = args.inference ? args.inference + g * (int64_t)(5 * p + 2) : nullptr;
 		if (core[p + 5] != 0.0) continue; // (queued groups carry a fit; anything else keeps its record)
-		const double *vec = args.moments + gl * (int64_t)wide_record_len(T) + (int64_t)NT * 256;
-		const double *sc = vec + 4 * P16;
+		const int64_t lo = args.row_offsets[g], hi = args.row_ends ? args.row_ends[g] : args.row_offsets[g + 1];
+		// row validity of one tile (ols.rs:59-66, wls.rs:76-86: every feature, y and a positive weight finite — also the
+		// constant features); l.wrow = the row's weight, 0 for rows that do not take part
+		auto tile_flags = [&](int64_t r0) {
+			__syncthreads();
+			if (tid < kDdTileRows) l.flag[tid] = 1;
+			__syncthreads();
+			for (int e = tid; e < kDdTileRows * (p + 2); e += kDdThreads) {
+				const int rr = e / (p + 2), c = e - rr * (p + 2);
+				const int64_t r = r0 + rr;
+				if (r >= hi) continue;
+				double v;
+				if (c < p) v = args.x[c][r];
+				else if (c == p) v = args.y[r];
+				else v = weighted ? args.w[r] : 1.0;
+				const bool ok = isfinite(v) && (c <= p || v > 0.0);
+				if (!ok) l.flag[rr] = 0; // (benign race: every writer writes 0)
+				if (c == p + 1) l.wrow[rr] = v;
+			}
+			__syncthreads();
+			if (tid < kDdTileRows) {
+				const bool in = r0 + tid < hi && l.flag[tid];
+				if (!in) l.wrow[tid] = 0.0;
+			}
+			__syncthreads();
+		};
+		// ---- pass 0: the first valid row and the constant-column predicate |x - x_first| < 1e-10 on every valid row (ols.rs:76-87) ----
+		int64_t rfirst = -1;
+		for (int64_t r0 = lo; r0 < hi && rfirst < 0; r0 += kDdTileRows) {
+			tile_flags(r0);
+			for (int rr = 0; rr < kDdTileRows; ++rr)
+				if (l.wrow[rr] != 0.0) { rfirst = r0 + rr; break; } // (uniform)
+		}
+		if (rfirst < 0) continue;
 		__syncthreads();
+		for (int c = tid; c <= p; c += kDdThreads) {
+			l.fx[c] = c < p ? args.x[c][rfirst] : args.y[rfirst];
+			if (c < p) l.nc[c] = 0;
+		}
+		__syncthreads();
+		double cnt0 = 0.0;
+		for (int64_t r0 = lo; r0 < hi; r0 += kDdTileRows) {
+			tile_flags(r0);
+			for (int rr = 0; rr < kDdTileRows; ++rr) cnt0 += l.wrow[rr] != 0.0 ? 1.0 : 0.0;
+			for (int e = tid; e < kDdTileRows * p; e += kDdThreads) {
+				const int rr = e / p, c = e - rr * p;
+				if (l.wrow[rr] == 0.0) continue;
+				if (!(fabs(args.x[c][r0 + rr] - l.fx[c]) < 1e-10)) l.nc[c] = 1; // (benign race)
+			}
+		}
+		__syncthreads();
+		if (cnt0 != core[p + 4]) continue; // (must agree with the fit's own row count; uniform)
 		// ---- the variables: 0 = ones, 1 .. pe = the non-constant features in their order, pe + 1 = y ----
 		if (tid == 0) {
 			int pe = 0;
 			l.col[0] = -1;
 			l.first[0] = 0.0;
 			for (int j = 0; j < p; ++j) {
-				if (vec[3 * P16 + j] != 0.0) {
+				if (l.nc[j]) {
 					++pe;
 					l.col[pe] = j;
-					l.first[pe] = icpt ? vec[2 * P16 + j] : 0.0;
+					l.first[pe] = icpt ? l.fx[j] : 0.0;
 				}
 			}
 			l.col[pe + 1] = -1;
-			l.first[pe + 1] = icpt ? sc[4] : 0.0;
+			l.first[pe + 1] = icpt ? l.fx[p] : 0.0;
 			l.flag[kDdTileRows - 1] = pe; // (hand-over below)
 		}
 		__syncthreads();
 		const int pe = l.flag[kDdTileRows - 1];
-		const bool hc_active = args.hc_type != ANOFOX_HC_NONE && args.inference && !ridge;
-		const bool keep_pattern = hc_active;
-		if (keep_pattern) // (before anything of the record is rewritten)
-			for (int v = 1 + tid; v <= pe; v += kDdThreads) l.live[v] = isnan(core[l.col[v]]) ? 0 : 1;
+		const bool hc_active = args.hc_type != ANOFOX_HC_NONE && args.inference && !ridge; // (ridge.rs has no HC branch)
 		const int m = pe + 2, yv = pe + 1;
 		const int E = m * (m + 1) / 2;
 		__syncthreads();
@@ -144,42 +220,25 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args
 			acc[k] = dd{0.0, 0.0};
 		}
 		// ---- the moments over the valid rows, tile by tile ----
-		const int64_t lo = args.row_offsets[g], hi = group_row_end(args, g);
 		double cnt_rows = 0.0;
-		for (int64_t r0 = lo; r0 < hi; r0 += kDdTileRows) {
-			__syncthreads();
-			if (tid < kDdTileRows) l.flag[tid] = 1;
-			__syncthreads();
-			// every feature of the row must be finite (ols.rs:59-66), also the constant ones
-			for (int e = tid; e < kDdTileRows * (p + 2); e += kDdThreads) {
-				const int rr = e / (p + 2), c = e - rr * (p + 2);
-				const int64_t r = r0 + rr;
-				if (r >= hi) continue;
-				double v;
-				if (c < p) v = args.x_table[c][r];
-				else if (c == p) v = args.y[r];
-				else v = weighted ? args.w[r] : 1.0;
-				const bool ok = isfinite(v) && (c <= p || v > 0.0);
-				if (!ok) l.flag[rr] = 0; // (benign race: every writer writes 0)
-				if (c == p + 1) l.wrow[rr] = v;
-			}
-			__syncthreads();
+		// one tile of rows into l.tile (z = (1, x - first .., y - first) per row, 0 for rows that do not take part) and l.wrow
+		auto load_tile = [&](int64_t r0) {
+			tile_flags(r0);
 			for (int e = tid; e < kDdTileRows * m; e += kDdThreads) {
 				const int rr = e / m, v = e - rr * m;
 				const int64_t r = r0 + rr;
 				double z = 0.0;
-				if (r < hi && l.flag[rr]) {
+				if (r < hi && l.wrow[rr] != 0.0) {
 					if (v == 0) z = 1.0;
 					else if (v == yv) z = args.y[r] - l.first[yv];
-					else z = args.x_table[l.col[v]][r] - l.first[v];
+					else z = args.x[l.col[v]][r] - l.first[v];
 				}
 				l.tile[rr * m + v] = z;
 			}
-			if (tid < kDdTileRows) {
-				const bool in = r0 + tid < hi && l.flag[tid];
-				if (!in) l.wrow[tid] = 0.0;
-			}
 			__syncthreads();
+		};
+		for (int64_t r0 = lo; r0 < hi; r0 += kDdTileRows) {
+			load_tile(r0);
 			for (int rr = 0; rr < kDdTileRows; ++rr) {
 				const double wv = l.wrow[rr];
 				if (wv == 0.0) continue; // (uniform)
@@ -202,7 +261,7 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args
 			if (tid + k * kDdThreads < E) l.M[tid + k * kDdThreads] = acc[k];
 		__syncthreads();
 		const double cnt = cnt_rows;
-		if (cnt < 2.0 || cnt != sc[3]) continue; // (must agree with the accumulate kernel's row count; uniform)
+		if (cnt < 2.0 || cnt != cnt0) continue; // (uniform)
 		const dd sw = l.M[tri(0, 0)];
 		// ---- uncentred squared norms of the columns of the decomposed design (the oracle's `full2`), then centring ----
 		// with an intercept the record's shift f is in the variables: sum w x^2 = q + 2 f s + f^2 sw
@@ -255,10 +314,7 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args
 			const dd ssum = block_sum_dd(part, l.red, tid);
 			const dd piv = l.M[tri(j, j)] - ssum;
 			const dd full = l.beta[j];
-			// (with HC standard errors the sandwich kernel factors the double-precision moments once more and must meet the same
-			// active set: the record's NaN pattern decides there, the reference's rule everywhere else)
-			const bool ok = keep_pattern ? (l.live[j] != 0 && piv.h > 0.0)
-			                             : ((double)accepted < rows_of_design && piv.h > 0.0 && (piv.h > 1e-14 * full.h));
+			const bool ok = (double)accepted < rows_of_design && piv.h > 0.0 && (piv.h > 1e-14 * full.h);
 			__syncthreads();
 			if (tid == 0) l.live[j] = ok ? 1 : 0;
 			if (!ok) {
@@ -323,7 +379,7 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args
 					}
 			}
 			l.beta[j] = b;
-			l.zv[j] = d; // (z is no longer needed)
+			l.dg[j] = d; // (NOT into zv: the other wavefronts still read z — with more than 64 variables that race gave garbage coefficients)
 		}
 		__syncthreads();
 		// ---- statistics (solve_wide.hip's conventions for ridge) ----
@@ -340,12 +396,15 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args
 		dd rss = cyy - zz_t;
 		if (!icpt) rss = tss_raw_y - zz_t;
 		if (ridge) rss = rss - dd_mul_d(bb_t, lam);
-		const double rss_d = dd_to_double(rss) > 0.0 ? dd_to_double(rss) : 0.0;
+		double rss_d = dd_to_double(rss) > 0.0 ? dd_to_double(rss) : 0.0;
 		const double tss_d = dd_to_double(tss);
 		const dd ymean = dd_make(l.first[yv]) + (icpt ? l.M[tri(yv, 0)] / sw : dd{0.0, 0.0});
 		const double b0 = icpt ? dd_to_double(ymean - xb_t) : nan64w();
 		const int n_par = rank + (icpt ? 1 : 0);
 		const double df = cnt - (double)n_par;
+		// no residual degrees of freedom: the reference's sigma = sqrt(rss / 0) is +inf because ITS rss is positive rounding noise;
+		// an exact 0 here would turn that into 0 / 0 = NaN (and adjusted r^2, F likewise): keep the reference's pattern
+		if (df <= 0.0 && rss_d == 0.0) rss_d = 2.2250738585072014e-308;
 		const double dfm = (double)rank;
 		const double r2 = 1.0 - rss_d / tss_d;
 		const double sigma2 = rss_d / df;
@@ -360,20 +419,77 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args
 			else v = sqrt(sigma2);
 			core[k] = v;
 		}
-		if (inf && !hc_active)
+		if (inf)
 			for (int k = tid; k < 5 * p + 2; k += kDdThreads) inf[k] = nan64w();
 		__syncthreads();
 		for (int j = 1 + tid; j <= pe; j += kDdThreads)
 			if (l.live[j]) core[l.col[j]] = dd_to_double(l.beta[j]);
+		if (inf && hc_active) {
+			// ---- HC0 .. HC3 (ols.rs:209-245, wls.rs:230-252; the estimator of solve_wide.hip's hc_wide_kernel): one more pass over
+			// the rows with S^-1 = W'W applied in double-double.  c = x - xbar (x without an intercept), u = S^-1 c,
+			// h = w (1 / sum w + c'u), e = y - fit, omega = w^2 e^2 [n / df | 1 / (1 - h) | 1 / (1 - h)^2], V_jj = sum omega u_j^2.
+			const int hc = args.hc_type;
+			const double hc1 = cnt / df, h0 = icpt ? 1.0 / dd_to_double(sw) : 0.0;
+			// the centred variables: c_j = z_j - s_j / sw (z is shifted by the first row already)
+			for (int v = 1 + tid; v <= yv; v += kDdThreads) l.zv[v] = icpt ? l.M[tri(v, 0)] / sw : dd{0.0, 0.0};
+			dd vacc = dd{0.0, 0.0};
+			const int j = 1 + tid; // this thread's variable (pe <= 128 < 256 threads)
+			const bool mine = j <= pe && l.live[j];
+			for (int64_t r0 = lo; r0 < hi; r0 += kDdTileRows) {
+				load_tile(r0);
+				for (int rr = 0; rr < kDdTileRows; ++rr) {
+					const double wv = l.wrow[rr];
+					if (wv == 0.0) continue; // (uniform)
+					const double *zr = l.tile + rr * m;
+					// c, then t = W c, are published through two small LDS arrays (every thread needs all of them)
+					dd cj = dd{0.0, 0.0};
+					if (j <= pe) cj = dd_make(zr[j]) - l.zv[j];
+					__syncthreads();
+					if (j <= pe) {
+						l.hc_c[2 * j] = cj.h;
+						l.hc_c[2 * j + 1] = cj.l;
+					}
+					__syncthreads();
+					dd ti = dd{0.0, 0.0};
+					if (mine)
+						for (int k = 1; k <= j; ++k)
+							if (l.live[k]) ti = ti + l.M[tri(j, k)] * dd{l.hc_c[2 * k], l.hc_c[2 * k + 1]};
+					__syncthreads();
+					if (j <= pe) {
+						l.hc_t[2 * j] = ti.h;
+						l.hc_t[2 * j + 1] = ti.l;
+					}
+					__syncthreads();
+					dd uj = dd{0.0, 0.0};
+					if (mine)
+						for (int i = j; i <= pe; ++i)
+							if (l.live[i]) uj = uj + l.M[tri(i, j)] * dd{l.hc_t[2 * i], l.hc_t[2 * i + 1]};
+					// c'u and b'c
+					const dd hp = block_sum_dd(mine ? cj * uj : dd{0.0, 0.0}, l.red, tid);
+					const dd ep = block_sum_dd(mine ? l.beta[j] * cj : dd{0.0, 0.0}, l.red, tid);
+					const dd ycen = dd_make(zr[yv]) - l.zv[yv]; // y - ybar (y itself without an intercept)
+					const double e = dd_to_double(ycen - ep);
+					const double lev = wv * (h0 + dd_to_double(hp));
+					double om = wv * wv * e * e;
+					if (hc == ANOFOX_HC_HC1) om *= hc1;
+					else if (hc == ANOFOX_HC_HC2) om /= (1.0 - lev);
+					else if (hc == ANOFOX_HC_HC3) om /= (1.0 - lev) * (1.0 - lev);
+					if (mine && isfinite(e) && isfinite(lev)) vacc = vacc + dd_mul_d(uj * uj, om); // (hc_wide_kernel's rule for a row that counts)
+				}
+			}
+			__syncthreads();
+			if (j <= pe) l.dg[j] = mine ? vacc : dd{0.0, 0.0}; // the sandwich's diagonal: the standard errors' squares
+			__syncthreads();
+		}
 		if (inf) {
 			if (tid == 0) l.red[8] = dm_tcrit_cached(static_cast<TcritSlot *>(args.tcrit_table), 0.5 * (1.0 + args.confidence_level), df);
 			__syncthreads();
 			const double tcrit = l.red[8];
 			for (int j = 1 + tid; j <= pe; j += kDdThreads) {
-				if (!l.live[j] || hc_active) continue; // (HC: the sandwich kernel that follows fills the per-coefficient arrays)
+				if (!l.live[j]) continue;
 				const int c = l.col[j];
 				const double b = dd_to_double(l.beta[j]);
-				const double se = sqrt(sigma2 * dd_to_double(l.zv[j]));
+				const double se = hc_active ? sqrt(dd_to_double(l.dg[j])) : sqrt(sigma2 * dd_to_double(l.dg[j]));
 				const double tv = b / se;
 				inf[c] = se;
 				inf[p + c] = tv;
@@ -392,20 +508,66 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_wide_kernel(WideArgs args
 } // namespace
 
 size_t refit_dd_lds_bytes() {
-	return sizeof(double) * (2 * (size_t)kDdMaxTri + (size_t)kDdTileRows * kDdMaxM + kDdTileRows + 4 * (size_t)kDdMaxM + kDdMaxM + 16 +
-	                         2 * ((kDdMaxM + 1) / 2) + kDdTileRows);
+	return sizeof(double) * (2 * (size_t)kDdMaxTri + (size_t)kDdTileRows * kDdMaxM + kDdTileRows + 10 * (size_t)kDdMaxM + kDdMaxM + 16 +
+	                         2 * ((kDdMaxM + 1) / 2) + kDdTileRows + (kWideMaxP + 1) / 2 + kWideMaxP + 1);
 }
 
-// after the last refinement mode and the inference finish kernel: the queued groups' records once more, in double-double
-hipError_t launch_refit_dd_wide(const WideArgs &a, hipStream_t stream) {
-	if (a.n_groups <= 0) return hipSuccess;
+namespace {
+// ~1-2 ms per wide group and workgroup, ~0.3 ms per narrow one; 256-512 workgroups in flight: a cap's worth costs 40-50 ms
+int refit_dd_cap(int p) {
+	static const int forced = getenv("ANOFOX_REFIT_DD_MAX") ? atoi(getenv("ANOFOX_REFIT_DD_MAX")) : -1;
+	if (forced >= 0) return forced;
+	return p <= kNarrowMaxP ? 65536 : 8192;
+}
+hipError_t launch_refit_dd(const RefitArgs &r, hipStream_t stream) {
 	static const bool attr_set = [] {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_dd_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refit_dd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 		return true;
 	}();
 	(void)attr_set;
-	hipLaunchKernelGGL(refit_dd_wide_kernel, dim3(256), dim3(kDdThreads), refit_dd_lds_bytes(), stream, a);
+	hipLaunchKernelGGL(refit_dd_kernel, dim3(256), dim3(kDdThreads), refit_dd_lds_bytes(), stream, r);
 	return hipGetLastError();
+}
+} // namespace
+
+// after every other kernel of the fit: the queued groups' records once more, in double-double
+hipError_t launch_refit_dd_wide(const WideArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	RefitArgs r;
+	memset(&r, 0, sizeof r);
+	r.row_offsets = a.row_offsets;
+	r.row_ends = a.row_ends;
+	r.y = a.y;
+	r.w = a.w;
+	for (int j = 0; j < a.p; ++j) r.x[j] = a.x_table[j];
+	r.group_base = a.group_base;
+	r.p = a.p; r.model = a.model; r.fit_intercept = a.fit_intercept; r.lambda_scaling = a.lambda_scaling; r.hc_type = a.hc_type;
+	r.confidence_level = a.confidence_level; r.alpha = a.alpha;
+	r.core = a.core; r.inference = a.inference;
+	r.refine_list = a.refine_list; r.refine_count = a.refine_count;
+	r.tcrit_table = a.tcrit_table;
+	r.max_items = refit_dd_cap(a.p);
+	return launch_refit_dd(r, stream);
+}
+
+// the same behind the narrow path (p <= 8): its refinement queue, its records
+hipError_t launch_refit_dd_narrow(const BatchArgs &a, hipStream_t stream) {
+	if (a.n_groups <= 0) return hipSuccess;
+	RefitArgs r;
+	memset(&r, 0, sizeof r);
+	r.row_offsets = a.row_offsets;
+	r.row_ends = a.row_ends;
+	r.y = a.y;
+	r.w = a.w;
+	for (int j = 0; j < a.p; ++j) r.x[j] = a.x[j];
+	r.group_base = 0;
+	r.p = a.p; r.model = a.model; r.fit_intercept = a.fit_intercept; r.lambda_scaling = a.lambda_scaling; r.hc_type = a.hc_type;
+	r.confidence_level = a.confidence_level; r.alpha = a.alpha;
+	r.core = a.core; r.inference = a.inference;
+	r.refine_list = a.refine_list; r.refine_count = a.refine_count;
+	r.tcrit_table = a.tcrit_table;
+	r.max_items = refit_dd_cap(a.p);
+	return launch_refit_dd(r, stream);
 }
 
 } // namespace anofox

@@ -113,6 +113,20 @@ __device__ __forceinline__ constexpr int slot(int i, int j) { // i <= j
 	return i * T - i * (i - 1) / 2 + (j - i);
 }
 
+// (r4) tiles parked in the wave's LDS at T = 8: the LAST block column and the top of the one before it.  Every slot is touched
+// once per block step, so a parked one costs 8 ds_read_b64 + 8 ds_write_b64 per step where a spilled register costs scratch
+// (HBM / L2) traffic: 35 registers were still spilled after the partial sums had moved to LDS.
+template <int T>
+__host__ __device__ constexpr int parked_tiles() { return T == 8 ? 10 : 0; } // (11: no scratch at all, but 41.6 KB per wave: three waves per CU instead of four)
+template <int T>
+__host__ __device__ constexpr int parked_index(int t) { // -1: the slot lives in registers
+	for (int i = 0; i < parked_tiles<T>(); ++i) { // the last block column from the top, then the one before it
+		const int col = i < T ? T - 1 : T - 2, row = i < T ? i : i - T;
+		if (t == slot<T>(row, col)) return i;
+	}
+	return -1;
+}
+
 constexpr int kDsLd = 18; // row stride of the diagonal-block image (doubles): 16-byte aligned rows
 constexpr int kXsLd = 17;
 
@@ -120,12 +134,22 @@ template <int T, int WPE>
 __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 	constexpr int P16 = 16 * T;
 	constexpr int NT = T * (T + 1) / 2;
-	__shared__ __attribute__((aligned(16))) double lds[17 * kDsLd + 16 * kXsLd + 16 + 2 * P16];
+	// (r4) PARK: at seven and eight column tiles the 28 / 36 tile slots (224 / 288 registers) plus the per-block partial sums —
+	// c (the y column), beta and diag of the inverse: three doubles per lane and block, 42-48 registers — did not fit the 512
+	// registers of one wave per SIMD: 59 registers spilled at T = 8, i.e. 1.9 GB read + 0.7 GB written of SCRATCH per 13 785-group
+	// launch against 1.1 GB of records (profiles/hbm_traffic.json, r03).  Those three arrays are touched once or twice per
+	// (block step, block) pair, so they live in the wave's own LDS instead ([block][lane]: conflict-free, 12 KB per wave of the
+	// 160 KB four waves share), and the column sums are re-read from the record where the statistics need them.
+	constexpr bool PARK = T >= 7;
+	constexpr int NPT = parked_tiles<T>();
+	__shared__ __attribute__((aligned(16))) double lds[17 * kDsLd + 16 * kXsLd + 16 + 2 * P16 + (PARK ? 3 * T * 64 : 0) + NPT * 256];
 	double *Ds = lds;                 // [17][18]: the diagonal block (rows 0..15) and the y column (row 16)
 	double *Xs = Ds + 17 * kDsLd;     // [16][17]: X = L_kk^-1
 	double *zs = Xs + 16 * kXsLd;     // [16]: z_k
 	double *d0s = zs + 16;            // [P16]: the diagonal before the factorisation
 	double *acts = d0s + P16;         // [P16]: 1.0 = column takes part
+	double *park = acts + P16;        // PARK: [3][T][64] c partial sums, beta partial sums, diag partial sums
+	double *ptile = park + (PARK ? 3 * T * 64 : 0); // [NPT][4][64]: the parked tile slots, register r of lane l at [r][l]
 
 	const int p = args.p;
 	const int lane = threadIdx.x;
@@ -214,6 +238,30 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		// (every index into tile[] is a constant expression — sfor, not a loop — so that the array is split into
 		// registers before any unrolling; as an unrolled loop nest the 36 tiles of T = 8 stayed in scratch memory)
 		d4 tile[NT];
+		// slot t, wherever it lives (t is a constant expression everywhere)
+		auto tget = [&](auto t_) __attribute__((always_inline)) -> d4 {
+			constexpr int t = decltype(t_)::value;
+			constexpr int pi = parked_index<T>(t);
+			if constexpr (pi >= 0) {
+				d4 v;
+#pragma unroll
+				for (int r = 0; r < 4; ++r) v[r] = ptile[(pi * 4 + r) * 64 + lane];
+				return v;
+			} else {
+				return tile[t];
+			}
+		};
+		auto tset = [&](auto t_, const d4 &v) __attribute__((always_inline)) {
+			constexpr int t = decltype(t_)::value;
+			constexpr int pi = parked_index<T>(t);
+			if constexpr (pi >= 0) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) ptile[(pi * 4 + r) * 64 + lane] = v[r];
+			} else {
+				tile[t] = v;
+			}
+		};
+#define TS(i, j) std::integral_constant<int, slot<T>(i, j)> {}
 		wave_lds_sync(); // the previous group's reads of d0s / acts are done
 		// (loaded and centred one tile row at a time, the next row's loads issued before this row's arithmetic: all 144
 		// loads of T = 8 at once need more than the 256 architectural registers a load can target and spilled)
@@ -221,8 +269,10 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 			constexpr int I = decltype(I_)::value;
 			sfor<I, T>([&](auto J_) __attribute__((always_inline)) {
 				constexpr int t = slot<T>(I, decltype(J_)::value);
+				d4 v;
 #pragma unroll
-				for (int r = 0; r < 4; ++r) tile[t][r] = rec[(int64_t)t * 256 + 64 * r + lane];
+				for (int r = 0; r < 4; ++r) v[r] = rec[(int64_t)t * 256 + 64 * r + lane];
+				tset(std::integral_constant<int, t>{}, v);
 			});
 		};
 		load_row(std::integral_constant<int, 0>{});
@@ -238,7 +288,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 			}
 			sfor<I, T>([&](auto J_) __attribute__((always_inline)) {
 				constexpr int J = decltype(J_)::value;
-				d4 &tl = tile[slot<T>(I, J)];
+				d4 tl = tget(TS(I, J));
 #pragma unroll
 				for (int r = 0; r < 4; ++r) {
 					double v = fma(-srow[r], scol[J], tl[r]);
@@ -249,6 +299,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 					}
 					tl[r] = v;
 				}
+				tset(TS(I, J), tl);
 			});
 			// the diagonal before the factorisation and the activity flags of block I, for the pivot tests
 			if (q == 0) {
@@ -265,7 +316,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 			}
 		});
 		// y column (centred Sxy), kept as partial sums over q: c_J[n] = sum_q cpart[J](q, n)
-		double cpart[T], bacc[T], dacc[T];
+		double cpart[PARK ? 1 : T], bacc[PARK ? 1 : T], dacc[PARK ? 1 : T];
 		sfor<0, T>([&](auto J_) __attribute__((always_inline)) {
 			constexpr int J = decltype(J_)::value;
 			const int col = 16 * J + n;
@@ -274,9 +325,13 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 				v = vec[1 * P16 + col];
 				if (icpt) v = fma(-scol[J] * inv_sw, sy, v);
 			}
-			cpart[J] = v;
-			bacc[J] = 0.0;
-			dacc[J] = 0.0;
+			if constexpr (PARK) {
+				park[(0 * T + J) * 64 + lane] = v;
+			} else {
+				cpart[J] = v;
+				bacc[J] = 0.0;
+				dacc[J] = 0.0;
+			}
 		});
 		wave_lds_sync();
 
@@ -294,10 +349,13 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 			(void)lane;
 			// ---- (1) diagonal block and y column -> row layout ----
 			{
-				const d4 &dk = tile[slot<T>(k, k)];
+				const d4 dk = tget(TS(k, k));
 #pragma unroll
 				for (int r = 0; r < 4; ++r) Ds[(q + 4 * r) * kDsLd + n] = dk[r];
-				const double ck = sum_q(cpart[k]);
+				double cpk;
+				if constexpr (PARK) cpk = park[(0 * T + k) * 64 + lane];
+				else cpk = cpart[k];
+				const double ck = sum_q(cpk);
 				if (q == 0) Ds[16 * kDsLd + n] = ck;
 			}
 			wave_lds_sync();
@@ -365,61 +423,89 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 				constexpr int j = decltype(j_)::value;
 				d4 w;
 				if constexpr (j < k) {
-					w = mfma4(XT, tile[slot<T>(j, k)], zero);
-					tile[slot<T>(j, k)] = w; // B operand of this step's R updates
+					w = mfma4(XT, tget(TS(j, k)), zero);
+					tset(TS(j, k), w); // B operand of this step's R updates
 				} else {
 					w = Xc;
 				}
+				if constexpr (PARK) {
+					double db = 0.0, dd2 = 0.0;
 #pragma unroll
-				for (int r = 0; r < 4; ++r) {
-					dacc[j] = fma(w[r], w[r], dacc[j]);
-					bacc[j] = fma(w[r], zq[r], bacc[j]);
+					for (int r = 0; r < 4; ++r) {
+						dd2 = fma(w[r], w[r], dd2);
+						db = fma(w[r], zq[r], db);
+					}
+					// (block j's first contribution comes at step k = j)
+					double *bp = park + (1 * T + j) * 64 + lane, *dp = park + (2 * T + j) * 64 + lane;
+					*bp = (j == k) ? db : *bp + db;
+					*dp = (j == k) ? dd2 : *dp + dd2;
+				} else {
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						dacc[j] = fma(w[r], w[r], dacc[j]);
+						bacc[j] = fma(w[r], zq[r], bacc[j]);
+					}
 				}
 			});
 			// ---- (5) panel: U_kj = X S_kj, and its share of the y column ----
 			sfor<k + 1, T>([&](auto j_) __attribute__((always_inline)) {
 				constexpr int j = decltype(j_)::value;
-				const d4 u = mfma4(XT, tile[slot<T>(k, j)], zero);
-				tile[slot<T>(k, j)] = u;
+				const d4 u = mfma4(XT, tget(TS(k, j)), zero);
+				tset(TS(k, j), u);
+				if constexpr (PARK) {
+					double dc = 0.0;
 #pragma unroll
-				for (int r = 0; r < 4; ++r) cpart[j] = fma(-u[r], zq[r], cpart[j]);
+					for (int r = 0; r < 4; ++r) dc = fma(-u[r], zq[r], dc);
+					park[(0 * T + j) * 64 + lane] += dc;
+				} else {
+#pragma unroll
+					for (int r = 0; r < 4; ++r) cpart[j] = fma(-u[r], zq[r], cpart[j]);
+				}
 			});
 			// ---- (6) trailing updates: S_ij -= U_ki' U_kj, R_ij -= U_ki' W_kj, and R_ik = -U_ki' X is born ----
 			sfor<k + 1, T>([&](auto i_) __attribute__((always_inline)) {
 				constexpr int i = decltype(i_)::value;
 				d4 nu;
+				const d4 uki = tget(TS(k, i));
 #pragma unroll
-				for (int r = 0; r < 4; ++r) nu[r] = -tile[slot<T>(k, i)][r];
+				for (int r = 0; r < 4; ++r) nu[r] = -uki[r];
 				sfor<i, T>([&](auto j_) __attribute__((always_inline)) {
 					constexpr int j = decltype(j_)::value;
-					tile[slot<T>(i, j)] = mfma4(nu, tile[slot<T>(k, j)], tile[slot<T>(i, j)]);
+					tset(TS(i, j), mfma4(nu, tget(TS(k, j)), tget(TS(i, j))));
 				});
 				sfor<0, k>([&](auto j_) __attribute__((always_inline)) {
 					constexpr int j = decltype(j_)::value;
-					tile[slot<T>(j, i)] = mfma4(nu, tile[slot<T>(j, k)], tile[slot<T>(j, i)]);
+					tset(TS(j, i), mfma4(nu, tget(TS(j, k)), tget(TS(j, i))));
 				});
-				tile[slot<T>(k, i)] = mfma4(nu, Xc, zero); // slot (k, i): U_ki is dead, R_ik takes its place
+				tset(TS(k, i), mfma4(nu, Xc, zero)); // slot (k, i): U_ki is dead, R_ik takes its place
 			});
 		});
 
+#undef TS
 		// ---- coefficients, diag((LL')^-1), statistics ----
 		double rk = 0.0, bc = 0.0, bb = 0.0, xb = 0.0;
 		double beta[T], dinv[T];
 		bool live[T];
 		sfor<0, T>([&](auto J_) __attribute__((always_inline)) {
 			constexpr int J = decltype(J_)::value;
-			beta[J] = sum_q(bacc[J]);
-			dinv[J] = sum_q(dacc[J]);
+			if constexpr (PARK) {
+				beta[J] = sum_q(park[(1 * T + J) * 64 + lane]);
+				dinv[J] = sum_q(park[(2 * T + J) * 64 + lane]);
+			} else {
+				beta[J] = sum_q(bacc[J]);
+				dinv[J] = sum_q(dacc[J]);
+			}
 			const int col = 16 * J + n;
 			live[J] = col < p && ((live_bits[J] >> n) & 1u) != 0u;
 			if (q == 0 && live[J]) {
 				rk += 1.0;
 				const double qv = vec[1 * P16 + col];
-				const double cj = icpt ? qv - scol[J] * sy / sw : qv;
+				const double sc_j = PARK ? vec[0 * P16 + col] : scol[J]; // (PARK: the column sum from the record again, not from a register kept for it)
+				const double cj = icpt ? qv - sc_j * sy / sw : qv;
 				const double fx = icpt ? vec[2 * P16 + col] : 0.0;
 				bc = fma(beta[J], cj, bc);
 				bb = fma(beta[J], beta[J], bb);
-				xb = fma(beta[J], fx + scol[J] / sw, xb);
+				xb = fma(beta[J], fx + sc_j / sw, xb);
 			}
 		});
 		const double rk_t = sum_wave(rk), bc_t = sum_wave(bc), bb_t = sum_wave(bb), xb_t = sum_wave(xb), zz_t = sum_wave(zz_l);

@@ -74,6 +74,10 @@ public:
 	}
 
 	uint32_t NewSlot() {
+		// (r4) a new execution of a prepared statement?  The arena lives in the bind data, which DuckDB re-uses: once an
+		// execution's states have all been finalized AND destroyed, the next Initialize starts from a clean device state
+		// (slot numbers from 0, the row log's budget whole again) instead of resting on what the last execution left.
+		if (fetched_.load(std::memory_order_acquire)) ResetIfIdle();
 		std::lock_guard<std::mutex> lk(mu_);
 		uint32_t s;
 		if (!free_.empty()) {
@@ -198,12 +202,72 @@ public:
 		}
 	}
 
+	// ---- (r4) Combine across devices: the source lives in ANOTHER arena (the glue shards a query's states over the node's GPUs) ----
+	// ExportRecords: the listed slots' moment records and accepted-row counts, as the device keeps them (pending rows flushed
+	// first).  MergeRecords: the same records into `targets` of THIS arena — through fresh slots, the library's ordinary combine
+	// (the imported rows count as arriving after the target's, ols_aggregate.cpp:224-233) and the slots' release.  ClearSlots:
+	// what a consuming Combine leaves of its sources (emptied on the device; the DuckDB states keep their slot numbers until
+	// Destroy).  Moment states only (up to 8 features, no HC errors): the library refuses log-only states, whose rows stay put.
+	size_t RecordLen() const { return state_ ? anofox_hip_agg_state_record_len(state_) : 0; }
+	void ExportRecords(const uint32_t *slots, size_t n, std::vector<double> &records, std::vector<int64_t> &counts) {
+		records.clear();
+		counts.clear();
+		if (n == 0) return;
+		std::lock_guard<std::mutex> ship(ship_mu_);
+		if (!state_) throw std::runtime_error("anofox_stats fit_agg (HIP): export from an arena without a device state");
+		FlushAllShipLocked();
+		DrainReleasesShipLocked();
+		Reserve();
+		const size_t rec = anofox_hip_agg_state_record_len(state_);
+		records.resize(n * rec);
+		counts.resize(n);
+		AnofoxError err;
+		if (!anofox_hip_agg_state_export_slots_host(state_, (int64_t)n, slots, records.data(), counts.data(), &err)) Throw(err);
+	}
+	void MergeRecords(const double *records, const int64_t *counts, const uint32_t *targets, size_t n) {
+		if (n == 0) return;
+		std::vector<uint32_t> tmp(n);
+		for (size_t i = 0; i < n; ++i) tmp[i] = NewSlot();
+		{
+			std::lock_guard<std::mutex> ship(ship_mu_);
+			if (!state_) throw std::runtime_error("anofox_stats fit_agg (HIP): import into an arena without a device state");
+			FlushAllShipLocked();
+			DrainReleasesShipLocked();
+			Reserve();
+			AnofoxError err;
+			if (!anofox_hip_agg_state_import_slots_host(state_, (int64_t)n, tmp.data(), records, counts, &err)) Throw(err);
+		}
+		Combine(tmp.data(), targets, n, false);
+		for (size_t i = 0; i < n; ++i) ReleaseSlot(tmp[i]);
+	}
+	void ClearSlots(const uint32_t *slots, size_t n) {
+		if (n == 0) return;
+		std::vector<uint32_t> rel(slots, slots + n);
+		std::sort(rel.begin(), rel.end());
+		rel.erase(std::unique(rel.begin(), rel.end()), rel.end());
+		std::lock_guard<std::mutex> ship(ship_mu_);
+		if (!state_) return;
+		FlushAllShipLocked();
+		Reserve();
+		AnofoxError err;
+		if (!anofox_hip_agg_state_release_slots(state_, (int64_t)rel.size(), rel.data(), &err)) Throw(err);
+		std::lock_guard<std::mutex> lk(mu_);
+		for (uint32_t s : rel) MarkDirtyLocked(s);
+	}
+	uint64_t Resets() const { return resets_.load(std::memory_order_relaxed); }
+
+	// the device state exists from the arena's first accepted row on; a cross-device Combine may reach an arena before that
+	void EnsureState(size_t n_features) {
+		if (p_.load(std::memory_order_acquire) == 0) (void)Init(n_features);
+	}
+
 	// Finalize of n states: out_core [n x (p + 6)], out_inf [n x (5 p + 2)] (nullptr unless inference was asked for),
 	// out_status[n] = the record's status word (0 = a fit; 100 = fewer than 2 accumulated rows; an AnofoxErrorCode; 101 =
 	// unrefined).  A query without any accepted row: every status 100.
 	void Fetch(const uint32_t *slots, size_t n, double *out_core, double *out_inf, int *out_status) {
 		std::lock_guard<std::mutex> ship(ship_mu_);
 		SolveShipLocked();
+		fetched_.store(true, std::memory_order_release);
 		const size_t p = p_.load(std::memory_order_acquire);
 		const size_t lc = p + 6, li = 5 * p + 2;
 		for (size_t i = 0; i < n; ++i) {
@@ -400,6 +464,34 @@ private:
 			free_.push_back(s);
 		}
 	}
+	// see NewSlot: only when nothing of the last execution is alive — no state holds a slot, no thread is inside an Update
+	void ResetIfIdle() {
+		std::lock_guard<std::mutex> ship(ship_mu_);
+		{
+			std::lock_guard<std::mutex> lk(mu_);
+			if (!fetched_.load(std::memory_order_acquire) || live_slots_ != 0) return;
+			const size_t n = n_chunks_.load(std::memory_order_acquire);
+			for (size_t k = 0; k < n; ++k) {
+				Chunk *c = chunk_tab_[k].load(std::memory_order_acquire);
+				if (c && (c->busy.load(std::memory_order_acquire) || c->fill != 0)) return; // rows of a running Update: not idle
+			}
+			fetched_.store(false, std::memory_order_release);
+			free_.clear();
+			pending_release_.clear();
+			std::fill(dirty_.begin(), dirty_.end(), 0);
+			dirty_list_.clear();
+			core_.clear();
+			inf_.clear();
+			n_slots_.store(0, std::memory_order_relaxed);
+			for (size_t k = 0; k < n; ++k)
+				if (Chunk *c = chunk_tab_[k].load(std::memory_order_acquire)) c->touched.clear();
+		}
+		if (state_) {
+			AnofoxError err;
+			if (!anofox_hip_agg_state_reset(state_, &err)) Throw(err);
+		}
+		resets_.fetch_add(1, std::memory_order_relaxed);
+	}
 	void Reserve() {
 		AnofoxError err;
 		if (!anofox_hip_agg_state_reserve(state_, (int64_t)n_slots_.load(std::memory_order_relaxed), &err)) Throw(err);
@@ -473,6 +565,8 @@ private:
 	std::vector<uint32_t> dirty_list_;
 	std::atomic<uint64_t> rows_ {0}, fit_calls_ {0}, slots_fitted_ {0};
 	std::atomic<int64_t> unrefined_ {0};
+	std::atomic<bool> fetched_ {false};  // a Finalize has handed records out since the last reset
+	std::atomic<uint64_t> resets_ {0};
 	std::vector<double> core_, inf_; // last fitted record of every slot
 };
 

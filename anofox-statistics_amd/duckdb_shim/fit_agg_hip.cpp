@@ -38,7 +38,10 @@
 
 #include "anofox_stats_hip.h" // coexists with the reference's anofox_stats_ffi.h (same structs and enums, guarded)
 #include "agg_arena.hpp"
+#include "sharded_arena.hpp" // hash64: the routing hash of SURVEY.md 8(e)
 #include "fit_agg_hip.hpp"
+
+#include <thread>
 
 namespace duckdb {
 
@@ -50,6 +53,7 @@ namespace {
 struct HipAggState {
 	int64_t slot;       // -1 until the first accepted row (Initialize has no access to the bind data)
 	int64_t n_features; // -1 = no accepted row yet
+	int64_t shard;      // (r4) which of the query's device states holds the slot: hash64(state address) % W at the first accepted row
 };
 
 enum class HipModel : uint8_t { OLS, RIDGE, WLS };
@@ -152,23 +156,63 @@ AnofoxHipBatchOptions MakeHipOptions(HipModel model, const HipFitOptions &o) {
 	return b;
 }
 
-// ---- the query's device states: one AggArena per feature count that occurs (normally one) ----
+// ---- the query's device states: per feature count that occurs (normally one), W AggArenas — one per GPU of the node ----
+// (r4, SURVEY.md 8e / north_star: "groups are hash-partitioned across the GPUs of one node").  DuckDB's callbacks see state
+// pointers, not keys, so a state is routed at its first accepted row by hash64(state address) % W and stays there; a Combine
+// whose source and target sit on different devices moves the source's O(p^2) moment record (528 bytes at p = 8) through the
+// host — anofox_hip_agg_state_export_slots_host / import — and merges it on the target's device; Finalize fits every device's
+// states in one batched call per device, concurrently.  ANOFOX_HIP_DEVICES: a count ("8" = devices 0 .. 7) or a list of
+// ordinals ("0,1,2,3"; "0,0" = two shards on one GPU, the single-GPU rehearsal of the tests); unset = one shard on the
+// calling thread's current device.  Designs of more than 8 features and HC standard errors keep ROWS on the device, not
+// moment records (log-only states): those stay on shard 0.
 struct HipArenaSet {
-	explicit HipArenaSet(const AnofoxHipBatchOptions &o) : options(o) {}
-	anofox_shim::AggArena &ForWidth(size_t p) {
+	explicit HipArenaSet(const AnofoxHipBatchOptions &o) : options(o) {
+		if (const char *v = getenv("ANOFOX_HIP_DEVICES")) {
+			string str(v);
+			if (str.find(',') == string::npos) {
+				const int n = atoi(str.c_str());
+				for (int k = 0; k < n && k < 64; ++k) devices.push_back(k);
+			} else {
+				size_t pos = 0;
+				while (pos <= str.size() && devices.size() < 64) {
+					const size_t next = str.find(',', pos);
+					const string item = str.substr(pos, next == string::npos ? string::npos : next - pos);
+					if (!item.empty()) devices.push_back(atoi(item.c_str()));
+					if (next == string::npos) break;
+					pos = next + 1;
+				}
+			}
+		}
+		if (devices.empty()) devices.push_back(-1);
+	}
+	// shards a state of this width may live on
+	uint32_t ShardCount(size_t p) const {
+		const bool log_only = p > 8 || (options.compute_inference && options.hc_type != ANOFOX_HC_NONE && options.model != ANOFOX_HIP_MODEL_RIDGE);
+		return log_only ? 1u : (uint32_t)devices.size();
+	}
+	uint32_t ShardOf(const void *state, size_t p) const {
+		const uint32_t w = ShardCount(p);
+		return w <= 1 ? 0u : (uint32_t)(anofox_shim::hash64((uint64_t)(uintptr_t)state) % w);
+	}
+	anofox_shim::AggArena &For(size_t p, uint32_t shard) {
 		std::lock_guard<std::mutex> lk(mu);
-		auto &slot = arenas[p];
-		if (!slot) slot.reset(new anofox_shim::AggArena(options));
+		auto &slot = arenas[std::make_pair(p, shard)];
+		if (!slot) {
+			// (the row-log budgets are per query: split over the shards)
+			const size_t w = ShardCount(p);
+			slot.reset(new anofox_shim::AggArena(options, (size_t)1 << 18, ((size_t)64 << 30) / w, ((size_t)32 << 30) / w, devices[shard % devices.size()]));
+		}
 		return *slot;
 	}
 	template <class F>
 	void ForEach(F &&f) {
 		std::lock_guard<std::mutex> lk(mu);
-		for (auto &kv : arenas) f(kv.first, *kv.second);
+		for (auto &kv : arenas) f(kv.first.first, *kv.second);
 	}
 	AnofoxHipBatchOptions options;
+	vector<int> devices;
 	std::mutex mu;
-	std::map<size_t, std::unique_ptr<anofox_shim::AggArena>> arenas;
+	std::map<std::pair<size_t, uint32_t>, std::unique_ptr<anofox_shim::AggArena>> arenas;
 };
 
 // ---- bind data: the parsed options and the query's arenas; Copy() shares them ----
@@ -225,6 +269,7 @@ void HipAggInitialize(const AggregateFunction &, data_ptr_t state_p) {
 	auto &st = *reinterpret_cast<HipAggState *>(state_p);
 	st.slot = -1;
 	st.n_features = -1;
+	st.shard = -1;
 }
 
 // Destroy: the state's slot goes back to its arena, which empties it on the device before handing it out again
@@ -236,9 +281,10 @@ void HipAggDestroy(Vector &state_vector, AggregateInputData &aggr_input_data, id
 	auto &arenas = *aggr_input_data.bind_data->Cast<HipAggBindData>().arenas;
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
-		if (state.slot >= 0) arenas.ForWidth((size_t)state.n_features).ReleaseSlot((uint32_t)state.slot);
+		if (state.slot >= 0) arenas.For((size_t)state.n_features, (uint32_t)state.shard).ReleaseSlot((uint32_t)state.slot);
 		state.slot = -1;
 		state.n_features = -1;
+		state.shard = -1;
 	}
 }
 
@@ -263,10 +309,11 @@ void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, idx_t in
 	auto states = (HipAggState **)sdata.data;
 	const idx_t max_features = anofox_hip_max_features();
 
-	// one Writer per feature count seen in this vector (one, unless the query's groups differ in width)
+	// one Writer per (feature count, device shard) seen in this vector
 	size_t cur_p = 0;
+	uint32_t cur_shard = 0;
 	anofox_shim::AggArena *cur_arena = nullptr;
-	std::map<size_t, std::unique_ptr<anofox_shim::AggArena::Writer>> writers;
+	std::map<std::pair<size_t, uint32_t>, std::unique_ptr<anofox_shim::AggArena::Writer>> writers;
 	anofox_shim::AggArena::Writer *writer = nullptr;
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
@@ -290,10 +337,12 @@ void HipAggUpdate(Vector inputs[], AggregateInputData &aggr_input_data, idx_t in
 		if (entry.length > max_features)
 			throw InvalidInputException("anofox_stats fit_agg (HIP): at most %llu features are supported, got %llu", (unsigned long long)max_features,
 			                            (unsigned long long)entry.length);
-		if (!writer || cur_p != entry.length) {
+		if (state.shard < 0) state.shard = (int64_t)arenas.ShardOf(&state, entry.length); // routed once, at the first accepted row
+		if (!writer || cur_p != entry.length || cur_shard != (uint32_t)state.shard) {
 			cur_p = entry.length;
-			cur_arena = &arenas.ForWidth(cur_p);
-			auto &wslot = writers[cur_p];
+			cur_shard = (uint32_t)state.shard;
+			cur_arena = &arenas.For(cur_p, cur_shard);
+			auto &wslot = writers[std::make_pair(cur_p, cur_shard)];
 			if (!wslot) wslot.reset(new anofox_shim::AggArena::Writer(*cur_arena));
 			writer = wslot.get();
 		}
@@ -315,7 +364,11 @@ void HipAggCombine(Vector &source_vector, Vector &target_vector, AggregateInputD
 	auto targets = (HipAggState **)target_data.data;
 	auto &arenas = *aggr_input_data.bind_data->Cast<HipAggBindData>().arenas;
 	const bool preserve = aggr_input_data.combine_type == AggregateCombineType::PRESERVE_INPUT;
-	std::map<size_t, std::pair<vector<uint32_t>, vector<uint32_t>>> pairs; // per feature count: sources, targets
+	struct Pairs {
+		vector<uint32_t> src, dst;
+	};
+	std::map<std::pair<size_t, uint32_t>, Pairs> local;                      // (width, shard): both sides on one device
+	std::map<std::pair<size_t, std::pair<uint32_t, uint32_t>>, Pairs> cross; // (width, (source shard, target shard))
 	for (idx_t i = 0; i < count; i++) {
 		auto &source = *sources[source_data.sel->get_index(i)];
 		auto &target = *targets[target_data.sel->get_index(i)];
@@ -323,24 +376,46 @@ void HipAggCombine(Vector &source_vector, Vector &target_vector, AggregateInputD
 		if (target.n_features < 0) {
 			target.n_features = source.n_features;
 			if (source.slot < 0) continue; // (rows with empty x lists only)
-			if (!preserve) {
+			if (!preserve) { // the reference moves the buffers: the target adopts the slot where it lives
 				target.slot = source.slot;
+				target.shard = source.shard;
 				source.slot = -1;
 				source.n_features = -1;
+				source.shard = -1;
 				continue;
 			}
-			target.slot = arenas.ForWidth((size_t)source.n_features).NewSlot();
+			target.shard = source.shard; // (an empty target has no home yet: it joins the source's device)
+			target.slot = arenas.For((size_t)source.n_features, (uint32_t)target.shard).NewSlot();
 		} else if (source.n_features != target.n_features) {
 			throw InvalidInputException("Cannot combine states with different feature counts: %llu vs %llu", (unsigned long long)source.n_features,
 			                            (unsigned long long)target.n_features); // :217-220
 		}
 		if (source.slot < 0) continue;
-		auto &pr = pairs[(size_t)source.n_features];
-		pr.first.push_back((uint32_t)source.slot);
-		pr.second.push_back((uint32_t)target.slot);
+		if (target.slot < 0) { // a target that has only seen rows with empty x lists: it gets a slot next to the source
+			target.shard = source.shard;
+			target.slot = arenas.For((size_t)source.n_features, (uint32_t)target.shard).NewSlot();
+		}
+		const size_t p = (size_t)source.n_features;
+		auto &pr = source.shard == target.shard ? local[std::make_pair(p, (uint32_t)source.shard)]
+		                                        : cross[std::make_pair(p, std::make_pair((uint32_t)source.shard, (uint32_t)target.shard))];
+		pr.src.push_back((uint32_t)source.slot);
+		pr.dst.push_back((uint32_t)target.slot);
 	}
 	try {
-		for (auto &kv : pairs) arenas.ForWidth(kv.first).Combine(kv.second.first.data(), kv.second.second.data(), kv.second.first.size(), preserve);
+		for (auto &kv : local) arenas.For(kv.first.first, kv.first.second).Combine(kv.second.src.data(), kv.second.dst.data(), kv.second.src.size(), preserve);
+		// source and target on different devices: the sources' moment records travel (export -> import into fresh slots ->
+		// the library's combine on the target's device); a consuming Combine then empties the sources where they were
+		for (auto &kv : cross) {
+			const size_t p = kv.first.first;
+			auto &from = arenas.For(p, kv.first.second.first);
+			auto &to = arenas.For(p, kv.first.second.second);
+			vector<double> rec;
+			vector<int64_t> cnt;
+			from.ExportRecords(kv.second.src.data(), kv.second.src.size(), rec, cnt);
+			to.EnsureState(p);
+			to.MergeRecords(rec.data(), cnt.data(), kv.second.dst.data(), kv.second.dst.size());
+			if (!preserve) from.ClearSlots(kv.second.src.data(), kv.second.src.size());
+		}
 	} catch (const std::runtime_error &e) {
 		throw InvalidInputException(string(e.what()));
 	}
@@ -371,31 +446,51 @@ void HipAggFinalize(Vector &state_vector, AggregateInputData &aggr_input_data, V
 	struct Batch {
 		vector<uint32_t> slots;
 		vector<idx_t> rows;
+		vector<int> status;
+		vector<double> core, inf;
+		string error;
 	};
-	std::map<size_t, Batch> batches;
+	std::map<std::pair<size_t, uint32_t>, Batch> batches; // (width, device shard)
 	for (idx_t i = 0; i < count; i++) {
 		auto &state = *states[sdata.sel->get_index(i)];
 		if (state.slot < 0) {
 			FlatVector::SetNull(result, i + offset, true); // no accepted row (or only rows with empty x lists)
 			continue;
 		}
-		auto &b = batches[(size_t)state.n_features];
+		auto &b = batches[std::make_pair((size_t)state.n_features, (uint32_t)state.shard)];
 		b.slots.push_back((uint32_t)state.slot);
 		b.rows.push_back(i + offset);
 	}
 	const bool inference = bind.opts.compute_inference;
 	auto &entries = StructVector::GetEntries(result);
 	idx_t unrefined = 0;
-	for (auto &kv : batches) {
-		const idx_t p = kv.first;
-		auto &b = kv.second;
-		vector<int> status(b.slots.size());
-		vector<double> core(b.slots.size() * (p + 6)), inf(inference ? b.slots.size() * (5 * p + 2) : 0);
+	// one batched fit per device state; several devices fit concurrently (each arena has its own context, stream and lock)
+	auto fetch = [&](const std::pair<size_t, uint32_t> &key, Batch &b) {
+		const idx_t p = key.first;
+		b.status.resize(b.slots.size());
+		b.core.resize(b.slots.size() * (p + 6));
+		b.inf.resize(inference ? b.slots.size() * (5 * p + 2) : 0);
 		try {
-			arenas.ForWidth(p).Fetch(b.slots.data(), b.slots.size(), core.data(), inference ? inf.data() : nullptr, status.data());
-		} catch (const std::runtime_error &e) {
-			throw InvalidInputException(string(e.what()));
+			arenas.For(p, key.second).Fetch(b.slots.data(), b.slots.size(), b.core.data(), inference ? b.inf.data() : nullptr, b.status.data());
+		} catch (const std::exception &e) {
+			b.error = e.what();
 		}
+	};
+	if (batches.size() <= 1) {
+		for (auto &kv : batches) fetch(kv.first, kv.second);
+	} else {
+		vector<std::thread> workers;
+		for (auto &kv : batches) workers.emplace_back([&fetch, &kv] { fetch(kv.first, kv.second); });
+		for (auto &t : workers) t.join();
+	}
+	for (auto &kv : batches)
+		if (!kv.second.error.empty()) throw InvalidInputException(kv.second.error);
+	for (auto &kv : batches) {
+		const idx_t p = kv.first.first;
+		auto &b = kv.second;
+		auto &status = b.status;
+		auto &core = b.core;
+		auto &inf = b.inf;
 		for (idx_t k = 0; k < b.slots.size(); k++) {
 			const idx_t r = b.rows[k];
 			if (status[k] != 0) {

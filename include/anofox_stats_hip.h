@@ -540,6 +540,21 @@ ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_slots_host(AnofoxHipAggState *
                                               double *inference, int64_t *out_unrefined, AnofoxError *out_error);
 /* Destroy of aggregate states (ols_aggregate.cpp:108-118): the listed slots become empty and may be handed out again. */
 ANOFOX_HIP_API bool anofox_hip_agg_state_release_slots(AnofoxHipAggState *state, int64_t n_list, const uint32_t *slots, AnofoxError *out_error);
+/* (r4) Cross-device Combine of moment states (n_features <= 8, no HC errors): the DuckDB glue shards a query's aggregate states
+ * over the node's GPUs by hash, and Combine (ols_aggregate.cpp:189-234) may pair a source on one device with a
+ * target on another.  export copies the listed slots' records out as the device keeps them — record_len() doubles and the
+ * accepted-row count per slot; import overwrites the listed (distinct) slots of ANOTHER state of the same width and options with
+ * them, after which an ordinary combine merges them into their targets.  Rows kept in a row log do not travel: both calls give
+ * the state's log up, and a group its moments cannot resolve is then flagged by Finalize (status 101), never handed out.
+ * Log-only states (wider designs, HC errors) refuse both: they stay on one device. */
+/* (r4) Back to the state as created (every slot empty, the row log released, slots() = 0), device buffers kept: between two
+ * executions of a prepared statement whose bind data — and with it the query's device state — DuckDB re-uses. */
+ANOFOX_HIP_API bool anofox_hip_agg_state_reset(AnofoxHipAggState *state, AnofoxError *out_error);
+ANOFOX_HIP_API size_t anofox_hip_agg_state_record_len(const AnofoxHipAggState *state);
+ANOFOX_HIP_API bool anofox_hip_agg_state_export_slots_host(AnofoxHipAggState *state, int64_t n_list, const uint32_t *slots, double *records,
+                                            int64_t *counts, AnofoxError *out_error);
+ANOFOX_HIP_API bool anofox_hip_agg_state_import_slots_host(AnofoxHipAggState *state, int64_t n_list, const uint32_t *slots, const double *records,
+                                            const int64_t *counts, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_host(AnofoxHipAggState *state, int64_t n_slots, double *core, double *inference,
                                         int64_t *out_unrefined, int32_t *out_unrefined_slots, AnofoxError *out_error);
 ANOFOX_HIP_API bool anofox_hip_agg_state_finalize_device(AnofoxHipAggState *state, int64_t n_slots, double *d_core, double *d_inference,

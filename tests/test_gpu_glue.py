@@ -100,6 +100,67 @@ def test_group_by_through_the_glue_matches_oracle(lib, fn, model, p, spec, kw):
                          None if rinf is None else rinf[fitted], what=f"glue GROUP BY {fn} p={p}")
 
 
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0,0"])
+@pytest.mark.parametrize("fn,model,p,spec,kw", [
+    ("ols_fit_agg", "ols", 8, b"compute_inference=true", dict(compute_inference=True)),
+    ("wls_fit_agg", "wls", 4, b"intercept=false", dict(fit_intercept=False)),
+    ("ridge_fit_agg", "ridge", 3, b"alpha=0.5", dict(alpha=0.5)),
+    ("ols_fit_agg", "ols", 20, None, {}),                       # log-only state: stays on one shard, same answers
+])
+def test_group_by_sharded_over_devices_through_the_glue(lib, devices, fn, model, p, spec, kw):
+    """SURVEY.md 8(e) behind the SQL aggregate: ANOFOX_HIP_DEVICES routes every aggregate state to one of W device states by
+    hash64(state address) % W at its first accepted row; the parallel hash aggregate's Combine then pairs thread-local sources
+    with targets on OTHER shards (moment records exported, imported and merged on the target's device), Finalize fits every
+    shard in its own batched call.  W = 2 and 4 shards on the one GPU of this box: the same records as one shard (merge order
+    may differ: 1e-12) and the oracle's; every row counted once; nothing flagged."""
+    rng = np.random.default_rng(77 + p)
+    K, n = 300, 50_000
+    key = rng.integers(0, K, n).astype(np.uint32)
+    X = rng.uniform(-5, 5, (n, p)) + 1.0
+    beta = rng.uniform(-3, 3, (K, p))
+    y = np.einsum("ij,ij->i", beta[key], X) + 4.0 + rng.standard_normal(n)
+    w = rng.uniform(0.5, 1.5, n)
+    zeros = np.zeros(n, dtype=np.uint8)
+    xe = np.zeros((n, p), dtype=np.uint8)
+    inference = kw.get("compute_inference", False)
+
+    def run(dev):
+        old = os.environ.pop("ANOFOX_HIP_DEVICES", None)
+        if dev is not None:
+            os.environ["ANOFOX_HIP_DEVICES"] = dev
+        try:
+            msg = C.create_string_buffer(512)
+            q = lib.glue_open(fn.encode(), spec, 0, msg)
+            assert q, msg.value
+            core = np.full((K, p + 6), np.nan)
+            inf = np.full((K, 5 * p + 2), np.nan) if inference else None
+            nn = np.zeros(K, dtype=np.uint8)
+            rc = lib.glue_group_by(q, n, p, _ptr(key), K, _ptr(y), _ptr(X), _ptr(w), _ptr(zeros), _ptr(zeros), _ptr(xe), _ptr(zeros),
+                                   6, 2048, 1, _ptr(core), _ptr(inf), _ptr(nn), msg)
+            assert rc == 0, msg.value
+            st = _stats(lib, q)
+            lib.glue_close(q)
+            return core, inf, nn, st
+        finally:
+            os.environ.pop("ANOFOX_HIP_DEVICES", None)
+            if old is not None:
+                os.environ["ANOFOX_HIP_DEVICES"] = old
+
+    core1, inf1, nn1, st1 = run(None)
+    coreW, infW, nnW, stW = run(devices)
+    W = len(devices.split(","))
+    assert st1["rows"] == n and stW["rows"] == n and stW["live"] == 0 and stW["unrefined"] == 0
+    assert st1["fit_calls"] == 1
+    assert stW["fit_calls"] == (1 if p > 8 else W)        # one batched fit per device state that holds groups
+    assert np.array_equal(nn1, nnW) and np.all(nnW == 0)
+    np.testing.assert_allclose(coreW[:, :p + 4], core1[:, :p + 4], rtol=1e-10, atol=1e-12)
+    order = np.argsort(key, kind="stable")
+    offs = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=K))]).astype(np.int64)
+    rcore, rinf = oracle.fit_groups(y[order], [np.ascontiguousarray(X[order, j]) for j in range(p)], offs,
+                                    w=(w[order] if model == "wls" else None), model=model, **kw)
+    assert_records_match(_fix_last_column(coreW, p), rcore, p, infW, rinf, what=f"glue GROUP BY over {W} shards, {fn} p={p}")
+
+
 def test_groups_of_different_widths_in_one_query(lib):
     """The reference fixes the feature count per STATE, at the state's first accepted row (ols_aggregate.cpp:164-175): the
     groups of one query may have x lists of different lengths, each result carries its own n_features and LIST lengths; a

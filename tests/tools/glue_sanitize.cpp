@@ -47,7 +47,7 @@ static void registration_and_bind() {
 		CHECK(f1.arguments.back() == LogicalType(LogicalType::ANY) && f0.return_type == LogicalType(LogicalType::ANY));
 		if (k == 2) CHECK(f0.arguments[2] == LogicalType(LogicalType::DOUBLE));
 		CHECK(f0.bind && f0.destructor && f0.combine && f0.update && f0.finalize && f0.initialize && !f0.simple_update);
-		CHECK(f0.state_size(f0) == 2 * sizeof(int64_t));
+		CHECK(f0.state_size(f0) == 3 * sizeof(int64_t)); // slot, feature count, device shard
 	}
 	// defaults (ols_aggregate.cpp:48-52): 7 fields, intercept, no inference, 0.95, solver svd, no HC
 	CHECK(q.ReturnType().children().size() == 7 && q.ReturnType().children()[0].first == "coefficients" && q.ReturnType().children()[6].first == "n_features");
@@ -127,7 +127,7 @@ static Data make_data(size_t n, size_t p, size_t n_keys, unsigned seed, bool nul
 	return d;
 }
 
-static void group_by(const char *fn, size_t p, int threads, size_t vsize, bool dictionary) {
+static void group_by(const char *fn, size_t p, int threads, size_t vsize, bool dictionary, int shards = 1) {
 	const bool weighted = std::string(fn).find("wls") != std::string::npos;
 	const size_t n = 5000, K = 37;
 	Data d = make_data(n, p, K, 99 + (unsigned)p, true);
@@ -156,7 +156,26 @@ static void group_by(const char *fn, size_t p, int threads, size_t vsize, bool d
 		CHECK(c[p + 5] == (double)p); // n_features
 	}
 	CHECK(q.Stats().live_slots == 0);                                     // every state was destroyed
-	CHECK(q.Stats().fit_calls == 1 && q.Stats().slots_fitted >= K - 1); // ONE batched fit for the whole GROUP BY
+	// ONE batched fit for the whole GROUP BY — per device state when ANOFOX_HIP_DEVICES shards the query's states
+	CHECK(q.Stats().fit_calls >= 1 && q.Stats().fit_calls <= (uint64_t)shards && q.Stats().slots_fitted >= K - 1);
+	if (shards == 1) CHECK(q.Stats().fit_calls == 1);
+}
+
+// A prepared statement executed twice: DuckDB re-uses the bind data (and with it the query's device state).  Once the first
+// execution's states have all been destroyed, the second one starts from a clean state — slot numbers from 0 again, the same
+// results — instead of resting on what the first left behind.
+static void prepared_twice() {
+	const size_t n = 3000, K = 23, p = 3;
+	Data d = make_data(n, p, K, 7, true);
+	Query q("ols_fit_agg", nullptr, false);
+	const int resets_before = g_reset_calls.load();
+	Records r1 = q.GroupBy(d.in(), d.key.data(), K, 3, 128, false);
+	const auto slots1 = q.Stats().slot_high_water;
+	Records r2 = q.GroupBy(d.in(), d.key.data(), K, 3, 128, false);
+	CHECK(g_reset_calls.load() == resets_before + 1);          // exactly one reset: at the second execution's first Initialize
+	CHECK(q.Stats().slot_high_water == slots1);                  // the slot numbering started over
+	CHECK(r1.is_null == r2.is_null && r1.core == r2.core);      // and the answers are the first execution's
+	CHECK(q.Stats().live_slots == 0);
 }
 
 static void window_replay() {
@@ -292,6 +311,18 @@ int main() {
 	group_by("ols_fit_agg", 3, 4, 64, true);
 	group_by("anofox_stats_wls_fit_agg", 8, 3, 100, true);
 	group_by("ridge_fit_agg", 12, 5, 2048, false);
+	// (r4) the query's states hash-partitioned over three device states: thread-local sources meet targets on other shards in
+	// Combine (records exported / imported / merged), every key's rows still arrive once and in order
+	setenv("ANOFOX_HIP_DEVICES", "0,0,0", 1);
+	{
+		const int before = g_export_calls.load();
+		group_by("anofox_stats_ols_fit_agg", 3, 4, 64, false, 3);
+		group_by("anofox_stats_wls_fit_agg", 8, 3, 100, true, 3);
+		CHECK(g_export_calls.load() > before && g_import_calls.load() > 0); // some pairs did cross shards
+		group_by("ridge_fit_agg", 12, 5, 2048, false, 1);                   // a log-only width stays on one shard
+	}
+	unsetenv("ANOFOX_HIP_DEVICES");
+	prepared_twice();
 	window_replay();
 	errors_and_flags();
 	CHECK(g_contexts == 0 && g_states == 0 && g_host_allocs == 0); // everything released

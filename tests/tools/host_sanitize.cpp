@@ -35,6 +35,7 @@ bool accumulate_quad_supports(int, bool, bool, bool) { return false; }
 STUB(launch_accumulate_tile(const WideArgs &, hipStream_t))
 bool accumulate_tile_supports(int, bool, bool, bool) { return false; }
 STUB(launch_refit_dd_wide(const WideArgs &, hipStream_t))
+STUB(launch_refit_dd_narrow(const BatchArgs &, hipStream_t))
 STUB(launch_solve_mid(const WideArgs &, int, hipStream_t))
 STUB(launch_hc_wide(const WideArgs &, hipStream_t))
 STUB(launch_accumulate_narrow(const BatchArgs &, hipStream_t))
@@ -63,6 +64,7 @@ STUB(launch_rowlog_positions(const uint32_t *, int64_t, int32_t *, int64_t, hipS
 STUB(launch_rowlog_map_queue(const int32_t *, const int32_t *, const uint32_t *, int32_t *, hipStream_t))
 STUB(launch_rowlog_invalidate(uint8_t *, int64_t, const uint32_t *, int64_t, const RowLogSlab *, int, hipStream_t))
 STUB(launch_ingest_gather_slots(const double *, const int64_t *, const uint32_t *, int64_t, int, double *, int64_t *, hipStream_t))
+STUB(launch_ingest_scatter_slots(double *, int64_t *, const uint32_t *, int64_t, int, const double *, const int64_t *, hipStream_t))
 STUB(launch_ingest_clear_slots(double *, int64_t *, const uint32_t *, int64_t, int, hipStream_t))
 STUB(launch_rowlog_remap(uint32_t *, int64_t, const uint32_t *, const uint32_t *, int64_t, const RowLogSlab *, int, hipStream_t))
 size_t rowlog_sort_temp_bytes(int64_t) { return 4096; }

@@ -137,6 +137,43 @@ bool anofox_hip_agg_state_release_slots(AnofoxHipAggState *s, int64_t n, const u
 		if (slots[i] < s->slots.size()) s->slots[slots[i]].clear();
 	return true;
 }
+// cross-device Combine: the mock's "record" of a slot is a handle to a copy of its rows (one double), the count its row count
+std::mutex g_export_mu;
+std::vector<std::vector<Row>> g_exported;
+std::atomic<int> g_export_calls {0}, g_import_calls {0};
+std::atomic<int> g_reset_calls {0};
+bool anofox_hip_agg_state_reset(AnofoxHipAggState *s, AnofoxError *) {
+	++g_reset_calls;
+	s->slots.clear();
+	return true;
+}
+size_t anofox_hip_agg_state_record_len(const AnofoxHipAggState *s) { return s ? 1 : 0; }
+bool anofox_hip_agg_state_export_slots_host(AnofoxHipAggState *s, int64_t n, const uint32_t *slots, double *records, int64_t *counts, AnofoxError *) {
+	++g_export_calls;
+	std::lock_guard<std::mutex> lk(g_export_mu);
+	for (int64_t i = 0; i < n; ++i) {
+		const std::vector<Row> rows = slots[i] < s->slots.size() ? s->slots[slots[i]] : std::vector<Row>();
+		records[i] = (double)g_exported.size();
+		counts[i] = (int64_t)rows.size();
+		g_exported.push_back(rows);
+	}
+	return true;
+}
+bool anofox_hip_agg_state_import_slots_host(AnofoxHipAggState *s, int64_t n, const uint32_t *slots, const double *records, const int64_t *counts,
+                                            AnofoxError *err) {
+	++g_import_calls;
+	std::lock_guard<std::mutex> lk(g_export_mu);
+	for (int64_t i = 0; i < n; ++i) {
+		const size_t h = (size_t)records[i];
+		if (h >= g_exported.size() || (int64_t)g_exported[h].size() != counts[i] || slots[i] >= s->slots.size()) {
+			err->code = ANOFOX_ERROR_INVALID_INPUT;
+			snprintf(err->message, sizeof err->message, "mock: bad import");
+			return false;
+		}
+		s->slots[slots[i]] = g_exported[h];
+	}
+	return true;
+}
 bool anofox_hip_agg_state_finalize_slots_host(AnofoxHipAggState *s, int64_t n, const uint32_t *slots, double *core, double *, int64_t *unrefined,
                                               AnofoxError *) {
 	++g_subset_calls;
