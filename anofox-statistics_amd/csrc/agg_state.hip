@@ -198,74 +198,87 @@ void log_free(AnofoxHipAggState *s) {
 	s->log_rows = 0;
 }
 
+// A new slab at the end of the log with room for at least `need` rows (1 = whatever the growth policy gives).  Slabs grow
+// geometrically from 64 Ki rows to 16 Mi rows or 2 GiB; HBM while its budget lasts, then page-locked host memory (the same kernels
+// read it over PCIe), then nothing: *dropped = the budgets (or the memory itself) are exhausted and the log was given up — an
+// error only for a log-only state, whose log IS the state.
+bool log_grow(AnofoxHipAggState *s, int64_t need, bool *dropped, AnofoxError *e) {
+	*dropped = false;
+	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
+	const size_t p = s->p, rb = log_row_bytes(s);
+	int64_t cap = s->slabs.empty() ? 65536 : s->slabs.back().cap * 2;
+	if (cap > (int64_t)1 << 24) cap = (int64_t)1 << 24;
+	if ((size_t)cap * rb > ((size_t)2 << 30) && cap > 65536) { // never more than 2 GiB per slab (1 KB rows at p = 128)
+		cap = (int64_t)(((size_t)2 << 30) / rb);
+		if (cap < 65536) cap = 65536;
+	}
+	auto fit_cap = [&](size_t left) { // rows of the next slab within `left` bytes; 0 = `need` rows do not fit
+		int64_t c = cap;
+		if ((size_t)c * rb > left) c = (int64_t)(left / rb);
+		if (c < need && (size_t)need * rb <= left) c = need;
+		return (c <= 0 || c < need) ? (int64_t)0 : c;
+	};
+	auto alloc_slab = [&](int64_t c, bool on_host, RowLogSlab *out) {
+		RowLogSlab nsl{};
+		nsl.cap = c;
+		nsl.first_row = s->log_rows;
+		nsl.on_host = on_host ? 1 : 0;
+		auto get = [&](void **q, size_t bytes) {
+			return (on_host ? hipHostMalloc(q, bytes, hipHostMallocDefault) : hipMalloc(q, bytes)) == hipSuccess;
+		};
+		const bool ok = get((void **)&nsl.x, (size_t)c * p * sizeof(double)) && get((void **)&nsl.y, (size_t)c * sizeof(double)) &&
+		                (!weighted || get((void **)&nsl.w, (size_t)c * sizeof(double))) &&
+		                get((void **)&nsl.slot, (size_t)c * sizeof(uint32_t)) && get((void **)&nsl.valid, (size_t)c);
+		if (!ok) {
+			(void)hipGetLastError();
+			slab_release(nsl);
+			return false;
+		}
+		*out = nsl;
+		return true;
+	};
+	RowLogSlab sl{};
+	bool have = false;
+	const int64_t cap_dev = fit_cap(s->log_budget > s->log_bytes ? s->log_budget - s->log_bytes : 0);
+	if (cap_dev > 0 && alloc_slab(cap_dev, false, &sl)) {
+		have = true;
+		s->log_bytes += (size_t)cap_dev * rb;
+	} else {
+		const int64_t cap_host = fit_cap(s->log_host_budget > s->log_host_bytes ? s->log_host_budget - s->log_host_bytes : 0);
+		if (cap_host > 0 && alloc_slab(cap_host, true, &sl)) {
+			have = true;
+			s->log_host_bytes += (size_t)cap_host * rb;
+		}
+	}
+	if (!have) { // both budgets (or the memory itself) are exhausted: stop retaining
+		if (s->log_only) {
+			set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE,
+			          "the aggregate state's row log exceeds its budgets (anofox_hip_agg_state_retain_rows / _retain_rows_host)");
+			return false;
+		}
+		log_free(s);
+		s->log_dropped = true;
+		*dropped = true;
+		return true;
+	}
+	s->slabs.push_back(sl);
+	return true;
+}
+
 // Append one chunk (device pointers, stream-ordered after whatever produced them) to the row log.  Exceeding the
 // budget is not an error: the log is dropped and Finalize reports the unrefined groups as it does without one.
 bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const double *d_y, const double *d_x, const double *d_w,
                 const uint8_t *d_valid, AnofoxError *e) {
 	if (!s->retain || s->log_dropped || n <= 0) return true;
 	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
-	const size_t p = s->p, rb = log_row_bytes(s);
+	const size_t p = s->p;
 	hipStream_t st = s->ctx->stream;
 	int64_t done = 0;
 	while (done < n) {
 		if (s->slabs.empty() || s->slabs.back().rows == s->slabs.back().cap) {
-			// slabs grow geometrically from 64 Ki rows to 16 Mi rows or 2 GiB, never beyond what the budget still allows
-			int64_t cap = s->slabs.empty() ? 65536 : s->slabs.back().cap * 2;
-			if (cap > (int64_t)1 << 24) cap = (int64_t)1 << 24;
-			if ((size_t)cap * rb > ((size_t)2 << 30) && cap > 65536) { // and never more than 2 GiB per slab (1 KB rows at p = 128)
-				cap = (int64_t)(((size_t)2 << 30) / rb);
-				if (cap < 65536) cap = 65536;
-			}
-			// HBM while its budget lasts, then page-locked host memory (the same kernels read it over PCIe), then nothing
-			auto fit_cap = [&](size_t left) { // rows of the next slab within `left` bytes; 0 = the rest of the chunk does not fit
-				int64_t c = cap;
-				if ((size_t)c * rb > left) c = (int64_t)(left / rb);
-				if (c < n - done && (size_t)(n - done) * rb <= left) c = n - done;
-				return (c <= 0 || c < n - done) ? (int64_t)0 : c;
-			};
-			auto alloc_slab = [&](int64_t c, bool on_host, RowLogSlab *out) {
-				RowLogSlab nsl{};
-				nsl.cap = c;
-				nsl.first_row = s->log_rows;
-				nsl.on_host = on_host ? 1 : 0;
-				auto get = [&](void **q, size_t bytes) {
-					return (on_host ? hipHostMalloc(q, bytes, hipHostMallocDefault) : hipMalloc(q, bytes)) == hipSuccess;
-				};
-				const bool ok = get((void **)&nsl.x, (size_t)c * p * sizeof(double)) && get((void **)&nsl.y, (size_t)c * sizeof(double)) &&
-				                (!weighted || get((void **)&nsl.w, (size_t)c * sizeof(double))) &&
-				                get((void **)&nsl.slot, (size_t)c * sizeof(uint32_t)) && get((void **)&nsl.valid, (size_t)c);
-				if (!ok) {
-					(void)hipGetLastError();
-					slab_release(nsl);
-					return false;
-				}
-				*out = nsl;
-				return true;
-			};
-			RowLogSlab sl{};
-			bool have = false;
-			const int64_t cap_dev = fit_cap(s->log_budget > s->log_bytes ? s->log_budget - s->log_bytes : 0);
-			if (cap_dev > 0 && alloc_slab(cap_dev, false, &sl)) {
-				have = true;
-				s->log_bytes += (size_t)cap_dev * rb;
-			} else {
-				const int64_t cap_host = fit_cap(s->log_host_budget > s->log_host_bytes ? s->log_host_budget - s->log_host_bytes : 0);
-				if (cap_host > 0 && alloc_slab(cap_host, true, &sl)) {
-					have = true;
-					s->log_host_bytes += (size_t)cap_host * rb;
-				}
-			}
-			if (!have) { // both budgets (or the memory itself) are exhausted: stop retaining
-				if (s->log_only) {
-					set_error(e, ANOFOX_ERROR_ALLOCATION_FAILURE,
-					          "the aggregate state's row log exceeds its budgets (anofox_hip_agg_state_retain_rows / _retain_rows_host)");
-					return false;
-				}
-				log_free(s);
-				s->log_dropped = true;
-				return true;
-			}
-			s->slabs.push_back(sl);
+			bool dropped = false;
+			if (!log_grow(s, n - done, &dropped, e)) return false;
+			if (dropped) return true;
 		}
 		RowLogSlab &sl = s->slabs.back();
 		const int64_t m = (n - done) < (sl.cap - sl.rows) ? (n - done) : (sl.cap - sl.rows);
@@ -284,6 +297,79 @@ bool log_append(AnofoxHipAggState *s, int64_t n, const uint32_t *d_slot, const d
 		done += m;
 	}
 	return true;
+}
+
+// A Combine that preserves its sources (DuckDB's AggregateCombineType::PRESERVE_INPUT: window segment trees): the targets get
+// their own copies of the sources' logged rows, as the reference's Combine copies the row buffers (ols_aggregate.cpp:224-233), so
+// that Finalize can refit the frames its moments cannot resolve (r3 gave the log up here: every exactly fitting frame of a
+// windowed aggregate came back NULL, and log-only states refused the call).  Host arrays; synchronises the stream.
+bool log_duplicate(AnofoxHipAggState *s, int64_t n_pairs, const uint32_t *src, const uint32_t *dst, AnofoxError *e) {
+	if (!(s->retain || s->log_only) || s->log_dropped || s->log_rows == 0 || n_pairs <= 0) return true;
+	hipStream_t st = s->ctx->stream;
+	// the pairs as a map source -> its targets
+	std::vector<int64_t> order((size_t)n_pairs);
+	for (int64_t i = 0; i < n_pairs; ++i) order[(size_t)i] = i;
+	std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return src[a] < src[b]; });
+	std::vector<uint32_t> usrc, utgt;
+	std::vector<int32_t> uoff;
+	for (int64_t i : order) {
+		if (src[i] == dst[i]) continue;
+		if (usrc.empty() || usrc.back() != src[i]) {
+			usrc.push_back(src[i]);
+			uoff.push_back((int32_t)utgt.size());
+		}
+		utgt.push_back(dst[i]);
+	}
+	if (usrc.empty()) return true;
+	uoff.push_back((int32_t)utgt.size());
+	const int m = (int)usrc.size();
+	int64_t n_tiles = 0;
+	std::vector<int64_t> src_rows;
+	for (auto &sl : s->slabs) {
+		n_tiles += rowlog_dup_tiles(sl.rows);
+		src_rows.push_back(sl.rows);
+	}
+	const size_t b_u = align_up((size_t)m * sizeof(uint32_t), 256), b_o = align_up((size_t)(m + 1) * sizeof(int32_t), 256);
+	const size_t b_t = align_up(utgt.size() * sizeof(uint32_t), 256), b_c = align_up((size_t)(n_tiles + 1) * sizeof(int64_t), 256);
+	if (hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e)) return false; // (the buffer may still be read by an earlier remap)
+	if (!ensure_buffer(&s->remap_buf, &s->remap_bytes, b_u + b_o + b_t + b_c, "row log duplication", e)) return false;
+	char *base = (char *)s->remap_buf;
+	uint32_t *d_usrc = (uint32_t *)base, *d_utgt = (uint32_t *)(base + b_u + b_o);
+	int32_t *d_uoff = (int32_t *)(base + b_u);
+	int64_t *d_cnt = (int64_t *)(base + b_u + b_o + b_t);
+	bool bad = hip_fail(hipMemcpyAsync(d_usrc, usrc.data(), (size_t)m * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", e);
+	bad = bad || hip_fail(hipMemcpyAsync(d_uoff, uoff.data(), (size_t)(m + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st), "H2D", e);
+	bad = bad || hip_fail(hipMemcpyAsync(d_utgt, utgt.data(), utgt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st), "H2D", e);
+	bad = bad || hip_fail(launch_rowlog_dup_count(s->slabs.data(), (int)s->slabs.size(), d_usrc, d_uoff, d_utgt, m, d_cnt, n_tiles, st),
+	                      "row log duplication (count)", e);
+	int64_t total = 0;
+	bad = bad || hip_fail(hipMemcpyAsync(&total, d_cnt + n_tiles, sizeof total, hipMemcpyDeviceToHost, st), "D2H", e);
+	bad = bad || hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e);
+	if (bad) return false;
+	if (total == 0) return true;
+	if (total > ((int64_t)1 << 24)) { // more copies than one slab may hold: not a window frame's Combine
+		if (s->log_only) {
+			set_error(e, ANOFOX_ERROR_INVALID_INPUT, "combine with preserved sources: more than 2^24 rows to copy in one call");
+			return false;
+		}
+		log_free(s);
+		s->log_dropped = true;
+		return true;
+	}
+	if (s->slabs.back().cap - s->slabs.back().rows < total) {
+		bool dropped = false;
+		if (!log_grow(s, total, &dropped, e)) return false;
+		if (dropped) return true;
+		src_rows.push_back(0); // (the new slab holds no source rows)
+	}
+	RowLogSlab &dsl = s->slabs.back();
+	if (hip_fail(launch_rowlog_dup_fill(s->slabs.data(), src_rows.data(), (int)s->slabs.size(), (int)s->p, s->opt.model == ANOFOX_HIP_MODEL_WLS ? 1 : 0,
+	                                    d_usrc, d_uoff, d_utgt, m, d_cnt, dsl, dsl.rows, st),
+	             "row log duplication (fill)", e))
+		return false;
+	dsl.rows += total;
+	s->log_rows += total;
+	return !hip_fail(hipStreamSynchronize(st), "hipStreamSynchronize", e);
 }
 
 // one pass (<= kIngestChunkRows rows) on device-resident inputs
@@ -581,13 +667,6 @@ bool anofox_hip_agg_state_combine_ex(AnofoxHipAggState *s, int64_t n_pairs, cons
 					return false;
 				}
 	}
-	if (preserve_sources && s->log_only) {
-		// a row belongs to one slot of the log: sources that live on cannot also count for their targets
-		set_error(out_error, ANOFOX_ERROR_INVALID_INPUT,
-		          "combine with preserved sources (window segment trees) is not available for designs of more than 8 features or HC "
-		          "standard errors: use the fit_predict window functions");
-		return false;
-	}
 	std::lock_guard<std::mutex> lk(s->ctx->mu);
 	if (hip_fail(hipSetDevice(s->ctx->device), "hipSetDevice", out_error)) return false;
 	const size_t b = align_up((size_t)n_pairs * sizeof(uint32_t), 256);
@@ -603,12 +682,10 @@ bool anofox_hip_agg_state_combine_ex(AnofoxHipAggState *s, int64_t n_pairs, cons
 	                                                   s->opt.fit_intercept ? 1 : 0, preserve_sources ? 1 : 0, st),
 	                             "combine kernel launch", out_error))
 		return false;
-	if (preserve_sources && s->retain && !s->log_dropped) {
-		// the log cannot say "these rows count twice": it is given up, and Finalize flags what the moments cannot resolve
-		log_free(s);
-		s->log_dropped = true;
-	}
-	if (s->retain && !s->log_dropped && s->log_rows > 0) { // the sources' rows in the log now belong to the targets
+	if (preserve_sources) {
+		// (r4) the sources live on AND count for their targets: the targets get copies of the sources' logged rows
+		if (!log_duplicate(s, n_pairs, source_slots, target_slots, out_error)) return false;
+	} else if ((s->retain || s->log_only) && !s->log_dropped && s->log_rows > 0) { // the sources' rows in the log now belong to the targets
 		if (!ensure_buffer(&s->remap_buf, &s->remap_bytes, (size_t)s->n_slots * sizeof(uint32_t), "row log remap", out_error)) return false;
 		if (hip_fail(launch_rowlog_remap((uint32_t *)s->remap_buf, s->n_slots, d_src, d_dst, n_pairs, s->slabs.data(), (int)s->slabs.size(), st),
 		             "row log remap launch", out_error))

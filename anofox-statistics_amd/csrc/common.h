@@ -451,6 +451,13 @@ struct RowLogSlab {
 	int32_t on_host; // 1: page-locked host memory (the spill beyond the HBM budget), read by the kernels over PCIe
 	int32_t pad;
 };
+// (r4) copies of the rows of preserved Combine sources, labelled with their targets (rowlog.hip)
+int64_t rowlog_dup_tiles(int64_t rows);
+hipError_t launch_rowlog_dup_count(const RowLogSlab *h_slabs, int n_slabs, const uint32_t *usrc, const int32_t *uoff, const uint32_t *utgt, int m,
+                                   int64_t *tile_cnt, int64_t n_tiles, hipStream_t st);
+hipError_t launch_rowlog_dup_fill(const RowLogSlab *h_slabs, const int64_t *src_rows, int n_slabs, int p, int weighted, const uint32_t *usrc,
+                                  const int32_t *uoff, const uint32_t *utgt, int m, const int64_t *tile_base, const RowLogSlab &dst, int64_t dst_at,
+                                  hipStream_t st);
 size_t rowlog_sort_temp_bytes(int64_t n);
 hipError_t launch_rowlog_sort_slots(const int32_t *in, int32_t *out, int64_t n, void *temp, size_t temp_bytes, hipStream_t st);
 hipError_t launch_rowlog_iota(int32_t *v, int64_t n, hipStream_t st); // v[i] = i

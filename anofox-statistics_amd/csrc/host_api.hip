@@ -161,11 +161,16 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		const bool quad = mid_acc_on && quad_on && accumulate_quad_supports((int)p, opt.model == ANOFOX_HIP_MODEL_WLS, opt.fit_intercept, a.no_fast_path != 0);
 		// (r4) 34 <= p <= 64: the wave-per-group speculative kernel on LDS-DMA (accumulate_mid.hip) before accumulate_wide's full version
 		const bool tile = mid_acc_on && !quad && accumulate_tile_supports((int)p, opt.model == ANOFOX_HIP_MODEL_WLS, opt.fit_intercept, a.no_fast_path != 0);
-		// the workgroup-per-group kernel with several slabs: its segment / redo kernels (idle unless a group needs them) go to the
-		// solve stream — on this one they queued behind the PREVIOUS slab's solve, whose wavefronts hold every SIMD's registers:
-		// 5 us or ~1 ms per launch depending on how far that solve had got (profiles/r04_idle_launches.md)
+		// The workgroup-per-group kernel's segment / redo kernels are idle unless a group needs them, yet an idle launch is not
+		// free next to another stream's kernel: every one of its workgroups needs a slot (74 KB of LDS, 4 x 237 registers) that
+		// the other kernel's wavefronts hold, so its trace duration is the time it QUEUED — 5 us, or ~1 ms behind the previous
+		// slab's solve (512 registers per wave, one wave per SIMD): round 3's "bimodal idle launch" (profiles/r04_idle_launches.md).
+		// Moving them to the solve stream (ANOFOX_WIDE_SPLIT=1) was built and measured: there the redo kernel's 13 785
+		// workgroups queue behind the NEXT slab's accumulate kernel instead (2-18 ms) and take the slab's solve with them — worse;
+		// they stay on this stream.
 		const bool plain_wide = !quad && !tile && !mid_acc;
-		a.launch_part = (plain_wide && overlap) ? 1 : 0;
+		static const bool split_on = getenv("ANOFOX_WIDE_SPLIT") && atoi(getenv("ANOFOX_WIDE_SPLIT")) == 1; // measurement switch
+		a.launch_part = (plain_wide && overlap && split_on) ? 1 : 0;
 		if (hip_fail(quad ? launch_accumulate_quad(a, st)
 		                  : (tile ? launch_accumulate_tile(a, st) : (mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st))),
 		             "wide accumulate kernel launch", e))

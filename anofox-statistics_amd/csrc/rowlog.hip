@@ -192,6 +192,109 @@ __global__ void rowlog_flag_unrefined_kernel(const int32_t *list, const int32_t 
 	}
 }
 
+// ---- (r4) duplication for a Combine that PRESERVES its sources (window segment trees) ----
+// A logged row belongs to one slot.  When a source lives on after it has been merged into one or several targets, the
+// targets need their own copies of its rows — the reference copies them too (ols_aggregate.cpp:224-233: target.x.insert(...)) —
+// or Finalize could not refit the frames its moments cannot resolve (every exactly fitting frame is one).  The copies are
+// appended to the log in the order of the rows they copy, labelled with the target.
+struct DupMap {
+	const uint32_t *usrc; // [m] distinct sources, ascending
+	const int32_t *uoff;  // [m + 1] their targets: utgt[uoff[k] .. uoff[k + 1])
+	const uint32_t *utgt;
+	int m;
+};
+constexpr int kDupIt = 16; // a wavefront's tile: 64 x 16 rows
+
+__device__ __forceinline__ int dup_find(const DupMap &d, uint32_t s) {
+	int lo = 0, hi = d.m - 1;
+	while (lo <= hi) {
+		const int mid = (lo + hi) >> 1;
+		const uint32_t v = d.usrc[mid];
+		if (v == s) return mid;
+		if (v < s) lo = mid + 1; else hi = mid - 1;
+	}
+	return -1;
+}
+__device__ __forceinline__ int dup_fanout(const DupMap &d, const uint32_t *slot, const uint8_t *valid, int64_t i, int64_t n, int *k_out) {
+	*k_out = -1;
+	if (i >= n || !valid[i]) return 0;
+	const int k = dup_find(d, slot[i]);
+	*k_out = k;
+	return k < 0 ? 0 : d.uoff[k + 1] - d.uoff[k];
+}
+// copies per wavefront tile
+__global__ void __launch_bounds__(kLogBlock) rowlog_dup_count_kernel(const uint32_t *slot, const uint8_t *valid, int64_t n, DupMap d, int64_t *tile_cnt) {
+	const int lane = threadIdx.x & 63;
+	const int64_t tile = (int64_t)blockIdx.x * (kLogBlock / 64) + (threadIdx.x >> 6);
+	const int64_t r0 = tile * 64 * kDupIt;
+	if (r0 >= n) return;
+	int64_t mine = 0;
+	for (int it = 0; it < kDupIt; ++it) {
+		int k;
+		mine += dup_fanout(d, slot, valid, r0 + (int64_t)it * 64 + lane, n, &k);
+	}
+	for (int msk = 32; msk >= 1; msk >>= 1) mine += __shfl_xor(mine, msk, 64);
+	if (lane == 0) tile_cnt[tile] = mine;
+}
+// in-place exclusive scan by ONE workgroup (a few hundred thousand tiles at most); total -> *total
+__global__ void __launch_bounds__(1024) rowlog_dup_scan_kernel(int64_t *cnt, int64_t n_tiles, int64_t *total) {
+	__shared__ int64_t part[1024];
+	const int t = threadIdx.x;
+	const int64_t per = (n_tiles + 1023) / 1024;
+	const int64_t lo = (int64_t)t * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+	int64_t sum = 0;
+	for (int64_t i = lo; i < hi; ++i) sum += cnt[i];
+	part[t] = sum;
+	__syncthreads();
+	if (t == 0) {
+		int64_t run = 0;
+		for (int k = 0; k < 1024; ++k) {
+			const int64_t v = part[k];
+			part[k] = run;
+			run += v;
+		}
+		*total = run;
+	}
+	__syncthreads();
+	int64_t run = part[t];
+	for (int64_t i = lo; i < hi; ++i) {
+		const int64_t v = cnt[i];
+		cnt[i] = run;
+		run += v;
+	}
+}
+// the copies of one source slab, written behind `dst_at` of the destination arrays in row order
+__global__ void __launch_bounds__(kLogBlock) rowlog_dup_fill_kernel(RowLogSlab src, int p, int weighted, DupMap d, const int64_t *tile_base,
+                                                                    RowLogSlab dst, int64_t dst_at) {
+	const int lane = threadIdx.x & 63;
+	const int64_t tile = (int64_t)blockIdx.x * (kLogBlock / 64) + (threadIdx.x >> 6);
+	const int64_t n = src.rows, r0 = tile * 64 * kDupIt;
+	if (r0 >= n) return;
+	int64_t at = dst_at + tile_base[tile];
+	for (int it = 0; it < kDupIt; ++it) {
+		const int64_t i = r0 + (int64_t)it * 64 + lane;
+		int k;
+		const int f = dup_fanout(d, src.slot, src.valid, i, n, &k);
+		int incl = f; // inclusive scan over the wave's lanes
+		for (int off = 1; off < 64; off <<= 1) {
+			const int v = __shfl_up(incl, off, 64);
+			if (lane >= off) incl += v;
+		}
+		const int total = __shfl(incl, 63, 64);
+		int64_t o = at + (incl - f);
+		for (int c = 0; c < f; ++c, ++o) {
+			dst.slot[o] = d.utgt[d.uoff[k] + c];
+			dst.valid[o] = 1;
+			dst.y[o] = src.y[i];
+			if (weighted) dst.w[o] = src.w[i];
+			const double *xs = src.x + (size_t)i * (size_t)p;
+			double *xd = dst.x + (size_t)o * (size_t)p;
+			for (int j = 0; j < p; ++j) xd[j] = xs[j];
+		}
+		at += total;
+	}
+}
+
 inline unsigned grid_for(int64_t n, int64_t cap = 1 << 16) {
 	int64_t g = (n + kLogBlock - 1) / kLogBlock;
 	if (g < 1) g = 1;
@@ -295,6 +398,42 @@ hipError_t launch_rowlog_invalidate(uint8_t *mark, int64_t n_slots, const uint32
 hipError_t launch_rowlog_flag_unrefined(const int32_t *list, const int32_t *count, int64_t n_slots, int p, double *core, double *inf,
                                         hipStream_t st) {
 	rowlog_flag_unrefined_kernel<<<1024, 64, 0, st>>>(list, count, n_slots, p, core, inf);
+	return hipGetLastError();
+}
+
+// tile_cnt: one int64 per wavefront tile of every slab, slab after slab (rowlog_dup_tiles), then one more for the total
+int64_t rowlog_dup_tiles(int64_t rows) { return (rows + 64 * kDupIt - 1) / (64 * kDupIt); }
+
+hipError_t launch_rowlog_dup_count(const RowLogSlab *h_slabs, int n_slabs, const uint32_t *usrc, const int32_t *uoff, const uint32_t *utgt, int m,
+                                   int64_t *tile_cnt, int64_t n_tiles, hipStream_t st) {
+	const DupMap d{usrc, uoff, utgt, m};
+	int64_t t0 = 0;
+	for (int k = 0; k < n_slabs; ++k) {
+		const int64_t tiles = rowlog_dup_tiles(h_slabs[k].rows);
+		if (tiles > 0)
+			rowlog_dup_count_kernel<<<(unsigned)((tiles + kLogBlock / 64 - 1) / (kLogBlock / 64)), kLogBlock, 0, st>>>(h_slabs[k].slot, h_slabs[k].valid,
+			                                                                                                      h_slabs[k].rows, d, tile_cnt + t0);
+		t0 += tiles;
+	}
+	rowlog_dup_scan_kernel<<<1, 1024, 0, st>>>(tile_cnt, n_tiles, tile_cnt + n_tiles);
+	return hipGetLastError();
+}
+
+// src_rows[k]: the rows slab k held when the copies were counted (the destination may be the last slab itself)
+hipError_t launch_rowlog_dup_fill(const RowLogSlab *h_slabs, const int64_t *src_rows, int n_slabs, int p, int weighted, const uint32_t *usrc,
+                                  const int32_t *uoff, const uint32_t *utgt, int m, const int64_t *tile_base, const RowLogSlab &dst, int64_t dst_at,
+                                  hipStream_t st) {
+	const DupMap d{usrc, uoff, utgt, m};
+	int64_t t0 = 0;
+	for (int k = 0; k < n_slabs; ++k) {
+		RowLogSlab src = h_slabs[k];
+		src.rows = src_rows[k];
+		const int64_t tiles = rowlog_dup_tiles(src.rows);
+		if (tiles > 0)
+			rowlog_dup_fill_kernel<<<(unsigned)((tiles + kLogBlock / 64 - 1) / (kLogBlock / 64)), kLogBlock, 0, st>>>(src, p, weighted, d, tile_base + t0, dst,
+			                                                                                                     dst_at);
+		t0 += tiles;
+	}
 	return hipGetLastError();
 }
 

@@ -28,6 +28,8 @@
 // right-looking pivot steps apply the same instruction to all of them, so X = L_kk^-1 and z_k = L_kk^-1 c_k cost
 // nothing extra.  Constant / aliased columns get inv = 0: column, row of X and z_j vanish (solve_wide.hip's rule).
 #pragma once
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -116,11 +118,11 @@ __device__ __forceinline__ constexpr int slot(int i, int j) { // i <= j
 // (r4) tiles parked in the wave's LDS at T = 8: the LAST block column and the top of the one before it.  Every slot is touched
 // once per block step, so a parked one costs 8 ds_read_b64 + 8 ds_write_b64 per step where a spilled register costs scratch
 // (HBM / L2) traffic: 35 registers were still spilled after the partial sums had moved to LDS.
-template <int T>
-__host__ __device__ constexpr int parked_tiles() { return T == 8 ? 10 : 0; } // (11: no scratch at all, but 41.6 KB per wave: three waves per CU instead of four)
-template <int T>
+template <int T, bool PARKED>
+__host__ __device__ constexpr int parked_tiles() { return (PARKED && T == 8) ? 10 : 0; } // (11: no scratch at all, but 41.6 KB per wave: three waves per CU instead of four)
+template <int T, bool PARKED>
 __host__ __device__ constexpr int parked_index(int t) { // -1: the slot lives in registers
-	for (int i = 0; i < parked_tiles<T>(); ++i) { // the last block column from the top, then the one before it
+	for (int i = 0; i < parked_tiles<T, PARKED>(); ++i) { // the last block column from the top, then the one before it
 		const int col = i < T ? T - 1 : T - 2, row = i < T ? i : i - T;
 		if (t == slot<T>(row, col)) return i;
 	}
@@ -130,7 +132,8 @@ __host__ __device__ constexpr int parked_index(int t) { // -1: the slot lives in
 constexpr int kDsLd = 18; // row stride of the diagonal-block image (doubles): 16-byte aligned rows
 constexpr int kXsLd = 17;
 
-template <int T, int WPE>
+// PARKED = false: everything in registers, as in round 3 (ANOFOX_SOLVE_PARK=0: the A/B switch of the measurement)
+template <int T, int WPE, bool PARKED = true>
 __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 	constexpr int P16 = 16 * T;
 	constexpr int NT = T * (T + 1) / 2;
@@ -140,8 +143,8 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 	// launch against 1.1 GB of records (profiles/hbm_traffic.json, r03).  Those three arrays are touched once or twice per
 	// (block step, block) pair, so they live in the wave's own LDS instead ([block][lane]: conflict-free, 12 KB per wave of the
 	// 160 KB four waves share), and the column sums are re-read from the record where the statistics need them.
-	constexpr bool PARK = T >= 7;
-	constexpr int NPT = parked_tiles<T>();
+	constexpr bool PARK = PARKED && T >= 7;
+	constexpr int NPT = parked_tiles<T, PARKED>();
 	__shared__ __attribute__((aligned(16))) double lds[17 * kDsLd + 16 * kXsLd + 16 + 2 * P16 + (PARK ? 3 * T * 64 : 0) + NPT * 256];
 	double *Ds = lds;                 // [17][18]: the diagonal block (rows 0..15) and the y column (row 16)
 	double *Xs = Ds + 17 * kDsLd;     // [16][17]: X = L_kk^-1
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		// slot t, wherever it lives (t is a constant expression everywhere)
 		auto tget = [&](auto t_) __attribute__((always_inline)) -> d4 {
 			constexpr int t = decltype(t_)::value;
-			constexpr int pi = parked_index<T>(t);
+			constexpr int pi = parked_index<T, PARKED>(t);
 			if constexpr (pi >= 0) {
 				d4 v;
 #pragma unroll
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		};
 		auto tset = [&](auto t_, const d4 &v) __attribute__((always_inline)) {
 			constexpr int t = decltype(t_)::value;
-			constexpr int pi = parked_index<T>(t);
+			constexpr int pi = parked_index<T, PARKED>(t);
 			if constexpr (pi >= 0) {
 #pragma unroll
 				for (int r = 0; r < 4; ++r) ptile[(pi * 4 + r) * 64 + lane] = v[r];
@@ -577,7 +580,15 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 template <int T, int WPE>
 hipError_t launch_solve_tiles_T(const WideArgs &a, hipStream_t stream) {
 	if (a.n_groups > (int64_t)0x7fffffff) return hipErrorInvalidValue; // (a slab of run_wide_batch holds at most 2^30 / 2.6 KB groups)
-	hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, WPE>), dim3((unsigned)a.n_groups), dim3(64), 0, stream, a);
+	static const bool park_on = !(getenv("ANOFOX_SOLVE_PARK") && atoi(getenv("ANOFOX_SOLVE_PARK")) == 0);
+	bool launched = false;
+	if constexpr (T >= 7) {
+		if (!park_on) {
+			hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, WPE, false>), dim3((unsigned)a.n_groups), dim3(64), 0, stream, a);
+			launched = true;
+		}
+	}
+	if (!launched) hipLaunchKernelGGL((tiles::solve_tiles_kernel<T, WPE>), dim3((unsigned)a.n_groups), dim3(64), 0, stream, a);
 	return hipGetLastError();
 }
 

@@ -531,8 +531,10 @@ ANOFOX_HIP_API bool anofox_hip_agg_state_combine(AnofoxHipAggState *state, int64
                                   const uint32_t *target_slots, AnofoxError *out_error);
 /* combine with preserve_sources = true leaves the sources as they are (DuckDB's AggregateCombineType::PRESERVE_INPUT: a
  * window segment tree combines one node into many frames); the same source may then feed several targets of a call.
- * A row log cannot count a row for two slots: it is given up on the first such call (unresolved groups are flagged by
- * Finalize), and log-only states refuse it. */
+ * (r4) A row log — and the rows of a log-only state — follow: every target gets its own copies of its sources' logged rows
+ * (the reference's Combine copies the row buffers as well, ols_aggregate.cpp:224-233), appended behind the target's own, so
+ * that Finalize refits exactly fitting or ill-conditioned frames as it does for a GROUP BY.  More than 2^24 rows to copy in ONE
+ * call is not a window frame's Combine: a moment state then gives its log up (flagged groups), a log-only state reports an error. */
 ANOFOX_HIP_API bool anofox_hip_agg_state_combine_ex(AnofoxHipAggState *state, int64_t n_pairs, const uint32_t *source_slots,
                                      const uint32_t *target_slots, bool preserve_sources, AnofoxError *out_error);
 /* Finalize of the listed (distinct) slots only: record k belongs to slots[k].  Same records as finalize_host. */

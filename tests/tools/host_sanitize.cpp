@@ -67,6 +67,10 @@ STUB(launch_ingest_gather_slots(const double *, const int64_t *, const uint32_t 
 STUB(launch_ingest_scatter_slots(double *, int64_t *, const uint32_t *, int64_t, int, const double *, const int64_t *, hipStream_t))
 STUB(launch_ingest_clear_slots(double *, int64_t *, const uint32_t *, int64_t, int, hipStream_t))
 STUB(launch_rowlog_remap(uint32_t *, int64_t, const uint32_t *, const uint32_t *, int64_t, const RowLogSlab *, int, hipStream_t))
+int64_t rowlog_dup_tiles(int64_t rows) { return (rows + 1023) / 1024; }
+STUB(launch_rowlog_dup_count(const RowLogSlab *, int, const uint32_t *, const int32_t *, const uint32_t *, int, int64_t *, int64_t, hipStream_t))
+STUB(launch_rowlog_dup_fill(const RowLogSlab *, const int64_t *, int, int, int, const uint32_t *, const int32_t *, const uint32_t *, int, const int64_t *,
+                            const RowLogSlab &, int64_t, hipStream_t))
 size_t rowlog_sort_temp_bytes(int64_t) { return 4096; }
 STUB(launch_rowlog_flag_unrefined(const int32_t *, const int32_t *, int64_t, int, double *, double *, hipStream_t))
 bool rowlog_key_bits(int64_t, int64_t, unsigned *rb, unsigned *eb) { *rb = 40; *eb = 64; return true; }
