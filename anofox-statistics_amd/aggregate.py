@@ -420,7 +420,9 @@ class _FitPredictAgg:
             train = np.array([s in ("train", "training") for s in sp], dtype=bool) & ~ynull
         else:
             train = ~ynull
-        train &= ~feat_null
+        if self.model == "ols":                                  # only the OLS file clears the flag on a NULL feature
+            train &= ~feat_null                                  # (ols_predict_aggregate.cpp:236-239); ridge / wls hand the row
+                                                                 # to the fit, whose row filter drops it
         if self.options.null_policy == "drop_y_zero_x":          # ols_predict_aggregate.cpp:241-249
             train &= ~np.any(X == 0.0, axis=1)
         wv = None
@@ -428,7 +430,9 @@ class _FitPredictAgg:
             if weights is None:
                 raise InvalidInputException(f"{self.sql_name} needs a weight argument")
             wv, wnull = _null_mask_1d(weights)
-            train &= ~wnull
+            keep &= ~wnull                                       # a NULL weight: the row does not exist (wls_predict_aggregate.cpp:170-174)
+            train &= ~wnull & (np.nan_to_num(wv, nan=0.0) > 0)   # weight <= 0: kept for the output, does not train (:212-217)
+            wv = np.where(train, wv, 1.0)
         self._seen_keys.append(keys)
         if keep.any():
             self._chunks.append((keys[keep], yv[keep], ynull[keep], X[keep], train[keep],

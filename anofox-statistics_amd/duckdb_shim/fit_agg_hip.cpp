@@ -40,6 +40,7 @@
 #include "agg_arena.hpp"
 #include "sharded_arena.hpp" // hash64: the routing hash of SURVEY.md 8(e)
 #include "fit_agg_hip.hpp"
+#include "hip_options.hpp"
 
 #include <thread>
 
@@ -56,105 +57,7 @@ struct HipAggState {
 	int64_t shard;      // (r4) which of the query's device states holds the slot: hash64(state address) % W at the first accepted row
 };
 
-enum class HipModel : uint8_t { OLS, RIDGE, WLS };
-
-// ---- options: the keys, aliases, defaults and error texts of the reference's parser ----
-// (RegressionMapOptions::ParseFromValue src/include/map_options_parser.cpp:637-750, ExtractBool :21-45,
-//  ExtractSolverType / ExtractHcType / ExtractLambdaScaling :222-266, VisitOptionEntries :343-373 — STRUCT and MAP
-//  literals, lower-cased keys, unknown keys ignored :798 — GetRegularizationStrength map_options_parser.hpp:265-270;
-//  defaults ols_aggregate.cpp:48-52, ridge_aggregate.cpp:49-54, wls_aggregate.cpp:49-54)
-struct HipFitOptions {
-	bool fit_intercept = true;
-	bool compute_inference = false;
-	double confidence_level = 0.95;
-	AnofoxSolverType solver = ANOFOX_SOLVER_SVD; // accepted; the GPU path has one solver (results agree within 1e-10)
-	AnofoxHcType hc_type = ANOFOX_HC_NONE;
-	double alpha = 1.0;
-	AnofoxLambdaScaling lambda_scaling = ANOFOX_LAMBDA_SCALING_RAW;
-	bool operator==(const HipFitOptions &o) const {
-		return fit_intercept == o.fit_intercept && compute_inference == o.compute_inference && confidence_level == o.confidence_level &&
-		       solver == o.solver && hc_type == o.hc_type && alpha == o.alpha && lambda_scaling == o.lambda_scaling;
-	}
-};
-
-string Lower(string s) {
-	std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
-	return s;
-}
-
-bool ExtractBool(const Value &v) {
-	switch (v.type().id()) {
-	case LogicalTypeId::BOOLEAN: return BooleanValue::Get(v);
-	case LogicalTypeId::INTEGER:
-	case LogicalTypeId::BIGINT: return v.GetValue<int64_t>() != 0;
-	case LogicalTypeId::DOUBLE: return v.GetValue<double>() != 0.0;
-	default: throw InvalidInputException("Cannot convert value of type %s to boolean", v.type().ToString().c_str());
-	}
-}
-
-template <class ENUM>
-ENUM ExtractEnum(const Value &v, const char *what, const char *valid, std::initializer_list<std::pair<const char *, ENUM>> table) {
-	const string s = Lower(v.type().id() == LogicalTypeId::VARCHAR ? StringValue::Get(v) : v.ToString());
-	for (auto &e : table)
-		if (s == e.first) return e.second;
-	throw InvalidInputException("Invalid %s: '%s'. Valid values are %s", what, s.c_str(), valid);
-}
-
-void ApplyOption(const string &raw_key, const Value &v, HipFitOptions &o, bool &has_alpha, double &alpha, bool &has_lambda, double &lambda) {
-	if (v.IsNull()) return;
-	const string key = Lower(raw_key);
-	if (key == "fit_intercept" || key == "intercept") o.fit_intercept = ExtractBool(v);
-	else if (key == "compute_inference" || key == "inference") o.compute_inference = ExtractBool(v);
-	else if (key == "confidence_level" || key == "confidence") o.confidence_level = v.GetValue<double>(); // no range check upstream
-	else if (key == "alpha") { has_alpha = true; alpha = v.GetValue<double>(); }
-	else if (key == "lambda") { has_lambda = true; lambda = v.GetValue<double>(); }
-	else if (key == "solver")
-		o.solver = ExtractEnum<AnofoxSolverType>(v, "solver", "'qr', 'svd', 'cholesky'",
-		                                         {{"qr", ANOFOX_SOLVER_QR}, {"svd", ANOFOX_SOLVER_SVD}, {"cholesky", ANOFOX_SOLVER_CHOLESKY}});
-	else if (key == "hc_type")
-		o.hc_type = ExtractEnum<AnofoxHcType>(v, "hc_type", "'none', 'hc0', 'hc1', 'hc2', 'hc3'",
-		                                      {{"none", ANOFOX_HC_NONE}, {"hc0", ANOFOX_HC_HC0}, {"hc1", ANOFOX_HC_HC1}, {"hc2", ANOFOX_HC_HC2}, {"hc3", ANOFOX_HC_HC3}});
-	else if (key == "lambda_scaling")
-		o.lambda_scaling = ExtractEnum<AnofoxLambdaScaling>(v, "lambda_scaling", "'raw', 'glmnet'",
-		                                                    {{"raw", ANOFOX_LAMBDA_SCALING_RAW}, {"glmnet", ANOFOX_LAMBDA_SCALING_GLMNET}});
-	// every other key: ignored, as upstream (the legacy {'full_output': true} of the reference's examples must bind)
-}
-
-void ParseHipFitOptions(const Value &v, HipFitOptions &o) {
-	if (v.IsNull()) return;
-	bool has_alpha = false, has_lambda = false;
-	double alpha = 0.0, lambda = 0.0;
-	if (v.type().id() == LogicalTypeId::STRUCT) {
-		auto &kids = StructValue::GetChildren(v);
-		for (idx_t i = 0; i < kids.size(); i++) ApplyOption(StructType::GetChildName(v.type(), i), kids[i], o, has_alpha, alpha, has_lambda, lambda);
-	} else if (v.type().id() == LogicalTypeId::MAP) {
-		for (auto &entry : MapValue::GetChildren(v)) { // a list of {key, value} structs
-			auto &kv = StructValue::GetChildren(entry);
-			if (kv.size() != 2 || kv[0].IsNull()) continue;
-			ApplyOption(kv[0].type().id() == LogicalTypeId::VARCHAR ? StringValue::Get(kv[0]) : kv[0].ToString(), kv[1], o, has_alpha, alpha,
-			            has_lambda, lambda);
-		}
-	} else {
-		throw InvalidInputException("Options must be a MAP or STRUCT, got %s", v.type().ToString().c_str());
-	}
-	if (has_alpha) o.alpha = alpha; // alpha wins over lambda
-	else if (has_lambda) o.alpha = lambda;
-}
-
-AnofoxHipBatchOptions MakeHipOptions(HipModel model, const HipFitOptions &o) {
-	AnofoxHipBatchOptions b;
-	memset(&b, 0, sizeof b);
-	b.model = model == HipModel::OLS ? ANOFOX_HIP_MODEL_OLS : (model == HipModel::RIDGE ? ANOFOX_HIP_MODEL_RIDGE : ANOFOX_HIP_MODEL_WLS);
-	b.fit_intercept = o.fit_intercept;
-	b.compute_inference = o.compute_inference;
-	b.confidence_level = o.confidence_level;
-	b.solver = o.solver;
-	// ridge: alpha and its scaling, no HC branch (ridge.rs:36-229); ols / wls: HC standard errors (ols.rs:209-245)
-	b.alpha = model == HipModel::RIDGE ? o.alpha : 0.0;
-	b.lambda_scaling = model == HipModel::RIDGE ? o.lambda_scaling : ANOFOX_LAMBDA_SCALING_RAW;
-	b.hc_type = model == HipModel::RIDGE ? ANOFOX_HC_NONE : o.hc_type;
-	return b;
-}
+using namespace hip_glue;
 
 // ---- the query's device states: per feature count that occurs (normally one), W AggArenas — one per GPU of the node ----
 // (r4, SURVEY.md 8e / north_star: "groups are hash-partitioned across the GPUs of one node").  DuckDB's callbacks see state

@@ -230,6 +230,49 @@ struct list_entry_t {
 	uint64_t offset;
 	uint64_t length;
 };
+// DuckDB's 16-byte string handle: up to 12 characters inline, longer ones behind a pointer the vector's string heap owns
+// (duckdb/common/types/string_type.hpp).  The stand-in keeps the layout and the accessors the glue uses.
+struct string_t {
+	static constexpr idx_t INLINE_LENGTH = 12;
+	string_t() { memset(&value_, 0, sizeof value_); }
+	string_t(const char *data, uint32_t len) {
+		memset(&value_, 0, sizeof value_);
+		value_.inlined.length = len;
+		if (len <= INLINE_LENGTH) {
+			memcpy(value_.inlined.inlined, data, len);
+		} else {
+			memcpy(value_.pointer.prefix, data, 4);
+			value_.pointer.ptr = data;
+		}
+	}
+	bool IsInlined() const { return GetSize() <= INLINE_LENGTH; }
+	const char *GetData() const { return IsInlined() ? value_.inlined.inlined : value_.pointer.ptr; }
+	idx_t GetSize() const { return value_.inlined.length; }
+	string GetString() const { return string(GetData(), GetSize()); }
+private:
+	union {
+		struct {
+			uint32_t length;
+			char prefix[4];
+			const char *ptr;
+		} pointer;
+		struct {
+			uint32_t length;
+			char inlined[12];
+		} inlined;
+	} value_;
+};
+static_assert(sizeof(string_t) == 16, "string_t is 16 bytes in DuckDB");
+inline idx_t StubTypeWidth(LogicalTypeId id) {
+	switch (id) {
+	case LogicalTypeId::BOOLEAN: return 1;
+	case LogicalTypeId::INTEGER: return 4;
+	case LogicalTypeId::VARCHAR: return 16;
+	case LogicalTypeId::LIST: return sizeof(list_entry_t);
+	case LogicalTypeId::STRUCT: return 0;
+	default: return 8;
+	}
+}
 class ValidityMask {
 public:
 	bool RowIsValid(idx_t i) const { return i >= invalid_.size() || !invalid_[i]; }
@@ -264,8 +307,13 @@ public:
 		case LogicalTypeId::STRUCT:
 			for (auto &c : type.children()) child_.push_back(make_uniq<Vector>(c.second, capacity));
 			break;
-		default: buffer_.assign(capacity * 8, 0); // every scalar type of this stand-in is 8 bytes wide (BOOLEAN excepted: unused)
+		default: buffer_.assign(capacity * StubTypeWidth(type.id()), 0); // exactly as wide as DuckDB's physical type: ASan sees an overrun
 		}
+	}
+	// stand-in helper: a VARCHAR vector's strings live as long as the vector (DuckDB: its string heap)
+	string_t AddString(const string &s) {
+		heap_.push_back(make_uniq<string>(s));
+		return string_t(heap_.back()->data(), (uint32_t)heap_.back()->size());
 	}
 	const LogicalType &GetType() const { return type_; }
 	VectorType GetVectorType() const { return vtype_; }
@@ -298,6 +346,16 @@ private:
 	vector<unique_ptr<Vector>> child_;
 	idx_t list_size_ = 0, list_capacity_ = 0;
 	vector<uint32_t> dict_, zeros_;
+	vector<unique_ptr<string>> heap_;
+	// grow to `cap` entries: a STRUCT grows its fields (a LIST(STRUCT) child), everything else its own buffer
+	void Grow(idx_t cap) {
+		if (type_.id() == LogicalTypeId::STRUCT) {
+			for (auto &c : child_) c->Grow(cap);
+		} else {
+			buffer_.resize(cap * StubTypeWidth(type_.id()), 0);
+		}
+		capacity_ = cap;
+	}
 };
 struct FlatVector {
 	template <class T>
@@ -322,9 +380,7 @@ struct ListVector {
 		if (required <= v.list_capacity_) return;
 		idx_t cap = v.list_capacity_ ? v.list_capacity_ : 16;
 		while (cap < required) cap *= 2;
-		Vector &c = *v.child_[0];
-		c.buffer_.resize(cap * 8, 0);
-		c.capacity_ = cap;
+		v.child_[0]->Grow(cap);
 		v.list_capacity_ = cap;
 	}
 	static void SetListSize(Vector &v, idx_t size) {

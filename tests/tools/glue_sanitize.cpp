@@ -5,6 +5,7 @@
 // order-sensitive, so a row that reaches the wrong slot, or the right slot in the wrong order, changes the result.
 // Test infrastructure only (tests/test_sanitizers_cpu.py); nothing here is shipped.
 #include "glue_driver.hpp"
+#include "family_driver.hpp"
 
 #include "mock_abi.hpp"
 
@@ -305,6 +306,270 @@ static void errors_and_flags() {
 	}
 }
 
+// ---- the rest of the family (duckdb_shim/family_agg_hip.cpp) ----
+static std::string family_error_of(const char *fn, const char *spec, bool split = false) {
+	try {
+		FamilyQuery q(fn, spec, false, split);
+	} catch (const std::exception &e) {
+		return e.what();
+	}
+	return "";
+}
+
+static void family_registration() {
+	FamilyQuery q("anofox_stats_ols_fit_predict_agg", nullptr, false, false);
+	auto &reg = q.Loader().registered;
+	CHECK(reg.size() == 3 * 4 + 3 * 2 + 2);
+	for (const char *m : {"ols", "ridge", "wls"}) {
+		const std::string model = m, primary = "anofox_stats_" + model + "_fit_predict_agg";
+		const size_t base = model == "wls" ? 3 : 2;
+		for (const std::string &name : {primary, model + "_fit_predict_agg", model + "_predict_agg", "anofox_stats_" + model + "_predict_agg"}) {
+			CHECK(reg.count(name));
+			auto &info = reg.at(name);
+			CHECK(info.on_conflict == OnCreateConflict::ALTER_ON_CONFLICT && info.alias_of == (name == primary ? "" : primary));
+			CHECK(info.functions.functions.size() == 4);
+			auto &fs = info.functions.functions;
+			CHECK(fs[0].arguments.size() == base && fs[1].arguments.size() == base + 1 && fs[2].arguments.size() == base + 1 && fs[3].arguments.size() == base + 2);
+			CHECK(fs[1].arguments.back() == LogicalType(LogicalType::ANY) && fs[2].arguments.back() == LogicalType(LogicalType::VARCHAR));
+			CHECK(fs[3].arguments[base] == LogicalType(LogicalType::VARCHAR) && fs[3].arguments.back() == LogicalType(LogicalType::ANY));
+			for (auto &f : fs) CHECK(f.bind && f.destructor && f.combine && f.update && f.finalize && f.initialize && f.state_size(f) == sizeof(void *));
+		}
+		CHECK(reg.at(primary).descriptions.size() == 4);
+		const std::string win = "anofox_stats_" + model + "_fit_predict";
+		CHECK(reg.count(win) && reg.count(model + "_fit_predict") && reg.at(model + "_fit_predict").alias_of == win);
+		CHECK(reg.at(win).functions.functions.size() == 2 && reg.at(win).descriptions.size() == 2);
+		CHECK(reg.at(win).functions.functions[0].return_type.id() == LogicalTypeId::STRUCT); // the window aggregates name their type at registration
+	}
+	CHECK(reg.count("anofox_stats_vif_agg") && reg.at("vif_agg").alias_of == "anofox_stats_vif_agg");
+	// result types
+	auto &row = q.ReturnType().children()[0].second;
+	CHECK(q.ReturnType().id() == LogicalTypeId::LIST && row.id() == LogicalTypeId::STRUCT && row.children().size() == 5);
+	CHECK(row.children()[0].first == "y" && row.children()[3].first == "yhat_upper" && row.children()[4].second == LogicalType(LogicalType::BOOLEAN));
+	FamilyQuery w("ridge_fit_predict", "alpha=0.5;fit_intercept=false", false, false);
+	CHECK(w.ReturnType().children().size() == 3 && w.ReturnType().children()[1].first == "yhat_lower");
+	FamilyQuery v("vif_agg", nullptr, false, false);
+	CHECK(v.ReturnType() == LogicalType::LIST(LogicalType::DOUBLE));
+	// option errors surface from bind with the reference's texts
+	CHECK(family_error_of("ols_fit_predict_agg", "null_policy=keep").find("Invalid null_policy: 'keep'. Valid values are 'drop', 'drop_y_zero_x'") != std::string::npos);
+	CHECK(family_error_of("wls_fit_predict_agg", "null_policy=DROP_Y_ZERO_X", true).empty());
+	CHECK(family_error_of("ols_fit_predict", "solver=lu").find("Invalid solver") != std::string::npos);
+	CHECK(error_of("ols_fit_agg", "null_policy=keep").find("Invalid null_policy") != std::string::npos); // every aggregate validates the key
+}
+
+// what the mock makes of a group's rows in the order the driver combines them (thread by thread, input order within a thread)
+static void family_group_by(const char *fn, size_t p, int threads, size_t vsize, bool dictionary, bool with_split, const char *spec) {
+	const std::string name = fn;
+	const bool weighted = name.find("wls") != std::string::npos, ols = name.find("ols") != std::string::npos;
+	const bool drop_zero = spec && std::string(spec).find("drop_y_zero_x") != std::string::npos;
+	const size_t n = 4000, K = 29;
+	Data d = make_data(n, p, K, 7 + (unsigned)p, true);
+	std::vector<uint8_t> split(n);
+	for (size_t i = 0; i < n; ++i) {
+		split[i] = (uint8_t)((i * 2654435761u >> 7) % kSplitStringCount);
+		if (i % 9 == 0) d.xe_null[i * p + (i % p)] = 1;   // NULL list elements
+		if (i % 14 == 0) d.x[i * p + ((i / 14) % p)] = 0.0; // exact zeros for drop_y_zero_x
+		if (weighted && i % 19 == 0) d.w[i] = i % 38 == 0 ? 0.0 : -1.0;
+	}
+	FamilyQuery q(fn, spec, false, with_split);
+	const int before = g_predict_calls.load();
+	FamilyOut out = q.GroupBy(d.in(), with_split ? split.data() : nullptr, d.key.data(), K, threads, vsize, dictionary);
+	CHECK(g_predict_calls.load() - before == 1); // ONE batched call for the whole vector of states
+	// the expected rows per key
+	for (size_t k = 0; k < K; ++k) {
+		std::vector<size_t> rows;
+		for (int t = 0; t < threads; ++t)
+			for (size_t i = 0; i < n; ++i)
+				if (d.key[i] == k && (int)((i / vsize) % (size_t)threads) == t && !d.x_null[i] && !(weighted && d.w_null[i])) rows.push_back(i);
+		std::vector<uint8_t> train(rows.size());
+		double S = 0.0;
+		int64_t n_train = 0, counted = 0;
+		for (size_t r = 0; r < rows.size(); ++r) {
+			const size_t i = rows[r];
+			bool tr = !d.y_null[i];
+			if (with_split) {
+				const char *sv = kSplitStrings[split[i]];
+				std::string low = sv ? sv : "";
+				for (auto &c : low) c = (char)tolower(c);
+				tr = tr && (low == "train" || low == "training");
+			}
+			bool null_feature = false, zero = false;
+			for (size_t j = 0; j < p; ++j) {
+				null_feature = null_feature || d.xe_null[i * p + j];
+				zero = zero || (!d.xe_null[i * p + j] && d.x[i * p + j] == 0.0);
+			}
+			if (weighted && !(d.w[i] > 0)) tr = false;
+			if (null_feature && ols) tr = false;
+			if (tr && drop_zero && zero) tr = false;
+			train[r] = tr;
+			counted += tr;
+			// the library's row filter: a training row with a NaN feature does not enter the sums (the mock sees its NaN y? no: its y)
+			if (tr) {
+				S += (double)(r + 1) * d.y[i] * (weighted ? d.w[i] : 1.0);
+				++n_train;
+			}
+		}
+		if (counted < 2) {
+			CHECK(out.is_null[k]);
+			continue;
+		}
+		CHECK(!out.is_null[k] && (size_t)(out.offsets[k + 1] - out.offsets[k]) == rows.size());
+		for (size_t r = 0; r < rows.size(); ++r) {
+			const size_t i = rows[r], at = (size_t)out.offsets[k] + r;
+			const uint8_t fl = out.flags[at];
+			CHECK(((fl & 1) != 0) == (d.y_null[i] != 0));
+			if (!d.y_null[i]) CHECK(out.vals[at * 4] == d.y[i]);
+			CHECK(((fl & 16) != 0) == (train[r] != 0));
+			const bool x_nan = d.xe_null[i * p] || d.xe_null[i * p + p - 1];
+			if (x_nan) {
+				CHECK((fl & 14) == 14); // a non-finite prediction: three NULLs
+			} else {
+				const double v = S + d.x[i * p] + d.x[i * p + p - 1];
+				CHECK((fl & 14) == 0 && out.vals[at * 4 + 1] == v && out.vals[at * 4 + 2] == v - (double)n_train && out.vals[at * 4 + 3] == v + (double)counted);
+			}
+		}
+	}
+}
+
+static void family_vif(size_t p, int threads, size_t vsize, bool dictionary) {
+	const size_t n = 3000, K = 23;
+	Data d = make_data(n, p, K, 31 + (unsigned)p, true);
+	for (size_t i = 0; i < n; ++i)
+		if (d.key[i] == 5 && i % 50 == 0) d.x[i * p + 1] = NAN; // key 5: column 1 comes out shorter -> NULL
+	for (size_t i = 0; i < n; ++i)
+		if (d.key[i] == 6) d.x_null[i] = i % 2 || i > 40;        // key 6: (almost) no rows
+	FamilyQuery q("anofox_stats_vif_agg", nullptr, false, false);
+	const int before = g_vif_calls.load();
+	FamilyOut out = q.GroupBy(d.in(), nullptr, d.key.data(), K, threads, vsize, dictionary);
+	CHECK(g_vif_calls.load() - before <= 1);
+	for (size_t k = 0; k < K; ++k) {
+		std::vector<size_t> rows;
+		for (int t = 0; t < threads; ++t)
+			for (size_t i = 0; i < n; ++i)
+				if (d.key[i] == k && (int)((i / vsize) % (size_t)threads) == t && !d.x_null[i]) rows.push_back(i);
+		bool ragged = false;
+		for (size_t i : rows) ragged = ragged || isnan(d.x[i * p + 1]);
+		if (p < 2 || rows.size() < 3 || ragged) {
+			CHECK(out.is_null[k]);
+			continue;
+		}
+		CHECK(!out.is_null[k] && (size_t)(out.offsets[k + 1] - out.offsets[k]) == p);
+		for (size_t j = 0; j < p; ++j) {
+			double s = 0.0;
+			for (size_t r = 0; r < rows.size(); ++r) s += (double)(r + 1) * d.x[rows[r] * p + j];
+			CHECK(out.vals[(size_t)out.offsets[k] + j] == s);
+		}
+	}
+}
+
+// the window aggregates: a frame per output row (naive aggregator) and leaves combined under PRESERVE_INPUT (segment tree)
+static void family_window(const char *fn, size_t p, bool intercept) {
+	const bool weighted = std::string(fn).find("wls") != std::string::npos;
+	const size_t n = 600;
+	Data d = make_data(n, p, 1, 17 + (unsigned)p, true);
+	FamilyQuery q(fn, intercept ? nullptr : "fit_intercept=false", false, false);
+	auto expect = [&](const std::vector<size_t> &frame, double *v3) -> bool { // false: NULL
+		double S = 0.0;
+		int64_t n_train = 0;
+		bool has_current = false;
+		size_t current = 0, pos = 0;
+		for (size_t i : frame) {
+			if (d.x_null[i]) {
+				has_current = false;
+				continue;
+			}
+			has_current = true;
+			current = i;
+			if (d.y_null[i] || (weighted && d.w_null[i])) continue;
+			S += (double)(++pos) * d.y[i] * (weighted ? d.w[i] : 1.0);
+			++n_train;
+		}
+		if (!has_current || n_train <= (int64_t)(p + (intercept ? 1 : 0))) return false;
+		const double v = S + d.x[current * p] + d.x[current * p + p - 1];
+		v3[0] = v;
+		v3[1] = v - (double)n_train;
+		v3[2] = v + (double)n_train;
+		return true;
+	};
+	for (size_t preceding : {(size_t)11, (size_t)40}) {
+		FamilyOut out = q.Window(d.in(), preceding, 128);
+		CHECK(out.is_null.size() == n);
+		for (size_t o = 0; o < n; ++o) {
+			std::vector<size_t> frame;
+			for (size_t r = o >= preceding ? o - preceding : 0; r <= o; ++r) frame.push_back(r);
+			double v[3];
+			const bool ok = expect(frame, v);
+			CHECK(ok == !out.is_null[o]);
+			if (ok) CHECK(out.vals[o * 3] == v[0] && out.vals[o * 3 + 1] == v[1] && out.vals[o * 3 + 2] == v[2]);
+		}
+	}
+	const size_t leaf = 7, back = 4;
+	FamilyOut tree = q.TreeWindow(d.in(), leaf, back, 64);
+	const size_t n_leaves = (n + leaf - 1) / leaf;
+	CHECK(tree.is_null.size() == n_leaves);
+	for (size_t o = 0; o < n_leaves; ++o) {
+		std::vector<size_t> frame;
+		for (size_t l = o >= back ? o - back : 0; l <= o; ++l)
+			for (size_t r = l * leaf; r < std::min(n, (l + 1) * leaf); ++r) frame.push_back(r);
+		// Combine keeps the target's current row unless the source has one: replay leaf by leaf
+		double S = 0.0;
+		int64_t n_train = 0;
+		bool has_current = false, initialised = false;
+		size_t current = 0, pos = 0;
+		for (size_t l = o >= back ? o - back : 0; l <= o; ++l) {
+			bool leaf_init = false, leaf_has = false;
+			size_t leaf_cur = 0;
+			for (size_t r = l * leaf; r < std::min(n, (l + 1) * leaf); ++r) {
+				if (d.x_null[r]) {
+					if (leaf_init) leaf_has = false;
+					continue;
+				}
+				leaf_init = true;
+				leaf_has = true;
+				leaf_cur = r;
+				if (d.y_null[r] || (weighted && d.w_null[r])) continue;
+				S += (double)(++pos) * d.y[r] * (weighted ? d.w[r] : 1.0);
+				++n_train;
+			}
+			if (!leaf_init) continue; // an uninitialised source is skipped
+			if (!initialised) {
+				initialised = true;
+				has_current = leaf_has;
+				current = leaf_cur;
+			} else if (leaf_has) {
+				has_current = true;
+				current = leaf_cur;
+			}
+		}
+		const bool ok = initialised && has_current && n_train > (int64_t)(p + (intercept ? 1 : 0));
+		CHECK(ok == !tree.is_null[o]);
+		if (ok) {
+			const double v = S + d.x[current * p] + d.x[current * p + p - 1];
+			CHECK(tree.vals[o * 3] == v && tree.vals[o * 3 + 1] == v - (double)n_train && tree.vals[o * 3 + 2] == v + (double)n_train);
+		}
+	}
+}
+
+static void family_errors() {
+	// a group whose rows disagree in width
+	const size_t n = 10, p = 3;
+	Data d = make_data(n, p, 1, 5, false);
+	std::vector<uint32_t> len(n, 3);
+	len[6] = 2;
+	Inputs in = d.in();
+	in.x_len = len.data();
+	for (const char *fn : {"ols_fit_predict_agg", "ridge_fit_predict_agg", "vif_agg"}) {
+		std::string msg;
+		try {
+			FamilyQuery q(fn, nullptr, false, false);
+			q.GroupBy(in, nullptr, d.key.data(), 1, 1, 2048, false);
+		} catch (const std::exception &e) {
+			msg = e.what();
+		}
+		CHECK(msg.find("Inconsistent feature count") != std::string::npos);
+		if (std::string(fn) != "ridge_fit_predict_agg") CHECK(msg.find("expected 3, got 2") != std::string::npos);
+	}
+}
+
 int main() {
 	registration_and_bind();
 	group_by("anofox_stats_ols_fit_agg", 3, 1, 2048, false);
@@ -325,6 +590,18 @@ int main() {
 	prepared_twice();
 	window_replay();
 	errors_and_flags();
+	family_registration();
+	family_group_by("anofox_stats_ols_fit_predict_agg", 3, 1, 2048, false, false, nullptr);
+	family_group_by("ols_predict_agg", 4, 4, 64, true, true, nullptr);
+	family_group_by("ridge_fit_predict_agg", 2, 3, 100, true, false, "null_policy=drop_y_zero_x;alpha=2");
+	family_group_by("anofox_stats_wls_fit_predict_agg", 5, 2, 333, false, true, "null_policy=drop_y_zero_x");
+	family_group_by("wls_predict_agg", 1, 5, 50, true, false, nullptr);
+	family_vif(4, 3, 128, true);
+	family_vif(2, 1, 2048, false);
+	family_window("anofox_stats_ols_fit_predict", 2, true);
+	family_window("ridge_fit_predict", 3, false);
+	family_window("wls_fit_predict", 1, true);
+	family_errors();
 	CHECK(g_contexts == 0 && g_states == 0 && g_host_allocs == 0); // everything released
 	printf("glue_sanitize: all scenarios passed\n");
 	return 0;

@@ -208,5 +208,51 @@ bool anofox_hip_fit_batch_host(AnofoxHipContext *, int64_t G, size_t p, int64_t 
 	}
 	return true;
 }
+// the mock's fit + predict: S = sum over the group's training rows (non-NaN y, in order, k = position in the group) of (k + 1) y_k w_k;
+// row r: { S + x0[r] + x_last[r], that - #training rows, that + train_counts[g] }; status 100 when fewer than 2 rows train
+std::atomic<int> g_predict_calls {0}, g_vif_calls {0};
+bool anofox_hip_fit_predict_batch_host(AnofoxHipContext *, int64_t G, size_t p, int64_t n_rows, const int64_t *offs, const double *y,
+                                       const double *const *x_cols, const double *w, const int64_t *train_counts, AnofoxHipBatchOptions,
+                                       double *core, double *pred, AnofoxError *) {
+	++g_predict_calls;
+	if (offs[G] != n_rows || p == 0) return false;
+	for (int64_t g = 0; g < G; ++g) {
+		double S = 0.0;
+		int64_t n_train = 0;
+		for (int64_t r = offs[g]; r < offs[g + 1]; ++r)
+			if (!isnan(y[r])) {
+				S += (double)(r - offs[g] + 1) * y[r] * (w ? w[r] : 1.0);
+				++n_train;
+			}
+		double *c = core + (size_t)g * (p + 6);
+		for (size_t k = 0; k < p + 6; ++k) c[k] = 0.0;
+		c[p + 4] = (double)n_train;
+		c[p + 5] = n_train < 2 ? (double)ANOFOX_HIP_STATUS_NULL_TOO_FEW_ROWS : 0.0;
+		for (int64_t r = offs[g]; r < offs[g + 1]; ++r) {
+			const double v = S + x_cols[0][r] + x_cols[p - 1][r];
+			pred[3 * r] = v;
+			pred[3 * r + 1] = v - (double)n_train;
+			pred[3 * r + 2] = v + (double)(train_counts ? train_counts[g] : offs[g + 1] - offs[g]);
+		}
+	}
+	return true;
+}
+size_t anofox_hip_vif_record_len(size_t p) { return p + 1; }
+size_t anofox_hip_vif_max_features(void) { return 129; }
+// the mock's VIF of feature j: sum over the group's rows of (k + 1) x_j[k]
+bool anofox_hip_vif_batch_host(AnofoxHipContext *, int64_t G, size_t p, int64_t n_rows, const int64_t *offs, const double *const *x_cols, double *vif,
+                               AnofoxError *) {
+	++g_vif_calls;
+	if (offs[G] != n_rows) return false;
+	for (int64_t g = 0; g < G; ++g) {
+		for (size_t j = 0; j < p; ++j) {
+			double s = 0.0;
+			for (int64_t r = offs[g]; r < offs[g + 1]; ++r) s += (double)(r - offs[g] + 1) * x_cols[j][r];
+			vif[(size_t)g * (p + 1) + j] = s;
+		}
+		vif[(size_t)g * (p + 1) + p] = offs[g + 1] - offs[g] < 3 ? 100.0 : 0.0;
+	}
+	return true;
+}
 }
 
