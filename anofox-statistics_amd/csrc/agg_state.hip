@@ -594,13 +594,13 @@ bool anofox_hip_agg_state_update_host(AnofoxHipAggState *s, int64_t n_rows, int6
 	const bool weighted = s->opt.model == ANOFOX_HIP_MODEL_WLS;
 	const size_t p = s->p;
 	// staging layout of one chunk: x | y | w | slot | valid
-	const size_t C = (size_t)kIngestChunkRows;
+	const size_t C = (size_t)kIngestStageRows;
 	const size_t b_x = align_up(C * p * sizeof(double), 256), b_y = align_up(C * sizeof(double), 256);
 	const size_t b_s = align_up(C * sizeof(uint32_t), 256), b_v = align_up(C, 256);
 	const size_t total = b_x + 2 * b_y + b_s + b_v;
 	hipStream_t st = s->ctx->stream, cs = s->copy_stream;
-	for (int64_t r0 = 0; r0 < n_rows; r0 += kIngestChunkRows) {
-		const size_t n = (size_t)(n_rows - r0 < kIngestChunkRows ? n_rows - r0 : kIngestChunkRows);
+	for (int64_t r0 = 0; r0 < n_rows; r0 += kIngestStageRows) {
+		const size_t n = (size_t)(n_rows - r0 < kIngestStageRows ? n_rows - r0 : kIngestStageRows);
 		auto &sg = s->stage[s->next_stage];
 		s->next_stage ^= 1;
 		if (!sg.buf) {

@@ -398,7 +398,9 @@ hipError_t launch_residuals_wide(const ResidualArgs &a, const double *const *d_x
 // A "slot" is one aggregate state (one GROUP BY key of one hash table).  The state keeps the narrow path's moment
 // record (MomentLayout<P>) per slot plus the number of rows the aggregate's Update accepted, i.e. what the
 // reference buffers as whole rows (src/aggregate_functions/ols_aggregate.cpp:19-42,120-186) reduced to O(p^2).
-constexpr int64_t kIngestChunkRows = 1 << 20; // rows folded per pass (bounds the staging and sort buffers)
+constexpr int64_t kIngestChunkRows = 1 << 22; // rows folded per pass (bounds the sort buffers); (r4) 2^20 -> 2^22: with rows in random state
+                                              // order a state's run in a pass is 4 x longer, its record read and written once per run
+constexpr int64_t kIngestStageRows = 1 << 20; // rows per host staging buffer of update_host (PCIe-bound whatever the pass size)
 constexpr int kIngestPieceRows = 2048;        // a run longer than this within one chunk is cut into pieces
 constexpr int kIngestMaxBig = (int)(kIngestChunkRows / kIngestPieceRows) + 8;
 constexpr int kIngestMaxPieces = 2 * (int)(kIngestChunkRows / kIngestPieceRows) + 16;

@@ -14,18 +14,11 @@
 //   predict x of the LAST row of the frame (ols_fit_predict.cpp:157-162) with the simplified interval of
 //           anofox_predict_with_interval (lib.rs:2264-2349): yhat -+ t sigma sqrt(1 + 1/n).
 // Cost: O(frame) rows per output row (the reference refits every frame from scratch as well).
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
 #include "common.h"
 
 namespace anofox {
 
 namespace {
-
-struct NotNan {
-	__host__ __device__ int64_t operator()(double v) const { return v == v ? 1 : 0; }
-};
 
 __global__ __launch_bounds__(256) void frames_spec_kernel(const int64_t *row_offsets, int64_t n_groups, int64_t n_rows, int64_t start_p,
                                                           int64_t end_p, int64_t *lo_out, int64_t *hi_out, const int32_t *list,
@@ -116,31 +109,92 @@ __global__ __launch_bounds__(256) void frames_predict_kernel(FrameArgs a) {
 
 } // namespace
 
-size_t frames_scan_temp_bytes(int64_t n_rows) {
-	size_t temp = 0;
-	const double *y = nullptr;
-	int64_t *out = nullptr;
-	(void)rocprim::exclusive_scan(nullptr, temp, rocprim::make_transform_iterator(y, NotNan()), out, (int64_t)0, (size_t)n_rows + 1,
-	                              rocprim::plus<int64_t>(), (hipStream_t) nullptr);
-	return temp;
+// ---- ynn[i] = number of rows r < i with y[r] not NaN, i = 0 .. n_rows ((r4) hand-written; rocPRIM's exclusive_scan until round 3) ----
+// Three launches: a workgroup counts the non-NaN rows of its tile (ballots), one workgroup scans the <= kScanMaxBlocks tile
+// counts, the workgroups walk their tiles again 256 rows at a time and write the running counts.
+constexpr unsigned kScanMaxBlocks = 2048;
+struct ScanPlan {
+	unsigned n_blocks;
+	int64_t tile; // rows per workgroup, a multiple of 256
+};
+static ScanPlan scan_plan(int64_t n) {
+	int64_t chunks = (n + 255) / 256, per = (chunks + kScanMaxBlocks - 1) / kScanMaxBlocks;
+	if (per < 1) per = 1;
+	ScanPlan p;
+	p.tile = per * 256;
+	p.n_blocks = (unsigned)((n + p.tile - 1) / p.tile);
+	if (p.n_blocks == 0) p.n_blocks = 1;
+	return p;
 }
 
-// ynn[i] = number of rows r < i with y[r] not NaN, i = 0 .. n_rows.  (The scan reads one element past y's rows to
-// produce ynn[n_rows]: y is therefore expected to be followed by readable memory — the callers pass a padded copy or
-// scan n_rows elements and finish the last entry with a one-thread kernel.)
-__global__ void frames_ynn_last_kernel(const double *y, int64_t n_rows, int64_t *ynn) {
-	if (n_rows > 0) ynn[n_rows] = ynn[n_rows - 1] + (y[n_rows - 1] == y[n_rows - 1] ? 1 : 0);
-	else ynn[0] = 0;
+__global__ __launch_bounds__(256) void frames_ynn_count_kernel(const double *y, int64_t n_rows, int64_t tile, int64_t *counts) {
+	__shared__ int64_t wsum[4];
+	const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < n_rows ? lo + tile : n_rows;
+	int64_t c = 0;
+	for (int64_t i0 = lo; i0 < hi; i0 += 256) {
+		const int64_t i = i0 + threadIdx.x;
+		c += (int64_t)__popcll(__ballot(i < hi && y[i] == y[i])); // (the same count in every lane of the wavefront)
+	}
+	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+	__syncthreads();
+	if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
+
+__global__ __launch_bounds__(1024) void frames_ynn_scan_kernel(int64_t *counts, unsigned n_blocks, int64_t *total_out) {
+	__shared__ int64_t part[1024];
+	const unsigned span = (n_blocks + 1023u) / 1024u;
+	const unsigned lo = threadIdx.x * span < n_blocks ? threadIdx.x * span : n_blocks, hi = lo + span < n_blocks ? lo + span : n_blocks;
+	int64_t s = 0;
+	for (unsigned i = lo; i < hi; ++i) s += counts[i];
+	part[threadIdx.x] = s;
+	__syncthreads();
+	for (int off = 1; off < 1024; off <<= 1) {
+		const int64_t v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+		__syncthreads();
+		part[threadIdx.x] += v;
+		__syncthreads();
+	}
+	int64_t base = threadIdx.x ? part[threadIdx.x - 1] : 0;
+	for (unsigned i = lo; i < hi; ++i) {
+		const int64_t c = counts[i];
+		counts[i] = base;
+		base += c;
+	}
+	if (threadIdx.x == 1023) *total_out = part[1023];
+}
+
+__global__ __launch_bounds__(256) void frames_ynn_write_kernel(const double *y, int64_t n_rows, int64_t tile, const int64_t *counts, int64_t *ynn) {
+	__shared__ int wcount[4];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < n_rows ? lo + tile : n_rows;
+	int64_t base = counts[blockIdx.x];
+	for (int64_t i0 = lo; i0 < hi; i0 += 256) {
+		const int64_t i = i0 + threadIdx.x;
+		const unsigned long long b = __ballot(i < hi && y[i] == y[i]);
+		if (lane == 0) wcount[w] = (int)__popcll(b);
+		__syncthreads();
+		int before = 0, all = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			before += k < w ? wcount[k] : 0;
+			all += wcount[k];
+		}
+		if (i < hi) ynn[i] = base + before + (int64_t)__popcll(b & ((1ull << lane) - 1ull));
+		base += all;
+		__syncthreads();
+	}
+}
+
+size_t frames_scan_temp_bytes(int64_t) { return (size_t)kScanMaxBlocks * sizeof(int64_t); }
 
 hipError_t launch_frames_ynn(const double *y, int64_t n_rows, int64_t *ynn, void *temp, size_t temp_bytes, hipStream_t stream) {
-	if (n_rows > 0) {
-		size_t tb = temp_bytes;
-		hipError_t rc = rocprim::exclusive_scan(temp, tb, rocprim::make_transform_iterator(y, NotNan()), ynn, (int64_t)0, (size_t)n_rows,
-		                                        rocprim::plus<int64_t>(), stream);
-		if (rc != hipSuccess) return rc;
-	}
-	hipLaunchKernelGGL(frames_ynn_last_kernel, dim3(1), dim3(1), 0, stream, y, n_rows, ynn);
+	if (n_rows < 0 || temp_bytes < frames_scan_temp_bytes(n_rows)) return hipErrorInvalidValue;
+	if (n_rows == 0) return hipMemsetAsync(ynn, 0, sizeof(int64_t), stream);
+	const ScanPlan pl = scan_plan(n_rows);
+	int64_t *counts = static_cast<int64_t *>(temp);
+	hipLaunchKernelGGL(frames_ynn_count_kernel, dim3(pl.n_blocks), dim3(256), 0, stream, y, n_rows, pl.tile, counts);
+	hipLaunchKernelGGL(frames_ynn_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, pl.n_blocks, ynn + n_rows);
+	hipLaunchKernelGGL(frames_ynn_write_kernel, dim3(pl.n_blocks), dim3(256), 0, stream, y, n_rows, pl.tile, counts, ynn);
 	return hipGetLastError();
 }
 

@@ -9,11 +9,13 @@
 //
 // One pass over a chunk (<= kIngestChunkRows rows), nothing synchronises with the host:
 //   keys    key = state index, or n_slots for rows the aggregate skips;
-//   sort    stable radix sort of (key, row number) on the bits that n_slots needs (rocPRIM's device sort — the
-//           one library primitive in this file): the rows of a state become one RUN, still in arrival order,
-//           so "the first valid row" (ols.rs:76-87) is the one the reference's buffer would hold first;
+//   sort    stable radix sort of (key, row number) on the bits that n_slots needs ((r4) radix_sort.h: hand-written,
+//           8-bit digits, three launches per digit; rounds 2-3 called rocPRIM here): the rows of a state become one
+//           RUN, still in arrival order, so "the first valid row" (ols.rs:76-87) is the one the reference's buffer
+//           would hold first;
 //   bounds  run boundaries -> run_start / run_end per state and a list of the states present in the chunk
-//           (one wave-aggregated atomic per wavefront);
+//           (one atomic per WORKGROUP: (r4) one per wavefront was 16 384 atomics on one address per 2^20 rows —
+//           0.19 ms of a 0.96 ms chunk);
 //   runs    one wavefront per run, TRANSPOSED against the batch kernel: lane k owns moment k (s_a, q_ab or sw)
 //           and every lane walks the run's rows, so there is no cross-lane reduction and the state record is
 //           read, updated and written back in place, one coalesced 528-byte access each way at p = 8.  A state
@@ -27,10 +29,8 @@
 // Bound: with rows arriving in random state order every row costs a read-modify-write of a 528-byte record —
 // ~1.1 KB of HBM traffic per 72-byte row — which at 4 TB/s is still 4-5x the 55 GB/s at which PCIe delivers
 // rows; sorted arrival is a streaming read.  The ingest is PCIe-bound from host memory.
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-
 #include "common.h"
+#include "radix_sort.h"
 
 namespace anofox {
 
@@ -83,13 +83,22 @@ __global__ __launch_bounds__(256) void ingest_bounds_kernel(IngestArgs a) {
 			if (end) a.run_end[k] = (int32_t)(i + 1);
 		}
 	}
-	// append the run to the chunk's list: one atomic per wavefront
+	// append the runs to the chunk's list: the wavefronts' counts meet in LDS, one atomic per workgroup
+	__shared__ int wave_count[4];
+	__shared__ int block_base;
+	const int w = threadIdx.x >> 6;
 	const unsigned long long b = __ballot(start);
-	if (b == 0ull) return;
-	int base = 0;
-	if (lane == (int)(__ffsll((long long)b) - 1)) base = atomicAdd(&a.counters[0], (int)__popcll(b));
-	base = __shfl(base, (int)(__ffsll((long long)b) - 1), 64);
-	if (start) a.run_list[base + (int)__popcll(b & ((1ull << lane) - 1ull))] = k;
+	if (lane == 0) wave_count[w] = (int)__popcll(b);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const int total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+		block_base = total ? atomicAdd(&a.counters[0], total) : 0;
+	}
+	__syncthreads();
+	if (!start) return;
+	int base = block_base;
+	for (int k2 = 0; k2 < w; ++k2) base += wave_count[k2];
+	a.run_list[base + (int)__popcll(b & ((1ull << lane) - 1ull))] = k;
 }
 
 // this lane's moment of the record: s_i (lane < Z), q_ij (upper triangle, row-major) or sw
@@ -126,15 +135,17 @@ __device__ __forceinline__ void ingest_rows(const IngestArgs &a, int64_t lo, int
 	unsigned mask = 0;
 	bool have = false;
 	if (from_state) {
-		const double c0 = rec[L::OFF_CNT];
-		if (c0 > 0.0) { // wave-uniform
-			have = true;
-			cnt = c0;
-			mask = (unsigned)rec[L::OFF_MASK];
-			fa = rec[L::OFF_FIRST + mi];
-			fb = rec[L::OFF_FIRST + mj];
-			acc = lane < L::KRED ? rec[lane] : 0.0;
-		}
+		// (r4) every field is loaded at once and SELECTED on the row count: with the loads behind `if (count > 0)` a run paid two
+		// dependent round trips to its record before its first row (an empty state's record is all zeros)
+		const double c0 = rec[L::OFF_CNT], m0 = rec[L::OFF_MASK];
+		const double f_a = rec[L::OFF_FIRST + mi], f_b = rec[L::OFF_FIRST + mj];
+		const double a0 = rec[lane < L::KRED ? lane : 0];
+		have = c0 > 0.0; // wave-uniform
+		cnt = have ? c0 : 0.0;
+		mask = have ? (unsigned)m0 : 0u;
+		fa = have ? f_a : 0.0;
+		fb = have ? f_b : 0.0;
+		acc = have && lane < L::KRED ? a0 : 0.0;
 	}
 	// operand a / b of this lane: column mi / mj of the row (x is row-major, y is its own array)
 	const double *pa = mi < P ? a.x + mi : a.y;
@@ -238,14 +249,9 @@ __device__ __forceinline__ void merge_into_state(double *state, const double *pi
 }
 
 template <int P, bool WEIGHTED, bool CENTER>
-__global__ __launch_bounds__(256) void ingest_runs_kernel(IngestArgs a) {
+__device__ __forceinline__ void ingest_one_run(const IngestArgs &a, uint32_t slot, int64_t lo, int64_t hi, int lane) {
 	using L = MomentLayout<P>;
-	const int lane = threadIdx.x & 63;
-	const int n_runs = a.counters[0];
-	const int n_waves = (int)gridDim.x * 4;
-	for (int v = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); v < n_runs; v += n_waves) {
-		const uint32_t slot = a.run_list[v];
-		const int64_t lo = a.run_start[slot], hi = a.run_end[slot];
+	{
 		if (lane == 0) a.n_accum[slot] += hi - lo; // rows Update accepted, valid or not (ols_aggregate.cpp:176)
 		if (hi - lo > kIngestPieceRows) {
 			// a single wavefront walks ~10 rows per microsecond: hand a long run to ingest_pieces_kernel in pieces
@@ -272,10 +278,35 @@ __global__ __launch_bounds__(256) void ingest_runs_kernel(IngestArgs a) {
 					if (big < 0) e.hi = e.lo; // reserved without a run slot: empty, unclaimed
 					pt_entries(a.piece_table)[base + k] = e;
 				}
-				if (big >= 0) continue;
+				if (big >= 0) return;
 			}
 		}
 		ingest_rows<P, WEIGHTED, CENTER>(a, lo, hi, a.moments + (int64_t)slot * L::REC, true, lane);
+	}
+}
+
+template <int P, bool WEIGHTED, bool CENTER>
+__global__ __launch_bounds__(256) void ingest_runs_kernel(IngestArgs a) {
+	const int lane = threadIdx.x & 63;
+	const int n_runs = a.counters[0];
+	const int n_waves = (int)gridDim.x * 4;
+	// (r4) the run list is walked two runs ahead: slot number of run v + 2 and bounds of run v + 1 are loaded before run v is
+	// folded, so that a run's chain of dependent loads is record / row numbers -> rows, not list -> bounds -> record -> ... -> rows
+	// (a run of a few rows — rows in random state order — is latency, not bytes)
+	int v = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (v >= n_runs) return;
+	uint32_t slot = a.run_list[v];
+	uint32_t slot_1 = v + n_waves < n_runs ? a.run_list[v + n_waves] : slot;
+	int64_t lo = a.run_start[slot], hi = a.run_end[slot];
+	for (; v < n_runs; v += n_waves) {
+		const int v2 = v + 2 * n_waves;
+		const uint32_t slot_2 = v2 < n_runs ? a.run_list[v2] : slot_1;
+		const int64_t lo_1 = a.run_start[slot_1], hi_1 = a.run_end[slot_1];
+		ingest_one_run<P, WEIGHTED, CENTER>(a, slot, lo, hi, lane);
+		slot = slot_1;
+		lo = lo_1;
+		hi = hi_1;
+		slot_1 = slot_2;
 	}
 }
 
@@ -326,9 +357,7 @@ hipError_t launch_chunk_p(const IngestArgs &a, hipStream_t st) {
 	// stable sort of (state index, row number) on the bits that n_slots (the key of skipped rows) needs
 	unsigned end_bit = 1;
 	while (end_bit < 32 && ((uint64_t)a.n_slots >> end_bit) != 0) ++end_bit;
-	size_t temp = a.sort_temp_bytes;
-	hipError_t rc = rocprim::radix_sort_pairs(a.sort_temp, temp, a.keys_in, a.keys_out, rocprim::counting_iterator<uint32_t>(0),
-	                                          a.rows_out, (size_t)a.n, 0u, end_bit, st);
+	hipError_t rc = rsort::sort<uint32_t, true>(a.keys_in, a.keys_out, a.rows_out, (size_t)a.n, end_bit, a.sort_temp, a.sort_temp_bytes, st);
 	if (rc != hipSuccess) return rc;
 	hipLaunchKernelGGL(ingest_bounds_kernel, dim3(rows_grid), dim3(256), 0, st, a);
 	unsigned run_grid = (unsigned)((a.n + 3) / 4);
@@ -367,10 +396,7 @@ size_t ingest_piece_table_bytes(int p) {
 }
 
 size_t ingest_sort_temp_bytes(int64_t n) {
-	size_t temp = 0;
-	uint32_t *k = nullptr;
-	(void)rocprim::radix_sort_pairs(nullptr, temp, k, k, rocprim::counting_iterator<uint32_t>(0), k, (size_t)n, 0u, 32u, (hipStream_t) nullptr);
-	return temp;
+	return rsort::temp_bytes<uint32_t, true>((size_t)n);
 }
 
 hipError_t launch_ingest_chunk(const IngestArgs &a, hipStream_t stream) {

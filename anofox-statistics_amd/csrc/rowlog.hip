@@ -16,9 +16,8 @@
 // streaming ones.  Combine re-labels the source slots' rows in the log (one pass over the slot column).
 #include <hip/hip_runtime.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "common.h"
+#include "radix_sort.h"
 
 namespace anofox {
 
@@ -305,16 +304,13 @@ inline unsigned grid_for(int64_t n, int64_t cap = 1 << 16) {
 } // namespace
 
 size_t rowlog_sort_temp_bytes(int64_t n) {
-	size_t a = 0, b = 0;
-	uint64_t *k64 = nullptr;
-	int32_t *k32 = nullptr;
-	(void)rocprim::radix_sort_keys(nullptr, a, k64, k64, (size_t)n, 0u, 64u, (hipStream_t) nullptr);
-	(void)rocprim::radix_sort_keys(nullptr, b, k32, k32, (size_t)n, 0u, 32u, (hipStream_t) nullptr);
+	const size_t a = rsort::temp_bytes<uint64_t, false>((size_t)n), b = rsort::temp_bytes<uint32_t, false>((size_t)n);
 	return a > b ? a : b;
 }
 
 hipError_t launch_rowlog_sort_slots(const int32_t *in, int32_t *out, int64_t n, void *temp, size_t temp_bytes, hipStream_t st) {
-	return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)n, 0u, 31u, st); // slot numbers are < 2^31
+	// slot numbers are < 2^31: sorted as unsigned 31-bit keys ((r4) radix_sort.h; rocPRIM until round 3)
+	return rsort::sort<uint32_t, false>(reinterpret_cast<const uint32_t *>(in), reinterpret_cast<uint32_t *>(out), nullptr, (size_t)n, 31u, temp, temp_bytes, st);
 }
 
 hipError_t launch_rowlog_iota(int32_t *v, int64_t n, hipStream_t st) {
@@ -354,7 +350,7 @@ bool rowlog_key_bits(int64_t log_rows, int64_t k_n, unsigned *row_bits, unsigned
 }
 
 hipError_t launch_rowlog_sort_keys(const uint64_t *in, uint64_t *out, int64_t m, unsigned end_bit, void *temp, size_t temp_bytes, hipStream_t st) {
-	return rocprim::radix_sort_keys(temp, temp_bytes, in, out, (size_t)m, 0u, end_bit, st);
+	return rsort::sort<uint64_t, false>(in, out, nullptr, (size_t)m, end_bit, temp, temp_bytes, st);
 }
 
 hipError_t launch_rowlog_gather(const uint64_t *keys, int64_t m, int64_t k_n, const RowLogSlab *d_slabs, int n_slabs, int p, int weighted,

@@ -2,13 +2,14 @@
 arriving in shuffled group order across many chunks, Combine of partial states, Finalize — against the oracle's fit
 of the same rows grouped (the reference buffers the rows, src/aggregate_functions/ols_aggregate.cpp:120-338, so its
 result is the fit of each group's rows in arrival order)."""
+import os
 import warnings
 
 import numpy as np
 import pytest
 
 import oracle
-from conftest import COEF_RTOL, DIAG_RTOL, assert_records_match, import_pkg, load_csv, load_json, nan_or
+from conftest import COEF_RTOL, DIAG_RTOL, ROOT, assert_records_match, import_pkg, load_csv, load_json, nan_or
 
 pytestmark = pytest.mark.gpu
 
@@ -565,3 +566,15 @@ def test_log_only_state_budget_and_bad_slots(pkg, ctx):
     core, inf, _ = st.finalize(3)
     assert np.all(core[:, p + 5] == 100)
     st.close()
+
+
+def test_radix_sort_against_stable_sort():
+    """csrc/radix_sort.h — the hand-written sort under the ingest passes and the row log (rocPRIM until round 3) — against
+    std::stable_sort: sizes around the wavefront / sub-tile / tile boundaries up to 8 Mi keys, constant / sorted / reversed /
+    two-valued / skewed inputs, every end_bit class, pairs (the value is the original position: stability) and 64-bit keys,
+    a guard element past the output and an untouched input (csrc/tools/radix_sort_check.hip, built with the library)."""
+    import subprocess
+    exe = os.path.join(ROOT, "anofox-statistics_amd", "csrc", "tools", "radix_sort_check")
+    assert os.path.exists(exe), "csrc/tools/radix_sort_check is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "radix_sort_check: ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
