@@ -4,6 +4,8 @@
 `group_base` > 0 to every kernel of the later slabs; the host entry point streams batches of more than 32M rows
 through the GPU in row slabs.  These tests make batches that need several slabs and compare groups from the FIRST,
 a MIDDLE and the LAST slab with the oracle, plus a whole-batch linearity property."""
+import os
+
 import numpy as np
 import pytest
 
@@ -167,3 +169,53 @@ def test_host_entry_point_beyond_one_row_slab(p, model):
         rcore, rinf = oracle.fit_groups(y[r0:r1], [c[r0:r1] for c in x_cols], offs[g0:g1 + 1] - r0,
                                         w=(w[r0:r1] if w is not None else None), model=model, n_threads=8, **kw)
         assert_records_match(core[g0:g1], rcore, p, inf[g0:g1], rinf, what=f"host slabs {model} [{g0}, {g1})")
+
+
+_OVERLAP_SCRIPT = r"""
+import hashlib, importlib, sys
+import torch
+sys.path.insert(0, sys.argv[1])
+pkg = importlib.import_module("anofox-statistics_amd")
+synth = importlib.import_module("anofox-statistics_amd.synth")
+p, n = int(sys.argv[2]), int(sys.argv[3])
+G = int(sys.argv[4])
+torch.manual_seed(5)
+offs, y, x_cols, w = synth.make_grouped(G, n, p, weights=True, device="cuda:0", chunk_groups=2048)
+ctx = pkg.Context(0)
+h = hashlib.sha256()
+for model, kw in (("ols", dict(compute_inference=True, hc_type="hc3")), ("wls", dict(compute_inference=True)),
+                  ("ridge", dict(alpha=0.5, compute_inference=True)), ("ols", dict(fit_intercept=False))):
+    opts = pkg.RegressionOptions(**kw).batch_options(model)
+    for _ in range(2):                                   # twice: buffers and events of the first call are reused by the second
+        core, inf = ctx.fit_batch_device(offs, y, x_cols, w if model == "wls" else None, opts)
+        torch.cuda.synchronize()
+        assert bool((core[:, p + 5] == 0).all())
+        h.update(core.cpu().numpy().tobytes())
+        if inf is not None:
+            h.update(inf.cpu().numpy().tobytes())
+print("records", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("p,n", [(128, 140), (40, 60)])
+def test_slab_overlap_on_and_off_agree_bit_for_bit(p, n, tmp_path):
+    """The slabs of a wide batch are solved on a second stream under the next slab's accumulate kernel (ANOFOX_WIDE_OVERLAP,
+    default on): doubled moment / list buffers, four events, and kernels of two streams sharing the context's tables.  A
+    regression in that sharing would show as a record that depends on timing — so: the same three-slab batch with inference,
+    HC3, weights and ridge, with the overlap on and off (one process each: the switch is read once), every record compared
+    bit for bit."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    release_device_memory()
+    slab = _slab_groups(p)
+    G = int(2.3 * slab) + 5
+    script = tmp_path / "overlap_case.py"
+    script.write_text(_OVERLAP_SCRIPT)
+    digests = {}
+    for setting in ("1", "0"):
+        env = dict(os.environ, ANOFOX_WIDE_OVERLAP=setting)
+        r = subprocess.run([sys.executable, str(script), ROOT, str(p), str(n), str(G)], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        digests[setting] = [ln for ln in r.stdout.splitlines() if ln.startswith("records ")][-1]
+    assert digests["1"] == digests["0"]
