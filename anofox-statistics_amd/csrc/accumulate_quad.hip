@@ -355,18 +355,22 @@ __device__ __forceinline__ bool quad_accumulate_rows(const WideArgs &args, int64
 // (M0 is written in the statement that uses it), so the compiler neither counts nor waits for them: the loop waits with
 // vmcnt(number of columns) — one block stays in flight — before it reads a half.  What is left per 32-row block: 4 NB - 1 DMA
 // instructions, 2 x (NB ds_read_b64 + NB subtractions + NB (NB + 1) / 2 v_mfma_f64_4x4x4) and nothing else.
-constexpr int kQuadDmaStride = 72; // doubles per column of the ring: 2 x 32 rows + 8 (= 8 mod 32: conflict-free ds_read_b64, see above)
-__host__ __device__ constexpr int quad_dma_slice_doubles(int p) {
-	const int data = (p + 1) * kQuadDmaStride;
+// doubles per column of a ring of RING 32-row blocks: 32 RING + 8 (= 8 mod 32: conflict-free ds_read_b64, see above)
+__host__ __device__ constexpr int quad_dma_stride(int ring) { return 32 * ring + 8; }
+__host__ __device__ constexpr int quad_dma_slice_doubles(int p, int ring) {
+	const int data = (p + 1) * quad_dma_stride(ring);
 	const int R = 4 * quad_blocks(p);
 	const int image = R * R + 2 * R;
 	return data > image ? data : image;
 }
 
-template <int NB>
+// RING = 2: block k + 1 lands while block k is read (one block in flight per wavefront).  RING = 3: blocks k + 1 and k + 2 are in
+// flight — the bytes in flight are what the HBM latency under load is paid with (one block per wavefront, eight wavefronts per
+// CU: 17.8 MB on the chip at p = 33, 3.8 us at the measured 4.7 TB/s) — at the price of a slice half as large again.
+template <int NB, int RING>
 __device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
 	constexpr int NPAIR = NB * (NB + 1) / 2;
-	constexpr int RS = kQuadDmaStride;
+	constexpr int RS = quad_dma_stride(RING);
 	const int p = args.p;
 	const int k = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3;
 	const int rsub = 4 * k + b;
@@ -416,9 +420,23 @@ __device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t
 			}
 		}
 	};
+	// all but the youngest block have landed (the loads retire in order; ncol = p + 1 of them per block, 4 NB - 4 .. 4 NB - 1)
+	auto wait_but_one_block = [&]() {
+		switch (p + 1 - (4 * NB - 4)) { // wave-uniform
+		case 0: lds_dma_wait_but<4 * NB - 4>(); break;
+		case 1: lds_dma_wait_but<4 * NB - 3>(); break;
+		case 2: lds_dma_wait_but<4 * NB - 2>(); break;
+		default: lds_dma_wait_but<4 * NB - 1>(); break;
+		}
+	};
 	int h = 0;
 	dma(lo, 0);
-	lds_dma_wait_all();
+	if (RING == 3 && lo + 32 < hi) {
+		dma(lo + 32, 1);
+		wait_but_one_block();
+	} else {
+		lds_dma_wait_all();
+	}
 	__builtin_amdgcn_wave_barrier();
 	{ // the shift: the group's first row (the constants are not shifted)
 #pragma unroll
@@ -428,14 +446,28 @@ __device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t
 	// full blocks in a loop without a branch around the matrix instructions, the partial last block after it (with the choice
 	// inside the loop the compiler copies the accumulators at every join)
 	int64_t blk = lo;
-	for (; blk + 32 <= hi; blk += 32, h ^= 1) {
-		if (blk + 32 < hi) dma(blk + 32, h ^ 1); // lands while this block's steps run
-		__builtin_amdgcn_wave_barrier();
-		const double *hb = buf + 32 * h;
-		step(hb, 0, true, 0xFFFFu);
-		step(hb, 1, true, 0xFFFFu);
-		__builtin_amdgcn_wave_barrier(); // the reads of this half before the DMA that refills it (next trip but one)
-		lds_dma_wait_all();              // the next block has landed (it had this block's steps to do so)
+	if constexpr (RING == 2) {
+		for (; blk + 32 <= hi; blk += 32, h ^= 1) {
+			if (blk + 32 < hi) dma(blk + 32, h ^ 1); // lands while this block's steps run
+			__builtin_amdgcn_wave_barrier();
+			const double *hb = buf + 32 * h;
+			step(hb, 0, true, 0xFFFFu);
+			step(hb, 1, true, 0xFFFFu);
+			__builtin_amdgcn_wave_barrier(); // the reads of this half before the DMA that refills it (next trip but one)
+			lds_dma_wait_all();              // the next block has landed (it had this block's steps to do so)
+		}
+	} else {
+		for (; blk + 32 <= hi; blk += 32, h = h == 2 ? 0 : h + 1) {
+			const bool more = blk + 64 < hi;
+			if (more) dma(blk + 64, h == 0 ? 2 : h - 1); // the third of the ring that the block before this one was read from
+			__builtin_amdgcn_wave_barrier();
+			const double *hb = buf + 32 * h;
+			step(hb, 0, true, 0xFFFFu);
+			step(hb, 1, true, 0xFFFFu);
+			__builtin_amdgcn_wave_barrier();
+			if (more) wait_but_one_block(); // block + 32 has landed, block + 64 may still be under way
+			else lds_dma_wait_all();
+		}
 	}
 	if (blk < hi) {
 		const int64_t left = hi - blk;
@@ -472,8 +504,9 @@ __global__ __launch_bounds__(256, WPS) void accumulate_quad_kernel(WideArgs args
 	}
 	double *rec = args.moments + gl * (int64_t)wide_record_len(T);
 	if constexpr (MODE == 3) { // the speculative version on LDS-DMA (its own slice size)
-		double *slice = quad_lds + (threadIdx.x >> 6) * quad_dma_slice_doubles(args.p);
-		if (hi > lo && quad_spec_dma_rows<NB>(args, lo, hi, rec, lane, slice)) return;
+		// (MODE 3: the template's RL parameter is the ring depth)
+		double *slice = quad_lds + (threadIdx.x >> 6) * quad_dma_slice_doubles(args.p, RL);
+		if (hi > lo && quad_spec_dma_rows<NB, RL>(args, lo, hi, rec, lane, slice)) return;
 		if (lane == 0) args.refine_list[atomicAdd(args.refine_count + kWideRedoCounter, 1)] = (int32_t)gl;
 		return;
 	}
@@ -524,13 +557,14 @@ hipError_t launch_quad_nb(const WideArgs &a, hipStream_t stream) {
 // NB = 8, 9 (p = 27 .. 34): only the speculative kernel exists here (the full version's registers do not fit two waves per
 // SIMD, see below); its give-ups go to accumulate_mid (p <= 32) or accumulate_wide (p = 33, 34: three column tiles, whose
 // segment table also takes this kernel's very large groups).
-template <int NB, int WPS>
+template <int NB, int WPS, int RING>
 hipError_t launch_quad_spec_only(const WideArgs &a, hipStream_t stream) {
-	constexpr int RL = 1;
-	// eight wavefronts per CU while their slices fit its 160 KB of LDS (p <= 34: 35 columns x 576 bytes x 8 = 161 280 bytes), six
-	// in workgroups of two beyond
-	const size_t slice_bytes = (size_t)quad_dma_slice_doubles(a.p) * sizeof(double);
-	const int waves = 8 * slice_bytes <= (size_t)160 * 1024 ? 4 : 2;
+	constexpr int RL = RING;
+	// eight wavefronts per CU while their slices fit its 160 KB of LDS (RING = 2, p <= 34: 35 columns x 576 bytes x 8 = 161 280
+	// bytes) in workgroups of four; beyond, the workgroup size that leaves the fewest bytes of the CU's LDS unused
+	const size_t slice_bytes = (size_t)quad_dma_slice_doubles(a.p, RING) * sizeof(double);
+	const int fit = (int)(((size_t)160 * 1024) / slice_bytes);
+	const int waves = fit >= 8 ? 4 : (fit % 2 == 0 ? 2 : 1);
 	const dim3 grid((unsigned)((a.n_groups + waves - 1) / waves)), block(64 * waves);
 	const size_t lds_bytes = (size_t)waves * slice_bytes;
 	static const bool attr_set = [] {
@@ -573,6 +607,7 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	// per SIMD was measured slower for every NB >= 4 (spills).  ANOFOX_QUAD_RL=1/2 forces one.
 	static const int env_rl = getenv("ANOFOX_QUAD_RL") ? atoi(getenv("ANOFOX_QUAD_RL")) : 0;
 	const int nb = quad_blocks(a.p);
+	static const bool ring3 = getenv("ANOFOX_QUAD_RING") && atoi(getenv("ANOFOX_QUAD_RING")) == 3; // (measurement switch)
 	int rl = (a.p <= 11 || (a.p >= 15 && a.p <= 17)) ? 2 : 1;
 	if (env_rl == 1 || (env_rl == 2 && a.p <= 18)) rl = env_rl;
 	switch (nb) { // p = 9, 10 | 11..14 | 15..18 | 19..22 | 23..26 | 27..30 | 31..34
@@ -581,10 +616,10 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	case 5: return rl == 2 ? launch_quad_nb<5, 2, 2>(a, stream) : launch_quad_nb<5, 1, 2>(a, stream);
 	case 6: return launch_quad_nb<6, 1, 2>(a, stream);
 	case 7: return launch_quad_nb<7, 1, 2>(a, stream);
-	case 8: return launch_quad_spec_only<8, 2>(a, stream);
-	case 9: return launch_quad_spec_only<9, 2>(a, stream);
-	case 10: return launch_quad_spec_only<10, 2>(a, stream);
-	case 11: return launch_quad_spec_only<11, 2>(a, stream);
+	case 8: return ring3 ? launch_quad_spec_only<8, 2, 3>(a, stream) : launch_quad_spec_only<8, 2, 2>(a, stream);
+	case 9: return ring3 ? launch_quad_spec_only<9, 2, 3>(a, stream) : launch_quad_spec_only<9, 2, 2>(a, stream);
+	case 10: return ring3 ? launch_quad_spec_only<10, 2, 3>(a, stream) : launch_quad_spec_only<10, 2, 2>(a, stream);
+	case 11: return ring3 ? launch_quad_spec_only<11, 2, 3>(a, stream) : launch_quad_spec_only<11, 2, 2>(a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

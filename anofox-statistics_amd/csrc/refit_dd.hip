@@ -190,11 +190,11 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_kernel(RefitArgs args) {
 				if (l.nc[j]) {
 					++pe;
 					l.col[pe] = j;
-					l.first[pe] = icpt ? l.fx[j] : 0.0;
+					l.first[pe] = icpt && !weighted ? l.fx[j] : 0.0; // (weighted: the rows are SCALED below, not shifted)
 				}
 			}
 			l.col[pe + 1] = -1;
-			l.first[pe + 1] = icpt ? l.fx[p] : 0.0;
+			l.first[pe + 1] = icpt && !weighted ? l.fx[p] : 0.0;
 			l.flag[kDdTileRows - 1] = pe; // (hand-over below)
 		}
 		__syncthreads();
@@ -221,7 +221,13 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_kernel(RefitArgs args) {
 		}
 		// ---- the moments over the valid rows, tile by tile ----
 		double cnt_rows = 0.0;
-		// one tile of rows into l.tile (z = (1, x - first .., y - first) per row, 0 for rows that do not take part) and l.wrow
+		// one tile of rows into l.tile, 0 for rows that do not take part, and l.wrow.  Unweighted: z = (1, x - first .., y - first).
+		// Weighted: z = (s, fl(s x) .., fl(s y)) with s = fl(sqrt(w)) — the rows of the sqrt(w)-SCALED design as the reference's
+		// algorithm class forms them in working precision (wls.rs:171-176 hands the weights to the solver; the oracle scales the
+		// rows, anofox_oracle.c "sw = sqrt(w)").  The exact weighted problem, sum w z z', differs from that one by a relative
+		// perturbation eps of every entry of the design: cond(X) eps in the coefficients — 1.1e-9 on an exactly determined
+		// 30 x 30 system with cond 2.4e8 (deep sweep, seed 92215), where the oracle agrees with the exact solution of the SCALED
+		// system to 2e-13.  Parity is with the reference's formulation, so the scaled rows are what is summed here, exactly.
 		auto load_tile = [&](int64_t r0) {
 			tile_flags(r0);
 			for (int e = tid; e < kDdTileRows * m; e += kDdThreads) {
@@ -229,9 +235,9 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_kernel(RefitArgs args) {
 				const int64_t r = r0 + rr;
 				double z = 0.0;
 				if (r < hi && l.wrow[rr] != 0.0) {
-					if (v == 0) z = 1.0;
-					else if (v == yv) z = args.y[r] - l.first[yv];
-					else z = args.x[l.col[v]][r] - l.first[v];
+					const double raw = v == 0 ? 1.0 : (v == yv ? args.y[r] : args.x[l.col[v]][r]);
+					if (weighted) z = sqrt(l.wrow[rr]) * raw;
+					else z = v == 0 ? 1.0 : raw - l.first[v];
 				}
 				l.tile[rr * m + v] = z;
 			}
@@ -247,10 +253,9 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_kernel(RefitArgs args) {
 #pragma unroll
 				for (int k = 0; k < kDdPerThread; ++k) {
 					if (tid + k * kDdThreads < E) {
-						// (the product z_i z_j exactly, THEN the weight: rounding w z_i first perturbs every entry of the
-						// matrix on its own — cond(X)^2 eps again, seen as 3e-9 on a weighted 31-column design)
-						const dd zz2 = dd_prod(zr[eij[k] >> 8], zr[eij[k] & 255]);
-						acc[k] = acc[k] + (weighted ? dd_mul_d(zz2, wv) : zz2);
+						// (the product z_i z_j exactly; the weight is in the rows, SYMMETRICALLY — rounding w z_i and multiplying by
+						// z_j perturbs every entry of the matrix on its own: cond(X)^2 eps, seen as 3e-9 on a weighted 31-column design)
+						acc[k] = acc[k] + dd_prod(zr[eij[k] >> 8], zr[eij[k] & 255]);
 					}
 				}
 			}
@@ -426,8 +431,9 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_kernel(RefitArgs args) {
 			if (l.live[j]) core[l.col[j]] = dd_to_double(l.beta[j]);
 		if (inf && hc_active) {
 			// ---- HC0 .. HC3 (ols.rs:209-245, wls.rs:230-252; the estimator of solve_wide.hip's hc_wide_kernel): one more pass over
-			// the rows with S^-1 = W'W applied in double-double.  c = x - xbar (x without an intercept), u = S^-1 c,
-			// h = w (1 / sum w + c'u), e = y - fit, omega = w^2 e^2 [n / df | 1 / (1 - h) | 1 / (1 - h)^2], V_jj = sum omega u_j^2.
+			// the rows with S^-1 = W'W applied in double-double, in the variables of the tile (z_0 = s = 1 or sqrt(w)): c = z - xbar z_0
+			// (z without an intercept), u = S^-1 c, h = z_0^2 / sum w + c'u, e = (y - fit) z_0, omega = e^2 [n / df | 1 / (1 - h) |
+			// 1 / (1 - h)^2], V_jj = sum omega u_j^2 — MacKinnon-White on the sqrt(w)-scaled design, as the oracle applies it.
 			const int hc = args.hc_type;
 			const double hc1 = cnt / df, h0 = icpt ? 1.0 / dd_to_double(sw) : 0.0;
 			// the centred variables: c_j = z_j - s_j / sw (z is shifted by the first row already)
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_kernel(RefitArgs args) {
 					const double *zr = l.tile + rr * m;
 					// c, then t = W c, are published through two small LDS arrays (every thread needs all of them)
 					dd cj = dd{0.0, 0.0};
-					if (j <= pe) cj = dd_make(zr[j]) - l.zv[j];
+					if (j <= pe) cj = dd_make(zr[j]) - dd_mul_d(l.zv[j], zr[0]);
 					__syncthreads();
 					if (j <= pe) {
 						l.hc_c[2 * j] = cj.h;
@@ -467,10 +473,10 @@ __global__ __launch_bounds__(kDdThreads) void refit_dd_kernel(RefitArgs args) {
 					// c'u and b'c
 					const dd hp = block_sum_dd(mine ? cj * uj : dd{0.0, 0.0}, l.red, tid);
 					const dd ep = block_sum_dd(mine ? l.beta[j] * cj : dd{0.0, 0.0}, l.red, tid);
-					const dd ycen = dd_make(zr[yv]) - l.zv[yv]; // y - ybar (y itself without an intercept)
+					const dd ycen = dd_make(zr[yv]) - dd_mul_d(l.zv[yv], zr[0]); // (y - ybar) z_0 (y z_0 without an intercept)
 					const double e = dd_to_double(ycen - ep);
-					const double lev = wv * (h0 + dd_to_double(hp));
-					double om = wv * wv * e * e;
+					const double lev = zr[0] * zr[0] * h0 + dd_to_double(hp);
+					double om = e * e;
 					if (hc == ANOFOX_HC_HC1) om *= hc1;
 					else if (hc == ANOFOX_HC_HC2) om /= (1.0 - lev);
 					else if (hc == ANOFOX_HC_HC3) om /= (1.0 - lev) * (1.0 - lev);

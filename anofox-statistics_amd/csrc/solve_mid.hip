@@ -108,10 +108,12 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 
 	// Cholesky (left-looking, in place), deactivating constant and aliased columns
 	double min_ratio = 1.0;
+	bool band = false; // (r4) a column dropped with a pivot that is not clearly zero: queued, the refit decides (solve_narrow.hip)
 	for (int j = 0; j < p; ++j) {
 		double d = A[tri(j, j)];
 		for (int k = 0; k < j; ++k) d -= A[tri(j, k)] * A[tri(j, k)];
 		const bool ok = ((active >> j) & 1u) && (d > kAliasTolM * diag0[j]) && (d > 0.0);
+		band = band || (((active >> j) & 1u) && !ok && d > 1e-15 * diag0[j]);
 		if (!ok) active &= ~(1u << j);
 		if (ok) min_ratio = fmin(min_ratio, d / diag0[j]);
 		const double ljj = ok ? sqrt(d) : 1.0;
@@ -153,7 +155,7 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 			bb += beta[i] * beta[i];
 		}
 		rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
-		refine = !(rss > kRefineTolM * tss) || (min_ratio < kPivotWarnM) || glmnet_cancels;
+		refine = !(rss > kRefineTolM * tss) || (min_ratio < kPivotWarnM) || glmnet_cancels || band;
 		double bmax = 0.0;
 		for (int i = 0; i < p; ++i) bmax = fmax(bmax, ((active >> i) & 1u) ? fabs(beta[i]) : 0.0);
 		for (int i = 0; i < p; ++i) refine = refine || (((active >> i) & 1u) && coef_bound_weak(beta[i], bmax, diag0[i], tss, min_ratio));

@@ -29,6 +29,7 @@ static_assert(sizeof(TcritSlot) * kTcritSlots == kTcritTableBytes, "t memo does 
 namespace {
 
 constexpr double kAliasTol = 1e-11;   // pivot / original diagonal below this => column aliased (collinear)
+constexpr double kAliasBand = 1e-15;  // ... and above this: not clearly zero — the refit applies the reference's rule
 constexpr double kRefineTol = 1e-7;   // RSS / TSS below this => recompute RSS from residuals
 constexpr double kPivotWarn = 1e-3;   // smallest pivot ratio below this => iterative refinement
 
@@ -131,12 +132,17 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 #pragma unroll
 		for (int j = 0; j < P; ++j) diag0[j] = A[j][j];
 		double min_ratio = 1.0;
+		// (r4) a non-constant column dropped with a pivot that is not clearly zero (1e-15 .. 1e-11 of the diagonal: sin of its angle to
+		// the earlier columns 3e-8 .. 3e-6) may be one the reference's rule (remaining norm >= 1e-7 of the column's norm) keeps: the
+		// group is queued, and the double-double refit decides with that rule (refit_dd.hip).  Exact copies leave |pivot| <~ 1e-16.
+		bool band = false;
 #pragma unroll
 		for (int j = 0; j < P; ++j) {
 			double d = A[j][j];
 #pragma unroll
 			for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
 			const bool ok = active[j] && (d > kAliasTol * diag0[j]) && (d > 0.0);
+			band = band || (active[j] && !ok && d > kAliasBand * diag0[j]);
 			active[j] = ok;
 			if (ok) min_ratio = fmin(min_ratio, d / diag0[j]);
 			const double ljj = ok ? sqrt(d) : 1.0;
@@ -185,7 +191,7 @@ __device__ void solve_one(const BatchArgs &args, int64_t g) {
 #pragma unroll
 			for (int i = 0; i < P; ++i) { zz += zf[i] * zf[i]; bc += beta[i] * c[i]; bb += beta[i] * beta[i]; }
 			rss = (model == ANOFOX_HIP_MODEL_RIDGE) ? tss - bc - lam * bb : tss - zz;
-			refine = !(rss > kRefineTol * tss) || (min_ratio < kPivotWarn) || glmnet_cancels;
+			refine = !(rss > kRefineTol * tss) || (min_ratio < kPivotWarn) || glmnet_cancels || band;
 			double bmax = 0.0;
 #pragma unroll
 			for (int i = 0; i < P; ++i) bmax = fmax(bmax, active[i] ? fabs(beta[i]) : 0.0);
