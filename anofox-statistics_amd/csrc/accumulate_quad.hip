@@ -480,6 +480,105 @@ __device__ __forceinline__ bool quad_spec_dma_rows(const WideArgs &args, int64_t
 	return quad_finish<NB, true>(args, rec, lane, buf, acc, first, dmax, isx_prev, isx_last, 0, lo, hi);
 }
 
+// ---- (r4) the same on `global_load_lds_dwordx4`: 128 rows of a column per wave-instruction ---------------------------------
+// What the dword form cannot give is the REQUEST SIZE: 256 bytes per column and instruction, 70 000 column streams in flight on
+// the chip.  The streaming kernels of this library that reach 6 TB/s ask for 1 KB per column and instruction (accumulate_narrow:
+// 16-byte loads, 128-row tiles; its 512-byte variant was 25 % slower, profiles/r03_hbm_read_variants.txt), the ones that ask for
+// 512 bytes reach 5.2-5.4 (accumulate_quad up to p = 26), the ones that ask for 256 stay at 4.1-5.0 (this kernel's dword form,
+// accumulate_wide) — and a third block in flight did not help the dword form (ANOFOX_QUAD_RING=3: slower at every width), so
+// bytes in flight are not what is missing.  Here a block is 128 rows, ONE buffer (stride 136 = 8 mod 32 doubles per column: the
+// slice of a 34-column group is 37 KB, four wavefronts per CU): load the block, wait, run its eight 16-row steps, next block —
+// nothing overlaps inside a wavefront, the other three of the CU's wavefronts cover the wait.  The last rows of a group (fewer
+// than 128) come in 32-row pieces through the dword form, whose clamped lane offsets touch nothing behind the group.
+template <int NB>
+__device__ __forceinline__ bool quad_spec_dma_rows_x4(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
+	constexpr int NPAIR = NB * (NB + 1) / 2;
+	constexpr int BR = 128;
+	constexpr int RS = quad_dma_stride(4);
+	const int p = args.p;
+	const int k = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3;
+	const int rsub = 4 * k + b;
+	const int base_off = c4 * RS + rsub;
+	const int c_last = 4 * (NB - 1) + c4;
+	const bool rd_last = c_last <= p;
+	const int last_off = (rd_last ? c_last : p) * RS + rsub;
+	const double fill_last = c_last == p + 1 ? 1.0 : 0.0;
+	const bool isx_prev = 4 * (NB - 2) + c4 < p, isx_last = c_last < p;
+	const unsigned lds0 = lds_dma_address(buf);
+	double acc[NPAIR];
+#pragma unroll
+	for (int t = 0; t < NPAIR; ++t) acc[t] = 0.0;
+	double first[NB], dmax[NB];
+#pragma unroll
+	for (int g = 0; g < NB; ++g) first[g] = dmax[g] = 0.0;
+	const lds_dma_table_t tab = lds_dma_table((unsigned)offsetof(WideArgs, x_table));
+	auto step = [&](int s, bool valid_all, unsigned rowmask) {
+		const long long rm = valid_all ? -1ll : -(long long)((rowmask >> rsub) & 1u);
+		double d[NB];
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+			double v;
+			if (g < NB - 1) {
+				v = buf[base_off + 16 * s + 4 * g * RS];
+			} else {
+				const double raw = buf[last_off + 16 * s];
+				v = rd_last ? raw : fill_last;
+			}
+			double dev = v - first[g];
+			if (!valid_all) dev = quad_mask(dev, rm);
+			d[g] = dev;
+		}
+		int t = 0;
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+#pragma unroll
+			for (int h = g; h < NB; ++h) {
+				acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(d[g], d[h], acc[t], 0, 0, 0);
+				++t;
+			}
+		}
+	};
+	auto fetch_first = [&]() { // the shift: the group's first row (the constants are not shifted)
+#pragma unroll
+		for (int g = 0; g < NB - 1; ++g) first[g] = buf[c4 * RS + 4 * g * RS];
+		first[NB - 1] = rd_last ? buf[(rd_last ? c_last : p) * RS] : 0.0;
+	};
+	int64_t blk = lo;
+	if (lo + BR <= hi) {
+		// full blocks; the first one is peeled for the shift (a branch around the matrix instructions inside the loop makes the
+		// compiler copy the accumulators at the join)
+		lds_dma_block<RS * 8, 4 * NB - 1, true>(tab, p + 1, blk, (unsigned)lane * 16u, lds0);
+		lds_dma_wait_all();
+		__builtin_amdgcn_wave_barrier();
+		fetch_first();
+#pragma unroll
+		for (int s = 0; s < BR / 16; ++s) step(s, true, 0xFFFFu);
+		__builtin_amdgcn_wave_barrier(); // the reads of this block before the DMA that overwrites it
+		for (blk += BR; blk + BR <= hi; blk += BR) {
+			lds_dma_block<RS * 8, 4 * NB - 1, true>(tab, p + 1, blk, (unsigned)lane * 16u, lds0);
+			lds_dma_wait_all();
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int s = 0; s < BR / 16; ++s) step(s, true, 0xFFFFu);
+			__builtin_amdgcn_wave_barrier();
+		}
+	}
+	if (blk < hi) { // the last 1 .. 127 rows: 32-row pieces through the dword form
+		const int left = (int)(hi - blk);
+		for (int sub = 0; 32 * sub < left; ++sub)
+			lds_dma_block<RS * 8, 4 * NB - 1, false>(tab, p + 1, blk + 32 * sub, lds_dma_offsets(lane, hi - (blk + 32 * sub)), lds0 + (unsigned)sub * 256u);
+		lds_dma_wait_all();
+		__builtin_amdgcn_wave_barrier();
+		if (blk == lo) fetch_first();
+		for (int s = 0; 16 * s < left; ++s) {
+			const int rows = left - 16 * s;
+			step(s, false, rows >= 16 ? 0xFFFFu : (1u << (unsigned)rows) - 1u);
+		}
+	}
+	lds_dma_wait_all();
+	return quad_finish<NB, true>(args, rec, lane, buf, acc, first, dmax, isx_prev, isx_last, 0, lo, hi);
+}
+
 // MODE 0: the full version on every group; 1: the speculative version, give-ups (and empty groups) listed for the full one —
 // the list borrows the refine queue and its counter word kWideRedoCounter, as accumulate_wide's does; 2: the full version on
 // the listed groups (launched with the batch's grid: one scalar load and out for the wavefronts beyond the list).
@@ -506,7 +605,11 @@ __global__ __launch_bounds__(256, WPS) void accumulate_quad_kernel(WideArgs args
 	if constexpr (MODE == 3) { // the speculative version on LDS-DMA (its own slice size)
 		// (MODE 3: the template's RL parameter is the ring depth)
 		double *slice = quad_lds + (threadIdx.x >> 6) * quad_dma_slice_doubles(args.p, RL);
-		if (hi > lo && quad_spec_dma_rows<NB, RL>(args, lo, hi, rec, lane, slice)) return;
+		if constexpr (RL == 4) { // (128-row blocks on the dwordx4 form)
+			if (hi > lo && quad_spec_dma_rows_x4<NB>(args, lo, hi, rec, lane, slice)) return;
+		} else {
+			if (hi > lo && quad_spec_dma_rows<NB, RL>(args, lo, hi, rec, lane, slice)) return;
+		}
 		if (lane == 0) args.refine_list[atomicAdd(args.refine_count + kWideRedoCounter, 1)] = (int32_t)gl;
 		return;
 	}
@@ -607,7 +710,7 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	// per SIMD was measured slower for every NB >= 4 (spills).  ANOFOX_QUAD_RL=1/2 forces one.
 	static const int env_rl = getenv("ANOFOX_QUAD_RL") ? atoi(getenv("ANOFOX_QUAD_RL")) : 0;
 	const int nb = quad_blocks(a.p);
-	static const bool ring3 = getenv("ANOFOX_QUAD_RING") && atoi(getenv("ANOFOX_QUAD_RING")) == 3; // (measurement switch)
+	static const int ring = getenv("ANOFOX_QUAD_RING") ? atoi(getenv("ANOFOX_QUAD_RING")) : 2; // (measurement switch: 3 = three 32-row blocks, 4 = 128-row blocks on dwordx4)
 	int rl = (a.p <= 11 || (a.p >= 15 && a.p <= 17)) ? 2 : 1;
 	if (env_rl == 1 || (env_rl == 2 && a.p <= 18)) rl = env_rl;
 	switch (nb) { // p = 9, 10 | 11..14 | 15..18 | 19..22 | 23..26 | 27..30 | 31..34
@@ -616,10 +719,10 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	case 5: return rl == 2 ? launch_quad_nb<5, 2, 2>(a, stream) : launch_quad_nb<5, 1, 2>(a, stream);
 	case 6: return launch_quad_nb<6, 1, 2>(a, stream);
 	case 7: return launch_quad_nb<7, 1, 2>(a, stream);
-	case 8: return ring3 ? launch_quad_spec_only<8, 2, 3>(a, stream) : launch_quad_spec_only<8, 2, 2>(a, stream);
-	case 9: return ring3 ? launch_quad_spec_only<9, 2, 3>(a, stream) : launch_quad_spec_only<9, 2, 2>(a, stream);
-	case 10: return ring3 ? launch_quad_spec_only<10, 2, 3>(a, stream) : launch_quad_spec_only<10, 2, 2>(a, stream);
-	case 11: return ring3 ? launch_quad_spec_only<11, 2, 3>(a, stream) : launch_quad_spec_only<11, 2, 2>(a, stream);
+	case 8: return ring == 4 ? launch_quad_spec_only<8, 2, 4>(a, stream) : ring == 3 ? launch_quad_spec_only<8, 2, 3>(a, stream) : launch_quad_spec_only<8, 2, 2>(a, stream);
+	case 9: return ring == 4 ? launch_quad_spec_only<9, 2, 4>(a, stream) : ring == 3 ? launch_quad_spec_only<9, 2, 3>(a, stream) : launch_quad_spec_only<9, 2, 2>(a, stream);
+	case 10: return ring == 4 ? launch_quad_spec_only<10, 2, 4>(a, stream) : ring == 3 ? launch_quad_spec_only<10, 2, 3>(a, stream) : launch_quad_spec_only<10, 2, 2>(a, stream);
+	case 11: return ring == 4 ? launch_quad_spec_only<11, 2, 4>(a, stream) : ring == 3 ? launch_quad_spec_only<11, 2, 3>(a, stream) : launch_quad_spec_only<11, 2, 2>(a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -16,19 +16,41 @@ __device__ __forceinline__ unsigned lds_dma_address(const double *slice) {
 	return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) double *)const_cast<double *>(slice));
 }
 
-// one column: 256 bytes from src + voff (per lane) to LDS address dst + 4 * lane
+// one column: 256 bytes from src + voff (per lane) to LDS address dst + 4 * lane.  X4 (`global_load_lds_dwordx4`, new on gfx950):
+// 1024 bytes = 128 rows of the column per wave-instruction, 16 bytes per lane to dst + 16 * lane (tools/lds_dma_x4_probe.hip) —
+// a request of 1 KB per column where the dword form makes four of 256 bytes.
+template <bool X4 = false>
 __device__ __forceinline__ void lds_dma1(unsigned voff, unsigned dst, const double *src) {
 	unsigned keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-	             : "=&s"(keep)
-	             : "v"(voff), "s"(dst), "s"(src)
-	             : "memory");
+	if constexpr (X4) {
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+		             : "=&s"(keep)
+		             : "v"(voff), "s"(dst), "s"(src)
+		             : "memory");
+	} else {
+		asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+		             : "=&s"(keep)
+		             : "v"(voff), "s"(dst), "s"(src)
+		             : "memory");
+	}
 }
 
 // four columns whose destinations are STRIDE bytes apart: M0 is saved once, stepped per load and restored
-template <int STRIDE>
+template <int STRIDE, bool X4 = false>
 __device__ __forceinline__ void lds_dma4(unsigned voff, unsigned dst, const double *c0, const double *c1, const double *c2, const double *c3) {
 	unsigned keep;
+	if constexpr (X4) {
+		asm volatile("s_mov_b32 %0, m0\n\t"
+		             "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+		             "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+		             "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+		             "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
+		             "s_mov_b32 m0, %0"
+		             : "=&s"(keep)
+		             : "v"(voff), "s"(dst), "s"(c0), "s"(c1), "s"(c2), "s"(c3), "n"(STRIDE)
+		             : "memory", "scc");
+		return;
+	}
 	asm volatile("s_mov_b32 %0, m0\n\t"
 	             "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\t"
 	             "s_add_u32 m0, m0, %7\n\ts_nop 0\n\tglobal_load_lds_dword %1, %4\n\t"
@@ -79,7 +101,7 @@ __device__ __forceinline__ LdsDmaPtr8 lds_dma_load8(lds_dma_table_t &tab, int c0
 }
 
 // MAXCOLS: compile-time bound of ncol (the loop is unrolled over groups of eight; a group beyond ncol costs one scalar branch)
-template <int STRIDE, int MAXCOLS>
+template <int STRIDE, int MAXCOLS, bool X4 = false>
 __device__ __forceinline__ void lds_dma_block(lds_dma_table_t tab, int ncol, int64_t blk, unsigned voff, unsigned dst) {
 	constexpr int NG = (MAXCOLS + 7) / 8;
 	// (the column count is loop-invariant for the caller's row loop: left alone, the compiler evaluates the ~3 comparisons per
@@ -97,11 +119,11 @@ __device__ __forceinline__ void lds_dma_block(lds_dma_table_t tab, int ncol, int
 			const int c = 8 * g + 4 * h;
 			const unsigned d = dst + (unsigned)c * (unsigned)STRIDE;
 			if (c + 4 <= ncol) {
-				lds_dma4<STRIDE>(voff, d, cur.c[4 * h] + blk, cur.c[4 * h + 1] + blk, cur.c[4 * h + 2] + blk, cur.c[4 * h + 3] + blk);
+				lds_dma4<STRIDE, X4>(voff, d, cur.c[4 * h] + blk, cur.c[4 * h + 1] + blk, cur.c[4 * h + 2] + blk, cur.c[4 * h + 3] + blk);
 			} else {
 #pragma unroll
 				for (int i = 0; i < 3; ++i)
-					if (c + i < ncol) lds_dma1(voff, d + (unsigned)i * (unsigned)STRIDE, cur.c[4 * h + i] + blk);
+					if (c + i < ncol) lds_dma1<X4>(voff, d + (unsigned)i * (unsigned)STRIDE, cur.c[4 * h + i] + blk);
 			}
 		}
 		cur = nxt;

@@ -346,7 +346,10 @@ def test_fuzz_wide_window_frames(pkg, ctx, seed):
 #   wide 92215 (r4) — WLS, an exactly determined 30 x 30 system with cond 2.4e8: the refit summed w z z' exactly where the
 #                    reference's formulation (and the oracle) decomposes the rows scaled by fl(sqrt(w)); the two problems differ
 #                    by cond eps = 1.1e-9.  The refit sums the scaled rows now.
+#   narrow 48439, 80249, 81020 (r4) — a column with sin(angle to the earlier ones) ~ 1e-6: dropped by the moment solve's 1e-11 pivot
+#                    test, kept by the reference's rule; such groups are queued now and the refit decides
 @pytest.mark.parametrize("family,seed", [("wide", 46944), ("narrow", 150447), ("narrow", 167199), ("narrow", 218686),
-                                         ("narrow", 186170), ("very", 56306), ("very", 36908), ("very", 53981), ("wide", 92215)])
+                                         ("narrow", 186170), ("very", 56306), ("very", 36908), ("very", 53981), ("wide", 92215),
+                                         ("narrow", 48439), ("narrow", 80249), ("narrow", 81020)])
 def test_deep_sweep_regressions(pkg, ctx, family, seed):
     _run(pkg, ctx, seed, {"narrow": False, "wide": True, "very": "very"}[family])
