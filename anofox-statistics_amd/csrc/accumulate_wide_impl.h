@@ -26,9 +26,11 @@
 // Roofline: FP64 MFMA (matrix-core) bound for p >= ~48: 2*256*4 flop per instruction, T(T+1)/2 instructions
 // per 4 rows; HBM traffic 8(p+1) B per row is read once.
 #pragma once
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
+#include "lds_dma.h"
 
 namespace anofox {
 
@@ -123,11 +125,13 @@ struct WideCfg {
 // the four waves.)
 // `between(t)` is called once per slab, after the slab's MFMAs: the staging work of the NEXT chunk is dealt over the
 // slabs of this one (iteration() below), so that a wave has no phase without MFMAs in flight.
-template <int T, int WAVE, bool WEIGHTED, bool CENTER, bool FAST, typename Between>
+// RAW ((r4) the LDS-DMA staging of the speculative version): the image holds the rows as they lie in memory and the shift by the
+// group's first row (`fsub` per column block of this lane, `fy`) is applied to the fragment on its way to the matrix cores.
+template <int T, int WAVE, bool WEIGHTED, bool CENTER, bool FAST, bool RAW = false, typename Between>
 __device__ __forceinline__ void compute_chunk(const double *img, const double *firstcol, int ycol, int lane, unsigned rowmask,
                                               dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
                                               double (&sxy)[WideCfg<T>::OWN], double (&dmax)[WideCfg<T>::OWN], unsigned &ncmask,
-                                              double &sy, double &syy, double &sw, Between &&between) {
+                                              double &sy, double &syy, double &sw, Between &&between, const double *fsub = nullptr, double fy = 0.0) {
 	constexpr int kChunkRows = WideCfg<T>::chunk_rows(WEIGHTED, CENTER), kLdsStride = WideCfg<T>::stride(WEIGHTED, CENTER), OWN = WideCfg<T>::OWN;
 	const int k = lane >> 4;
 	const int i = lane & 15;
@@ -145,8 +149,8 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 	auto read_slab = [&](int t, int s) {
 		const int row = 4 * t + k;
 #pragma unroll
-		for (int I = 0; I < T; ++I) d[s][I] = img[(16 * I + i) * kLdsStride + row];
-		dy[s] = img[ycol * kLdsStride + row];
+		for (int I = 0; I < T; ++I) d[s][I] = RAW ? img[(16 * I + i) * kLdsStride + row] - fsub[I] : img[(16 * I + i) * kLdsStride + row];
+		dy[s] = RAW ? img[ycol * kLdsStride + row] - fy : img[ycol * kLdsStride + row];
 		w[s] = WEIGHTED ? img[(ycol + 1) * kLdsStride + row] : 1.0;
 	};
 	read_slab(0, 0);
@@ -216,10 +220,11 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 // constant (|x - x_first| < 1e-10 on every row, ols.rs:76-87) if sum d^2 < 1e-20 and not constant if
 // sum d^2 >= n 1e-20.  Anything else — a NaN / inf somewhere, a column in between — returns false, and the caller
 // runs the full version on the group.  Returns true when the record at `rec` is complete.
-template <int T, int WAVE, bool WEIGHTED, bool CENTER, bool FAST = false>
+template <int T, int WAVE, bool WEIGHTED, bool CENTER, bool FAST = false, bool DMA = false>
 __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
                                                           const double *forced_first) {
 	static_assert(!FAST || (!WEIGHTED && CENTER), "the speculative version exists for the unweighted fit with an intercept");
+	static_assert(!DMA || FAST, "the LDS-DMA staging exists for the speculative version");
 	using Cfg = WideCfg<T>;
 	constexpr int kChunkRows = Cfg::chunk_rows(WEIGHTED, CENTER), kLdsStride = Cfg::stride(WEIGHTED, CENTER);
 	constexpr bool kWideChunk = kChunkRows == 32;
@@ -303,7 +308,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		if (CENTER && forced_first && src <= p) fq[q] = src < p ? forced_first[src] : forced_first[P16];
 	}
 
-	if (FAST) { // the shift is the group's first row (nrows > 0: the caller's condition)
+	if (FAST && !DMA) { // the shift is the group's first row (nrows > 0: the caller's condition)
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
 			const int src = 8 * (wave + kWaves * q) + colsub;
@@ -591,6 +596,62 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 #endif
 	};
 
+	if constexpr (FAST && DMA) {
+		// ---- (r4) the speculative version staged by `global_load_lds_dword` (lds_dma.h): no row passes through a register on its way
+		// into the image, no vector instruction shifts or stores it.  The x columns are dealt to the four wavefronts in contiguous
+		// ranges (the pointer table of the kernel arguments is walked as in accumulate_quad's kernel), the last wavefront also brings
+		// y; chunk c + 1 lands in the other image while the slabs of chunk c run, one barrier per chunk as before.  The image holds
+		// RAW rows: the shift by the first row is one subtraction per fragment (compute_chunk RAW).  The rows of the last chunk
+		// that lie behind the group are overwritten with the first row's values (difference 0) by the wavefront that loaded them.
+		static_assert(kChunkRows == 32, "the speculative version stages 32 rows per chunk");
+		constexpr int QMAX = (P16 + kWaves - 1) / kWaves;
+		const int q_cols = (p + kWaves - 1) / kWaves;
+		const int c_begin = WAVE * q_cols;
+		int n_mine = p - c_begin;
+		n_mine = n_mine < 0 ? 0 : (n_mine > q_cols ? q_cols : n_mine);
+		// the first row, by image column (x in place, y at 16 T); the loop's first barrier orders these writes before the reads
+		for (int c = threadIdx.x; c <= p; c += kThreads) firstcol[c < p ? c : ycol] = c < p ? args.x_table[c][lo] : args.y[lo];
+		const lds_dma_table_t tab = lds_dma_table((unsigned)offsetof(WideArgs, x_table)) + c_begin;
+		const unsigned img0 = lds_dma_address(image);
+		auto dma_chunk = [&](int64_t c, int buf) {
+			const int64_t blk = lo + c * kChunkRows;
+			const unsigned voff = lds_dma_offsets(lane, hi - blk);
+			if (n_mine > 0) lds_dma_block<kLdsStride * 8, QMAX>(tab, n_mine, blk, voff, img0 + (unsigned)((buf * ncol_pad + c_begin) * kLdsStride * 8));
+			if (WAVE == kWaves - 1) lds_dma1(voff, img0 + (unsigned)((buf * ncol_pad + ycol) * kLdsStride * 8), args.y + blk);
+		};
+		auto fill_tail = [&](int buf, int left) { // rows left .. 31 of the columns this wavefront loaded := the first row
+			double *img = image + buf * ncol_pad * kLdsStride;
+			const int nr = kChunkRows - left;
+			for (int e = lane; e < n_mine * nr; e += 64) {
+				const int cc = c_begin + e / nr, r = left + e % nr;
+				img[cc * kLdsStride + r] = firstcol[cc];
+			}
+			if (WAVE == kWaves - 1)
+				for (int r = left + lane; r < kChunkRows; r += 64) img[ycol * kLdsStride + r] = firstcol[ycol];
+		};
+		const int tail = (int)(nrows % kChunkRows);
+		dma_chunk(0, 0);
+		lds_dma_wait_all();
+		__syncthreads(); // (firstcol complete, chunk 0 landed)
+		if (n_chunks == 1 && tail) {
+			fill_tail(0, tail);
+			__syncthreads();
+		}
+		double fsub[T];
+#pragma unroll
+		for (int I = 0; I < T; ++I) fsub[I] = firstcol[16 * I + (lane & 15)];
+		const double fy = firstcol[ycol];
+		for (int64_t c = 0; c < n_chunks; ++c) {
+			const int buf = (int)(c & 1);
+			const bool more = c + 1 < n_chunks; // wave-uniform
+			if (more) dma_chunk(c + 1, buf ^ 1);
+			compute_chunk<T, WAVE, WEIGHTED, CENTER, FAST, true>(image + buf * ncol_pad * kLdsStride, firstcol, ycol, lane, kFullMask, acc, sx, sxy, dmax, ncmask,
+			                                                    sy, syy, sw, [](int) {}, fsub, fy);
+			lds_dma_wait_all();
+			if (more && c + 2 == n_chunks && tail) fill_tail(buf ^ 1, tail);
+			__syncthreads();
+		}
+	} else {
 	Stage sg;
 	if (n_chunks > 0) {
 		stage_load(0, sg);
@@ -603,6 +664,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		for (; c + 1 < n_full; ++c) iteration(std::true_type(), c, sg); // (nothing of chunk c + 1 is loaded yet)
 		if (c + 1 < n_chunks) stage_load(c + 1, sg);                    // the generic iterations expect the next chunk in registers
 		for (; c < n_chunks; ++c) iteration(std::false_type(), c, sg);
+	}
 	}
 
 	ACC_STAMP_FLUSH();
@@ -720,28 +782,28 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 
 // FAST: the speculative version (every wave returns the same verdict); otherwise the full one (always true).
 // The two never share a kernel: together they need more registers than there are (1110 spilled at T = 8).
-template <int T, bool WEIGHTED, bool CENTER, bool FAST = false>
+template <int T, bool WEIGHTED, bool CENTER, bool FAST = false, bool DMA = false>
 __device__ __forceinline__ bool wide_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
                                                      const double *forced_first) {
 	switch (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) {
-	case 0: return wide_accumulate_rows_wave<T, 0, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
-	case 1: return wide_accumulate_rows_wave<T, 1, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
-	case 2: return wide_accumulate_rows_wave<T, 2, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
+	case 0: return wide_accumulate_rows_wave<T, 0, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
+	case 1: return wide_accumulate_rows_wave<T, 1, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
+	case 2: return wide_accumulate_rows_wave<T, 2, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
 #if ANOFOX_WIDE_WAVES == 8
-	case 3: return wide_accumulate_rows_wave<T, 3, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
-	case 4: return wide_accumulate_rows_wave<T, 4, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
-	case 5: return wide_accumulate_rows_wave<T, 5, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
-	case 6: return wide_accumulate_rows_wave<T, 6, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
-	default: return wide_accumulate_rows_wave<T, 7, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
+	case 3: return wide_accumulate_rows_wave<T, 3, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
+	case 4: return wide_accumulate_rows_wave<T, 4, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
+	case 5: return wide_accumulate_rows_wave<T, 5, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
+	case 6: return wide_accumulate_rows_wave<T, 6, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
+	default: return wide_accumulate_rows_wave<T, 7, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
 #else
-	default: return wide_accumulate_rows_wave<T, 3, WEIGHTED, CENTER, FAST>(args, lo, hi, rec, forced_first);
+	default: return wide_accumulate_rows_wave<T, 3, WEIGHTED, CENTER, FAST, DMA>(args, lo, hi, rec, forced_first);
 #endif
 	}
 }
 
 // FAST: the speculative version on every group; the groups it gives up on (and empty ones) go to a list — borrowed
 // from the refine queue, which the solve that follows starts to fill only later — for accumulate_wide_redo_kernel.
-template <int T, bool WEIGHTED, bool CENTER, bool FAST>
+template <int T, bool WEIGHTED, bool CENTER, bool FAST, bool DMA = false>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void accumulate_wide_kernel(WideArgs args) {
 	const int64_t g = blockIdx.x;
 	const int64_t lo = args.row_offsets[args.group_base + g];
@@ -758,7 +820,7 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void accumulate_wide_kerne
 	}
 	double *rec = args.moments + g * (int64_t)wide_record_len(T);
 	if constexpr (FAST) {
-		if (hi > lo && wide_accumulate_rows<T, WEIGHTED, CENTER, true>(args, lo, hi, rec, nullptr)) return;
+		if (hi > lo && wide_accumulate_rows<T, WEIGHTED, CENTER, true, DMA>(args, lo, hi, rec, nullptr)) return;
 		if (threadIdx.x == 0) args.refine_list[atomicAdd(args.refine_count + kWideRedoCounter, 1)] = (int32_t)g;
 	} else {
 		wide_accumulate_rows<T, WEIGHTED, CENTER>(args, lo, hi, rec, nullptr);
@@ -840,7 +902,11 @@ hipError_t launch_accumulate_wide_T(const WideArgs &a, hipStream_t stream) {
 		ANOFOX_WIDE_LAUNCH(false, true);
 	} else {
 		// speculative kernel, then the full version on whatever it listed (the counter is zeroed by the caller)
-		if (main_part) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT)>), grid, block, lds, stream, a);
+		// (r4) ANOFOX_WIDE_DMA=1: its LDS-DMA staging (3 and 4 column tiles: 35 <= p <= 64, the widths accumulate_quad does not take)
+		static const bool dma_on = getenv("ANOFOX_WIDE_DMA") && atoi(getenv("ANOFOX_WIDE_DMA")) != 0;
+		constexpr bool kHasDma = T >= kWideFastMinT && T <= 4 && kWaves == 4;
+		if (main_part && kHasDma && dma_on) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT), kHasDma>), grid, block, lds, stream, a);
+		else if (main_part) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT)>), grid, block, lds, stream, a);
 		if (rest_part && a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, false, true>), seg_grid, block, lds, stream, a);
 		if (rest_part) hipLaunchKernelGGL((accumulate_wide_redo_kernel<T, false, true>), grid, block, lds, stream, a);
 	}

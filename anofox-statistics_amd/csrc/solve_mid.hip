@@ -113,7 +113,7 @@ __device__ void solve_mid_one(const WideArgs &args, int64_t gl) {
 		double d = A[tri(j, j)];
 		for (int k = 0; k < j; ++k) d -= A[tri(j, k)] * A[tri(j, k)];
 		const bool ok = ((active >> j) & 1u) && (d > kAliasTolM * diag0[j]) && (d > 0.0);
-		band = band || (((active >> j) & 1u) && !ok && d > 1e-15 * diag0[j]);
+		band = band || (((active >> j) & 1u) && !ok && d > 1e-13 * diag0[j]);
 		if (!ok) active &= ~(1u << j);
 		if (ok) min_ratio = fmin(min_ratio, d / diag0[j]);
 		const double ljj = ok ? sqrt(d) : 1.0;

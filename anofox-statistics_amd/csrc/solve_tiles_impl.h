@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 		wave_lds_sync();
 
 		double min_ratio = 1.0, zz_l = 0.0;
-		bool band = false; // (r4) a column dropped with a pivot in 1e-15 .. 1e-11 of its diagonal: queued, the refit decides (solve_narrow.hip)
+		bool band = false; // (r4) a column dropped with a pivot in 1e-13 .. 1e-11 of its diagonal: queued, the refit decides (solve_narrow.hip)
 		unsigned live_bits[T];
 
 		sfor<0, T>([&](auto k_) __attribute__((always_inline)) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(64, WPE) void solve_tiles_kernel(WideArgs args) {
 				// (the pivot is wave-uniform; kept in vector registers so that the test becomes a select, not a branch)
 				asm volatile("" : "+v"(d), "+v"(th));
 				const bool ok = d > th;
-				band = band || (!ok && d * 1e4 > th); // (th = 1e-11 diag0, +inf for a column that takes no part)
+				band = band || (!ok && d * 1e2 > th); // (th = 1e-11 diag0, +inf for a column that takes no part)
 				const double inv = ok ? rsqrt_pos(ok ? d : 1.0) : 0.0;
 				const double lj = reg[j] * inv;
 				reg[j] = lj;

@@ -1614,3 +1614,37 @@ def test_information_criteria_batch_matches_reference_formula(pkg, ctx, model, p
     d = ctx.information_criteria_device(torch.from_numpy(core).cuda(), opts)
     torch.cuda.synchronize()
     assert np.array_equal(np.nan_to_num(d.cpu().numpy(), nan=-7.0), np.nan_to_num(out, nan=-7.0))
+
+
+@pytest.mark.parametrize("p,kind", [(4, "copy"), (6, "dummy"), (12, "copy"), (20, "dummy"), (40, "copy"), (70, "dummy")])
+def test_exactly_aliased_columns_are_not_queued(pkg, ctx, p, kind):
+    """(r4) A solve that drops a non-constant column queues the group for the double-double refit only when the pivot is ABOVE the
+    rounding noise of the moments (1e-13 .. 1e-11 of the diagonal: the band in which the reference's rule may keep the column).
+    Exact copies (x_b = 2 x_a) and dummy-variable traps (indicator columns that sum to the intercept) — every group of many real
+    workloads — must stay on the fast path: NaN for the later column as the reference's rule gives it, and (almost) nothing queued."""
+    rng = np.random.default_rng(1000 + p)
+    G, n = 4000, 120 + 3 * p
+    offs = (np.arange(G + 1) * n).astype(np.int64)
+    N = G * n
+    X = rng.standard_normal((N, p)) * 10.0 ** rng.uniform(-1, 2, p) + rng.choice([0.0, 5.0, 300.0], p)
+    if kind == "copy":
+        a, b = 1, p - 1
+        X[:, b] = 2.0 * X[:, a]
+        dropped = b
+    else:                                                           # three indicator columns that sum to one: the last is aliased to the intercept
+        lvl = rng.integers(0, 3, N)
+        for k in range(3):
+            X[:, k] = (lvl == k).astype(np.float64)
+        dropped = 2
+    beta = rng.uniform(-2, 2, p)
+    y = X @ beta + 3.0 + rng.standard_normal(N)
+    x_cols = [np.ascontiguousarray(X[:, j]) for j in range(p)]
+    core, inf = _host_fit(pkg, ctx, "ols", offs, y, x_cols, None, compute_inference=True)
+    queued = ctx.last_refine_count()
+    assert queued <= G // 100, f"{queued} of {G} groups queued"
+    assert np.all(core[:, p + 5] == 0) and np.all(np.isnan(core[:, dropped])) and np.all(np.isnan(inf[:, dropped]))
+    keep = [j for j in range(p) if j != dropped]
+    assert not np.isnan(core[:, keep]).any()
+    S = 64                                                          # a sample against the oracle
+    rcore, rinf = oracle.fit_groups(y[:S * n], [c[:S * n] for c in x_cols], offs[:S + 1], model="ols", compute_inference=True)
+    assert_records_match(core[:S], rcore, p, inf[:S], rinf, what=f"aliased {kind} p={p}")
