@@ -107,11 +107,52 @@ __device__ __forceinline__ int first_row_of_mask(unsigned m) { // lowest row who
 template <int T>
 struct WideCfg {
 	static constexpr int NT = T * (T + 1) / 2;             // upper-triangular tiles
-	static constexpr int TPW = (NT + kWaves - 1) / kWaves; // tiles per wave
+	// (r4) Tiles to wavefronts.  Dealt round-robin, 6 tiles (T = 3) give two wavefronts two tiles and two wavefronts one — and
+	// every chunk ends in a barrier, so the workgroup runs at the pace of the two-tile wavefronts; wavefront w of every workgroup
+	// sits on SIMD w, so SIMDs 0 and 1 carry twice the matrix work of SIMDs 2 and 3 (the 60-65 % "matrix pipe busy" of the
+	// round-4 counters is the average of 85 % and 42 %).  Neither a lighter staging side nor LDS-DMA changes that (measured:
+	// ANOFOX_WIDE_DMA=1, -3 %).  So: the first 4 F = 4 floor(NT / 4) tiles go round-robin as before, and the R = NT mod 4 that
+	// are left are SPLIT ALONG THE ROWS — a tile in halves between two wavefronts (even / odd slabs of every chunk), or in
+	// quarters between all four — each wavefront keeping a partial sum that the tile's owner collects once, at the end of the
+	// group.  Busiest wavefront per chunk: T = 3: 2 -> 1.5 tiles, T = 4: 3 -> 2.5, T = 5: 4 -> 3.75, T = 6: 6 -> 5.25 (T = 7, 8: R = 0).
+#ifdef ANOFOX_WIDE_NOSPLIT // (measurement build: the round-robin deal of rounds 1-3, csrc/Makefile target `nosplit`)
+	static constexpr bool kSplit = false;
+#else
+	static constexpr bool kSplit = kWaves == 4;
+#endif
+	static constexpr int F = kSplit ? NT / 4 : 0, R = kSplit ? NT % 4 : 0;
+	static constexpr int TPW = kSplit ? F + (R > 0 ? 1 : 0) + (R == 3 ? 1 : 0) : (NT + kWaves - 1) / kWaves; // accumulator tiles per wave
+	// remaining tile j = tile - 4 F: split in halves between wavefronts 2 j, 2 j + 1 (R = 2; R = 3: j < 2) or in quarters (R = 1; R = 3: j = 2)
+	static constexpr bool quartered(int tile) { return kSplit && tile >= 4 * F && (R == 1 || (R == 3 && tile - 4 * F == 2)); }
+	static constexpr bool halved(int tile) { return kSplit && tile >= 4 * F && !quartered(tile); }
+	static constexpr int acc_index(int tile) { return !kSplit ? tile / kWaves : (tile < 4 * F ? tile / 4 : (R == 3 && tile - 4 * F == 2 ? F + 1 : F)); }
+	// the wavefront that holds the tile at the end of the group (checks it, writes it to the record)
+	static constexpr int owner(int tile) { return !kSplit ? tile % kWaves : (tile < 4 * F ? tile % 4 : (quartered(tile) ? 0 : 2 * (tile - 4 * F))); }
+	// does wavefront `wave` issue the tile's matrix instruction in slab `slab` of a chunk
+	static constexpr bool works(int tile, int wave, int slab) {
+		if (!kSplit) return tile % kWaves == wave;
+		if (tile < 4 * F) return tile % 4 == wave;
+		if (quartered(tile)) return (slab & 3) == wave;
+		return (wave >> 1) == tile - 4 * F && (slab & 1) == (wave & 1);
+	}
 	static constexpr int OWN = (T + kWaves - 1) / kWaves;  // column blocks owned per wave
 	// rows staged per barrier: the per-chunk costs that are latency, not work (row masks through LDS, issuing the next
 	// chunk's loads, the barrier) are as long as the MFMAs of 16 rows at T = 8, so chunks are 32 rows for every width
 	// (except where 32 rows of staging registers spill: ANOFOX_WIDE_SHORT_CHUNK)
+	// (r4) chunks the staging loads run ahead of the chunk being multiplied.  A chunk of 3 or 4 column tiles is 0.4-0.7 us of
+	// matrix work; with the loads of chunk c + 1 issued behind the first slab of chunk c and needed behind its last slabs, they have
+	// less than that to cross the memory system — a wavefront then waits on them in every chunk.  The staging registers of such a
+	// chunk are few (16-24 per lane), so narrow designs keep two chunks in flight; from 5 tiles on a chunk is long enough.
+	// Measured on one box (scripts/wide_depth_ab.sh, builds of `make variant`), kernel ms at 50 000 x 1000 x p = 48 / 56 / 64:
+	// rounds 1-3 (round-robin deal, one chunk ahead) 5.59 / 7.81 / 8.43; split tiles 5.43 / 7.60 / 8.45; + two chunks ahead
+	// 5.50 / 7.52 / 8.13; three 5.41 / 7.92 / 8.51; four 5.47 / 8.01 / 8.61 (registers).  Two it is: +2 ... 4 %, not the
+	// +20 ... 33 % the arithmetic of the tile deal promised — the chunk takes its ~4 us whatever is done to its parts.
+	// (The speculative version only: the full one — row masks, repairs, weights — has no registers to spare: 224-476 bytes of
+	// scratch per lane with three chunks in flight.)
+#ifndef ANOFOX_WIDE_DEPTH
+#define ANOFOX_WIDE_DEPTH(T) ((T) <= 4 ? 2 : 1)
+#endif
+	static constexpr int depth(bool fast) { return kWaves == 4 && fast ? ANOFOX_WIDE_DEPTH(T) : 1; }
 	static constexpr int chunk_rows(bool weighted, bool center = true) { return ANOFOX_WIDE_SHORT_CHUNK(T, weighted, center) ? 16 : 32; }
 	static constexpr int stride(bool weighted, bool center = true) { return chunk_rows(weighted, center) + 2; } // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
 };
@@ -127,12 +168,13 @@ struct WideCfg {
 // slabs of this one (iteration() below), so that a wave has no phase without MFMAs in flight.
 // RAW ((r4) the LDS-DMA staging of the speculative version): the image holds the rows as they lie in memory and the shift by the
 // group's first row (`fsub` per column block of this lane, `fy`) is applied to the fragment on its way to the matrix cores.
-template <int T, int WAVE, bool WEIGHTED, bool CENTER, bool FAST, bool RAW = false, typename Between>
+template <int T, int WAVE, bool WEIGHTED, bool CENTER, bool FAST, bool RAW = false, int CH = 0, typename Between>
 __device__ __forceinline__ void compute_chunk(const double *img, const double *firstcol, int ycol, int lane, unsigned rowmask,
                                               dbl4 (&acc)[WideCfg<T>::TPW], double (&sx)[WideCfg<T>::OWN],
                                               double (&sxy)[WideCfg<T>::OWN], double (&dmax)[WideCfg<T>::OWN], unsigned &ncmask,
                                               double &sy, double &syy, double &sw, Between &&between, const double *fsub = nullptr, double fy = 0.0) {
-	constexpr int kChunkRows = WideCfg<T>::chunk_rows(WEIGHTED, CENTER), kLdsStride = WideCfg<T>::stride(WEIGHTED, CENTER), OWN = WideCfg<T>::OWN;
+	// (CH: rows per chunk when the caller's image is not the configuration's — the 64-row chunks of the LDS-DMA staging)
+	constexpr int kChunkRows = CH ? CH : WideCfg<T>::chunk_rows(WEIGHTED, CENTER), kLdsStride = CH ? CH + 2 : WideCfg<T>::stride(WEIGHTED, CENTER), OWN = WideCfg<T>::OWN;
 	const int k = lane >> 4;
 	const int i = lane & 15;
 	// without an intercept the image holds raw values; the constant-column test still compares with the first valid row
@@ -168,8 +210,8 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 		for (int I = 0; I < T; ++I) {
 #pragma unroll
 			for (int J = I; J < T; ++J) {
-				if (tile % kWaves == WAVE)
-					acc[tile / kWaves] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[s][J], acc[tile / kWaves], 0, 0, 0);
+				if (WideCfg<T>::works(tile, WAVE, t))
+					acc[WideCfg<T>::acc_index(tile)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[s][J], acc[WideCfg<T>::acc_index(tile)], 0, 0, 0);
 				++tile;
 			}
 		}
@@ -220,13 +262,13 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 // constant (|x - x_first| < 1e-10 on every row, ols.rs:76-87) if sum d^2 < 1e-20 and not constant if
 // sum d^2 >= n 1e-20.  Anything else — a NaN / inf somewhere, a column in between — returns false, and the caller
 // runs the full version on the group.  Returns true when the record at `rec` is complete.
-template <int T, int WAVE, bool WEIGHTED, bool CENTER, bool FAST = false, bool DMA = false>
+template <int T, int WAVE, bool WEIGHTED, bool CENTER, bool FAST = false, int DMA = 0> // DMA: rows per chunk of the LDS-DMA staging (0: registers)
 __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
                                                           const double *forced_first) {
 	static_assert(!FAST || (!WEIGHTED && CENTER), "the speculative version exists for the unweighted fit with an intercept");
-	static_assert(!DMA || FAST, "the LDS-DMA staging exists for the speculative version");
+	static_assert(DMA == 0 || FAST, "the LDS-DMA staging exists for the speculative version");
 	using Cfg = WideCfg<T>;
-	constexpr int kChunkRows = Cfg::chunk_rows(WEIGHTED, CENTER), kLdsStride = Cfg::stride(WEIGHTED, CENTER);
+	constexpr int kChunkRows = DMA ? DMA : Cfg::chunk_rows(WEIGHTED, CENTER), kLdsStride = DMA ? DMA + 2 : Cfg::stride(WEIGHTED, CENTER);
 	constexpr bool kWideChunk = kChunkRows == 32;
 	constexpr unsigned kFullMask = kWideChunk ? 0xffffffffu : 0xffffu;
 	constexpr int P16 = 16 * T;
@@ -308,7 +350,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		if (CENTER && forced_first && src <= p) fq[q] = src < p ? forced_first[src] : forced_first[P16];
 	}
 
-	if (FAST && !DMA) { // the shift is the group's first row (nrows > 0: the caller's condition)
+	if (FAST && DMA == 0) { // the shift is the group's first row (nrows > 0: the caller's condition)
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
 			const int src = 8 * (wave + kWaves * q) + colsub;
@@ -499,7 +541,8 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	// One chunk.  The loads run one chunk ahead and are stored to the other image once this chunk's MFMAs are issued.
 	ACC_STAMP_DECL;
 	// steady = std::true_type: chunks c and c + 1 are full (the branch-free staging pieces)
-	auto iteration = [&](auto steady, int64_t c, Stage &ahead) {
+	// STEADY: the loads of chunk c + depth go into `ahead`, chunk c + 1 is stored from `landed` (the same registers when kDepth = 1)
+	auto iteration = [&](auto steady, int64_t c, Stage &ahead, Stage &landed) {
 		constexpr bool STEADY = decltype(steady)::value;
 		ACC_STAMP_START();
 		const int buf = (int)(c & 1);
@@ -560,7 +603,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 				if (t == 0) {
 					__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-					for (int q = 0; q < kMaxLoads; ++q) stage_load_piece_steady(c + 1, ahead, q);
+					for (int q = 0; q < kMaxLoads; ++q) stage_load_piece_steady(c + Cfg::depth(FAST), ahead, q);
 					__builtin_amdgcn_sched_barrier(0);
 				}
 #pragma unroll
@@ -571,7 +614,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 						// (fences for the instruction scheduler: left alone it gathers the subtractions of all slots
 						// behind one wait for the last load)
 						__builtin_amdgcn_sched_barrier(0);
-						stage_store_piece_steady(buf ^ 1, ahead, ss, q);
+						stage_store_piece_steady(buf ^ 1, landed, ss, q);
 						__builtin_amdgcn_sched_barrier(0);
 					}
 				}
@@ -596,14 +639,14 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 #endif
 	};
 
-	if constexpr (FAST && DMA) {
+	if constexpr (FAST && DMA != 0) {
 		// ---- (r4) the speculative version staged by `global_load_lds_dword` (lds_dma.h): no row passes through a register on its way
 		// into the image, no vector instruction shifts or stores it.  The x columns are dealt to the four wavefronts in contiguous
 		// ranges (the pointer table of the kernel arguments is walked as in accumulate_quad's kernel), the last wavefront also brings
 		// y; chunk c + 1 lands in the other image while the slabs of chunk c run, one barrier per chunk as before.  The image holds
 		// RAW rows: the shift by the first row is one subtraction per fragment (compute_chunk RAW).  The rows of the last chunk
 		// that lie behind the group are overwritten with the first row's values (difference 0) by the wavefront that loaded them.
-		static_assert(kChunkRows == 32, "the speculative version stages 32 rows per chunk");
+		static_assert(kChunkRows == 32 || kChunkRows == 64, "32 or 64 rows per chunk");
 		constexpr int QMAX = (P16 + kWaves - 1) / kWaves;
 		const int q_cols = (p + kWaves - 1) / kWaves;
 		const int c_begin = WAVE * q_cols;
@@ -614,10 +657,14 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		const lds_dma_table_t tab = lds_dma_table((unsigned)offsetof(WideArgs, x_table)) + c_begin;
 		const unsigned img0 = lds_dma_address(image);
 		auto dma_chunk = [&](int64_t c, int buf) {
-			const int64_t blk = lo + c * kChunkRows;
-			const unsigned voff = lds_dma_offsets(lane, hi - blk);
-			if (n_mine > 0) lds_dma_block<kLdsStride * 8, QMAX>(tab, n_mine, blk, voff, img0 + (unsigned)((buf * ncol_pad + c_begin) * kLdsStride * 8));
-			if (WAVE == kWaves - 1) lds_dma1(voff, img0 + (unsigned)((buf * ncol_pad + ycol) * kLdsStride * 8), args.y + blk);
+#pragma unroll
+			for (int sub = 0; sub < kChunkRows / 32; ++sub) { // 256 bytes of a column per instruction: a 64-row chunk takes two per column
+				const int64_t blk = lo + c * kChunkRows + 32 * sub;
+				if (blk >= hi) break; // wave-uniform (the rows are filled by fill_tail)
+				const unsigned voff = lds_dma_offsets(lane, hi - blk);
+				if (n_mine > 0) lds_dma_block<kLdsStride * 8, QMAX>(tab, n_mine, blk, voff, img0 + (unsigned)((buf * ncol_pad + c_begin) * kLdsStride * 8 + sub * 256));
+				if (WAVE == kWaves - 1) lds_dma1(voff, img0 + (unsigned)((buf * ncol_pad + ycol) * kLdsStride * 8 + sub * 256), args.y + blk);
+			}
 		};
 		auto fill_tail = [&](int buf, int left) { // rows left .. 31 of the columns this wavefront loaded := the first row
 			double *img = image + buf * ncol_pad * kLdsStride;
@@ -645,29 +692,75 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 			const int buf = (int)(c & 1);
 			const bool more = c + 1 < n_chunks; // wave-uniform
 			if (more) dma_chunk(c + 1, buf ^ 1);
-			compute_chunk<T, WAVE, WEIGHTED, CENTER, FAST, true>(image + buf * ncol_pad * kLdsStride, firstcol, ycol, lane, kFullMask, acc, sx, sxy, dmax, ncmask,
+			compute_chunk<T, WAVE, WEIGHTED, CENTER, FAST, true, kChunkRows>(image + buf * ncol_pad * kLdsStride, firstcol, ycol, lane, kFullMask, acc, sx, sxy, dmax, ncmask,
 			                                                    sy, syy, sw, [](int) {}, fsub, fy);
 			lds_dma_wait_all();
 			if (more && c + 2 == n_chunks && tail) fill_tail(buf ^ 1, tail);
 			__syncthreads();
 		}
 	} else {
-	Stage sg;
+	constexpr int D = Cfg::depth(FAST);
+	Stage st[D];
 	if (n_chunks > 0) {
-		stage_load(0, sg);
-		stage_store(0, 0, sg);
+		stage_load(0, st[0]);
+		stage_store(0, 0, st[0]);
 	}
 	__syncthreads();
 	{
 		int64_t c = 0;
 		const int64_t n_full = nrows / kChunkRows; // full chunks
-		for (; c + 1 < n_full; ++c) iteration(std::true_type(), c, sg); // (nothing of chunk c + 1 is loaded yet)
-		if (c + 1 < n_chunks) stage_load(c + 1, sg);                    // the generic iterations expect the next chunk in registers
-		for (; c < n_chunks; ++c) iteration(std::false_type(), c, sg);
+		if constexpr (D == 1) {
+			for (; c + 1 < n_full; ++c) iteration(std::true_type(), c, st[0], st[0]); // (nothing of chunk c + 1 is loaded yet)
+		} else {
+			// trips of D chunks, so that which registers hold which chunk is known at compile time: chunk c + j + 1 sits in st[(j + 1) % D]
+			// when chunk c + j is multiplied, and the loads of chunk c + j + D go into st[j], whose chunk was stored one iteration ago
+			if (c + 2 * D - 1 < n_full) {
+#pragma unroll
+				for (int j = 1; j < D; ++j) stage_load(j, st[j]);
+				for (; c + 2 * D - 1 < n_full; c += D) {
+#pragma unroll
+					for (int j = 0; j < D; ++j) iteration(std::true_type(), c + j, st[j], st[(j + 1) % D]);
+				}
+			}
+		}
+		// (the generic iterations expect the next chunk in registers; after steady trips it is there already and is read once more)
+		if (c + 1 < n_chunks) stage_load(c + 1, st[1 % D]);
+		for (; c < n_chunks; ++c) iteration(std::false_type(), c, st[1 % D], st[1 % D]);
 	}
 	}
 
 	ACC_STAMP_FLUSH();
+	// (r4) the tiles that were split along the rows: the partial sums go through the image (free since the loop's last barrier)
+	// to the tile's owner, element for element (every wavefront holds a tile in the same lane / register layout)
+	if constexpr (Cfg::R > 0) {
+		int slot = 0; // 256 doubles per partial
+		bool wrote = false;
+#pragma unroll
+		for (int tile = 4 * Cfg::F; tile < Cfg::NT; ++tile) {
+			const int parts = Cfg::quartered(tile) ? 4 : 2, first = Cfg::owner(tile);
+			if (WAVE > first && WAVE < first + parts) {
+#pragma unroll
+				for (int r = 0; r < 4; ++r) image[(slot + WAVE - first - 1) * 256 + 64 * r + lane] = acc[Cfg::acc_index(tile)][r];
+				wrote = true;
+			}
+			slot += parts - 1;
+		}
+		(void)wrote;
+		__syncthreads();
+		slot = 0;
+#pragma unroll
+		for (int tile = 4 * Cfg::F; tile < Cfg::NT; ++tile) {
+			const int parts = Cfg::quartered(tile) ? 4 : 2, first = Cfg::owner(tile);
+			if (WAVE == first) {
+#pragma unroll
+				for (int k = 0; k < parts - 1; ++k)
+#pragma unroll
+					for (int r = 0; r < 4; ++r) acc[Cfg::acc_index(tile)][r] += image[(slot + k) * 256 + 64 * r + lane];
+			}
+			slot += parts - 1;
+		}
+		__syncthreads(); // (the callers rewrite the LDS)
+	}
 	unsigned fast_nc[Cfg::TPW]; // FAST: constant-column flags of the diagonal tiles this wave holds (bit r: element r)
 	if (FAST) {
 		// what the speculation assumed, checked on the result: every moment finite, every column clearly constant or
@@ -685,18 +778,18 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		for (int I = 0; I < T; ++I) {
 #pragma unroll
 			for (int J = I; J < T; ++J) {
-				if (tile % kWaves == WAVE) {
-					fast_nc[tile / kWaves] = 0u;
+				if (Cfg::owner(tile) == WAVE) {
+					fast_nc[Cfg::acc_index(tile)] = 0u;
 					if (J == I) {
 						// diagonal element (j, j), j = lane & 15: held by the lane with lane >> 4 == j % 4, in element j / 4
 						const int j = lane & 15;
 						if ((lane >> 4) == (j & 3)) {
-							double mjj = acc[tile / kWaves][0];
+							double mjj = acc[Cfg::acc_index(tile)][0];
 #pragma unroll
-							for (int r = 1; r < 4; ++r) mjj = (j >> 2) == r ? acc[tile / kWaves][r] : mjj;
+							for (int r = 1; r < 4; ++r) mjj = (j >> 2) == r ? acc[Cfg::acc_index(tile)][r] : mjj;
 							const bool moved = mjj >= n_d * 1e-20;
 							bad = bad || (!moved && !(mjj < 1e-20));
-							fast_nc[tile / kWaves] = moved ? 1u : 0u;
+							fast_nc[Cfg::acc_index(tile)] = moved ? 1u : 0u;
 						}
 					}
 				}
@@ -721,10 +814,10 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		for (int I = 0; I < T; ++I) {
 #pragma unroll
 			for (int J = I; J < T; ++J) {
-				if (tile % kWaves == wave) {
+				if (Cfg::owner(tile) == wave) {
 					double *tp = rec + (int64_t)tile * 256;
 #pragma unroll
-					for (int r = 0; r < 4; ++r) tp[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[tile / kWaves][r];
+					for (int r = 0; r < 4; ++r) tp[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[Cfg::acc_index(tile)][r];
 				}
 				++tile;
 			}
@@ -737,8 +830,8 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		for (int I = 0; I < T; ++I) {
 #pragma unroll
 			for (int J = I; J < T; ++J) {
-				if (tile % kWaves == wave && J == I && (lane >> 4) == (lane & 3))
-					vec[3 * P16 + 16 * I + (lane & 15)] = (double)fast_nc[tile / kWaves];
+				if (Cfg::owner(tile) == wave && J == I && (lane >> 4) == (lane & 3))
+					vec[3 * P16 + 16 * I + (lane & 15)] = (double)fast_nc[Cfg::acc_index(tile)];
 				++tile;
 			}
 		}
@@ -782,7 +875,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 
 // FAST: the speculative version (every wave returns the same verdict); otherwise the full one (always true).
 // The two never share a kernel: together they need more registers than there are (1110 spilled at T = 8).
-template <int T, bool WEIGHTED, bool CENTER, bool FAST = false, bool DMA = false>
+template <int T, bool WEIGHTED, bool CENTER, bool FAST = false, int DMA = 0>
 __device__ __forceinline__ bool wide_accumulate_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec,
                                                      const double *forced_first) {
 	switch (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) {
@@ -803,7 +896,7 @@ __device__ __forceinline__ bool wide_accumulate_rows(const WideArgs &args, int64
 
 // FAST: the speculative version on every group; the groups it gives up on (and empty ones) go to a list — borrowed
 // from the refine queue, which the solve that follows starts to fill only later — for accumulate_wide_redo_kernel.
-template <int T, bool WEIGHTED, bool CENTER, bool FAST, bool DMA = false>
+template <int T, bool WEIGHTED, bool CENTER, bool FAST, int DMA = 0>
 __global__ __launch_bounds__(kThreads, kWavesPerSimd) void accumulate_wide_kernel(WideArgs args) {
 	const int64_t g = blockIdx.x;
 	const int64_t lo = args.row_offsets[args.group_base + g];
@@ -903,10 +996,20 @@ hipError_t launch_accumulate_wide_T(const WideArgs &a, hipStream_t stream) {
 	} else {
 		// speculative kernel, then the full version on whatever it listed (the counter is zeroed by the caller)
 		// (r4) ANOFOX_WIDE_DMA=1: its LDS-DMA staging (3 and 4 column tiles: 35 <= p <= 64, the widths accumulate_quad does not take)
-		static const bool dma_on = getenv("ANOFOX_WIDE_DMA") && atoi(getenv("ANOFOX_WIDE_DMA")) != 0;
+		static const int dma_rows = getenv("ANOFOX_WIDE_DMA") ? atoi(getenv("ANOFOX_WIDE_DMA")) : 0; // 1 / 32: 32-row chunks, 64: 64-row chunks
 		constexpr bool kHasDma = T >= kWideFastMinT && T <= 4 && kWaves == 4;
-		if (main_part && kHasDma && dma_on) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT), kHasDma>), grid, block, lds, stream, a);
-		else if (main_part) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT)>), grid, block, lds, stream, a);
+		const size_t lds64 = (size_t)2 * ncol_pad * 66 * sizeof(double) + (size_t)ncol_pad * (sizeof(double *) + sizeof(double)) + 64;
+		if (main_part && kHasDma && dma_rows == 64) {
+			static const bool attr_set = [] {
+				(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT), (kHasDma ? 64 : 0)>),
+				                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+				return true;
+			}();
+			(void)attr_set;
+			hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT), (kHasDma ? 64 : 0)>), grid, block, lds64, stream, a);
+		} else if (main_part && kHasDma && dma_rows != 0) {
+			hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT), (kHasDma ? 32 : 0)>), grid, block, lds, stream, a);
+		} else if (main_part) hipLaunchKernelGGL((accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT)>), grid, block, lds, stream, a);
 		if (rest_part && a.seg_table) hipLaunchKernelGGL((accumulate_wide_segments_kernel<T, false, true>), seg_grid, block, lds, stream, a);
 		if (rest_part) hipLaunchKernelGGL((accumulate_wide_redo_kernel<T, false, true>), grid, block, lds, stream, a);
 	}
