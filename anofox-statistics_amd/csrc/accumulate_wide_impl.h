@@ -1002,7 +1002,7 @@ hipError_t launch_accumulate_wide_T(const WideArgs &a, hipStream_t stream) {
 		if (main_part && kHasDma && dma_rows == 64) {
 			static const bool attr_set = [] {
 				(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_wide_kernel<T, false, true, (T >= kWideFastMinT), (kHasDma ? 64 : 0)>),
-				                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+				                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); // (the kernel has 4 bytes of static LDS)
 				return true;
 			}();
 			(void)attr_set;
