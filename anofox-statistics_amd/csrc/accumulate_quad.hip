@@ -697,9 +697,13 @@ hipError_t launch_quad_spec_only(const WideArgs &a, hipStream_t stream) {
 bool accumulate_quad_supports(int p, bool weighted, bool center, bool no_fast_path) {
 	static const bool spec_on = !(getenv("ANOFOX_QUAD_SPEC") && atoi(getenv("ANOFOX_QUAD_SPEC")) == 0);
 	// (NB = 10, 11: p = 35 .. 42 — 55 / 66 accumulators, six wavefronts per CU; measured against accumulate_wide in docs/MEASUREMENTS.md)
-	static const int spec_max_p = getenv("ANOFOX_QUAD_SPEC_MAXP") ? atoi(getenv("ANOFOX_QUAD_SPEC_MAXP")) : 42;
+	// (r4, NB = 12, 13: 224 / 252 registers, no scratch.  Against accumulate_wide on one box, scripts/quad50_ab.sh: level at p = 43, 44,
+	// 6-10 % behind at p = 46, 48 (three column tiles are well filled there), 10 % ahead at p = 49, 50 — where four column tiles pad 51
+	// columns to 64: 160 matrix cycles per row against 91.  So: up to 42, and 49, 50.  ANOFOX_QUAD_SPEC_MAXP=50 takes 43 .. 48 as well.)
+	static const int spec_max_p = getenv("ANOFOX_QUAD_SPEC_MAXP") ? atoi(getenv("ANOFOX_QUAD_SPEC_MAXP")) : 0;
 	if (p > kNarrowMaxP && p <= 26) return true;
-	return p > 26 && p <= 42 && p <= spec_max_p && spec_on && !weighted && center && !no_fast_path;
+	const bool in_range = spec_max_p > 0 ? p <= spec_max_p : (p <= 42 || p == 49 || p == 50);
+	return p > 26 && p <= 50 && in_range && spec_on && !weighted && center && !no_fast_path;
 }
 
 hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
@@ -723,6 +727,8 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	case 9: return ring == 4 ? launch_quad_spec_only<9, 2, 4>(a, stream) : ring == 3 ? launch_quad_spec_only<9, 2, 3>(a, stream) : launch_quad_spec_only<9, 2, 2>(a, stream);
 	case 10: return ring == 4 ? launch_quad_spec_only<10, 2, 4>(a, stream) : ring == 3 ? launch_quad_spec_only<10, 2, 3>(a, stream) : launch_quad_spec_only<10, 2, 2>(a, stream);
 	case 11: return ring == 4 ? launch_quad_spec_only<11, 2, 4>(a, stream) : ring == 3 ? launch_quad_spec_only<11, 2, 3>(a, stream) : launch_quad_spec_only<11, 2, 2>(a, stream);
+	case 12: return launch_quad_spec_only<12, 2, 2>(a, stream);
+	case 13: return launch_quad_spec_only<13, 2, 2>(a, stream);
 	default: return hipErrorInvalidValue;
 	}
 }

@@ -523,8 +523,10 @@ def main():
             achieved = per_step / (acc_step_ms * 1e-3) / 1e9 if acc_step_ms > 0 else 0.0
         else:
             # (the speculative accumulate_quad kernel also takes p = 27 .. 33 of the unweighted fit with an intercept)
-            quad_max = 42 if (not weighted and os.environ.get("ANOFOX_QUAD_SPEC", "1") != "0") else 26
-            kernel = "accumulate_quad_kernel" if p <= quad_max else ("accumulate_mid_kernel" if p <= 32 else "accumulate_wide_kernel")
+            # (csrc/accumulate_quad.hip: accumulate_quad_supports — the speculative LDS-DMA kernel takes 27 .. 42 and 49, 50)
+            spec = not weighted and os.environ.get("ANOFOX_QUAD_SPEC", "1") != "0"
+            quad = p <= 26 or (spec and (p <= 42 or p in (49, 50)))
+            kernel = "accumulate_quad_kernel" if quad else ("accumulate_mid_kernel" if p <= 32 else "accumulate_wide_kernel")
             # which roof bounds this width: arithmetic intensity against the ridge point peak_flops / peak_bytes
             # (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B).  p + 1 = 2 * 9.8 - 3 => widths up to p ~ 75 are HBM-bound
             intensity = algorithmic_flops_per_fit(n, p) / bytes_fit
