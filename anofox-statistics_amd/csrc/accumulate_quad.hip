@@ -640,7 +640,9 @@ hipError_t launch_quad_nb(const WideArgs &a, hipStream_t stream) {
 	// the unweighted fit with an intercept first runs the speculative kernel, then the full version on what it listed (the
 	// counter is zeroed by the caller; ANOFOX_WIDE_FAST=0 / ANOFOX_QUAD_SPEC=0: the full version only)
 	static const bool spec_on = !(getenv("ANOFOX_QUAD_SPEC") && atoi(getenv("ANOFOX_QUAD_SPEC")) == 0);
-	const bool spec = spec_on && !a.no_fast_path && !weighted && center;
+	// (NB = 3, 4 — p = 9 .. 14 — stay with the full version: measured 2-5 % faster there on two boxes, profiles/r04_widths_n1000.txt,
+	// r04_final_widths_n1000.txt; the speculative one pays a second launch and wins only from p = 15 on)
+	const bool spec = spec_on && !a.no_fast_path && !weighted && center && NB >= 5;
 	if (weighted) {
 		if (center) hipLaunchKernelGGL((accumulate_quad_kernel<NB, true, true, RL, WPS>), grid, block, lds_bytes, stream, a);
 		else hipLaunchKernelGGL((accumulate_quad_kernel<NB, true, false, RL, WPS>), grid, block, lds_bytes, stream, a);
