@@ -531,6 +531,8 @@ hipError_t launch_accumulate_mid_segments(const WideArgs &a, hipStream_t stream)
 bool accumulate_quad_supports(int p, bool weighted, bool center, bool no_fast_path);
 hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream);
 // accumulate_wide.hip: the segment kernel + the full version on the redo list, behind accumulate_quad's speculative kernel at p = 33, 34
+// (r4) accumulate_prefix.hip: the moment records of frames that extend one another (expanding windows), frames_per_block per workgroup
+hipError_t launch_accumulate_prefix(const WideArgs &a, int frames_per_block, hipStream_t stream);
 hipError_t launch_accumulate_wide_followup(const WideArgs &a, hipStream_t stream);
 // accumulate_mid.hip: the full version on the redo list (p = 27 .. 32)
 hipError_t launch_accumulate_mid_redo(const WideArgs &a, hipStream_t stream);

@@ -33,6 +33,7 @@ struct AnofoxHipContext {
 	hipEvent_t gate_wait = nullptr, gate_record = nullptr; // anofox_hip_context_set_accumulate_gate
 	// set around a fit call by the window-frame path (frames.hip): group g owns rows [row_offsets[g], frame_ends[g])
 	const int64_t *frame_ends = nullptr;
+	bool frame_prefix = false; // (r4) the frames of this call extend one another (UNBOUNDED PRECEDING): accumulate_prefix.hip writes their records
 	int64_t last_window_flagged = 0; // frames of the last in-register window call that were refitted with refinement
 	void *frames_buf = nullptr; // scratch of that path (prefix counts, rule counts, records of one slab of frames)
 	size_t frames_bytes = 0;

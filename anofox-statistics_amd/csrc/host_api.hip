@@ -171,8 +171,14 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		const bool plain_wide = !quad && !tile && !mid_acc;
 		static const bool split_on = getenv("ANOFOX_WIDE_SPLIT") && atoi(getenv("ANOFOX_WIDE_SPLIT")) == 1; // measurement switch
 		a.launch_part = (plain_wide && overlap && split_on) ? 1 : 0;
-		if (hip_fail(quad ? launch_accumulate_quad(a, st)
-		                  : (tile ? launch_accumulate_tile(a, st) : (mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st))),
+		// (r4) expanding window frames (run_window): every frame is its predecessor plus a row — their records come from
+		// accumulate_prefix.hip, n / (2 K) + 1 rows read per frame instead of n / 2.  ANOFOX_FRAMES_PREFIX=0: the kernels below.
+		static const bool prefix_on = !(getenv("ANOFOX_FRAMES_PREFIX") && atoi(getenv("ANOFOX_FRAMES_PREFIX")) == 0);
+		static const int prefix_k = getenv("ANOFOX_FRAMES_PREFIX_K") ? atoi(getenv("ANOFOX_FRAMES_PREFIX_K")) : 128;
+		const bool prefix = prefix_on && ctx->frame_prefix && a.row_ends != nullptr;
+		if (hip_fail(prefix ? launch_accumulate_prefix(a, prefix_k > 0 ? prefix_k : 128, st)
+		                    : (quad ? launch_accumulate_quad(a, st)
+		                            : (tile ? launch_accumulate_tile(a, st) : (mid_acc ? launch_accumulate_mid(a, st) : launch_accumulate_wide(a, st)))),
 		             "wide accumulate kernel launch", e))
 			return false;
 		if (ctx->timing) (void)hipEventRecord(e1, st);
@@ -867,7 +873,10 @@ bool run_window(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, cons
 		if (hip_fail(launch_frames_from_rows_spec(d_off, G, n_rows, frame.start_preceding, frame.end_preceding, fs.lo, fs.hi, st),
 		             "frame bounds kernel launch", e))
 			return false;
-		return run_frames(ctx, fs, n_rows, p, n_rows, d_y, x_cols, d_w, fs.lo, fs.hi, opt, d_pred, nullptr, e);
+		ctx->frame_prefix = frame.start_preceding == ANOFOX_HIP_FRAME_UNBOUNDED; // (every frame starts at its partition's first row)
+		const bool ok = run_frames(ctx, fs, n_rows, p, n_rows, d_y, x_cols, d_w, fs.lo, fs.hi, opt, d_pred, nullptr, e);
+		ctx->frame_prefix = false;
+		return ok;
 	}
 	if (!ensure_buffer(&ctx->wtab, &ctx->wtab_bytes, (size_t)(kWindowTcritCap + 1) * sizeof(double), "t table", e)) return false;
 	hipStream_t st = ctx->stream;

@@ -33,6 +33,7 @@ STUB(launch_accumulate_mid(const WideArgs &, hipStream_t))
 STUB(launch_accumulate_quad(const WideArgs &, hipStream_t))
 bool accumulate_quad_supports(int, bool, bool, bool) { return false; }
 STUB(launch_accumulate_tile(const WideArgs &, hipStream_t))
+STUB(launch_accumulate_prefix(const WideArgs &, int, hipStream_t))
 bool accumulate_tile_supports(int, bool, bool, bool) { return false; }
 STUB(launch_refit_dd_wide(const WideArgs &, hipStream_t))
 STUB(launch_refit_dd_narrow(const BatchArgs &, hipStream_t))
