@@ -45,6 +45,9 @@ __global__ __launch_bounds__(kPrefixThreads) void accumulate_prefix_kernel(WideA
 	// this thread's column (x_tid, y, w), read once: the table is indexed by the thread number only here
 	const double *col = tid < p ? args.x_table[tid] : (tid == p ? args.y : (WEIGHTED && tid == p + 1 ? args.w : nullptr));
 	int64_t cur_lo = -1, cur_hi = -1; // rows [cur_lo, cur_hi) are in the record
+	double v_next = 0.0;              // this thread's value of row `next_row`, loaded ahead
+	int64_t next_row = -1;
+	bool have_next = false;
 	bool have_first = false;          // (uniform)
 
 	auto reset = [&]() {
@@ -55,11 +58,10 @@ __global__ __launch_bounds__(kPrefixThreads) void accumulate_prefix_kernel(WideA
 		__syncthreads();
 	};
 	// this thread's elements of the tiles: element k of the record, k = tile * 256 + r * 16 + c -> (16 I + r, 16 J + c)
-	auto add_row = [&](int64_t r) {
-		// load: thread j < p column j, thread p: y, thread p + 1: w; everything finite (and w > 0) or the row does not take part
-		double v = 0.0;
+	// `v` = this thread's value of row r (loaded one row ahead by the caller: a row per memory round trip would be the kernel)
+	auto add_row = [&](double v) {
+		// thread j < p column j, thread p: y, thread p + 1: w; everything finite (and w > 0) or the row does not take part
 		bool bad = false;
-		if (col) v = col[r];
 		if (tid <= p + (WEIGHTED ? 1 : 0)) bad = !isfinite(v) || (WEIGHTED && tid == p + 1 && !(v > 0.0));
 		if (tid == 0) *vote = 0;
 		__syncthreads();
@@ -119,8 +121,32 @@ __global__ __launch_bounds__(kPrefixThreads) void accumulate_prefix_kernel(WideA
 			cur_lo = lo;
 			cur_hi = lo;
 		}
-		for (int64_t r = cur_hi; r < hi; ++r) add_row(r);
-		if (hi > cur_hi) cur_hi = hi;
+		// rows this block will still add after this frame's (the frames that extend it): the prefetch may run that far
+		if (hi > cur_hi) {
+			int64_t run_end = hi;
+			for (int64_t g2 = g + 1; g2 < g_end && g2 < g + 4; ++g2) {
+				if (args.row_offsets[args.group_base + g2] != lo) break;
+				const int64_t h2 = group_row_end(args, args.group_base + g2);
+				if (h2 < run_end) break;
+				run_end = h2;
+			}
+			if (!have_next || next_row != cur_hi) {
+				v_next = col ? col[cur_hi] : 0.0;
+				next_row = cur_hi;
+				have_next = true;
+			}
+			for (int64_t r = cur_hi; r < hi; ++r) {
+				const double v = v_next;
+				if (r + 1 < run_end) {
+					v_next = col ? col[r + 1] : 0.0;
+					next_row = r + 1;
+				} else {
+					have_next = false;
+				}
+				add_row(v);
+			}
+			cur_hi = hi;
+		}
 		// the record of this frame (first valid row and y's first value with it)
 		double *out = args.moments + g * (int64_t)reclen;
 		for (int k = tid; k < reclen; k += kPrefixThreads) {
