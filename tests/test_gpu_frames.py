@@ -136,3 +136,36 @@ def test_frames_argument_errors(pkg, ctx):
         pkg.fit_predict_frames_host(y, [y], None, [0, 0, 0, 0, 0], [9, 1, 1, 1, 1], opts, ctx=ctx)     # hi beyond n_rows
     with pytest.raises(pkg.AnofoxStatsError):
         pkg.fit_predict_frames_host(y, [y], None, [0, 0, 0, 0, 0], [5, 5, 5, 5, 5], pkg.RegressionOptions().batch_options("wls"), ctx=ctx)
+
+
+@pytest.mark.parametrize("model,p,frame", [("ols", 9, (None, 0)), ("wls", 17, (None, 2)), ("ols", 33, (None, -3)), ("ridge", 12, (None, 0)),
+                                           ("ols", 100, (None, 0)), ("wls", 128, (None, 1))])
+def test_expanding_frames_of_wide_designs_across_block_boundaries(pkg, ctx, model, p, frame):
+    """(r4) csrc/accumulate_prefix.hip writes the moment records of `UNBOUNDED PRECEDING` frames incrementally, 128 consecutive frames
+    per workgroup: partitions shorter and longer than a workgroup's share, ending on and next to its boundaries, one of a single row;
+    the first rows of a partition without y (the first valid row comes later), rows with a NULL feature, weights <= 0; frames that
+    end before and after the current row — against the oracle's refit of every frame."""
+    rng = np.random.default_rng(7 * p + len(model))
+    ns = np.array([1, 127, 128, 129, 2 * p + 150, 3, 64, p + 2, 300])
+    offs = np.concatenate([[0], np.cumsum(ns)]).astype(np.int64)
+    N = int(offs[-1])
+    G = len(ns)
+    x_cols = [rng.uniform(-10, 10, N) for _ in range(p)]
+    gid = np.repeat(np.arange(G), ns)
+    beta = rng.uniform(-3, 3, (G, p))
+    y = rng.uniform(-10, 10, G)[gid] + sum(beta[gid, j] * x_cols[j] for j in range(p)) + 0.5 * rng.standard_normal(N)
+    w = rng.uniform(0.5, 1.5, N)
+    y[rng.random(N) < 0.08] = np.nan
+    x_cols[p // 2][rng.random(N) < 0.01] = np.nan
+    for g in (1, 4):                                   # partitions whose first rows do not train
+        y[offs[g]:offs[g] + 3] = np.nan
+    w[rng.random(N) < 0.02] = 0.0
+    for icpt in (True, False):
+        kw = dict(fit_intercept=icpt, confidence_level=0.95)
+        if model == "ridge":
+            kw["alpha"] = 0.3
+        wv = w if model == "wls" else None
+        opts = pkg.RegressionOptions(**kw).batch_options(model)
+        pred = pkg.fit_predict_window_host(offs, y, x_cols, wv, opts, frame, ctx=ctx)
+        ref = oracle.fit_predict_window(y, x_cols, offs, w=wv, start_preceding=frame[0], end_preceding=frame[1], model=model, **kw)
+        _check(pred, ref, f"prefix {model} p={p} icpt={icpt} frame={frame}")
