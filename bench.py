@@ -662,6 +662,12 @@ def main():
             out["multi_gpu"] = multi
     if rank == 0:
         if world == 1 and p <= 8 and not (args.no_end_to_end or args.vif or args.window or args.predict or args.inference):
+            # The pipelined driver of the timed loop (two more contexts, each with its own streams) is finished with: while its streams
+            # exist the H2D copies of the leg below run at 47-48 GB/s instead of the 55 GB/s the same leg reaches in a process without
+            # them (scripts/e2e_bisect.py: with the driver alive 47.6, after dropping it 55.0).  A DuckDB process holds the arena's
+            # contexts only.
+            sharded.close()
+            torch.cuda.synchronize()
             try:
                 out["end_to_end"] = end_to_end_leg(pkg, ctx, offs, y, x_cols, w, opts, args.model, kw, G, n, p)
                 if args.end_to_end_row_log:

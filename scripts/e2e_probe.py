@@ -67,3 +67,18 @@ n_slots = 1_000_000
 slot = (torch.randint(0, 62500, (N,), device=dev, dtype=torch.int32, generator=g) + 62500 * ((torch.arange(N, device=dev) // (4 << 20)) % 16).to(torch.int32))
 hs = slot.cpu().pin_memory()
 run("torch pinned, windowed 62500-slot batches", n_slots, None, hx.data_ptr(), hy.data_ptr(), hs.data_ptr())
+# the same pattern sustained for as many rows as the bench's end_to_end leg streams (1e9): does the rate hold over 1.5 s?
+err = abi.AnofoxError()
+st = pkg.AggState(ctx, p, opts, initial_slots=n_slots, retain_bytes=0)
+ctx.synchronize(); t0 = time.perf_counter()
+rows = 0
+for rep in range(30):
+    for r0 in range(0, N, 1 << 22):
+        r1 = min(N, r0 + (1 << 22))
+        ok = lib.anofox_hip_agg_state_update_host(st._h, r1 - r0, n_slots, hs.data_ptr() + 4 * r0, hy.data_ptr() + 8 * r0, hx.data_ptr() + 8 * p * r0, None, None, C.byref(err))
+        assert ok, err.text()
+        rows += r1 - r0
+    if rep in (0, 9, 19, 29):
+        ctx.synchronize()
+        print(f"sustained windowed, after {rows / 1e9:.2f} G rows: {rows * 76 / (time.perf_counter() - t0) / 1e9:.1f} GB/s", flush=True)
+st.close()
