@@ -26,6 +26,8 @@
 #include <stddef.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "lds_dma.h"
 
@@ -579,6 +581,174 @@ __device__ __forceinline__ bool quad_spec_dma_rows_x4(const WideArgs &args, int6
 	return quad_finish<NB, true>(args, rec, lane, buf, acc, first, dmax, isx_prev, isx_last, 0, lo, hi);
 }
 
+// ---- (r4) the fine ring: 16-row sub-blocks of EIGHT columns per `global_load_lds_dwordx4` -------------------------------------
+// What the 32-row ring above keeps in flight per wavefront is one block — half its slice — and never more than the 63 vector-memory
+// instructions a wavefront may have outstanding, 256 bytes each; with the slices of 36 .. 65 columns a CU holds six, then four
+// wavefronts, and blocks in flight / memory latency is what those widths run at (profiles/r04_widths_n1000.md: 16.1 MB on the chip at
+// p = 40 -> 4.2 TB/s, 13.4 MB at p = 50 -> 3.1 TB/s: 3.8-4.3 us either way).  Here eight lanes carry one column: an instruction moves
+// 16 rows x 8 columns = 1 KB, each lane with its own 64-bit address (column pointer of its group of eight, two rows per lane), a
+// sub-block is ceil((p + 1) / 8) instructions, and the slice is a ring of RING sub-blocks of which RING - 1 are in flight while one
+// is read: three quarters of the slice at RING = 4 instead of one half, in an eighth of the instructions.
+// LDS of a sub-block: chunk i (1 KB) = columns 8 i .. 8 i + 7, 128 bytes each (the hardware's M0 + 16 * lane), and inside a column
+// the row PAIR pr sits at position pr ^ 4 * ((column >> 1) & 1) — the lane picks its source rows accordingly — so that the 32 lanes
+// of a half-wave of the fragment read (ds_read_b64: 4 columns x 8 rows) touch every bank once.
+// (The instruction's immediate offset cannot carry the row step of consecutive sub-blocks: the hardware adds it to the LDS address
+// as well as to the source — the first version of this loader scattered its sub-blocks over the slice that way.)
+// The last 1 .. 15 rows of a group: a lane whose pair would end behind the group loads the pair (hi - 2, hi - 1) instead; the lanes
+// of the masked step that read row `left - 1` of an odd remainder find it in the second half of that pair.  (A group of one row
+// goes to the full version.)
+__host__ __device__ constexpr int quad_fine_chunks(int p) { return (p + 1 + 7) / 8; }
+__host__ __device__ constexpr int quad_fine_slice_doubles(int p, int ring) {
+	const int data = ring * quad_fine_chunks(p) * 128;
+	const int R = 4 * quad_blocks(p);
+	const int image = R * R + 2 * R;
+	return data > image ? data : image;
+}
+
+template <int OFF> // 16 bytes from each lane's own address (+ OFF) to dst + 16 * lane
+__device__ __forceinline__ void lds_dma_x4_lanes(const double *src, unsigned dst) {
+	unsigned keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep)
+	             : "v"(src), "s"(dst), "n"(OFF)
+	             : "memory");
+}
+
+template <int NI, int RING>
+__device__ __forceinline__ void quad_fine_wait(int younger) { // all but the `younger` most recent sub-blocks have landed (wave-uniform)
+	static_assert((RING - 1) * NI <= 63, "vmcnt");
+	switch (younger) {
+	case 0: lds_dma_wait_but<0>(); break;
+	case 1: lds_dma_wait_but<NI>(); break;
+	case 2: lds_dma_wait_but<(RING > 2 ? 2 : 0) * NI>(); break;
+	case 3: lds_dma_wait_but<(RING > 3 ? 3 : 0) * NI>(); break;
+	case 4: lds_dma_wait_but<(RING > 4 ? 4 : 0) * NI>(); break;
+	case 5: lds_dma_wait_but<(RING > 5 ? 5 : 0) * NI>(); break;
+	case 6: lds_dma_wait_but<(RING > 6 ? 6 : 0) * NI>(); break;
+	default: lds_dma_wait_but<(RING > 7 ? 7 : 0) * NI>(); break;
+	}
+}
+
+template <int NB, int RING>
+__device__ __forceinline__ bool quad_spec_fine_rows(const WideArgs &args, int64_t lo, int64_t hi, double *rec, int lane, double *buf) {
+	static_assert(RING >= 2 && RING <= 8, "ring depth");
+	constexpr int NPAIR = NB * (NB + 1) / 2;
+	constexpr int NIMAX = (4 * NB - 1 + 7) / 8; // chunks of the widest design with NB blocks; the narrowest has NIMAX or NIMAX - 1
+	if (hi - lo < 2) return false;
+	const int p = args.p;
+	const int ni = (p + 1 + 7) >> 3;
+	const int k = lane >> 4, b = (lane >> 2) & 3, c4 = lane & 3;
+	const int rsub = 4 * k + b;
+	// the fragment read of column 4 g + c4, row rsub of a sub-block: 64 g + rd_off doubles
+	const int rd_off = 16 * c4 + 2 * ((rsub >> 1) ^ (4 * (c4 >> 1))) + (rsub & 1);
+	const int c_last = 4 * (NB - 1) + c4;
+	const bool rd_last = c_last <= p;
+	const int cl = rd_last ? c_last : p;
+	const int last_off = (cl >> 3) * 128 + (cl & 7) * 16 + 2 * ((rsub >> 1) ^ (4 * ((cl >> 1) & 1))) + (rsub & 1);
+	const double fill_last = c_last == p + 1 ? 1.0 : 0.0;
+	const bool isx_prev = 4 * (NB - 2) + c4 < p, isx_last = c_last < p;
+	const unsigned lds0 = lds_dma_address(buf);
+	const unsigned sb_bytes = (unsigned)ni * 1024u;
+	double acc[NPAIR];
+#pragma unroll
+	for (int t = 0; t < NPAIR; ++t) acc[t] = 0.0;
+	double first[NB], dmax[NB];
+#pragma unroll
+	for (int g = 0; g < NB; ++g) first[g] = dmax[g] = 0.0;
+
+	// the lane's sources: column 8 i + (lane >> 3) (columns past y repeat y: the same addresses, no traffic), row pair `pr`
+	const int s8 = lane >> 3, pr = (lane & 7) ^ (4 * ((s8 >> 1) & 1));
+	const lds_dma_table_t tab = lds_dma_table((unsigned)offsetof(WideArgs, x_table)); // (y sits behind the last feature: host_api.hip)
+	const double *ptr[NIMAX];
+#pragma unroll
+	for (int i = 0; i < NIMAX; ++i) {
+		int c = 8 * i + s8;
+		c = c < p ? c : p;
+		ptr[i] = tab[c] + lo + 2 * pr;
+	}
+	const int64_t n = hi - lo;
+	const int nfull = (int)(n >> 4), left = (int)(n & 15), nsb = nfull + (left ? 1 : 0);
+	// (the remainder) doubles to step back so that the lane's pair ends inside the group
+	const int tail_back = 2 * pr + 1 >= left ? 2 * pr - (left - 2) : 0;
+
+	// sub-block `sub` into its slot; the lanes' pointers move on by 16 rows.  (The instruction's immediate offset cannot carry the
+	// row step: the hardware adds it to the LDS address as well.)
+	auto dma = [&](int sub) {
+		const unsigned dst = lds0 + (unsigned)(sub % RING) * sb_bytes;
+		if (sub >= nfull) { // (wave-uniform) the remainder
+#pragma unroll
+			for (int i = 0; i < NIMAX; ++i)
+				if (i < ni) lds_dma_x4_lanes<0>(ptr[i] - tail_back, dst + (unsigned)i * 1024u);
+			return;
+		}
+#pragma unroll
+		for (int i = 0; i < NIMAX; ++i) {
+			if (i < ni) lds_dma_x4_lanes<0>(ptr[i], dst + (unsigned)i * 1024u);
+			ptr[i] += 16;
+		}
+	};
+	auto wait = [&](int younger) {
+		if (ni == NIMAX) quad_fine_wait<NIMAX, RING>(younger);
+		else quad_fine_wait<(NIMAX > 1 ? NIMAX - 1 : 1), RING>(younger);
+	};
+	auto step = [&](const double *hb, bool valid_all, long long rm, int fix) {
+		double d[NB];
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+			double v;
+			if (g < NB - 1) {
+				v = hb[64 * g + rd_off + fix];
+			} else {
+				const double raw = hb[last_off + fix];
+				v = rd_last ? raw : fill_last;
+			}
+			double dev = v - first[g];
+			if (!valid_all) dev = quad_mask(dev, rm);
+			d[g] = dev;
+		}
+		int t = 0;
+#pragma unroll
+		for (int g = 0; g < NB; ++g) {
+#pragma unroll
+			for (int h = g; h < NB; ++h) {
+				acc[t] = __builtin_amdgcn_mfma_f64_4x4x4f64(d[g], d[h], acc[t], 0, 0, 0);
+				++t;
+			}
+		}
+	};
+
+	int issued = 0;
+	for (; issued < RING - 1 && issued < nsb; ++issued) dma(issued);
+	wait(issued - 1);
+	__builtin_amdgcn_wave_barrier();
+	{ // the shift: the group's first row (the constants are not shifted)
+		const int f_off = 16 * c4 + 2 * (4 * (c4 >> 1));
+#pragma unroll
+		for (int g = 0; g < NB - 1; ++g) first[g] = buf[64 * g + f_off];
+		first[NB - 1] = rd_last ? buf[(cl >> 3) * 128 + (cl & 7) * 16 + 2 * (4 * ((cl >> 1) & 1))] : 0.0;
+	}
+	for (int j = 0; j < nfull; ++j) {
+		if (issued < nsb) { // (the slot read in the trip before this one)
+			dma(issued);
+			++issued;
+		}
+		wait(issued - 1 - j);
+		__builtin_amdgcn_wave_barrier();
+		step(buf + (size_t)(j % RING) * (size_t)(ni * 128), true, -1ll, 0);
+		__builtin_amdgcn_wave_barrier(); // the reads of this slot before the DMA that refills it
+	}
+	if (left) {
+		lds_dma_wait_all();
+		__builtin_amdgcn_wave_barrier();
+		const long long rm = rsub < left ? -1ll : 0ll;
+		const int fix = ((left & 1) && rsub == left - 1) ? 1 : 0;
+		step(buf + (size_t)(nfull % RING) * (size_t)(ni * 128), false, rm, fix);
+	}
+	lds_dma_wait_all();
+	__builtin_amdgcn_wave_barrier();
+	return quad_finish<NB, true>(args, rec, lane, buf, acc, first, dmax, isx_prev, isx_last, 0, lo, hi);
+}
+
 // MODE 0: the full version on every group; 1: the speculative version, give-ups (and empty groups) listed for the full one —
 // the list borrows the refine queue and its counter word kWideRedoCounter, as accumulate_wide's does; 2: the full version on
 // the listed groups (launched with the batch's grid: one scalar load and out for the wavefronts beyond the list).
@@ -602,6 +772,12 @@ __global__ __launch_bounds__(256, WPS) void accumulate_quad_kernel(WideArgs args
 		if (wide_register_big_group(args, gl, lo, hi, T, lane, T <= 2 ? kSegMaxBig : kWideSegMaxBig, T <= 2 ? kSegMaxSegments : kWideSegMaxSegments)) return;
 	}
 	double *rec = args.moments + gl * (int64_t)wide_record_len(T);
+	if constexpr (MODE == 4) { // the speculative version on the fine LDS-DMA ring (the template's RL parameter is the ring depth)
+		double *slice = quad_lds + (threadIdx.x >> 6) * quad_fine_slice_doubles(args.p, RL);
+		if (hi > lo && quad_spec_fine_rows<NB, RL>(args, lo, hi, rec, lane, slice)) return;
+		if (lane == 0) args.refine_list[atomicAdd(args.refine_count + kWideRedoCounter, 1)] = (int32_t)gl;
+		return;
+	}
 	if constexpr (MODE == 3) { // the speculative version on LDS-DMA (its own slice size)
 		// (MODE 3: the template's RL parameter is the ring depth)
 		double *slice = quad_lds + (threadIdx.x >> 6) * quad_dma_slice_doubles(args.p, RL);
@@ -687,6 +863,50 @@ hipError_t launch_quad_spec_only(const WideArgs &a, hipStream_t stream) {
 	return launch_accumulate_wide_followup(a, stream);
 }
 
+// the fine ring (measurement switch ANOFOX_QUAD_FINE=3 | 4 = ring depth; OFF by default): NB = 8 .. 17, p = 27 .. 64.
+// Measured on one box (scripts/quad_fine_ab.sh, 100 000 / 50 000 groups x 1000 rows, TB/s of the kernel, default | ring 4 | ring 3):
+//   p = 33: 4.08 | 3.63 | 3.68      p = 40: 3.79 | 3.71 | 3.82      p = 50: 3.13 | 2.35 | 2.51      p = 64 (accumulate_wide<4>): 3.24 | 2.10 | 2.11
+// Correct (the GPU suite passes with it on), and slower at every width although it keeps half as much again in flight per wavefront
+// in an eighth of the instructions — so neither the bytes in flight nor the instruction count is what holds these widths.  What
+// changed for the worse is the contiguous run per column and request: 128 bytes here, 256 in the 32-row ring, 512 in the
+// register-staged accumulate_quad (5.2-5.4 TB/s), 1 KB in accumulate_narrow (6.0) — the order of the measured rates.  A columnar
+// table of 35 .. 65 columns is that many DRAM streams per wavefront; the rows of a block (LDS per wavefront / columns) set the run
+// length, and the run length sets the rate.  NB >= 15 also spill here (20-296 bytes: 512 registers hold 120-153 accumulators and
+// little else).
+template <int NB, int WPS, int RING>
+hipError_t launch_quad_spec_fine(const WideArgs &a, hipStream_t stream) {
+	const size_t slice_bytes = (size_t)quad_fine_slice_doubles(a.p, RING) * sizeof(double);
+	int fit = (int)(((size_t)160 * 1024) / slice_bytes);
+	if (fit > 4 * WPS) fit = 4 * WPS;
+	const int waves = fit >= 8 ? 4 : (fit % 4 == 0 ? 4 : (fit % 2 == 0 ? 2 : 1));
+	const dim3 grid((unsigned)((a.n_groups + waves - 1) / waves)), block(64 * waves);
+	const size_t lds_bytes = (size_t)waves * slice_bytes;
+	static const bool attr_set = [] {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_quad_kernel<NB, false, true, RING, WPS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+		return true;
+	}();
+	(void)attr_set;
+	hipLaunchKernelGGL((accumulate_quad_kernel<NB, false, true, RING, WPS, 4>), grid, block, lds_bytes, stream, a);
+	hipError_t rc = hipGetLastError();
+	if (rc != hipSuccess) return rc;
+	if (wide_tiles(a.p) <= 2) {
+		if (a.seg_table && (rc = launch_accumulate_mid_segments(a, stream)) != hipSuccess) return rc;
+		return launch_accumulate_mid_redo(a, stream);
+	}
+	return launch_accumulate_wide_followup(a, stream);
+}
+
+template <int NB, int WPS>
+hipError_t launch_quad_spec_fine_ring(const WideArgs &a, int ring, hipStream_t stream) {
+	if (ring == 3) return launch_quad_spec_fine<NB, WPS, 3>(a, stream);
+	return launch_quad_spec_fine<NB, WPS, 4>(a, stream);
+}
+
+int quad_fine_ring() {
+	static const int ring = getenv("ANOFOX_QUAD_FINE") ? atoi(getenv("ANOFOX_QUAD_FINE")) : 0;
+	return ring;
+}
+
 } // namespace
 
 // The full version at p = 27 .. 32 (NB = 8, 9) stays with accumulate_mid: 36 / 45 accumulators + the staged block + the running
@@ -704,6 +924,7 @@ bool accumulate_quad_supports(int p, bool weighted, bool center, bool no_fast_pa
 	// columns to 64: 160 matrix cycles per row against 91.  So: up to 42, and 49, 50.  ANOFOX_QUAD_SPEC_MAXP=50 takes 43 .. 48 as well.)
 	static const int spec_max_p = getenv("ANOFOX_QUAD_SPEC_MAXP") ? atoi(getenv("ANOFOX_QUAD_SPEC_MAXP")) : 0;
 	if (p > kNarrowMaxP && p <= 26) return true;
+	if (quad_fine_ring() > 0 && p > 26 && p <= 64) return spec_on && !weighted && center && !no_fast_path;
 	const bool in_range = spec_max_p > 0 ? p <= spec_max_p : (p <= 42 || p == 49 || p == 50);
 	return p > 26 && p <= 50 && in_range && spec_on && !weighted && center && !no_fast_path;
 }
@@ -719,6 +940,21 @@ hipError_t launch_accumulate_quad(const WideArgs &a, hipStream_t stream) {
 	static const int ring = getenv("ANOFOX_QUAD_RING") ? atoi(getenv("ANOFOX_QUAD_RING")) : 2; // (measurement switch: 3 = three 32-row blocks, 4 = 128-row blocks on dwordx4)
 	int rl = (a.p <= 11 || (a.p >= 15 && a.p <= 17)) ? 2 : 1;
 	if (env_rl == 1 || (env_rl == 2 && a.p <= 18)) rl = env_rl;
+	if (const int fine = quad_fine_ring(); fine > 0 && nb >= 8) {
+		switch (nb) {
+		case 8: return launch_quad_spec_fine_ring<8, 2>(a, fine, stream);
+		case 9: return launch_quad_spec_fine_ring<9, 2>(a, fine, stream);
+		case 10: return launch_quad_spec_fine_ring<10, 2>(a, fine, stream);
+		case 11: return launch_quad_spec_fine_ring<11, 2>(a, fine, stream);
+		case 12: return launch_quad_spec_fine_ring<12, 2>(a, fine, stream);
+		case 13: return launch_quad_spec_fine_ring<13, 2>(a, fine, stream);
+		case 14: return launch_quad_spec_fine_ring<14, 1>(a, fine, stream);
+		case 15: return launch_quad_spec_fine_ring<15, 1>(a, fine, stream);
+		case 16: return launch_quad_spec_fine_ring<16, 1>(a, fine, stream);
+		case 17: return launch_quad_spec_fine_ring<17, 1>(a, fine, stream);
+		default: return hipErrorInvalidValue;
+		}
+	}
 	switch (nb) { // p = 9, 10 | 11..14 | 15..18 | 19..22 | 23..26 | 27..30 | 31..34
 	case 3: return rl == 2 ? launch_quad_nb<3, 2, 3>(a, stream) : launch_quad_nb<3, 1, 3>(a, stream);
 	case 4: return rl == 2 ? launch_quad_nb<4, 2, 2>(a, stream) : launch_quad_nb<4, 1, 2>(a, stream);
