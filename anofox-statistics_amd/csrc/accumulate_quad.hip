@@ -867,12 +867,10 @@ hipError_t launch_quad_spec_only(const WideArgs &a, hipStream_t stream) {
 // Measured on one box (scripts/quad_fine_ab.sh, 100 000 / 50 000 groups x 1000 rows, TB/s of the kernel, default | ring 4 | ring 3):
 //   p = 33: 4.08 | 3.63 | 3.68      p = 40: 3.79 | 3.71 | 3.82      p = 50: 3.13 | 2.35 | 2.51      p = 64 (accumulate_wide<4>): 3.24 | 2.10 | 2.11
 // Correct (the GPU suite passes with it on), and slower at every width although it keeps half as much again in flight per wavefront
-// in an eighth of the instructions — so neither the bytes in flight nor the instruction count is what holds these widths.  What
-// changed for the worse is the contiguous run per column and request: 128 bytes here, 256 in the 32-row ring, 512 in the
-// register-staged accumulate_quad (5.2-5.4 TB/s), 1 KB in accumulate_narrow (6.0) — the order of the measured rates.  A columnar
-// table of 35 .. 65 columns is that many DRAM streams per wavefront; the rows of a block (LDS per wavefront / columns) set the run
-// length, and the run length sets the rate.  NB >= 15 also spill here (20-296 bytes: 512 registers hold 120-153 accumulators and
-// little else).
+// in an eighth of the instructions — so neither the bytes in flight per wavefront nor the instruction count is what holds these
+// widths.  (The contiguous run per column and request halves to 128 bytes here; that is not it either: accumulate_wide staged with
+// 256-byte instead of 128-byte runs measures the same, profiles/r04_wide_run256_ab.txt.)  NB >= 15 also spill here (20-296 bytes:
+// 512 registers hold 120-153 accumulators and little else).
 template <int NB, int WPS, int RING>
 hipError_t launch_quad_spec_fine(const WideArgs &a, hipStream_t stream) {
 	const size_t slice_bytes = (size_t)quad_fine_slice_doubles(a.p, RING) * sizeof(double);

@@ -152,6 +152,9 @@ struct WideCfg {
 #ifndef ANOFOX_WIDE_DEPTH
 #define ANOFOX_WIDE_DEPTH(T) ((T) <= 4 ? 2 : 1)
 #endif
+#ifndef ANOFOX_WIDE_RUN256
+#define ANOFOX_WIDE_RUN256(T) 0
+#endif
 	static constexpr int depth(bool fast) { return kWaves == 4 && fast ? ANOFOX_WIDE_DEPTH(T) : 1; }
 	static constexpr int chunk_rows(bool weighted, bool center = true) { return ANOFOX_WIDE_SHORT_CHUNK(T, weighted, center) ? 16 : 32; }
 	static constexpr int stride(bool weighted, bool center = true) { return chunk_rows(weighted, center) + 2; } // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
@@ -270,6 +273,10 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	using Cfg = WideCfg<T>;
 	constexpr int kChunkRows = DMA ? DMA : Cfg::chunk_rows(WEIGHTED, CENTER), kLdsStride = DMA ? DMA + 2 : Cfg::stride(WEIGHTED, CENTER);
 	constexpr bool kWideChunk = kChunkRows == 32;
+	// (r4) kRun: the speculative version's lanes stage 32 rows of FOUR columns per load instruction (16 lanes x 16 bytes = a run of 256
+	// bytes per column and request) instead of 16 rows of eight columns (128 bytes): registers `a` of a slot hold its first four columns,
+	// `b` its last four, both the same 32 rows.  (The full version keeps the 16-row classes its row masks are built from.)
+	constexpr bool kRun = FAST && DMA == 0 && kWideChunk && ANOFOX_WIDE_RUN256(T);
 	constexpr unsigned kFullMask = kWideChunk ? 0xffffffffu : 0xffffu;
 	constexpr int P16 = 16 * T;
 	const int p = args.p;
@@ -311,11 +318,13 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	// with the pointers parked in LDS every load of a chunk waited for its own ds_read round trip, ~1000 cycles per
 	// chunk of pure latency (phase stamps, scripts/dbg_acc_stamps.py).
 	constexpr int kMaxLoads = (P16 + 2 + 7) / 8 / kWaves + 1;
-	const int colsub = lane >> 3;
-	const int rp = lane & 7;
+	const int colsub = kRun ? lane >> 4 : lane >> 3;
+	const int rp = kRun ? lane & 15 : lane & 7;
 	const int n_loads_total = (ncol + 7) / 8; // load slots: 8 source columns each
 	gptr_t colp[kMaxLoads]; // this lane's column of slot q, at the group's first row + 2 rp
 	int dcol[kMaxLoads];    // element offset of (image column, row 2 rp) within an image
+	gptr_t colpB[kRun ? kMaxLoads : 1]; // (kRun) the same for the lane's column of the slot's second half
+	int dcolB[kRun ? kMaxLoads : 1];
 	unsigned actbits = 0;   // bit q: the column exists (slots beyond ncol read y again and store into a spare column)
 	unsigned wbits = 0;     // bit q: the column is the weight column
 #pragma unroll
@@ -326,6 +335,13 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		if (!active) col = ycol + 2 + (colsub % 6); // spare columns 16T+2 .. 16T+7: nothing reads them
 		dcol[q] = col * kLdsStride + 2 * rp;
 		colp[q] = reinterpret_cast<gptr_t>(colbase[src < ncol_pad ? src : ncol_pad - 1]) + 2 * rp;
+		if constexpr (kRun) {
+			const int srcB = src + 4;
+			int colB = srcB < p ? srcB : ycol + (srcB - p);
+			if (srcB >= ncol) colB = ycol + 2 + ((colsub + 4) % 6);
+			dcolB[q] = colB * kLdsStride + 2 * rp;
+			colpB[q] = reinterpret_cast<gptr_t>(colbase[srcB < ncol_pad ? srcB : ncol_pad - 1]) + 2 * rp;
+		}
 		actbits |= active ? (1u << q) : 0u;
 		wbits |= (WEIGHTED && src == p + 1) ? (1u << q) : 0u;
 	}
@@ -343,6 +359,9 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	// the shift the staging side applies to the columns THIS lane stages (0 until the first valid row is known, 0 for
 	// the weight column and when there is no intercept)
 	double fq[kMaxLoads];
+	double fqB[kRun ? kMaxLoads : 1]; // (kRun: forced_first does not come with the speculative version)
+#pragma unroll
+	for (int q = 0; q < (kRun ? kMaxLoads : 1); ++q) fqB[q] = 0.0;
 #pragma unroll
 	for (int q = 0; q < kMaxLoads; ++q) {
 		fq[q] = 0.0;
@@ -359,6 +378,14 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 				fq[q] = f;
 				if (rp == 0) firstcol[src < p ? src : ycol] = f;
 			}
+			if constexpr (kRun) {
+				const int srcB = src + 4;
+				if (wave + kWaves * q < n_loads_total && srcB <= p) {
+					const double f = colpB[q][-2 * rp];
+					fqB[q] = f;
+					if (rp == 0) firstcol[srcB < p ? srcB : ycol] = f;
+				}
+			}
 		}
 		have_first = true;
 	}
@@ -367,6 +394,8 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	// for the loop's own loads)
 #pragma unroll
 	for (int q = 0; q < kMaxLoads; ++q) asm volatile("" : "+v"(fq[q]));
+#pragma unroll
+	for (int q = 0; q < (kRun ? kMaxLoads : 0); ++q) asm volatile("" : "+v"(fqB[q]));
 	const int64_t n_chunks = (nrows + kChunkRows - 1) / kChunkRows;
 	// staging registers of one chunk: rows 2 rp, 2 rp + 1 (v0, v1) and 16 + 2 rp, 17 + 2 rp (v2, v3) of this lane's columns
 	struct Stage {
@@ -381,7 +410,17 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 			sg.b[q] = (dbl2u){0.0, 0.0};
 			if (wave + kWaves * q < n_loads_total) { // wave-uniform
 				const gptr_t b = colp[q] + c0;
-				if (full) {
+				if constexpr (kRun) {
+					const gptr_t b2 = colpB[q] + c0;
+					if (full) {
+						sg.a[q] = *reinterpret_cast<gptr2_t>(b);
+						sg.b[q] = *reinterpret_cast<gptr2_t>(b2);
+					} else {
+						const int64_t r0 = c0 + 2 * rp;
+						if (r0 < nrows) sg.a[q].x = b[0], sg.b[q].x = b2[0];
+						if (r0 + 1 < nrows) sg.a[q].y = b[1], sg.b[q].y = b2[1];
+					}
+				} else if (full) {
 					sg.a[q] = *reinterpret_cast<gptr2_t>(b);
 					if (kWideChunk) sg.b[q] = *reinterpret_cast<gptr2_t>(b + 16);
 				} else {
@@ -409,7 +448,8 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	auto stage_load_piece_steady = [&](int64_t chunk, Stage &sg, int q) {
 		const gptr_t b = colp[q] + chunk * kChunkRows;
 		sg.a[q] = *reinterpret_cast<gptr2_t>(b);
-		if (kWideChunk) sg.b[q] = *reinterpret_cast<gptr2_t>(b + 16);
+		if constexpr (kRun) sg.b[q] = *reinterpret_cast<gptr2_t>(colpB[q] + chunk * kChunkRows);
+		else if (kWideChunk) sg.b[q] = *reinterpret_cast<gptr2_t>(b + 16);
 	};
 
 	// registers -> LDS image `buf` (shifted by fq; rows past the end of the group as zeros), plus this wave's partial
@@ -447,7 +487,14 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 				ss.wbad3 = ss.wbad3 || (isw && !(sg.b[q].y > 0.0));
 			}
 			double *dst = img + dcol[q];
-			if (left >= kChunkRows) { // wave-uniform: every row of the chunk exists
+			if constexpr (kRun) {
+				double *dstB = img + dcolB[q];
+				const bool in0 = 2 * rp < left, in1 = 2 * rp + 1 < left;
+				dst[0] = in0 ? sg.a[q].x - fq[q] : 0.0;
+				dst[1] = in1 ? sg.a[q].y - fq[q] : 0.0;
+				dstB[0] = in0 ? sg.b[q].x - fqB[q] : 0.0;
+				dstB[1] = in1 ? sg.b[q].y - fqB[q] : 0.0;
+			} else if (left >= kChunkRows) { // wave-uniform: every row of the chunk exists
 				dst[0] = sg.a[q].x - fq[q];
 				dst[1] = sg.a[q].y - fq[q];
 				if (kWideChunk) {
@@ -484,7 +531,11 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		double *dst = image + buf * ncol_pad * kLdsStride + dcol[q];
 		dst[0] = sg.a[q].x - fq[q];
 		dst[1] = sg.a[q].y - fq[q];
-		if (kWideChunk) {
+		if constexpr (kRun) {
+			double *dstB = image + buf * ncol_pad * kLdsStride + dcolB[q];
+			dstB[0] = sg.b[q].x - fqB[q];
+			dstB[1] = sg.b[q].y - fqB[q];
+		} else if (kWideChunk) {
 			dst[16] = sg.b[q].x - fq[q];
 			dst[17] = sg.b[q].y - fq[q];
 		}
