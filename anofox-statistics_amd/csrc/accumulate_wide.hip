@@ -42,3 +42,12 @@ hipError_t launch_accumulate_wide_followup(const WideArgs &a, hipStream_t stream
 }
 
 } // namespace anofox
+
+#ifdef ANOFOX_SOLVE_STAMPS
+// diagnostic build: the phase stamps and milestones of the kernels of 1 .. 4 column tiles (this translation unit's copies)
+extern "C" __attribute__((visibility("default"))) int anofox_hip_diag_acc_stamps_t4(unsigned long long *out16) {
+	hipError_t rc = hipMemcpyFromSymbol(out16, HIP_SYMBOL(anofox::g_acc_stamps), 8 * sizeof(unsigned long long));
+	if (rc != hipSuccess) return (int)rc;
+	return (int)hipMemcpyFromSymbol(out16 + 8, HIP_SYMBOL(anofox::g_acc_marks), 8 * sizeof(unsigned long long));
+}
+#endif

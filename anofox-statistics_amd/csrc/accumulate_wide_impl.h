@@ -48,11 +48,19 @@ typedef const dbl2u __attribute__((address_space(1))) *gptr2_t;
 // [6] chunks  [7] whole group.
 #ifdef ANOFOX_SOLVE_STAMPS
 static __device__ unsigned long long g_acc_stamps[8];
-#define ACC_STAMP_DECL unsigned long long st_t = 0, st_acc[6] = {0, 0, 0, 0, 0, 0}, st_n = 0; const bool st_on = blockIdx.x == 0 && WAVE == 0; const unsigned long long st_begin = __builtin_amdgcn_s_memtime()
+// (r4) milestones of one group's life, s_memtime since the function's entry: [0] setup + barrier  [1] first row known  [2] chunk 0 staged
+// [3] steady trips done  [4] chunk loop done  [5] split tiles collected  [6] speculation checked  [7] record written.  The workgroup in
+// the middle of the grid, so that the chip is loaded.
+static __device__ unsigned long long g_acc_marks[8];
+#define ACC_MARK_DECL const bool mk_on = blockIdx.x == gridDim.x / 2 && WAVE == 0 && (threadIdx.x & 63) == 0; const unsigned long long mk_begin = __builtin_amdgcn_s_memtime()
+#define ACC_MARK(k) do { if (mk_on) g_acc_marks[k] = __builtin_amdgcn_s_memtime() - mk_begin; } while (0)
+#define ACC_STAMP_DECL unsigned long long st_t = 0, st_acc[6] = {0, 0, 0, 0, 0, 0}, st_n = 0; const bool st_on = blockIdx.x == gridDim.x / 2 && WAVE == 0; const unsigned long long st_begin = __builtin_amdgcn_s_memtime()
 #define ACC_STAMP_START() do { if (st_on) st_t = __builtin_amdgcn_s_memtime(); } while (0)
 #define ACC_STAMP(k) do { if (st_on) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += now_ - st_t; st_t = now_; } } while (0)
 #define ACC_STAMP_FLUSH() do { if (st_on && threadIdx.x == 0) { for (int k_ = 0; k_ < 6; ++k_) g_acc_stamps[k_] = st_acc[k_]; g_acc_stamps[6] = st_n; g_acc_stamps[7] = __builtin_amdgcn_s_memtime() - st_begin; } } while (0)
 #else
+#define ACC_MARK_DECL do { } while (0)
+#define ACC_MARK(k) do { } while (0)
 #define ACC_STAMP_DECL do { } while (0)
 #define ACC_STAMP_START() do { } while (0)
 #define ACC_STAMP(k) do { } while (0)
@@ -155,6 +163,19 @@ struct WideCfg {
 #ifndef ANOFOX_WIDE_RUN256
 #define ANOFOX_WIDE_RUN256(T) 0
 #endif
+// (r4) the ends of a group in the speculative version with two chunks of loads in flight (ANOFOX_WIDE_TAIL2=0: as before; see kTail2)
+#ifndef ANOFOX_WIDE_TAIL2
+#define ANOFOX_WIDE_TAIL2 0
+#endif
+#ifndef ANOFOX_WIDE_STAGGER
+#define ANOFOX_WIDE_STAGGER 0
+#endif
+// what-if builds of the speculative version's steady state (never shipped: the results are wrong; `make variant`): bit 0 = one v_fma_f64
+// in place of every matrix instruction, 1 = no global loads (the staging registers keep the first chunk), 2 = no barrier per chunk,
+// 3 = the fragments of a chunk's first slab are used for all of its slabs (one eighth of the LDS reads), 4 = the staged chunk is not written to LDS
+#ifndef ANOFOX_WIDE_SKIP
+#define ANOFOX_WIDE_SKIP 0
+#endif
 	static constexpr int depth(bool fast) { return kWaves == 4 && fast ? ANOFOX_WIDE_DEPTH(T) : 1; }
 	static constexpr int chunk_rows(bool weighted, bool center = true) { return ANOFOX_WIDE_SHORT_CHUNK(T, weighted, center) ? 16 : 32; }
 	static constexpr int stride(bool weighted, bool center = true) { return chunk_rows(weighted, center) + 2; } // doubles per column in the LDS image (+2 pad: conflict-free b64 reads)
@@ -203,6 +224,16 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 	for (int t = 0; t < NS; ++t) {
 		const int s = t & 1;
 		const int row = 4 * t + k;
+#if ANOFOX_WIDE_SKIP & 8
+		if (FAST) {
+			if (t + 1 < NS) {
+#pragma unroll
+				for (int I = 0; I < T; ++I) d[s ^ 1][I] = d[s][I];
+				dy[s ^ 1] = dy[s];
+				w[s ^ 1] = w[s];
+			}
+		} else
+#endif
 		if (t + 1 < NS) read_slab(t + 1, s ^ 1);
 		double a[T];
 #pragma unroll
@@ -213,8 +244,13 @@ __device__ __forceinline__ void compute_chunk(const double *img, const double *f
 		for (int I = 0; I < T; ++I) {
 #pragma unroll
 			for (int J = I; J < T; ++J) {
-				if (WideCfg<T>::works(tile, WAVE, t))
+				if (WideCfg<T>::works(tile, WAVE, t)) {
+#if ANOFOX_WIDE_SKIP & 1
+					if (FAST) acc[WideCfg<T>::acc_index(tile)][0] = fma(a[I], d[s][J], acc[WideCfg<T>::acc_index(tile)][0]);
+					else
+#endif
 					acc[WideCfg<T>::acc_index(tile)] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], d[s][J], acc[WideCfg<T>::acc_index(tile)], 0, 0, 0);
+				}
 				++tile;
 			}
 		}
@@ -277,6 +313,15 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	// bytes per column and request) instead of 16 rows of eight columns (128 bytes): registers `a` of a slot hold its first four columns,
 	// `b` its last four, both the same 32 rows.  (The full version keeps the 16-row classes its row masks are built from.)
 	constexpr bool kRun = FAST && DMA == 0 && kWideChunk && ANOFOX_WIDE_RUN256(T);
+	// (r4) kTail2 (measurement build -DANOFOX_WIDE_TAIL2=1; OFF).  A load takes ~9 000 cycles to come back on the loaded chip and a chunk of
+	// 3-4 column tiles ~3 500 (milestones of a group's life, profiles/r04_wide_group_life.md): at 1000 rows per group a quarter of a
+	// workgroup's life goes into its two ends — 9 500 cycles for the first row (the shift) before chunk 0 is even asked for, and ~7 800
+	// per chunk in the last four chunks, which the generic iteration loads ONE chunk ahead into the registers it has just stored.  With
+	// kTail2 chunks 0 and 1 are requested first and the shift is taken from chunk 0's registers (the lane that holds row 0 of the
+	// column), and the last chunks alternate between the two register sets of the steady state.  Correct (GPU suite), and NOT faster:
+	// T = 3 level, T = 4 3-4 % slower (scripts/wide_tail_ab.sh) — a workgroup's idle ends are filled by the CU's other workgroups
+	// already; the CU is bound by what its SIMDs issue (matrix + vector instructions add up to ~88 % of the steady chunk).
+	constexpr bool kTail2 = FAST && DMA == 0 && Cfg::depth(FAST) == 2 && ANOFOX_WIDE_TAIL2;
 	constexpr unsigned kFullMask = kWideChunk ? 0xffffffffu : 0xffffu;
 	constexpr int P16 = 16 * T;
 	const int p = args.p;
@@ -284,6 +329,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	const int lane = threadIdx.x & 63;
 	constexpr int wave = WAVE;
 	const int64_t nrows = hi - lo;
+	ACC_MARK_DECL;
 
 	extern __shared__ double lds[];
 	// layout: image[2][ncol_pad][STRIDE] | colbase[ncol_pad] (as pointers) | firstcol[ncol_pad] | rowmask partials [2][4]
@@ -312,6 +358,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		image[bufi * ncol_pad * kLdsStride + p * kLdsStride + rem] = 0.0;
 	}
 	__syncthreads();
+	ACC_MARK(0);
 
 	// staging assignment: load instruction q of this wave covers columns 8*(wave + 4q) .. +7; lane -> (col, row pair).
 	// Everything a lane needs to know about its load slots lives in registers (column pointer, LDS destination, flags):
@@ -369,7 +416,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		if (CENTER && forced_first && src <= p) fq[q] = src < p ? forced_first[src] : forced_first[P16];
 	}
 
-	if (FAST && DMA == 0) { // the shift is the group's first row (nrows > 0: the caller's condition)
+	if (FAST && DMA == 0 && !kTail2) { // the shift is the group's first row (nrows > 0: the caller's condition)
 #pragma unroll
 		for (int q = 0; q < kMaxLoads; ++q) {
 			const int src = 8 * (wave + kWaves * q) + colsub;
@@ -396,6 +443,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	for (int q = 0; q < kMaxLoads; ++q) asm volatile("" : "+v"(fq[q]));
 #pragma unroll
 	for (int q = 0; q < (kRun ? kMaxLoads : 0); ++q) asm volatile("" : "+v"(fqB[q]));
+	ACC_MARK(1);
 	const int64_t n_chunks = (nrows + kChunkRows - 1) / kChunkRows;
 	// staging registers of one chunk: rows 2 rp, 2 rp + 1 (v0, v1) and 16 + 2 rp, 17 + 2 rp (v2, v3) of this lane's columns
 	struct Stage {
@@ -447,6 +495,9 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	// and broke as soon as the compiler had a reason to copy a register whose load had not landed.)
 	auto stage_load_piece_steady = [&](int64_t chunk, Stage &sg, int q) {
 		const gptr_t b = colp[q] + chunk * kChunkRows;
+#if ANOFOX_WIDE_SKIP & 2
+		if (FAST) return;
+#endif
 		sg.a[q] = *reinterpret_cast<gptr2_t>(b);
 		if constexpr (kRun) sg.b[q] = *reinterpret_cast<gptr2_t>(colpB[q] + chunk * kChunkRows);
 		else if (kWideChunk) sg.b[q] = *reinterpret_cast<gptr2_t>(b + 16);
@@ -529,6 +580,9 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 			ss.wbad3 = ss.wbad3 || (isw && !(sg.b[q].y > 0.0));
 		}
 		double *dst = image + buf * ncol_pad * kLdsStride + dcol[q];
+#if ANOFOX_WIDE_SKIP & 16
+		if (FAST) { asm volatile("" ::"v"(sg.a[q].x), "v"(sg.a[q].y), "v"(sg.b[q].x), "v"(sg.b[q].y)); return; }
+#endif
 		dst[0] = sg.a[q].x - fq[q];
 		dst[1] = sg.a[q].y - fq[q];
 		if constexpr (kRun) {
@@ -593,7 +647,8 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	ACC_STAMP_DECL;
 	// steady = std::true_type: chunks c and c + 1 are full (the branch-free staging pieces)
 	// STEADY: the loads of chunk c + depth go into `ahead`, chunk c + 1 is stored from `landed` (the same registers when kDepth = 1)
-	auto iteration = [&](auto steady, int64_t c, Stage &ahead, Stage &landed) {
+	// (generic iterations: `ga` = how many chunks beyond c + 1 the chunk lies that is loaded into `ahead` once chunk c + 1 is stored from it)
+	auto iteration = [&](auto steady, int64_t c, Stage &ahead, Stage &landed, int ga) {
 		constexpr bool STEADY = decltype(steady)::value;
 		ACC_STAMP_START();
 		const int buf = (int)(c & 1);
@@ -676,13 +731,16 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 			for (int q = 0; q < kMaxLoads; ++q) {
 				if ((q * NS) / kMaxLoads == t) { // slab behind which slot q is stored
 					stage_store_piece(c + 1, buf ^ 1, ahead, ss, q);
-					if (c + 2 < n_chunks) stage_load_piece(c + 2, ahead, q);
+					if (c + 1 + ga < n_chunks) stage_load_piece(c + 1 + ga, ahead, q);
 				}
 			}
 		});
 		ACC_STAMP(2);
 		if (more) stage_store_finish(c + 1, buf ^ 1, ss);
 		ACC_STAMP(4);
+#if ANOFOX_WIDE_SKIP & 4
+		if (!(FAST && STEADY))
+#endif
 		__syncthreads();
 		ACC_STAMP(5);
 #ifdef ANOFOX_SOLVE_STAMPS
@@ -752,35 +810,77 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 	} else {
 	constexpr int D = Cfg::depth(FAST);
 	Stage st[D];
-	if (n_chunks > 0) {
+	if constexpr (kTail2) {
+		stage_load(0, st[0]);
+		if (n_chunks > 1) stage_load(1, st[1]);
+		// the shift = the group's first row (nrows > 0: the caller's condition): rows 0, 1 of a column sit in the lane with rp == 0
+#pragma unroll
+		for (int q = 0; q < kMaxLoads; ++q) {
+			const int src = 8 * (wave + kWaves * q) + colsub;
+			const double f = __shfl(st[0].a[q].x, lane & (kRun ? ~15 : ~7), 64);
+			if (wave + kWaves * q < n_loads_total && src <= p) {
+				fq[q] = f;
+				if (rp == 0) firstcol[src < p ? src : ycol] = f;
+			}
+			if constexpr (kRun) {
+				const int srcB = src + 4;
+				const double fb = __shfl(st[0].b[q].x, lane & ~15, 64);
+				if (wave + kWaves * q < n_loads_total && srcB <= p) {
+					fqB[q] = fb;
+					if (rp == 0) firstcol[srcB < p ? srcB : ycol] = fb;
+				}
+			}
+		}
+		have_first = true;
+		stage_store(0, 0, st[0]);
+	} else if (n_chunks > 0) {
 		stage_load(0, st[0]);
 		stage_store(0, 0, st[0]);
 	}
 	__syncthreads();
+	ACC_MARK(2);
 	{
 		int64_t c = 0;
 		const int64_t n_full = nrows / kChunkRows; // full chunks
 		if constexpr (D == 1) {
-			for (; c + 1 < n_full; ++c) iteration(std::true_type(), c, st[0], st[0]); // (nothing of chunk c + 1 is loaded yet)
+			for (; c + 1 < n_full; ++c) iteration(std::true_type(), c, st[0], st[0], 1); // (nothing of chunk c + 1 is loaded yet)
 		} else {
 			// trips of D chunks, so that which registers hold which chunk is known at compile time: chunk c + j + 1 sits in st[(j + 1) % D]
 			// when chunk c + j is multiplied, and the loads of chunk c + j + D go into st[j], whose chunk was stored one iteration ago
 			if (c + 2 * D - 1 < n_full) {
+				if constexpr (!kTail2) {
 #pragma unroll
-				for (int j = 1; j < D; ++j) stage_load(j, st[j]);
+					for (int j = 1; j < D; ++j) stage_load(j, st[j]);
+				}
 				for (; c + 2 * D - 1 < n_full; c += D) {
 #pragma unroll
-					for (int j = 0; j < D; ++j) iteration(std::true_type(), c + j, st[j], st[(j + 1) % D]);
+					for (int j = 0; j < D; ++j) iteration(std::true_type(), c + j, st[j], st[(j + 1) % D], 1);
 				}
 			}
 		}
-		// (the generic iterations expect the next chunk in registers; after steady trips it is there already and is read once more)
-		if (c + 1 < n_chunks) stage_load(c + 1, st[1 % D]);
-		for (; c < n_chunks; ++c) iteration(std::false_type(), c, st[1 % D], st[1 % D]);
+		ACC_MARK(3);
+		if constexpr (kTail2) {
+			// chunk c is staged and chunk c + 1 sits in st[1] (from before the loop, or from its last trip); chunk c + 2 goes into st[0] now and
+			// the remaining iterations alternate between the two sets
+			if (c + 2 < n_chunks) stage_load(c + 2, st[0]);
+			for (;;) {
+				if (c >= n_chunks) break;
+				iteration(std::false_type(), c, st[1], st[1], 2);
+				++c;
+				if (c >= n_chunks) break;
+				iteration(std::false_type(), c, st[0], st[0], 2);
+				++c;
+			}
+		} else {
+			// (the generic iterations expect the next chunk in registers; after steady trips it is there already and is read once more)
+			if (c + 1 < n_chunks) stage_load(c + 1, st[1 % D]);
+			for (; c < n_chunks; ++c) iteration(std::false_type(), c, st[1 % D], st[1 % D], 1);
+		}
 	}
 	}
 
 	ACC_STAMP_FLUSH();
+	ACC_MARK(4);
 	// (r4) the tiles that were split along the rows: the partial sums go through the image (free since the loop's last barrier)
 	// to the tile's owner, element for element (every wavefront holds a tile in the same lane / register layout)
 	if constexpr (Cfg::R > 0) {
@@ -812,6 +912,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		}
 		__syncthreads(); // (the callers rewrite the LDS)
 	}
+	ACC_MARK(5);
 	unsigned fast_nc[Cfg::TPW]; // FAST: constant-column flags of the diagonal tiles this wave holds (bit r: element r)
 	if (FAST) {
 		// what the speculation assumed, checked on the result: every moment finite, every column clearly constant or
@@ -857,6 +958,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 		if (__builtin_amdgcn_readfirstlane(any_bad) != 0u) return false;
 		cnt = (int)nrows;
 	}
+	ACC_MARK(6);
 	// ---- write the moment record ----
 	// tiles: tile-major, 256 doubles each, element (row, col) at row*16 + col
 	{
@@ -921,6 +1023,7 @@ __device__ __forceinline__ bool wide_accumulate_rows_wave(const WideArgs &args, 
 			sc[4] = firstcol[ycol];
 		}
 	}
+	ACC_MARK(7);
 	return true;
 }
 
@@ -947,8 +1050,12 @@ __device__ __forceinline__ bool wide_accumulate_rows(const WideArgs &args, int64
 
 // FAST: the speculative version on every group; the groups it gives up on (and empty ones) go to a list — borrowed
 // from the refine queue, which the solve that follows starts to fill only later — for accumulate_wide_redo_kernel.
+// (measurement builds: the register budget of the speculative version cut for more wavefronts per SIMD, `-DANOFOX_WIDE_FAST_WPS(T)=3`)
+#ifndef ANOFOX_WIDE_FAST_WPS
+#define ANOFOX_WIDE_FAST_WPS(T) kWavesPerSimd
+#endif
 template <int T, bool WEIGHTED, bool CENTER, bool FAST, int DMA = 0>
-__global__ __launch_bounds__(kThreads, kWavesPerSimd) void accumulate_wide_kernel(WideArgs args) {
+__global__ __launch_bounds__(kThreads, (FAST ? ANOFOX_WIDE_FAST_WPS(T) : kWavesPerSimd)) void accumulate_wide_kernel(WideArgs args) {
 	const int64_t g = blockIdx.x;
 	const int64_t lo = args.row_offsets[args.group_base + g];
 	const int64_t hi = group_row_end(args, args.group_base + g);
@@ -964,6 +1071,17 @@ __global__ __launch_bounds__(kThreads, kWavesPerSimd) void accumulate_wide_kerne
 	}
 	double *rec = args.moments + g * (int64_t)wide_record_len(T);
 	if constexpr (FAST) {
+#if ANOFOX_WIDE_STAGGER
+		// Groups of equal length keep the workgroups that share a CU in step: they start together, share the SIMDs evenly and reach their
+		// latency-bound ends (first loads, last chunks, record) together, with nothing left to fill the matrix pipe.  The workgroups of the
+		// grid's first wave therefore start a random fraction of one group's time apart (s_sleep, ~4 us per step; large grids only).
+		if (gridDim.x >= 4096 && blockIdx.x < 1024) {
+			unsigned steps = (unsigned)(((hi - lo) * (int64_t)(args.p + 1) * 8) / (6500 * 4)); // a group's time at ~6.5 GB/s per workgroup
+			steps = steps > 64u ? 64u : steps;
+			const unsigned k = steps ? ((blockIdx.x * 2654435761u) >> 20) % steps : 0u;
+			for (unsigned i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
+		}
+#endif
 		if (hi > lo && wide_accumulate_rows<T, WEIGHTED, CENTER, true, DMA>(args, lo, hi, rec, nullptr)) return;
 		if (threadIdx.x == 0) args.refine_list[atomicAdd(args.refine_count + kWideRedoCounter, 1)] = (int32_t)g;
 	} else {

@@ -126,11 +126,27 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	a.seg_table = w_seg; // (per buffer below)
 	a.seg_rows = mid_acc ? seg_rows_for(n_rows) : wide_seg_rows_for(n_rows);
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
+	// (r4) the slabs' sizes.  With two streams slab k's solve runs under slab k + 1's accumulate kernel, so what is exposed is the LAST
+	// slab's solve — a short last slab is welcome — but a last slab much shorter than its predecessor leaves most of the predecessor's
+	// solve exposed as well (50 000 x 1000 x 64: 47 583 + 2 417 groups, the solve of the first 1.7 ms, the accumulate kernel of the
+	// second 0.4 ms).  A remainder below a quarter of a slab therefore takes groups from the slab before it: 3 : 1.
+	std::vector<int64_t> slab_sizes;
+	for (int64_t left = G; left > 0;) {
+		const int64_t take = left < slab ? left : slab;
+		slab_sizes.push_back(take);
+		left -= take;
+	}
+	static const bool slab_balance_on = !(getenv("ANOFOX_WIDE_SLAB_BALANCE") && atoi(getenv("ANOFOX_WIDE_SLAB_BALANCE")) == 0); // A/B switch
+	if (const size_t K = slab_sizes.size(); slab_balance_on && K >= 2 && slab_sizes[K - 1] < slab / 4) {
+		const int64_t both = slab_sizes[K - 2] + slab_sizes[K - 1];
+		slab_sizes[K - 1] = both / 4;
+		slab_sizes[K - 2] = both - both / 4;
+	}
 	int64_t k_slab = 0;
-	for (int64_t g0 = 0; g0 < G; g0 += slab, ++k_slab) {
+	for (int64_t g0 = 0; g0 < G; g0 += slab_sizes[(size_t)k_slab], ++k_slab) {
 		const int buf = overlap ? (int)(k_slab & 1) : 0;
 		a.group_base = g0;
-		a.n_groups = (G - g0 < slab) ? G - g0 : slab;
+		a.n_groups = slab_sizes[(size_t)k_slab];
 		a.moments = (double *)(base + buf * b_mom);
 		a.refine_list = (int32_t *)(w_lst + buf * b_lst);
 		a.refine_count = (int32_t *)(w_cnt + buf * 256);
@@ -182,7 +198,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 		             "wide accumulate kernel launch", e))
 			return false;
 		if (ctx->timing) (void)hipEventRecord(e1, st);
-		if (g0 + slab >= G && ctx->gate_record) {
+		if (g0 + a.n_groups >= G && ctx->gate_record) {
 			hipEvent_t gr = ctx->gate_record;
 			ctx->gate_record = nullptr;
 			if (hip_fail(hipEventRecord(gr, st), "hipEventRecord", e)) return false;
