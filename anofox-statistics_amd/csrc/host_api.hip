@@ -128,7 +128,7 @@ bool run_wide_batch(AnofoxHipContext *ctx, int64_t G, size_t p, int64_t n_rows, 
 	if (hip_fail(hipMemsetAsync(a.tcrit_table, 0, kTcritTableBytes, st), "hipMemsetAsync", e)) return false;
 	// (r4) the slabs' sizes.  With two streams slab k's solve runs under slab k + 1's accumulate kernel, so what is exposed is the LAST
 	// slab's solve — a short last slab is welcome — but a last slab much shorter than its predecessor leaves most of the predecessor's
-	// solve exposed as well (50 000 x 1000 x 64: 47 583 + 2 417 groups, the solve of the first 1.7 ms, the accumulate kernel of the
+	// solve exposed as well (50 000 x 1000 x 64: 47 527 + 2 473 groups, the solve of the first 1.7 ms, the accumulate kernel of the
 	// second 0.4 ms).  A remainder below a quarter of a slab therefore takes groups from the slab before it: 3 : 1.
 	std::vector<int64_t> slab_sizes;
 	for (int64_t left = G; left > 0;) {

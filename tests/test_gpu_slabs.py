@@ -22,13 +22,37 @@ def _slab_groups(p):
     return max(256, (1 << 30) // rec_bytes)
 
 
+def _slab_sizes(G, slab):
+    """The slabs of a batch of G groups, as csrc/host_api.hip::run_wide_batch cuts them: slabs of the maximal size, and a remainder
+    below a quarter of a slab takes groups from the slab before it (3 : 1)."""
+    sizes = []
+    left = G
+    while left > 0:
+        take = min(left, slab)
+        sizes.append(take)
+        left -= take
+    if len(sizes) >= 2 and sizes[-1] < slab // 4:
+        both = sizes[-2] + sizes[-1]
+        sizes[-1] = both // 4
+        sizes[-2] = both - both // 4
+    return sizes
+
+
 def _windows(G, slab, k):
-    """k groups at the head of the first slab, straddling every slab boundary's far side, and at the very end."""
+    """k groups at the head of the first slab, straddling every slab boundary (the balanced ones and the places where
+    maximal slabs would have ended), and at the very end."""
     w = [(0, k)]
+    edges = set()
+    g = 0
+    for size in _slab_sizes(G, slab)[:-1]:
+        g += size
+        edges.add(g)
     g = slab
     while g < G:
-        w.append((g - k // 2, min(G, g + k // 2)))   # last groups of one slab and first groups of the next
+        edges.add(g)
         g += slab
+    for g in sorted(edges):
+        w.append((g - k // 2, min(G, g + k // 2)))   # last groups of one slab and first groups of the next
     w.append((G - k, G))
     return w
 
